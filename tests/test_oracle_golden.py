@@ -1,0 +1,57 @@
+"""CPU: the oracle restatement reproduces the committed reference outputs (tests/golden/*.pt were
+produced by oracle/make_golden.py running the real reference)."""
+import torch
+
+from oracle import iplan_oracle as O
+
+
+def close(a, b, tol=1e-5):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
+
+
+def test_gat_forward_matches_reference(golden):
+    for tag in ("small", "hwy", "wide"):
+        g = golden("gat_" + tag)
+        out = O.gat_forward(g["params"], g["obs"], g["h_prev"], g["noise"])
+        assert close(out, g["out"]), tag
+
+
+def test_gat_grads_match_reference(golden):
+    g = golden("gat_small")
+    p = {k: v.double().requires_grad_(True) for k, v in g["params"].items()}
+    out = O.gat_forward(p, g["obs"].double(), g["h_prev"].double(), g["noise"].double())
+    (out * g["gout"].double()).sum().backward()
+    for k, ref in g["grads"].items():
+        assert close(p[k].grad, ref, 2e-4), k
+
+
+def test_encoder_decoder_match_reference(golden):
+    g = golden("encoder")
+    seq, hL, lat = O.encoder_forward(g["params"], g["x"], g["h0"])
+    assert close(seq, g["seq"]) and close(hL, g["hL"]) and close(lat, g["latent"])
+    g = golden("decoder")
+    y, hT = O.decoder_forward(O.strip_prefix(g["params"], "decoder."), g["dec_in"], g["h0"], g["mask"], 0.1)
+    assert close(y, g["y"]) and close(hT, g["hT"])
+    g = golden("pred_decoder")
+    pred = O.prediction_decoder_forward(g["params"], g["last"], g["hidden"], 5, g["masks"], 0.1)
+    assert close(pred, g["pred"])
+
+
+def test_behavior_learn_loss_matches_reference(golden):
+    g = golden("behavior_learn")
+    a = g["args"]
+    hist = g["fields"]["history"][:, :-1]
+    term = g["fields"]["terminated"][:, :-1]
+    J = hist.shape[1] - 1 - a["max_history_len"]
+    for i in range(a["n_agents"]):
+        masks = torch.stack(g["dropout"][i * J:(i + 1) * J])
+        beh, stab, _ = O.behavior_learn_loss(g["pre"]["enc"][i], g["pre"]["dec"][i], hist[:, :, i],
+                                             term[:, :, i, 0], a["max_history_len"], a["soft_update_coef"],
+                                             masks, a["decoder_dropout"])
+        assert close(beh, g["behavior_loss"][i]) and close(stab, g["stability_loss"][i])
+
+
+def test_huber_is_one_sided():
+    e = torch.tensor([-20.0, -5.0, 5.0, 20.0])
+    assert torch.allclose(O.huber_loss(e, 10.0), torch.tensor([0.0, 12.5, 12.5, 150.0]))
