@@ -1,0 +1,57 @@
+"""Stacked parameter arenas.
+
+The reference keeps ``n_agents`` private copies of every network as separate nn.Modules and loops
+over them in Python.  Here the modules still exist (same classes, same ``state_dict`` keys, so
+checkpoints interchange), but their Parameters are *views* into one contiguous fp32 arena
+``[n_nets, P]`` (and their ``.grad`` into a twin gradient arena).  Consequences:
+  * one kernel launch reads every net's weights via (arena pointer, net stride, per-tensor offset);
+  * clip_grad_norm_ / Adam / zero_grad are single flat-buffer kernels instead of per-tensor loops;
+  * the data-parallel gradient all-reduce is ONE RCCL call on the gradient arena.
+"""
+import torch
+
+
+class ParamArena:
+    def __init__(self, modules, device):
+        """modules: list of structurally identical nn.Modules (one per net)."""
+        self.modules = list(modules)
+        self.n_nets = len(self.modules)
+        named = list(self.modules[0].named_parameters())
+        self.names = [k for k, _ in named]
+        self.shapes = {k: tuple(v.shape) for k, v in named}
+        self.offsets = {}
+        off = 0
+        for k, v in named:
+            self.offsets[k] = off
+            off += (v.numel() + 3) // 4 * 4           # keep every tensor 16-byte aligned
+        self.size = off
+        self.trainable = {k: v.requires_grad for k, v in named}
+        self.data = torch.zeros(self.n_nets, self.size, dtype=torch.float32, device=device)
+        self.grad = torch.zeros_like(self.data)
+        for i, m in enumerate(self.modules):
+            for k, p in m.named_parameters():
+                view = self.data[i, self.offsets[k]:self.offsets[k] + p.numel()].view(p.shape)
+                view.copy_(p.data.to(device=device, dtype=torch.float32))
+                p.data = view
+                p.grad = self.grad[i, self.offsets[k]:self.offsets[k] + p.numel()].view(p.shape) \
+                    if p.requires_grad else None
+
+    @property
+    def net_stride(self):
+        return self.size
+
+    def off(self, name):
+        return self.offsets[name]
+
+    def ranges(self, names=None):
+        """(offset, numel) of each named tensor (default: all), in arena order."""
+        names = self.names if names is None else names
+        return [(self.offsets[k], int(torch.Size(self.shapes[k]).numel())) for k in names]
+
+    def param(self, net, name):
+        n = int(torch.Size(self.shapes[name]).numel())
+        return self.data[net, self.offsets[name]:self.offsets[name] + n].view(self.shapes[name])
+
+    def grad_of(self, net, name):
+        n = int(torch.Size(self.shapes[name]).numel())
+        return self.grad[net, self.offsets[name]:self.offsets[name] + n].view(self.shapes[name])

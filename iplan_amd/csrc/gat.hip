@@ -1,0 +1,281 @@
+// GAT-RNN instant-incentive encoder: forward pass of GAT_Net (nova/GAT_Net.py:41-142) for every
+// (net, env) scene in one launch.
+//
+// One 512-thread workgroup (8 waves) owns one scene = N <= 64 entities of one (agent-net, env):
+//   phase 1  node encode + per-node projections (MFMA): h = ReLU(W_enc x + b); the bi-GRU input
+//            projection is separable, W_ih [h_i ; h_j] = W_a h_i + W_b h_j, so the
+//            [N-1, B*N, 2H] pair tensor the reference materialises (GAT_Net.py:57-75, 55 % of its
+//            CPU time) never exists: W_a h_i stays in registers of the wave that owns chain i,
+//            W_b h_j goes to LDS.  q, k, v also go to LDS.
+//   phase 2  hard-attention bi-GRU: wave (dir, tile) runs 16 ego chains for N-1 steps; W_hh lives in
+//            registers as MFMA A fragments, the hidden state never leaves the D layout, gates are
+//            lane-local.  At step s every chain needs W_b h_j for j = s + [s >= i], i.e. one of two
+//            LDS rows -> near-broadcast reads.  Each step's contribution to the 2 hard logits is
+//            reduced over the 4 lane groups and parked in LDS.
+//   phase 3  per ego (one wave each): scaled dot-product scores, wave-shuffle softmax over the
+//            N-1 neighbours, gumbel-softmax gate (tau = 0.01), gated aggregation of v.
+//   phase 4  output GRUCell (MFMA) -> new attention latent.
+// HBM traffic per scene is the compulsory obs + h_prev + noise + out (~1.4 MB per net at cfg3);
+// everything else lives in the 150 KB of LDS / registers.  Training launches additionally stream
+// the activations the backward pass needs.
+#include "api_util.h"
+#include "wave_tile.h"
+
+namespace iplan {
+
+constexpr int GH = IPLAN_GAT_HIDDEN;   // H == A == 32
+constexpr int NP = IPLAN_MAX_ENTITIES; // 64
+constexpr int BST = 100;               // padded row stride (floats) of the W_b h_j table
+constexpr int QST = 33;                // padded row stride of q/k/v/x tables
+
+__global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_B[2][NP][BST];
+    __shared__ float s_q[NP][QST];
+    __shared__ float s_k[NP][QST];
+    __shared__ float s_v[NP][QST];
+    __shared__ float s_x[NP][QST];
+    __shared__ float s_pl[2][NP][NP][2];
+
+    const int net = (int)blockIdx.x / a.B;
+    const int b = (int)blockIdx.x % a.B;
+    const int N = a.N;
+    const int D = a.d0 + a.d1;
+    const float* __restrict__ P = a.params + (int64_t)net * a.params_s_net;
+    const int l = lane_id(), w = wave_id();
+    const int n = l & 15, g = l >> 4;
+    const int tile = w & 3, dir = w >> 2;
+    const int node = 16 * tile + n;
+    const bool tile_live = 16 * tile < N;
+    const bool valid = node < N;
+    const int64_t sb = (int64_t)net * a.B + b;
+    const IplanGatSaved& sv = a.saved;
+
+    const float* bih = P + a.off[dir ? IPLAN_GAT_R_BIH : IPLAN_GAT_F_BIH];
+    const float* bhh = P + a.off[dir ? IPLAN_GAT_R_BHH : IPLAN_GAT_F_BHH];
+
+    // ---------------------------------------------------------------- phase 1: node projections
+    f32x4 areg[6];
+    for (int t = 0; t < 6; ++t) areg[t] = splat4(0.f);
+    if (tile_live) {
+        f32x4 h[2];
+        {
+            f32x4 acc0 = bfrag(P + a.off[IPLAN_GAT_ENC_B], GH, 0);
+            f32x4 acc1 = bfrag(P + a.off[IPLAN_GAT_ENC_B], GH, 1);
+            const float* r0 = a.src0 + (int64_t)net * a.src0_s_net + (int64_t)b * a.src0_s_b + (int64_t)node * a.d0;
+            const float* r1 = a.d1 > 0 ? a.src1 + (int64_t)net * a.src1_s_net + (int64_t)b * a.src1_s_b + (int64_t)node * a.d1 : nullptr;
+            const float* Wenc = P + a.off[IPLAN_GAT_ENC_W];
+            const int KT = (D + 15) / 16;
+            for (int T = 0; T < KT; ++T) {
+                f32x4 x = splat4(0.f);
+                if (valid) {
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = 16 * T + 4 * g + q;
+                        if (c < a.d0) x[q] = r0[c];
+                        else if (c < D) x[q] = r1[c - a.d0];
+                    }
+                }
+                acc0 = mma_block(wfrag(Wenc, D, GH, D, 0, 16 * T), x, acc0);
+                acc1 = mma_block(wfrag(Wenc, D, GH, D, 16, 16 * T), x, acc1);
+            }
+            h[0] = relu4(acc0);
+            h[1] = relu4(acc1);
+        }
+        if (sv.h_enc && dir == 0) {
+            float* row = sv.h_enc + (sb * N + node) * GH;
+            vstore(row, valid, GH, 0, h[0]);
+            vstore(row, valid, GH, 1, h[1]);
+        }
+        const float* Wih = P + a.off[dir ? IPLAN_GAT_R_WIH : IPLAN_GAT_F_WIH];   // [3H][2H]
+        for (int t = 0; t < 6; ++t) {
+            f32x4 ac = bfrag(bih, 3 * GH, t);
+            if (t < 4) ac += bfrag(bhh, 3 * GH, t);          // r,z gates: both biases sit outside r*(.)
+            f32x4 bc = splat4(0.f);
+            for (int T = 0; T < 2; ++T) {
+                ac = mma_block(wfrag(Wih, 2 * GH, 3 * GH, 2 * GH, 16 * t, 16 * T), h[T], ac);
+                bc = mma_block(wfrag(Wih, 2 * GH, 3 * GH, 2 * GH, 16 * t, GH + 16 * T), h[T], bc);
+            }
+            areg[t] = ac;
+            if (valid) *reinterpret_cast<f32x4*>(&s_B[dir][node][16 * t + 4 * g]) = bc;
+        }
+        if (dir == 0) {
+            for (int which = 0; which < 2; ++which) {
+                const float* Wm = P + a.off[which ? IPLAN_GAT_K_W : IPLAN_GAT_Q_W];
+                float (*dst)[QST] = which ? s_k : s_q;
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 ac = splat4(0.f);
+                    for (int T = 0; T < 2; ++T) ac = mma_block(wfrag(Wm, GH, GH, GH, 16 * t, 16 * T), h[T], ac);
+                    if (valid)
+                        for (int q = 0; q < 4; ++q) dst[node][16 * t + 4 * g + q] = ac[q];
+                    if (sv.qkv) vstore(sv.qkv + ((sb * 3 + which) * N + node) * GH, valid, GH, t, ac);
+                }
+            }
+        } else {
+            const float* Wm = P + a.off[IPLAN_GAT_V_W];
+            for (int t = 0; t < 2; ++t) {
+                f32x4 ac = bfrag(P + a.off[IPLAN_GAT_V_B], GH, t);
+                for (int T = 0; T < 2; ++T) ac = mma_block(wfrag(Wm, GH, GH, GH, 16 * t, 16 * T), h[T], ac);
+                ac = relu4(ac);
+                if (valid)
+                    for (int q = 0; q < 4; ++q) s_v[node][16 * t + 4 * g + q] = ac[q];
+                if (sv.qkv) vstore(sv.qkv + ((sb * 3 + 2) * N + node) * GH, valid, GH, t, ac);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- phase 2: hard-attention bi-GRU
+    if (tile_live) {
+        const float* Whh = P + a.off[dir ? IPLAN_GAT_R_WHH : IPLAN_GAT_F_WHH];   // [3H][H]
+        f32x4 whh[6][2];
+        for (int t = 0; t < 6; ++t)
+            for (int T = 0; T < 2; ++T) whh[t][T] = wfrag(Whh, GH, 3 * GH, GH, 16 * t, 16 * T);
+        const f32x4 bhn0 = bfrag(bhh, 3 * GH, 4), bhn1 = bfrag(bhh, 3 * GH, 5);
+        const float* Wh = P + a.off[IPLAN_GAT_HARD_W];                           // [2][2H]
+        const f32x4 wl00 = bfrag(Wh + dir * GH, GH, 0), wl01 = bfrag(Wh + dir * GH, GH, 1);
+        const f32x4 wl10 = bfrag(Wh + 2 * GH + dir * GH, GH, 0), wl11 = bfrag(Wh + 2 * GH + dir * GH, GH, 1);
+        f32x4 h0 = splat4(0.f), h1 = splat4(0.f);
+        for (int it = 0; it < N - 1; ++it) {
+            const int s = dir ? (N - 2 - it) : it;
+            int j = s + (s >= node ? 1 : 0);
+            if (j > N - 1) j = N - 1;
+            const float* Bj = &s_B[dir][j][4 * g];
+            f32x4 pr0 = areg[0] + *reinterpret_cast<const f32x4*>(Bj);
+            f32x4 pr1 = areg[1] + *reinterpret_cast<const f32x4*>(Bj + 16);
+            f32x4 pz0 = areg[2] + *reinterpret_cast<const f32x4*>(Bj + 32);
+            f32x4 pz1 = areg[3] + *reinterpret_cast<const f32x4*>(Bj + 48);
+            const f32x4 gn0 = areg[4] + *reinterpret_cast<const f32x4*>(Bj + 64);
+            const f32x4 gn1 = areg[5] + *reinterpret_cast<const f32x4*>(Bj + 80);
+            f32x4 hn0 = bhn0, hn1 = bhn1;
+            pr0 = mma_block(whh[0][0], h0, pr0); pr0 = mma_block(whh[0][1], h1, pr0);
+            pr1 = mma_block(whh[1][0], h0, pr1); pr1 = mma_block(whh[1][1], h1, pr1);
+            pz0 = mma_block(whh[2][0], h0, pz0); pz0 = mma_block(whh[2][1], h1, pz0);
+            pz1 = mma_block(whh[3][0], h0, pz1); pz1 = mma_block(whh[3][1], h1, pz1);
+            hn0 = mma_block(whh[4][0], h0, hn0); hn0 = mma_block(whh[4][1], h1, hn0);
+            hn1 = mma_block(whh[5][0], h0, hn1); hn1 = mma_block(whh[5][1], h1, hn1);
+            const GruGates o0 = gru_gates(pr0, pz0, gn0, hn0, h0);
+            const GruGates o1 = gru_gates(pr1, pz1, gn1, hn1, h1);
+            h0 = o0.h;
+            h1 = o1.h;
+            if (sv.gru) {
+                float* row = sv.gru + ((((sb * 2 + dir) * N + node) * (N - 1)) + s) * (5 * GH);
+                vstore(row, valid, GH, 0, o0.h);          vstore(row, valid, GH, 1, o1.h);
+                vstore(row + GH, valid, GH, 0, o0.r);     vstore(row + GH, valid, GH, 1, o1.r);
+                vstore(row + 2 * GH, valid, GH, 0, o0.z); vstore(row + 2 * GH, valid, GH, 1, o1.z);
+                vstore(row + 3 * GH, valid, GH, 0, o0.n); vstore(row + 3 * GH, valid, GH, 1, o1.n);
+                vstore(row + 4 * GH, valid, GH, 0, o0.hn); vstore(row + 4 * GH, valid, GH, 1, o1.hn);
+            }
+            float p0 = 0.f, p1 = 0.f;
+            for (int q = 0; q < 4; ++q) {
+                p0 = fmaf(wl00[q], h0[q], p0); p0 = fmaf(wl01[q], h1[q], p0);
+                p1 = fmaf(wl10[q], h0[q], p1); p1 = fmaf(wl11[q], h1[q], p1);
+            }
+            p0 = group_sum(p0);
+            p1 = group_sum(p1);
+            if (g == 0 && valid) {
+                s_pl[dir][node][s][0] = p0;
+                s_pl[dir][node][s][1] = p1;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- phase 3: gated soft attention
+    {
+        const float hb0 = P[a.off[IPLAN_GAT_HARD_B]], hb1 = P[a.off[IPLAN_GAT_HARD_B] + 1];
+        const float* noise = a.noise + sb * N * (N - 1) * 2;
+        for (int i = w; i < N; i += 8) {
+            const int s = l;
+            const bool live = s < N - 1;
+            const int j = live ? s + (s >= i ? 1 : 0) : 0;
+            float sc = 0.f;
+            for (int c = 0; c < GH; ++c) sc = fmaf(s_q[i][c], s_k[j][c], sc);
+            sc = sc / 5.656854249492381f;                       // / sqrt(attention_dim)  (GAT_Net.py:126)
+            const float m = wave_max(live ? sc : -INFINITY);
+            const float e = live ? expf(sc - m) : 0.f;
+            const float soft = e / wave_sum(e);
+            float hard = 0.f;
+            if (live) {
+                const float l0 = hb0 + s_pl[0][i][s][0] + s_pl[1][i][s][0];
+                const float l1 = hb1 + s_pl[0][i][s][1] + s_pl[1][i][s][1];
+                const float* gz = noise + ((int64_t)i * (N - 1) + s) * 2;
+                const float y0 = (l0 + gz[0]) / a.tau, y1 = (l1 + gz[1]) / a.tau;   // gumbel_softmax, GAT_Net.py:93
+                const float mm = fmaxf(y0, y1);
+                const float e0 = expf(y0 - mm), e1 = expf(y1 - mm);
+                hard = e1 / (e0 + e1);
+                if (sv.soft) sv.soft[(sb * N + i) * (N - 1) + s] = soft;
+                if (sv.hard) sv.hard[(sb * N + i) * (N - 1) + s] = hard;
+            }
+            const int c = l & 31, hf = l >> 5;
+            float acc = 0.f;
+            for (int it = 0; 2 * it < N - 1; ++it) {
+                const int s2 = 2 * it + hf;
+                const float so = __shfl(soft, s2), ha = __shfl(hard, s2);
+                const int j2 = s2 < N - 1 ? s2 + (s2 >= i ? 1 : 0) : 0;
+                acc += (s_v[j2][c] * so) * ha;                 // no renormalisation (GAT_Net.py:132)
+            }
+            acc += __shfl_xor(acc, 32);
+            if (l < 32) {
+                s_x[i][c] = acc;
+                if (sv.x) sv.x[(sb * N + i) * GH + c] = acc;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- phase 4: output GRUCell
+    if (tile_live) {
+        const int t = dir;                                      // wave (dir,tile) produces output tile `dir`
+        f32x4 x[2], hp[2];
+        const float* hrow = a.h_prev + (int64_t)net * a.h_s_net + (int64_t)b * a.h_s_b + (int64_t)node * GH;
+        for (int T = 0; T < 2; ++T) {
+            x[T] = splat4(0.f);
+            if (valid)
+                for (int q = 0; q < 4; ++q) x[T][q] = s_x[node][16 * T + 4 * g + q];
+            hp[T] = vload(hrow, valid, GH, T);
+        }
+        const float* Wi = P + a.off[IPLAN_GAT_C_WIH];
+        const float* Wc = P + a.off[IPLAN_GAT_C_WHH];
+        const float* bi = P + a.off[IPLAN_GAT_C_BIH];
+        const float* bc = P + a.off[IPLAN_GAT_C_BHH];
+        f32x4 pr = bfrag(bi, 3 * GH, t) + bfrag(bc, 3 * GH, t);
+        f32x4 pz = bfrag(bi, 3 * GH, 2 + t) + bfrag(bc, 3 * GH, 2 + t);
+        f32x4 gn = bfrag(bi, 3 * GH, 4 + t);
+        f32x4 hn = bfrag(bc, 3 * GH, 4 + t);
+        for (int T = 0; T < 2; ++T) {
+            pr = mma_block(wfrag(Wi, GH, 3 * GH, GH, 16 * t, 16 * T), x[T], pr);
+            pr = mma_block(wfrag(Wc, GH, 3 * GH, GH, 16 * t, 16 * T), hp[T], pr);
+            pz = mma_block(wfrag(Wi, GH, 3 * GH, GH, GH + 16 * t, 16 * T), x[T], pz);
+            pz = mma_block(wfrag(Wc, GH, 3 * GH, GH, GH + 16 * t, 16 * T), hp[T], pz);
+            gn = mma_block(wfrag(Wi, GH, 3 * GH, GH, 2 * GH + 16 * t, 16 * T), x[T], gn);
+            hn = mma_block(wfrag(Wc, GH, 3 * GH, GH, 2 * GH + 16 * t, 16 * T), hp[T], hn);
+        }
+        const GruGates o = gru_gates(pr, pz, gn, hn, hp[t]);
+        float* orow = a.out + (int64_t)net * a.out_s_net + (int64_t)b * a.out_s_b + (int64_t)node * GH;
+        vstore(orow, valid, GH, t, o.h);
+        if (sv.cell) {
+            float* row = sv.cell + (sb * N + node) * (4 * GH);
+            vstore(row, valid, GH, t, o.r);
+            vstore(row + GH, valid, GH, t, o.z);
+            vstore(row + 2 * GH, valid, GH, t, o.n);
+            vstore(row + 3 * GH, valid, GH, t, o.hn);
+        }
+    }
+}
+
+}  // namespace iplan
+
+extern "C" int iplan_gat_fwd(const IplanGatFwdArgs* a, iplan_stream_t stream) {
+    using namespace iplan;
+    if (!a) return fail(IPLAN_EINVAL, "iplan_gat_fwd: null args");
+    if (a->N < 2 || a->N > IPLAN_MAX_ENTITIES)
+        return fail(IPLAN_EINVAL, "iplan_gat_fwd: N=%d outside [2,%d]", a->N, IPLAN_MAX_ENTITIES);
+    if (a->n_nets < 1 || a->B < 1 || a->d0 < 1 || a->d1 < 0)
+        return fail(IPLAN_EINVAL, "iplan_gat_fwd: bad dims n_nets=%d B=%d d0=%d d1=%d", a->n_nets, a->B, a->d0, a->d1);
+    if (!a->src0 || (a->d1 > 0 && !a->src1) || !a->h_prev || !a->out || !a->noise || !a->params)
+        return fail(IPLAN_EINVAL, "iplan_gat_fwd: null tensor pointer");
+    if (!aligned16(a->h_prev) || !aligned16(a->out) || (a->h_s_net & 3) || (a->h_s_b & 3) ||
+        (a->out_s_net & 3) || (a->out_s_b & 3))
+        return fail(IPLAN_EALIGN, "iplan_gat_fwd: h_prev/out must be 16-byte aligned with strides %% 4 == 0");
+    hipLaunchKernelGGL(gat_fwd_kernel, dim3((unsigned)(a->n_nets * a->B)), dim3(512), 0, (hipStream_t)stream, *a);
+    return check_launch("iplan_gat_fwd");
+}

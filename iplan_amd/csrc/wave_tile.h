@@ -1,0 +1,161 @@
+// Wave-tile engine: the building blocks every iplan_amd kernel is written in.
+//
+// One wavefront (64 lanes) owns a tile of 16 independent "chains" (rows of a batch: an entity, an
+// (env,entity) pair, a PPO sample ...).  A per-chain vector of dimension Dm (multiple of 16) lives
+// in registers in the *D layout* of v_mfma_f32_16x16x4_f32:
+//
+//      lane l = (n = l & 15, g = l >> 4)  holds  vec_n[16*t + 4*g + r]   in  v[t][r],  t < Dm/16, r < 4
+//
+// With that layout a dense layer y = W x (+ b) is, per 16-output tile t', a chain of MFMAs
+//      acc = mfma(A = W[16t'+m][16T+4g+r]  (lane m=l&15,g),  B = x[T][r],  acc)      T < In/16, r < 4
+// because the hardware contracts over the 4 lane-groups g and the K index may be visited in any
+// order as long as A and B agree.  The result lands in the D layout again (col = chain n,
+// row = 4g+reg), so GRU gates, activations, LayerNorm terms and the next layer's B operand are
+// all lane-local: no transposes, no LDS round trip between layers or between time steps.
+// The A fragment of a row-major weight matrix is 4 consecutive floats -> one 16-byte load.
+//
+// All arithmetic is fp32; v_mfma_f32_16x16x4_f32 is an exact fp32 fma chain (guide §3), which is
+// what the 1e-5 parity contract with the reference's fp32 CPU path needs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace iplan {
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 splat4(float v) {
+    f32x4 r = {v, v, v, v};
+    return r;
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) { return tanhf(x); }
+
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    f32x4 r;
+    for (int q = 0; q < 4; ++q) r[q] = v[q] > 0.0f ? v[q] : 0.0f;
+    return r;
+}
+
+// ---- A-operand fragments ----------------------------------------------------------------------
+// Fragment of a row-major [rows x cols] matrix (leading dimension ld): lane (m,g) gets
+// W[o0+m][k0+4g .. k0+4g+3]; out-of-range elements read as 0 (this is how odd dims are padded).
+__device__ __forceinline__ f32x4 wfrag(const float* __restrict__ W, int ld, int rows, int cols,
+                                       int o0, int k0) {
+    const int l = lane_id();
+    const int r = o0 + (l & 15);
+    const int c = k0 + 4 * (l >> 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+        const float* p = W + (size_t)r * ld + c;
+        if (c + 3 < cols && ((ld & 3) == 0) && ((((size_t)p) & 15) == 0)) {
+            v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+            for (int q = 0; q < 4; ++q)
+                if (c + q < cols) v[q] = p[q];
+        }
+    }
+    return v;
+}
+
+// Fragment of the TRANSPOSE of a row-major [rows x cols] matrix: lane (m,g) gets
+// W[k0+4g+q][o0+m], q<4  (A operand of  y = W^T x).
+__device__ __forceinline__ f32x4 wfrag_t(const float* __restrict__ W, int ld, int rows, int cols,
+                                         int o0, int k0) {
+    const int l = lane_id();
+    const int c = o0 + (l & 15);
+    const int r = k0 + 4 * (l >> 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols)
+        for (int q = 0; q < 4; ++q)
+            if (r + q < rows) v[q] = W[(size_t)(r + q) * ld + c];
+    return v;
+}
+
+// ---- D-layout vectors ---------------------------------------------------------------------------
+// Bias / per-feature vector in D layout: lane (n,g) gets b[16t+4g .. +3] (same for all chains).
+__device__ __forceinline__ f32x4 bfrag(const float* __restrict__ b, int dim, int t) {
+    const int c = 16 * t + 4 * (lane_id() >> 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; ++q)
+        if (c + q < dim) v[q] = b[c + q];
+    return v;
+}
+
+// Load tile t of a per-chain vector from a row pointer (one row per chain); `valid` = chain exists.
+__device__ __forceinline__ f32x4 vload(const float* __restrict__ row, bool valid, int dim, int t) {
+    const int c = 16 * t + 4 * (lane_id() >> 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+        if (c + 3 < dim && ((((size_t)(row + c)) & 15) == 0)) {
+            v = *reinterpret_cast<const f32x4*>(row + c);
+        } else {
+            for (int q = 0; q < 4; ++q)
+                if (c + q < dim) v[q] = row[c + q];
+        }
+    }
+    return v;
+}
+
+__device__ __forceinline__ void vstore(float* __restrict__ row, bool valid, int dim, int t, f32x4 v) {
+    const int c = 16 * t + 4 * (lane_id() >> 4);
+    if (valid) {
+        if (c + 3 < dim && ((((size_t)(row + c)) & 15) == 0)) {
+            *reinterpret_cast<f32x4*>(row + c) = v;
+        } else {
+            for (int q = 0; q < 4; ++q)
+                if (c + q < dim) row[c + q] = v[q];
+        }
+    }
+}
+
+// acc += W[o0.., k0..k0+15] . x   (one 16x16 weight block against tile T of the input vector)
+__device__ __forceinline__ f32x4 mma_block(f32x4 w, f32x4 x, f32x4 acc) {
+    acc = mfma4(w[0], x[0], acc);
+    acc = mfma4(w[1], x[1], acc);
+    acc = mfma4(w[2], x[2], acc);
+    acc = mfma4(w[3], x[3], acc);
+    return acc;
+}
+
+// Sum over the 4 lane-groups g (lanes n, n+16, n+32, n+48): every lane ends with the total.
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// Sum / max over all 64 lanes.
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// GRU gate math on one 4-element slice (PyTorch gate order r,z,n; b_hn inside the r* term).
+struct GruGates {
+    f32x4 r, z, n, hn, h;
+};
+__device__ __forceinline__ GruGates gru_gates(f32x4 pre_r, f32x4 pre_z, f32x4 gi_n, f32x4 gh_n, f32x4 h_prev) {
+    GruGates o;
+    for (int q = 0; q < 4; ++q) {
+        o.r[q] = sigmoid_f(pre_r[q]);
+        o.z[q] = sigmoid_f(pre_z[q]);
+        o.hn[q] = gh_n[q];
+        o.n[q] = tanh_f(gi_n[q] + o.r[q] * gh_n[q]);
+        o.h[q] = (1.0f - o.z[q]) * o.n[q] + o.z[q] * h_prev[q];
+    }
+    return o;
+}
+
+}  // namespace iplan
