@@ -106,6 +106,156 @@ typedef struct {
 
 int iplan_gat_fwd(const IplanGatFwdArgs* args, iplan_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * EncoderRNN.forward + soft latent update (nova/behavior_net.py:17-22,
+ * nova/stable_behavior_policy.py:83-123): Linear(d->R)+ReLU -> GRU(R) over the L-step window from
+ * the carried hidden state -> Linear(R->Z) -> softmax -> new = (1-c)*prev + c*latent.
+ * Rows are (net, b, i) with i < N; R == 32, d <= 16, Z <= 16 in this build.
+ */
+enum {
+    IPLAN_ENC_LIN_W = 0,    /* linear.weight      [R, d]  */
+    IPLAN_ENC_LIN_B,        /* linear.bias        [R]     */
+    IPLAN_ENC_WIH,          /* rnn.weight_ih_l0   [3R, R] */
+    IPLAN_ENC_WHH,          /* rnn.weight_hh_l0   [3R, R] */
+    IPLAN_ENC_BIH,          /* rnn.bias_ih_l0     [3R]    */
+    IPLAN_ENC_BHH,          /* rnn.bias_hh_l0     [3R]    */
+    IPLAN_ENC_OUT_W,        /* out.weight         [Z, R]  */
+    IPLAN_ENC_OUT_B,        /* out.bias           [Z]     */
+    IPLAN_ENC_NPARAM
+};
+
+typedef struct {
+    int32_t n_nets, B, N, L, d, Z;
+    const float* x;            /* window (net,b,i) at x + net*x_s_net + b*x_s_b + i*L*d, [L][d] */
+    int64_t x_s_net, x_s_b;
+    const float* h0;           /* carried hidden, rows of 32 floats */
+    int64_t h0_s_net, h0_s_b;
+    float* hL;                 /* new hidden */
+    int64_t hL_s_net, hL_s_b;
+    const float* prev_latent;  /* rows of Z floats; NULL -> latent_out = softmax only */
+    int64_t pl_s_net, pl_s_b;
+    float* latent_out;         /* rows of Z floats */
+    int64_t lo_s_net, lo_s_b;
+    float one_minus_c, c;      /* soft_update_coef (config/default.yaml:75) */
+    const float* params;
+    int64_t params_s_net;
+    int64_t off[IPLAN_ENC_NPARAM];
+} IplanEncFwdArgs;
+
+int iplan_enc_fwd(const IplanEncFwdArgs* args, iplan_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * R_Actor / R_Critic forward (modules/agents/ippo_actor.py:43-102, modules/critics/ippo_critic.py:47-65,
+ * utils/mappo_utils/{mlp,rnn,act,distributions,popart}.py) fused with the feature assembly of
+ * DcntrlMAC._build_inputs / _build_inputs_ippo (controllers/dcntrl_controller.py:187-213, 87-115):
+ *   x = [ per entity i<N: src0[i] || src1[i] || src2[i] ] || onehot(last_action) || onehot(agent)
+ *   LN(F) -> Linear(F->M)+ReLU -> LN -> Linear(M->M)+ReLU -> LN -> GRU(M) one step -> LN -> head
+ * for every agent (grid.y) and for actor and critic (grid.z) in one launch.  M == 64.
+ * The [rows, F] input matrix the reference materialises (231 MB per agent in PPO) never exists.
+ */
+enum {
+    IPLAN_AC_FN_W = 0,      /* base.feature_norm.weight   [F]     */
+    IPLAN_AC_FN_B,          /* base.feature_norm.bias     [F]     */
+    IPLAN_AC_FC1_W,         /* base.mlp.fc1.0.weight      [M, F]  */
+    IPLAN_AC_FC1_B,         /* base.mlp.fc1.0.bias        [M]     */
+    IPLAN_AC_LN1_W,         /* base.mlp.fc1.2.weight      [M]     */
+    IPLAN_AC_LN1_B,         /* base.mlp.fc1.2.bias        [M]     */
+    IPLAN_AC_FC2_W,         /* base.mlp.fc2.0.0.weight    [M, M]  */
+    IPLAN_AC_FC2_B,         /* base.mlp.fc2.0.0.bias      [M]     */
+    IPLAN_AC_LN2_W,         /* base.mlp.fc2.0.2.weight    [M]     */
+    IPLAN_AC_LN2_B,         /* base.mlp.fc2.0.2.bias      [M]     */
+    IPLAN_AC_WIH,           /* rnn.rnn.weight_ih_l0       [3M, M] */
+    IPLAN_AC_WHH,           /* rnn.rnn.weight_hh_l0       [3M, M] */
+    IPLAN_AC_BIH,           /* rnn.rnn.bias_ih_l0         [3M]    */
+    IPLAN_AC_BHH,           /* rnn.rnn.bias_hh_l0         [3M]    */
+    IPLAN_AC_LN3_W,         /* rnn.norm.weight            [M]     */
+    IPLAN_AC_LN3_B,         /* rnn.norm.bias              [M]     */
+    IPLAN_AC_HEAD_W,        /* act.action_out.linear.weight [n_act, M]  |  v_out.weight [1, M] */
+    IPLAN_AC_HEAD_B,        /* act.action_out.linear.bias   [n_act]     |  v_out.bias   [1]    */
+    IPLAN_AC_NPARAM
+};
+#define IPLAN_AC_HIDDEN 64
+#define IPLAN_AC_SAVE_FLOATS (10 * IPLAN_AC_HIDDEN + 8)
+
+typedef struct {
+    const float* params;        /* arena of the actors (or critics) */
+    int64_t params_s_net;
+    int64_t off[IPLAN_AC_NPARAM];
+    int32_t n_out;              /* n_actions for actors, 1 for critics */
+} IplanAcNet;
+
+/* Row r (< rows) of agent `net` lives at physical row  pr = (r / T) * T_phys + r % T  of each
+ * source; entity i of source k at  src[k] + net*s_net[k] + pr*s_row[k] + i*w[k]. */
+typedef struct {
+    int32_t N;
+    int32_t w[3];               /* widths per entity (0 = source absent) */
+    const float* src[3];
+    int64_t s_net[3], s_row[3];
+    int32_t n_actions;          /* width of the last-action one-hot (0 = obs_last_action False) */
+    const int32_t* last_action; /* hot index per row or -1 (all zeros): last_action[net*la_s_net + pr*la_s_row] */
+    int64_t la_s_net, la_s_row;
+    int32_t n_id;               /* width of the agent-id one-hot (0 = obs_agent_id False); hot index = net */
+    int32_t T, T_phys;          /* logical / physical steps per episode (equal when rows are contiguous) */
+} IplanAcFeatures;
+
+typedef struct {
+    int32_t n_agents, rows;
+    int32_t which;              /* 0 = actors only, 1 = critics only, 2 = both */
+    int32_t ksplit;             /* 1 or 8: waves cooperating on the F-contraction of one 16-row tile */
+    IplanAcFeatures feat;
+    IplanAcNet actor, critic;
+    const float* h_actor;       /* GRU state rows of M floats: h + net*hs_net + pr*hs_row */
+    const float* h_critic;
+    int64_t hs_net, hs_row;
+    float* h_actor_out;         /* [n_agents, rows, M] contiguous (NULL = discard) */
+    float* h_critic_out;
+    /* actor head */
+    const int32_t* avail;       /* [.., n_actions] int32, avail + net*av_s_net + pr*av_s_row; NULL = all available */
+    int64_t av_s_net, av_s_row;
+    int32_t mode;               /* 0 = argmax(probs), 1 = sample argmax(probs / q), 2 = evaluate given actions */
+    const float* q_noise;       /* mode 1: Exp(1) samples [n_agents, rows, n_actions] (torch.multinomial's trick) */
+    const int64_t* actions_in;  /* mode 2: actions_in[net*act_s_net + pr*act_s_row] */
+    int64_t act_s_net, act_s_row;
+    int64_t* actions_out;       /* [n_agents, rows] (modes 0,1) */
+    float* logp;                /* [n_agents, rows] log-prob of the chosen / given action */
+    float* entropy;             /* [n_agents, rows] per-row entropy (NULL = skip) */
+    float* probs;               /* [n_agents, rows, n_actions] (NULL = skip) */
+    /* critic head */
+    float* values;              /* [n_agents, rows] */
+    /* activations for the backward pass, [2, n_agents, rows, IPLAN_AC_SAVE_FLOATS] (NULL = inference) */
+    float* saved;
+} IplanAcFwdArgs;
+
+int iplan_ac_fwd(const IplanAcFwdArgs* args, iplan_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * clip_grad_norm_ + torch.optim.Adam on flat arenas (learners/ippo_learner.py:204-221,
+ * nova/prediction_policy.py:231-241, nova/stable_behavior_policy.py:252-262), all nets per launch.
+ */
+#define IPLAN_MAX_NETS 16
+
+/* out[net*out_stride + slot] = sum of squares of grad[net*stride + off .. + n) (fixed order). */
+int iplan_grad_sqnorm(const float* grad, int64_t stride, int64_t off, int64_t n, int32_t n_nets,
+                      float* out, int32_t out_stride, int32_t slot, iplan_stream_t stream);
+
+typedef struct {
+    float* param;               /* arena base; net k slice at + k*stride + off, n elements        */
+    float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t stride, off, n;
+    int32_t n_nets;
+    const float* sqnorm;        /* squared grad norms (iplan_grad_sqnorm output); NULL = no clip  */
+    int32_t sqnorm_stride, sqnorm_slot;
+    float max_norm;             /* grads scaled by min(1, max_norm / (norm + 1e-6))               */
+    int32_t write_clipped;      /* store the clipped gradient back (clip_grad_norm_ is in place)  */
+    float lr, beta1, beta2, eps;
+    float bc1[IPLAN_MAX_NETS];      /* 1 - beta1^step   per net                                   */
+    float bc2_sqrt[IPLAN_MAX_NETS]; /* sqrt(1 - beta2^step)                                       */
+} IplanAdamArgs;
+
+int iplan_adam_step(const IplanAdamArgs* args, iplan_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,11 @@ class IplanError(RuntimeError):
     pass
 
 
+# every entry point include/iplan_hip.h declares
+ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step"]
+RAW_ENTRY_POINTS = ["iplan_grad_sqnorm"]      # non (args*, stream) signatures
+
+
 class Lib:
     """Thin typed wrapper around a loaded libiplan_*.so."""
 
@@ -54,10 +59,16 @@ class Lib:
         self.c = cdll
         cdll.iplan_last_error.restype = C.c_char_p
         cdll.iplan_version.restype = C.c_int
-        for name in ("iplan_gat_fwd",):
+        for name in ENTRY_POINTS:
+            if not hasattr(cdll, name):
+                raise IplanError(f"{name} missing from the loaded library")
             fn = getattr(cdll, name)
             fn.restype = C.c_int
             fn.argtypes = [C.c_void_p, C.c_void_p]
+        for name in RAW_ENTRY_POINTS:
+            if not hasattr(cdll, name):
+                raise IplanError(f"{name} missing from the loaded library")
+            getattr(cdll, name).restype = C.c_int
 
     def call(self, name, args, stream=None):
         rc = getattr(self.c, name)(C.byref(args), C.c_void_p(stream or 0))
@@ -99,3 +110,77 @@ def current_stream(device):
 
 def ptr(t):
     return None if t is None else t.data_ptr()
+
+
+# ---- encoder -------------------------------------------------------------------------------------
+ENC_PARAM_ORDER = ["linear.weight", "linear.bias", "rnn.weight_ih_l0", "rnn.weight_hh_l0",
+                   "rnn.bias_ih_l0", "rnn.bias_hh_l0", "out.weight", "out.bias"]
+
+
+class EncFwdArgs(C.Structure):
+    _fields_ = [
+        ("n_nets", i32), ("B", i32), ("N", i32), ("L", i32), ("d", i32), ("Z", i32),
+        ("x", fp), ("x_s_net", i64), ("x_s_b", i64),
+        ("h0", fp), ("h0_s_net", i64), ("h0_s_b", i64),
+        ("hL", fp), ("hL_s_net", i64), ("hL_s_b", i64),
+        ("prev_latent", fp), ("pl_s_net", i64), ("pl_s_b", i64),
+        ("latent_out", fp), ("lo_s_net", i64), ("lo_s_b", i64),
+        ("one_minus_c", C.c_float), ("c", C.c_float),
+        ("params", fp), ("params_s_net", i64), ("off", i64 * len(ENC_PARAM_ORDER)),
+    ]
+
+
+# ---- actor / critic --------------------------------------------------------------------------------
+AC_TRUNK_ORDER = [
+    "base.feature_norm.weight", "base.feature_norm.bias",
+    "base.mlp.fc1.0.weight", "base.mlp.fc1.0.bias", "base.mlp.fc1.2.weight", "base.mlp.fc1.2.bias",
+    "base.mlp.fc2.0.0.weight", "base.mlp.fc2.0.0.bias", "base.mlp.fc2.0.2.weight", "base.mlp.fc2.0.2.bias",
+    "rnn.rnn.weight_ih_l0", "rnn.rnn.weight_hh_l0", "rnn.rnn.bias_ih_l0", "rnn.rnn.bias_hh_l0",
+    "rnn.norm.weight", "rnn.norm.bias",
+]
+ACTOR_PARAM_ORDER = AC_TRUNK_ORDER + ["act.action_out.linear.weight", "act.action_out.linear.bias"]
+CRITIC_PARAM_ORDER = AC_TRUNK_ORDER + ["v_out.weight", "v_out.bias"]
+AC_NPARAM = 18
+AC_HIDDEN = 64
+AC_SAVE_FLOATS = 10 * AC_HIDDEN + 8
+
+
+class AcNet(C.Structure):
+    _fields_ = [("params", fp), ("params_s_net", i64), ("off", i64 * AC_NPARAM), ("n_out", i32)]
+
+
+class AcFeatures(C.Structure):
+    _fields_ = [
+        ("N", i32), ("w", i32 * 3), ("src", fp * 3), ("s_net", i64 * 3), ("s_row", i64 * 3),
+        ("n_actions", i32), ("last_action", fp), ("la_s_net", i64), ("la_s_row", i64),
+        ("n_id", i32), ("T", i32), ("T_phys", i32),
+    ]
+
+
+class AcFwdArgs(C.Structure):
+    _fields_ = [
+        ("n_agents", i32), ("rows", i32), ("which", i32), ("ksplit", i32),
+        ("feat", AcFeatures), ("actor", AcNet), ("critic", AcNet),
+        ("h_actor", fp), ("h_critic", fp), ("hs_net", i64), ("hs_row", i64),
+        ("h_actor_out", fp), ("h_critic_out", fp),
+        ("avail", fp), ("av_s_net", i64), ("av_s_row", i64),
+        ("mode", i32), ("q_noise", fp),
+        ("actions_in", fp), ("act_s_net", i64), ("act_s_row", i64),
+        ("actions_out", fp), ("logp", fp), ("entropy", fp), ("probs", fp),
+        ("values", fp), ("saved", fp),
+    ]
+
+
+# ---- optimiser -------------------------------------------------------------------------------------
+MAX_NETS = 16
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [
+        ("param", fp), ("grad", fp), ("exp_avg", fp), ("exp_avg_sq", fp),
+        ("stride", i64), ("off", i64), ("n", i64), ("n_nets", i32),
+        ("sqnorm", fp), ("sqnorm_stride", i32), ("sqnorm_slot", i32),
+        ("max_norm", C.c_float), ("write_clipped", i32),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("bc1", C.c_float * MAX_NETS), ("bc2_sqrt", C.c_float * MAX_NETS),
+    ]

@@ -1,0 +1,101 @@
+// LDS-resident weights + GRU / dense steps on wave tiles (see wave_tile.h for the layout).
+#pragma once
+#include "wave_tile.h"
+
+namespace iplan {
+
+// Cooperative copy of a row-major [rows x cols] global matrix into LDS as [rows_pad x ld]
+// (zero padded; ld % 4 == 0, ld >= cols rounded up to 16).  All threads of the block call it.
+__device__ __forceinline__ void stage_matrix(float* __restrict__ dst, int ld, int rows_pad,
+                                             const float* __restrict__ src, int rows, int cols) {
+    const int total = rows_pad * ld;
+    for (int idx = (int)threadIdx.x; idx < total; idx += (int)blockDim.x) {
+        const int r = idx / ld, c = idx - r * ld;
+        dst[idx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.0f;
+    }
+}
+
+// Transposed staging: dst[c][r] = src[r][c]  (dst is [cols_pad x ld], zero padded).
+__device__ __forceinline__ void stage_matrix_t(float* __restrict__ dst, int ld, int cols_pad,
+                                               const float* __restrict__ src, int rows, int cols) {
+    const int total = cols_pad * ld;
+    for (int idx = (int)threadIdx.x; idx < total; idx += (int)blockDim.x) {
+        const int c = idx / ld, r = idx - c * ld;
+        dst[idx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ void stage_vector(float* __restrict__ dst, int n_pad,
+                                             const float* __restrict__ src, int n) {
+    for (int idx = (int)threadIdx.x; idx < n_pad; idx += (int)blockDim.x) dst[idx] = idx < n ? src[idx] : 0.0f;
+}
+
+// A fragment from an LDS-staged matrix: lane (m,g) reads W[o0+m][k0+4g .. +3] (one ds_read_b128).
+__device__ __forceinline__ f32x4 wfrag_lds(const float* __restrict__ sW, int ld, int o0, int k0) {
+    const int l = lane_id();
+    return *reinterpret_cast<const f32x4*>(sW + (o0 + (l & 15)) * ld + k0 + 4 * (l >> 4));
+}
+
+// Bias tile from LDS: lane (n,g) reads b[16t+4g .. +3].
+__device__ __forceinline__ f32x4 bfrag_lds(const float* __restrict__ sb, int t) {
+    return *reinterpret_cast<const f32x4*>(sb + 16 * t + 4 * (lane_id() >> 4));
+}
+
+// y[t'] (+)= W[16t'.., :] x  for one output tile, weights in LDS, KT input tiles.
+template <int KT>
+__device__ __forceinline__ f32x4 dense_tile(const float* __restrict__ sW, int ld, int o0,
+                                            const f32x4 (&x)[KT], f32x4 acc) {
+    for (int T = 0; T < KT; ++T) acc = mma_block(wfrag_lds(sW, ld, o0, 16 * T), x[T], acc);
+    return acc;
+}
+
+// One GRU step with LDS-resident weights.  HT = H/16 hidden tiles, XT = input tiles.
+// sWih: [3H x ldi], sWhh: [3H x ldh], sbih/sbhh: [3H].  h is updated in place; when `keep` is
+// non-null the gate activations (r, z, n, hn) of every tile are returned for the backward pass.
+template <int HT, int XT>
+__device__ __forceinline__ void gru_step_lds(const float* __restrict__ sWih, int ldi,
+                                             const float* __restrict__ sWhh, int ldh,
+                                             const float* __restrict__ sbih, const float* __restrict__ sbhh,
+                                             const f32x4 (&x)[XT], f32x4 (&h)[HT], GruGates* keep) {
+    constexpr int H = 16 * HT;
+    f32x4 hnew[HT];
+    for (int t = 0; t < HT; ++t) {
+        f32x4 pr = bfrag_lds(sbih, t) + bfrag_lds(sbhh, t);
+        f32x4 pz = bfrag_lds(sbih, HT + t) + bfrag_lds(sbhh, HT + t);
+        f32x4 gn = bfrag_lds(sbih, 2 * HT + t);
+        f32x4 hn = bfrag_lds(sbhh, 2 * HT + t);
+        pr = dense_tile<XT>(sWih, ldi, 16 * t, x, pr);
+        pr = dense_tile<HT>(sWhh, ldh, 16 * t, h, pr);
+        pz = dense_tile<XT>(sWih, ldi, H + 16 * t, x, pz);
+        pz = dense_tile<HT>(sWhh, ldh, H + 16 * t, h, pz);
+        gn = dense_tile<XT>(sWih, ldi, 2 * H + 16 * t, x, gn);
+        hn = dense_tile<HT>(sWhh, ldh, 2 * H + 16 * t, h, hn);
+        const GruGates o = gru_gates(pr, pz, gn, hn, h[t]);
+        hnew[t] = o.h;
+        if (keep) keep[t] = o;
+    }
+    for (int t = 0; t < HT; ++t) h[t] = hnew[t];
+}
+
+// LayerNorm over a per-chain vector of DT*16 real features (all tiles fully populated) held in
+// D layout: statistics reduce over the 4 lane groups of the chain.  eps = 1e-5, biased variance.
+template <int DT>
+__device__ __forceinline__ void layer_norm_tiles(f32x4 (&v)[DT], const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float* mean_out, float* rstd_out) {
+    constexpr float inv = 1.0f / (16 * DT);
+    float s = 0.f;
+    for (int t = 0; t < DT; ++t) s += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
+    const float mu = group_sum(s) * inv;
+    float q = 0.f;
+    for (int t = 0; t < DT; ++t)
+        for (int k = 0; k < 4; ++k) { const float d = v[t][k] - mu; q = fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(group_sum(q) * inv + 1e-5f);
+    for (int t = 0; t < DT; ++t) {
+        const f32x4 gm = bfrag(gamma, 16 * DT, t), bt = bfrag(beta, 16 * DT, t);
+        for (int k = 0; k < 4; ++k) v[t][k] = (v[t][k] - mu) * rstd * gm[k] + bt[k];
+    }
+    if (mean_out) *mean_out = mu;
+    if (rstd_out) *rstd_out = rstd;
+}
+
+}  // namespace iplan

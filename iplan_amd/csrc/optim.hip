@@ -1,0 +1,68 @@
+// Flat-arena optimiser kernels: L2 norm of a gradient slice, and clip + Adam fused.
+// (clip_grad_norm_ + torch.optim.Adam of learners/ippo_learner.py:204-221,
+//  nova/prediction_policy.py:231-241, nova/stable_behavior_policy.py:252-262.)
+// Pure streaming fp32: bound by HBM (4 reads + 3 writes of the slice); at these sizes (<= 1 MB per
+// net) it is launch-latency bound, which is why all nets go through one launch.
+#include "api_util.h"
+#include "wave_tile.h"
+
+namespace iplan {
+
+// out[net*out_stride + slot] = sum(g[net*g_stride + off .. + n)^2); one block per net, fixed order.
+__global__ __launch_bounds__(1024) void sqnorm_kernel(const float* __restrict__ g, int64_t g_stride, int64_t off,
+                                                      int64_t n, float* __restrict__ out, int out_stride, int slot) {
+    __shared__ float s_part[16];
+    const float* p = g + (int64_t)blockIdx.x * g_stride + off;
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc = fmaf(p[i], p[i], acc);
+    acc = wave_sum(acc);
+    if (lane_id() == 0) s_part[wave_id()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_part[w];
+        out[(int64_t)blockIdx.x * out_stride + slot] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(IplanAdamArgs a) {
+    const int net = (int)blockIdx.y;
+    float scale = 1.0f;
+    if (a.sqnorm) {
+        const float nrm = sqrtf(a.sqnorm[(int64_t)net * a.sqnorm_stride + a.sqnorm_slot]);
+        scale = fminf(1.0f, a.max_norm / (nrm + 1e-6f));               // clip_grad_norm_ semantics
+    }
+    const int64_t base = (int64_t)net * a.stride + a.off;
+    const float bc1 = a.bc1[net], bc2s = a.bc2_sqrt[net];
+    const float step_size = a.lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = a.grad[base + i] * scale;
+        if (a.write_clipped) a.grad[base + i] = g;
+        const float m = a.exp_avg[base + i] * a.beta1 + (1.0f - a.beta1) * g;
+        const float v = a.exp_avg_sq[base + i] * a.beta2 + (1.0f - a.beta2) * g * g;
+        a.exp_avg[base + i] = m;
+        a.exp_avg_sq[base + i] = v;
+        const float denom = sqrtf(v) / bc2s + a.eps;
+        a.param[base + i] -= step_size * (m / denom);
+    }
+}
+
+}  // namespace iplan
+
+extern "C" int iplan_grad_sqnorm(const float* grad, int64_t stride, int64_t off, int64_t n, int32_t n_nets,
+                                 float* out, int32_t out_stride, int32_t slot, iplan_stream_t stream) {
+    using namespace iplan;
+    if (!grad || !out || n < 0 || n_nets < 1) return fail(IPLAN_EINVAL, "iplan_grad_sqnorm: bad arguments");
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)n_nets), dim3(1024), 0, (hipStream_t)stream, grad, stride, off, n,
+                       out, (int)out_stride, (int)slot);
+    return check_launch("iplan_grad_sqnorm");
+}
+
+extern "C" int iplan_adam_step(const IplanAdamArgs* a, iplan_stream_t stream) {
+    using namespace iplan;
+    if (!a || !a->param || !a->grad || !a->exp_avg || !a->exp_avg_sq || a->n_nets < 1 || a->n_nets > IPLAN_MAX_NETS)
+        return fail(IPLAN_EINVAL, "iplan_adam_step: bad arguments");
+    const unsigned blocks = (unsigned)((a->n + 255) / 256 > 1024 ? 1024 : (a->n + 255) / 256);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks ? blocks : 1, (unsigned)a->n_nets), dim3(256), 0, (hipStream_t)stream, *a);
+    return check_launch("iplan_adam_step");
+}

@@ -70,3 +70,134 @@ def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None
             setattr(a.saved, k, v.data_ptr())
     lib.call("iplan_gat_fwd", a, L.current_stream(dev))
     return out, saved
+
+
+def enc_forward(arena, x, h0, prev_latent, coef, Z, lib=None):
+    """EncoderRNN + soft update for all nets.  x [n_nets,B,N,L,d], h0 [n_nets,B,N,R],
+    prev_latent [n_nets,B,N,Z] or None (first two dims may be strided views).
+    Returns (latent [n_nets,B,N,Z], hL [n_nets,B,N,R])."""
+    lib = _lib(lib)
+    n_nets, B, N, Lw, d = x.shape
+    R = h0.shape[-1]
+    dev = x.device
+    a = L.EncFwdArgs()
+    a.n_nets, a.B, a.N, a.L, a.d, a.Z = n_nets, B, N, Lw, d, Z
+    a.x = x.data_ptr()
+    a.x_s_net, a.x_s_b = _nb_strides(x, N * Lw * d)
+    a.h0 = h0.data_ptr()
+    a.h0_s_net, a.h0_s_b = _nb_strides(h0, N * R)
+    hL = torch.empty(n_nets, B, N, R, dtype=torch.float32, device=dev)
+    a.hL = hL.data_ptr()
+    a.hL_s_net, a.hL_s_b = _nb_strides(hL, N * R)
+    if prev_latent is not None:
+        a.prev_latent = prev_latent.data_ptr()
+        a.pl_s_net, a.pl_s_b = _nb_strides(prev_latent, N * Z)
+    lat = torch.empty(n_nets, B, N, Z, dtype=torch.float32, device=dev)
+    a.latent_out = lat.data_ptr()
+    a.lo_s_net, a.lo_s_b = _nb_strides(lat, N * Z)
+    a.one_minus_c = 1.0 - coef
+    a.c = coef
+    a.params = arena.data.data_ptr()
+    a.params_s_net = arena.net_stride
+    for i, k in enumerate(L.ENC_PARAM_ORDER):
+        a.off[i] = arena.off(k)
+    lib.call("iplan_enc_fwd", a, L.current_stream(dev))
+    return lat, hL
+
+
+class AcFeatureSpec:
+    """Where the actor/critic input row comes from (DcntrlMAC._build_inputs[_ippo] fused into the
+    kernel).  ``sources``: up to three (tensor, width, s_net, s_row) per-entity fields; tensors are
+    only referenced (kept alive) -- the kernel reads them in place."""
+
+    def __init__(self, N, sources, n_actions=0, last_action=None, la_strides=(0, 0), n_id=0, T=1, T_phys=1):
+        self.N, self.sources, self.n_actions = N, sources, n_actions
+        self.last_action, self.la_strides, self.n_id, self.T, self.T_phys = last_action, la_strides, n_id, T, T_phys
+
+    @property
+    def F(self):
+        return self.N * sum(s[1] for s in self.sources) + self.n_actions + self.n_id
+
+    def fill(self, f):
+        f.N = self.N
+        for k in range(3):
+            if k < len(self.sources):
+                t, w, s_net, s_row = self.sources[k]
+                assert t.dtype == torch.float32
+                f.w[k], f.src[k], f.s_net[k], f.s_row[k] = w, t.data_ptr(), s_net, s_row
+            else:
+                f.w[k], f.src[k], f.s_net[k], f.s_row[k] = 0, None, 0, 0
+        f.n_actions = self.n_actions
+        if self.last_action is not None:
+            assert self.last_action.dtype == torch.int32
+            f.last_action = self.last_action.data_ptr()
+            f.la_s_net, f.la_s_row = self.la_strides
+        f.n_id = self.n_id
+        f.T, f.T_phys = self.T, self.T_phys
+
+
+def _fill_acnet(dst, arena, order, n_out):
+    dst.params = arena.data.data_ptr()
+    dst.params_s_net = arena.net_stride
+    for i, k in enumerate(order):
+        dst.off[i] = arena.off(k)
+    dst.n_out = n_out
+
+
+def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=None, h_critic=None,
+               h_strides=(0, 0), avail=None, avail_strides=(0, 0), mode=0, q_noise=None, actions_in=None,
+               act_strides=(0, 0), n_actions=5, ksplit=None, save=False, want_probs=False, want_entropy=False,
+               want_h=True, lib=None):
+    """Fused actor (which=0) / critic (1) / both (2) forward for all agents.
+    Returns a dict with the requested outputs, each laid out [n_agents, rows, ...]."""
+    lib = _lib(lib)
+    dev = (actor_arena if which != 1 else critic_arena).data.device
+    a = L.AcFwdArgs()
+    a.n_agents, a.rows, a.which = n_agents, rows, which
+    a.ksplit = ksplit if ksplit is not None else (8 if rows <= 512 else 1)
+    spec.fill(a.feat)
+    out = {}
+    f32 = dict(dtype=torch.float32, device=dev)
+    if which != 1:
+        _fill_acnet(a.actor, actor_arena, L.ACTOR_PARAM_ORDER, n_actions)
+        a.h_actor = h_actor.data_ptr()
+        if want_h:
+            out["h_actor"] = torch.empty(n_agents, rows, L.AC_HIDDEN, **f32)
+            a.h_actor_out = out["h_actor"].data_ptr()
+        if avail is not None:
+            assert avail.dtype == torch.int32
+            a.avail = avail.data_ptr()
+            a.av_s_net, a.av_s_row = avail_strides
+        a.mode = mode
+        if mode == 1:
+            assert q_noise.shape == (n_agents, rows, n_actions) and q_noise.is_contiguous()
+            a.q_noise = q_noise.data_ptr()
+        if mode == 2:
+            assert actions_in.dtype == torch.int64
+            a.actions_in = actions_in.data_ptr()
+            a.act_s_net, a.act_s_row = act_strides
+        else:
+            out["actions"] = torch.empty(n_agents, rows, dtype=torch.int64, device=dev)
+            a.actions_out = out["actions"].data_ptr()
+        out["logp"] = torch.empty(n_agents, rows, **f32)
+        a.logp = out["logp"].data_ptr()
+        if want_entropy:
+            out["entropy"] = torch.empty(n_agents, rows, **f32)
+            a.entropy = out["entropy"].data_ptr()
+        if want_probs:
+            out["probs"] = torch.empty(n_agents, rows, n_actions, **f32)
+            a.probs = out["probs"].data_ptr()
+    if which != 0:
+        _fill_acnet(a.critic, critic_arena, L.CRITIC_PARAM_ORDER, 1)
+        a.h_critic = h_critic.data_ptr()
+        if want_h:
+            out["h_critic"] = torch.empty(n_agents, rows, L.AC_HIDDEN, **f32)
+            a.h_critic_out = out["h_critic"].data_ptr()
+        out["values"] = torch.empty(n_agents, rows, **f32)
+        a.values = out["values"].data_ptr()
+    a.hs_net, a.hs_row = h_strides
+    if save:
+        out["saved"] = torch.empty(2, n_agents, rows, L.AC_SAVE_FLOATS, **f32)
+        a.saved = out["saved"].data_ptr()
+    lib.call("iplan_ac_fwd", a, L.current_stream(dev))
+    return out
