@@ -1,0 +1,102 @@
+"""Synthetic training-loop harness: plays the role of run_ippo.run_sequential + ParallelRunner.run
+(run_ippo.py:261-332, runners/ippo_parallel_runner.py:105-281) around the hot-path classes, with the
+environment and observation_wrapper replaced by pre-generated observation tensors (the simulators
+are not installable offline).  Everything stays device resident: the only thing a real
+runner would need back on the host per step is the [E, nA] action array.
+"""
+import torch
+
+from . import synth
+from .controllers.dcntrl_controller import DcntrlMAC
+from .nova.prediction_policy import Prediction_policy
+from .nova.stable_behavior_policy import Behavior_policy
+
+
+class NullLogger:
+    def __init__(self):
+        self.stats = {}
+
+    def log_stat(self, key, value, t):
+        self.stats[key] = value
+
+
+class SyntheticLoop:
+    def __init__(self, args, E, seed=0, device="cuda", n_obs_sets=2):
+        self.args, self.E, self.device = args, E, device
+        self.logger = NullLogger()
+        torch.manual_seed(seed)
+        self.scheme = synth.make_scheme(args)
+        self.mac = DcntrlMAC(self.scheme, {"agents": args.n_agents}, args)
+        self.prediction = Prediction_policy(args, self.logger) if args.GAT_enable else None
+        self.behavior = Behavior_policy(args, self.logger) if args.Behavior_enable else None
+        self.learner = None
+        gen = torch.Generator().manual_seed(seed + 1)
+        T1, nA, N = args.episode_limit + 1, args.n_agents, args.max_vehicle_num
+        d, L = args.obs_shape_single, args.max_history_len
+        # pre-generated "environment": per-step entity observations; the L-window is a sliding view
+        self.obs_sets = []
+        for _ in range(n_obs_sets):
+            hist = synth.make_history(gen, (T1 + L - 1, E, nA), N, d)        # [T1+L-1, E, nA, N, d]
+            self.obs_sets.append(dict(
+                hist=hist.to(device),
+                reward=torch.randn(T1, E, nA, 1, generator=gen).to(device),
+                terminated=(torch.rand(T1, E, nA, 1, generator=gen) < 0.1).to(torch.uint8).to(device),
+            ))
+        self._rollouts = 0
+
+    def new_batch(self):
+        a, E = self.args, self.E
+        T1, nA, N = a.episode_limit + 1, a.n_agents, a.max_vehicle_num
+        dev = self.device
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
+        data = dict(
+            history=z(E, T1, nA, N, a.obs_shape_single), behavior_latent=z(E, T1, nA, N, a.latent_dim),
+            attention_latent=z(E, T1, nA, N, a.attention_dim), rnn_states_actors=z(E, T1, nA, a.rnn_hidden_dim),
+            rnn_states_critics=z(E, T1, nA, a.rnn_hidden_dim), reward=z(E, T1, nA, 1),
+            terminated=z(E, T1, nA, 1, dtype=torch.uint8), actions=z(E, T1, nA, 1, dtype=torch.long),
+            actions_onehot=z(E, T1, nA, a.n_actions), avail_actions=torch.ones(E, T1, nA, a.n_actions, dtype=torch.int32, device=dev),
+            obs=z(E, T1, nA, a.obs_shape), state=z(E, T1, a.state_shape), speed=z(E, T1, nA, 1),
+            filled=torch.ones(E, T1, 1, dtype=torch.long, device=dev))
+        return synth.DictBatch(data, E, T1, dev)
+
+    @torch.no_grad()
+    def rollout(self):
+        """One vectorised episode of E envs x T steps (ippo_parallel_runner.py:105-281 order of calls)."""
+        a, E = self.args, self.E
+        T, nA, N, L = a.episode_limit, a.n_agents, a.max_vehicle_num, a.max_history_len
+        dev = self.device
+        obs = self.obs_sets[self._rollouts % len(self.obs_sets)]
+        self._rollouts += 1
+        batch = self.new_batch()
+        D = batch.data
+        att = torch.zeros(E, nA, N, a.attention_dim, device=dev)
+        lat = torch.zeros(E, nA, N, a.latent_dim, device=dev)
+        eh = torch.zeros(E, 1, nA, N, a.encoder_rnn_dim, device=dev)
+        ha = torch.zeros(E, nA, a.rnn_hidden_dim, device=dev)
+        hc = torch.zeros(E, nA, a.rnn_hidden_dim, device=dev)
+        hist_all = obs["hist"]
+        single = hist_all[L - 1]
+        if self.prediction is not None:
+            att = self.prediction.GAT_latent_update(single, att, lat)
+        D["history"][:, 0] = single
+        D["attention_latent"][:, 0] = att
+        D["behavior_latent"][:, 0] = lat
+        for t in range(T):
+            _, actions, _, ha_new, hc_new = self.mac.select_actions_ippo(batch, t, test_mode=False, as_numpy=False)
+            D["actions"][:, t, :, 0] = actions
+            D["actions_onehot"][:, t].zero_().scatter_(-1, actions.unsqueeze(-1), 1.0)
+            # env.step would run here; its outputs are the pre-generated tensors
+            single = hist_all[L + t]
+            if self.prediction is not None:
+                att = self.prediction.GAT_latent_update(single, att, lat)
+            if self.behavior is not None:
+                window = hist_all[t + 1:t + 1 + L].permute(1, 2, 3, 0, 4)          # [E, nA, N, L, d] view
+                lat, eh = self.behavior.latent_update(window.contiguous(), eh, lat)
+            D["reward"][:, t] = obs["reward"][t]
+            D["terminated"][:, t] = obs["terminated"][t]
+            D["history"][:, t + 1] = single
+            D["attention_latent"][:, t + 1] = att
+            D["behavior_latent"][:, t + 1] = lat
+            D["rnn_states_actors"][:, t + 1] = ha_new[0]
+            D["rnn_states_critics"][:, t + 1] = hc_new[0]
+        return batch

@@ -134,3 +134,19 @@ def test_clip_adam_emulated():
                 assert rel_err(p.detach(), r) < 1e-6
     sd = opts[0].state_dict()
     assert set(sd["state"].keys()) == {0, 1} and sd["state"][0]["exp_avg"].shape == (5, 7)
+
+
+def test_harness_rollout_emulated():
+    """The synthetic training loop (device-resident stand-in for ParallelRunner) runs end to end."""
+    from iplan_amd.config import default_args
+    from iplan_amd.harness import SyntheticLoop
+    args = default_args("highway", use_cuda=False, max_vehicle_num=5, n_agents=2, episode_limit=3, batch_size_run=2)
+    loop = SyntheticLoop(args, 2, seed=0, device="cpu")
+    batch = loop.rollout()
+    assert torch.isfinite(batch["attention_latent"]).all()
+    assert batch["attention_latent"][:, 1:].abs().sum() > 0
+    # latent starts at 0 and moves 10 % towards a simplex point every step: row sums are 1 - 0.9^t
+    sums = batch["behavior_latent"].sum(-1)
+    for t in range(1, 4):
+        assert (sums[:, t] - (1 - 0.9 ** t)).abs().max() < 1e-5
+    assert batch["actions"].max() < args.n_actions
