@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--envs", type=int, default=32, help="parallel envs per GPU (config 3: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     opt = ap.parse_args()
+    if os.environ.get("IPLAN_BENCH_WATCHDOG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["IPLAN_BENCH_WATCHDOG"]), repeat=True)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
