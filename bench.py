@@ -40,7 +40,10 @@ def cpu_baseline(args, E, budget_s=20.0):
     sample of the same workload.  Reported beside the GPU number, never mixed into it."""
     from oracle import iplan_oracle as O
     from iplan_amd import synth
-    cores = os.cpu_count() or 1
+    # intra-op threads: the reference's hot path is thousands of tiny ATen ops; beyond ~16 threads the
+    # fork/join overhead dominates (with 256 threads on the GPU box's 2 x 64-core EPYC one vector step
+    # took minutes), so the baseline uses min(host cores, 16) threads and says so in `cores`.
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     nA, N, d, Z, A, L = args.n_agents, args.max_vehicle_num, args.obs_shape_single, args.latent_dim, args.attention_dim, args.max_history_len
@@ -77,10 +80,13 @@ def cpu_baseline(args, E, budget_s=20.0):
             for i in range(nA):
                 O.actor_logits(act[i], x[:, i], ha[:, i])
                 O.critic_value(cri[i], x[:, i], ha[:, i])
+    t0 = time.time()
     vector_step()                                   # warm-up (first call pays one-time init)
+    warm = time.time() - t0
+    budget_s = max(2.0, min(budget_s, 60.0 - warm))
     t0 = time.time()
     n = 0
-    while time.time() - t0 < budget_s and n < 200:
+    while n < 1 or (time.time() - t0 < budget_s and n < 200):
         vector_step()
         n += 1
     dt = time.time() - t0

@@ -256,6 +256,49 @@ typedef struct {
 
 int iplan_adam_step(const IplanAdamArgs* args, iplan_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Weight-gradient contraction (the autograd of every nn.Linear / nn.GRU / nn.GRUCell weight on the
+ * path: torch's addmm/GRU backward under loss.backward() at nova/prediction_policy.py:228,
+ * nova/stable_behavior_policy.py:249, learners/ippo_learner.py:202,216):
+ *     dW[o][k] = scale * sum_rows dY[row][ocol(o)] * X[row'][x_col0 + k],   db[o] = scale * sum_rows dY[row][ocol(o)]
+ * rows = (outer, inner), outer < n_outer, inner < n_inner;  row' = (outer, inner + x_shift); when
+ * inner + x_shift falls outside [0, n_inner) the row x0[outer] is used (zeros if x0 == NULL).
+ * ocol(o) = o < seg_split ? seg_c0 + o : seg_c1 + (o - seg_split)  selects the columns of dY.
+ * Results are written (beta = 0) or accumulated (beta = 1) into the gradient arena of each net at
+ * dw_off + o*dw_ld + dw_col0 + k  /  db_off + o  (offset -1 = not wanted).  Fixed summation order.
+ */
+#define IPLAN_WGRAD_MAX 16
+#define IPLAN_WGRAD_MAX_CHUNKS 128
+
+typedef struct {
+    const float* dy;
+    int64_t dy_s_net, dy_s_outer, dy_s_inner;
+    const float* x;
+    int64_t x_s_net, x_s_outer, x_s_inner;
+    const float* x0;
+    int64_t x0_s_net, x0_s_outer;
+    int64_t dw_off, db_off;
+    int64_t ws_off;             /* filled by the library */
+    int32_t O, K;
+    int32_t seg_split, seg_c0, seg_c1;
+    int32_t x_col0, x_shift;
+    int32_t n_outer, n_inner;
+    int32_t dw_ld, dw_col0;
+    float beta, scale;
+} IplanWgradProblem;
+
+typedef struct {
+    int32_t n_problems, n_nets;
+    float* grad;                /* gradient arena base */
+    int64_t grad_s_net;
+    float* workspace;           /* >= iplan_wgrad_workspace_floats() floats */
+    int64_t workspace_floats;
+    IplanWgradProblem p[IPLAN_WGRAD_MAX];
+} IplanWgradArgs;
+
+size_t iplan_wgrad_workspace_floats(const IplanWgradArgs* args);
+int iplan_wgrad(IplanWgradArgs* args, iplan_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

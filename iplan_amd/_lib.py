@@ -48,8 +48,8 @@ class IplanError(RuntimeError):
 
 
 # every entry point include/iplan_hip.h declares
-ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step"]
-RAW_ENTRY_POINTS = ["iplan_grad_sqnorm"]      # non (args*, stream) signatures
+ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step", "iplan_wgrad"]
+RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats"]      # non (args*, stream) signatures
 
 
 class Lib:
@@ -69,6 +69,8 @@ class Lib:
             if not hasattr(cdll, name):
                 raise IplanError(f"{name} missing from the loaded library")
             getattr(cdll, name).restype = C.c_int
+        cdll.iplan_wgrad_workspace_floats.restype = C.c_size_t
+        cdll.iplan_wgrad_workspace_floats.argtypes = [C.c_void_p]
 
     def call(self, name, args, stream=None):
         rc = getattr(self.c, name)(C.byref(args), C.c_void_p(stream or 0))
@@ -183,4 +185,27 @@ class AdamArgs(C.Structure):
         ("max_norm", C.c_float), ("write_clipped", i32),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
         ("bc1", C.c_float * MAX_NETS), ("bc2_sqrt", C.c_float * MAX_NETS),
+    ]
+
+
+# ---- weight-gradient contraction ---------------------------------------------------------------------
+WGRAD_MAX = 16
+
+
+class WgradProblem(C.Structure):
+    _fields_ = [
+        ("dy", fp), ("dy_s_net", i64), ("dy_s_outer", i64), ("dy_s_inner", i64),
+        ("x", fp), ("x_s_net", i64), ("x_s_outer", i64), ("x_s_inner", i64),
+        ("x0", fp), ("x0_s_net", i64), ("x0_s_outer", i64),
+        ("dw_off", i64), ("db_off", i64), ("ws_off", i64),
+        ("O", i32), ("K", i32), ("seg_split", i32), ("seg_c0", i32), ("seg_c1", i32),
+        ("x_col0", i32), ("x_shift", i32), ("n_outer", i32), ("n_inner", i32),
+        ("dw_ld", i32), ("dw_col0", i32), ("beta", C.c_float), ("scale", C.c_float),
+    ]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [
+        ("n_problems", i32), ("n_nets", i32), ("grad", fp), ("grad_s_net", i64),
+        ("workspace", fp), ("workspace_floats", i64), ("p", WgradProblem * WGRAD_MAX),
     ]

@@ -5,6 +5,8 @@ pointers / strides, (c) calls the entry point on torch's current stream.  No ari
 here.  ``lib`` defaults to the gfx950 build; the CPU test-suite passes the host-emulated build of
 the same kernel sources instead.
 """
+import ctypes as C
+
 import torch
 
 from . import _lib as L
@@ -201,3 +203,65 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
         a.saved = out["saved"].data_ptr()
     lib.call("iplan_ac_fwd", a, L.current_stream(dev))
     return out
+
+
+# ---- weight gradients ----------------------------------------------------------------------------------
+_WORKSPACES = {}
+
+
+def workspace(device, floats, tag="wgrad"):
+    """Grow-only scratch buffer per (device, tag) -- owned by torch's caching allocator."""
+    key = (str(device), tag)
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < floats:
+        buf = torch.empty(max(int(floats), 1), dtype=torch.float32, device=device)
+        _WORKSPACES[key] = buf
+    return buf
+
+
+class Wgrad:
+    """Batch of dW = dY^T X problems (include/iplan_hip.h: IplanWgradProblem) written into a gradient arena."""
+
+    def __init__(self, grad, n_nets):
+        self.grad, self.n_nets = grad, n_nets
+        self.problems = []
+        self._keep = []
+
+    def add(self, dy, dy_strides, O, n_outer, n_inner, x=None, x_strides=(0, 0, 0), K=0, dw_off=-1, db_off=-1,
+            dw_ld=None, dw_col0=0, seg=None, x_col0=0, x_shift=0, x0=None, x0_strides=(0, 0), beta=0.0, scale=1.0):
+        p = L.WgradProblem()
+        p.dy = dy.data_ptr() if torch.is_tensor(dy) else dy
+        p.dy_s_net, p.dy_s_outer, p.dy_s_inner = dy_strides
+        if x is not None:
+            p.x = x.data_ptr() if torch.is_tensor(x) else x
+            p.x_s_net, p.x_s_outer, p.x_s_inner = x_strides
+        if x0 is not None:
+            p.x0 = x0.data_ptr() if torch.is_tensor(x0) else x0
+            p.x0_s_net, p.x0_s_outer = x0_strides
+        p.dw_off, p.db_off = dw_off, db_off
+        p.O, p.K = O, K
+        p.seg_split, p.seg_c0, p.seg_c1 = seg if seg is not None else (O, 0, 0)
+        p.x_col0, p.x_shift, p.n_outer, p.n_inner = x_col0, x_shift, n_outer, n_inner
+        p.dw_ld = K if dw_ld is None else dw_ld
+        p.dw_col0 = dw_col0
+        p.beta, p.scale = beta, scale
+        self.problems.append(p)
+        self._keep += [dy, x, x0]
+        return self
+
+    def run(self, lib=None):
+        lib = _lib(lib)
+        dev = self.grad.device
+        stream = L.current_stream(dev)
+        for i0 in range(0, len(self.problems), L.WGRAD_MAX):
+            chunk = self.problems[i0:i0 + L.WGRAD_MAX]
+            a = L.WgradArgs()
+            a.n_problems, a.n_nets = len(chunk), self.n_nets
+            a.grad = self.grad.data_ptr()
+            a.grad_s_net = self.grad.stride(0)
+            for i, p in enumerate(chunk):
+                a.p[i] = p
+            need = lib.c.iplan_wgrad_workspace_floats(C.byref(a))
+            ws = workspace(dev, need)
+            a.workspace, a.workspace_floats = ws.data_ptr(), ws.numel()
+            lib.call("iplan_wgrad", a, stream)

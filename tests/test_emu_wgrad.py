@@ -1,0 +1,66 @@
+"""CPU (host-emulated kernel build): the weight-gradient contraction against plain torch."""
+import pytest
+import torch
+
+from iplan_amd import _lib as L
+from iplan_amd import ops
+from tests.emu.emu_lib import get_emu_lib
+
+
+@pytest.fixture(autouse=True)
+def emu():
+    L.use_library_for_tests(get_emu_lib())
+    yield
+    L.use_library_for_tests(None)
+
+
+def test_wgrad_dense_and_recurrent():
+    torch.manual_seed(0)
+    n_nets, n_outer, n_inner, H = 2, 7, 5, 32
+    dy = torch.randn(n_nets, n_outer, n_inner, 4 * H)          # [dr, dz, dn_i, dn_h]
+    hs = torch.randn(n_nets, n_outer, n_inner, H)
+    h0 = torch.randn(n_nets, n_outer, H)
+    xin = torch.randn(n_nets, n_outer, n_inner, 13)
+    grad = torch.zeros(n_nets, 20000)
+    grad[:, 5000:5000 + 96 * 13] = 1.0                           # beta = 1 target
+    w = ops.Wgrad(grad, n_nets)
+    st = (dy.stride(0), dy.stride(1), dy.stride(2))
+    # W_hh: dgh = [dr, dz, dn_h] against h_{t-1} (shift -1, h0 for the first step); bias too
+    w.add(dy, st, 3 * H, n_outer, n_inner, x=hs, x_strides=(hs.stride(0), hs.stride(1), hs.stride(2)), K=H,
+          dw_off=0, db_off=4000, seg=(2 * H, 0, 3 * H), x_shift=-1, x0=h0, x0_strides=(h0.stride(0), h0.stride(1)))
+    # W_ih: dgi = [dr, dz, dn_i] against the step input (odd K), accumulated, scaled
+    w.add(dy, st, 3 * H, n_outer, n_inner, x=xin, x_strides=(xin.stride(0), xin.stride(1), xin.stride(2)), K=13,
+          dw_off=5000, db_off=-1, beta=1.0, scale=0.5)
+    # reverse-direction recurrent weight: previous state is step + 1, zeros beyond the end; strided dW
+    w.add(dy, st, 3 * H, n_outer, n_inner, x=hs, x_strides=(hs.stride(0), hs.stride(1), hs.stride(2)), K=H,
+          dw_off=8000, dw_ld=2 * H, dw_col0=H, x_shift=1)
+    # bias only
+    w.add(dy, st, 4 * H, n_outer, n_inner, db_off=16000)
+    w.run()
+    for n in range(n_nets):
+        d = dy[n].reshape(-1, 4 * H)
+        dgh = torch.cat([d[:, :2 * H], d[:, 3 * H:]], 1)
+        hprev = torch.cat([h0[n][:, None], hs[n][:, :-1]], 1).reshape(-1, H)
+        ref = dgh.t() @ hprev
+        assert torch.allclose(grad[n, :96 * H].view(96, H), ref, rtol=1e-5, atol=1e-5)
+        assert torch.allclose(grad[n, 4000:4096], dgh.sum(0), rtol=1e-5, atol=1e-5)
+        ref = 1.0 + 0.5 * (d[:, :3 * H].t() @ xin[n].reshape(-1, 13))
+        assert torch.allclose(grad[n, 5000:5000 + 96 * 13].view(96, 13), ref, rtol=1e-5, atol=1e-5)
+        hnext = torch.cat([hs[n][:, 1:], torch.zeros(n_outer, 1, H)], 1).reshape(-1, H)
+        ref = d[:, :3 * H].t() @ hnext
+        got = grad[n, 8000:8000 + 96 * 2 * H].view(96, 2 * H)
+        assert torch.allclose(got[:, H:], ref, rtol=1e-5, atol=1e-5)
+        assert got[:, :H].abs().max() == 0
+        assert torch.allclose(grad[n, 16000:16000 + 4 * H], d.sum(0), rtol=1e-5, atol=1e-5)
+
+
+def test_wgrad_many_rows_chunked():
+    torch.manual_seed(1)
+    R = 1000
+    dy = torch.randn(1, R, 1, 20)
+    x = torch.randn(1, R, 1, 70)
+    grad = torch.zeros(1, 4000)
+    ops.Wgrad(grad, 1).add(dy, (0, 20, 20), 20, R, 1, x=x, x_strides=(0, 70, 70), K=70, dw_off=0, db_off=3000).run()
+    ref = dy[0, :, 0].t() @ x[0, :, 0]
+    assert torch.allclose(grad[0, :1400].view(20, 70), ref, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(grad[0, 3000:3020], dy[0, :, 0].sum(0), rtol=1e-5, atol=1e-4)
