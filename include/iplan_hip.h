@@ -299,6 +299,81 @@ typedef struct {
 size_t iplan_wgrad_workspace_floats(const IplanWgradArgs* args);
 int iplan_wgrad(IplanWgradArgs* args, iplan_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Backward of the recurrent actor / critic (autograd of R_Actor.evaluate_actions /
+ * R_Critic.forward under learners/ippo_learner.py:202,216).  Launch order:
+ *   iplan_ac_fwd(mode 2, saved != NULL) -> loss gradients per row -> iplan_ac_bwd_tail ->
+ *   iplan_wgrad problems for the 64-wide layers (host assembles them from `dsave` / `saved`) and
+ *   iplan_ac_bwd_fc1 -> iplan_ac_bwd_fc1_finalize (needs fc1.bias' gradient from iplan_wgrad).
+ */
+#define IPLAN_AC_DSAVE_FLOATS (6 * IPLAN_AC_HIDDEN + 16) /* dz1 | dz2 | dr dz dn_i dn_h | dhead(16) */
+#define IPLAN_AC_LNPART_FLOATS (6 * IPLAN_AC_HIDDEN)     /* [rnn.norm w,b | fc2.0.2 w,b | fc1.2 w,b] */
+
+typedef struct {
+    IplanAcFwdArgs fwd;         /* the descriptor of the forward launch (mode 2, saved != NULL)        */
+    const float* g_logp;        /* [n_agents, rows] dLoss/dlogp                                          */
+    const float* g_entropy;     /* [n_agents, rows] dLoss/d(entropy of the row); NULL -> g_entropy_const */
+    float g_entropy_const;
+    const float* g_values;      /* [n_agents, rows] dLoss/dvalue                                         */
+    float* dsave;               /* [2, n_agents, rows, IPLAN_AC_DSAVE_FLOATS]                            */
+    float* ln_part;             /* [2, n_agents, ceil(rows/16), IPLAN_AC_LNPART_FLOATS]                  */
+    float* g_part;              /* [2, n_agents, fc1_chunks, 64, Fpad] partial G tiles (Fpad = ceil(F/64)*64) */
+    int32_t fc1_chunk_rows;     /* rows per chunk, multiple of 16                                        */
+    int32_t fc1_chunks;
+    float* actor_grad;          /* gradient arenas (fc1.weight, feature_norm.* are written by finalize)  */
+    float* critic_grad;
+    int64_t actor_grad_s_net, critic_grad_s_net;
+} IplanAcBwdArgs;
+
+int iplan_ac_bwd_tail(const IplanAcBwdArgs* args, iplan_stream_t stream);
+int iplan_ac_bwd_fc1(const IplanAcBwdArgs* args, iplan_stream_t stream);
+int iplan_ac_bwd_fc1_finalize(const IplanAcBwdArgs* args, iplan_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PPO bookkeeping of IPPOLearner.train (learners/ippo_learner.py).
+ * iplan_ppo_prepare: compute_returns (:344-365, GAE) + advantage normalisation (:273-279):
+ *   mask_t = 1 - terminated_t;  delta_t = r_t + gamma V_{t+1} mask_{t+1} - V_t;
+ *   gae_t = delta_t + gamma lam mask_{t+1} gae_{t+1};  ret_t = gae_t + V_t;
+ *   adv = (ret - V) zeroed where mask == 0, then (adv - mean) / (unbiased std + 1e-5) over all bs*T.
+ */
+typedef struct {
+    int32_t n_agents, bs, T;
+    const float* reward;         /* reward[net*rw_s_net + b*rw_s_ep + t*rw_s_t], t < T              */
+    int64_t rw_s_net, rw_s_ep, rw_s_t;
+    const uint8_t* terminated;   /* same addressing, t <= T                                          */
+    int64_t tm_s_net, tm_s_ep, tm_s_t;
+    const float* values;         /* [n_agents, bs, T+1] critic values of every stored step           */
+    float gamma, lam;
+    float* returns;              /* [n_agents, bs, T]                                                */
+    float* adv;                  /* [n_agents, bs, T] normalised advantages                          */
+    float* mask;                 /* [n_agents, bs, T] 1 - terminated                                 */
+    float* value_preds;          /* [n_agents, bs, T] = values[:, :, :T]                             */
+} IplanPpoPrepareArgs;
+
+int iplan_ppo_prepare(const IplanPpoPrepareArgs* args, iplan_stream_t stream);
+
+/* iplan_ppo_loss: ppo_update's losses (:185-197) and cal_value_loss (:128-159) over the first
+ * `rows` rows of every agent, plus dLoss/dlogp and d(value_loss_coef * value_loss)/dvalue per row.
+ * stats[net][0..4] = policy_loss, value_loss, mean ratio, mean entropy, sum(mask).              */
+typedef struct {
+    int32_t n_agents, rows;
+    int64_t row_stride;          /* per-agent stride of the [n_agents, bs*T] inputs below            */
+    const float* logp;           /* [n_agents, rows] current log-probs (iplan_ac_fwd output)         */
+    const float* entropy;        /* [n_agents, rows]                                                 */
+    const float* values;         /* [n_agents, rows] current values                                  */
+    const float* old_logp;       /* [n_agents, row_stride]                                           */
+    const float* adv;
+    const float* value_preds;
+    const float* returns;
+    const float* mask;
+    float clip, huber_delta, value_loss_coef;
+    float* g_logp;               /* [n_agents, rows]                                                 */
+    float* g_values;             /* [n_agents, rows]                                                 */
+    float* stats;                /* [n_agents, 8]                                                    */
+} IplanPpoLossArgs;
+
+int iplan_ppo_loss(const IplanPpoLossArgs* args, iplan_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,7 +48,8 @@ class IplanError(RuntimeError):
 
 
 # every entry point include/iplan_hip.h declares
-ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step", "iplan_wgrad"]
+ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step", "iplan_wgrad",
+                "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_loss"]
 RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats"]      # non (args*, stream) signatures
 
 
@@ -208,4 +209,38 @@ class WgradArgs(C.Structure):
     _fields_ = [
         ("n_problems", i32), ("n_nets", i32), ("grad", fp), ("grad_s_net", i64),
         ("workspace", fp), ("workspace_floats", i64), ("p", WgradProblem * WGRAD_MAX),
+    ]
+
+
+# ---- actor / critic backward + PPO -------------------------------------------------------------------
+AC_DSAVE_FLOATS = 6 * AC_HIDDEN + 16
+AC_LNPART_FLOATS = 6 * AC_HIDDEN
+
+
+class AcBwdArgs(C.Structure):
+    _fields_ = [
+        ("fwd", AcFwdArgs), ("g_logp", fp), ("g_entropy", fp), ("g_entropy_const", C.c_float),
+        ("g_values", fp), ("dsave", fp), ("ln_part", fp), ("g_part", fp),
+        ("fc1_chunk_rows", i32), ("fc1_chunks", i32), ("actor_grad", fp), ("critic_grad", fp),
+        ("actor_grad_s_net", i64), ("critic_grad_s_net", i64),
+    ]
+
+
+class PpoPrepareArgs(C.Structure):
+    _fields_ = [
+        ("n_agents", i32), ("bs", i32), ("T", i32),
+        ("reward", fp), ("rw_s_net", i64), ("rw_s_ep", i64), ("rw_s_t", i64),
+        ("terminated", fp), ("tm_s_net", i64), ("tm_s_ep", i64), ("tm_s_t", i64),
+        ("values", fp), ("gamma", C.c_float), ("lam", C.c_float),
+        ("returns", fp), ("adv", fp), ("mask", fp), ("value_preds", fp),
+    ]
+
+
+class PpoLossArgs(C.Structure):
+    _fields_ = [
+        ("n_agents", i32), ("rows", i32), ("row_stride", i64),
+        ("logp", fp), ("entropy", fp), ("values", fp), ("old_logp", fp), ("adv", fp),
+        ("value_preds", fp), ("returns", fp), ("mask", fp),
+        ("clip", C.c_float), ("huber_delta", C.c_float), ("value_loss_coef", C.c_float),
+        ("g_logp", fp), ("g_values", fp), ("stats", fp),
     ]

@@ -41,13 +41,6 @@ struct FeatCursor {
     }
 };
 
-template <int KT>
-__device__ __forceinline__ f32x4 dense_tile_g(const float* __restrict__ W, int ld, int rows, int cols, int o0,
-                                              const f32x4 (&x)[KT], f32x4 acc) {
-    for (int T = 0; T < KT; ++T) acc = mma_block(wfrag(W, ld, rows, cols, o0, 16 * T), x[T], acc);
-    return acc;
-}
-
 __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     __shared__ float s_red[8][16];
     __shared__ __attribute__((aligned(16))) f32x4 s_acc[8][AT][64];

@@ -49,6 +49,43 @@ __device__ __forceinline__ f32x4 dense_tile(const float* __restrict__ sW, int ld
     return acc;
 }
 
+// Same with the weights read straight from global memory (L1/L2 resident; row-major [rows x cols]).
+template <int KT>
+__device__ __forceinline__ f32x4 dense_tile_g(const float* __restrict__ W, int ld, int rows, int cols, int o0,
+                                              const f32x4 (&x)[KT], f32x4 acc) {
+    for (int T = 0; T < KT; ++T) acc = mma_block(wfrag(W, ld, rows, cols, o0, 16 * T), x[T], acc);
+    return acc;
+}
+
+// acc += (W^T x)[o0 .. o0+15]: W row-major [rows x cols], x has `rows` entries in KT tiles
+// (backward-data of a dense layer: dx = W^T dy).
+template <int KT>
+__device__ __forceinline__ f32x4 dense_tile_gt(const float* __restrict__ W, int ld, int rows, int cols, int o0,
+                                               const f32x4 (&x)[KT], f32x4 acc) {
+    for (int T = 0; T < KT; ++T) acc = mma_block(wfrag_t(W, ld, rows, cols, o0, 16 * T), x[T], acc);
+    return acc;
+}
+
+// GRU step backward, lane-local (PyTorch gate equations, see gru_gates()).  Given dh = dL/dh_new and
+// the saved gate activations, returns the pre-activation gradients and the direct path to h_prev.
+struct GruGrads {
+    f32x4 dr, dz, dni, dnh, dh_direct;   // dni = d/d(gi_n), dnh = d/d(gh_n) = dni * r
+};
+__device__ __forceinline__ GruGrads gru_gates_bwd(f32x4 dh, f32x4 r, f32x4 z, f32x4 n, f32x4 hn, f32x4 h_prev) {
+    GruGrads o;
+    for (int q = 0; q < 4; ++q) {
+        const float dn = dh[q] * (1.0f - z[q]);
+        const float dzg = dh[q] * (h_prev[q] - n[q]);
+        o.dni[q] = dn * (1.0f - n[q] * n[q]);
+        const float dr = o.dni[q] * hn[q];
+        o.dnh[q] = o.dni[q] * r[q];
+        o.dr[q] = dr * r[q] * (1.0f - r[q]);
+        o.dz[q] = dzg * z[q] * (1.0f - z[q]);
+        o.dh_direct[q] = dh[q] * z[q];
+    }
+    return o;
+}
+
 // One GRU step with LDS-resident weights.  HT = H/16 hidden tiles, XT = input tiles.
 // sWih: [3H x ldi], sWhh: [3H x ldh], sbih/sbhh: [3H].  h is updated in place; when `keep` is
 // non-null the gate activations (r, z, n, hn) of every tile are returned for the backward pass.

@@ -1,0 +1,140 @@
+// PPO bookkeeping kernels of IPPOLearner.train (learners/ippo_learner.py:227-317): GAE returns +
+// advantage normalisation, and the clipped policy / clipped-Huber value losses with their
+// gradients w.r.t. log-prob and value.  One 1024-thread workgroup per agent, fixed summation order
+// (a row-strided partial per thread, then a tree over the workgroup) -> reproducible.
+#include "api_util.h"
+#include "wave_tile.h"
+
+namespace iplan {
+
+__device__ __forceinline__ float block_sum_1024(float v, float* s_part) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane_id() == 0) s_part[wave_id()] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_part[w];
+    return t;
+}
+
+// compute_returns (ippo_learner.py:344-365) + advantage normalisation (:273-279)
+__global__ __launch_bounds__(1024) void ppo_prepare_kernel(IplanPpoPrepareArgs a) {
+    __shared__ float s_part[16];
+    const int net = (int)blockIdx.x;
+    const int T = a.T, T1 = a.T + 1, bs = a.bs;
+    const float* __restrict__ val = a.values + (int64_t)net * bs * T1;
+    float* __restrict__ ret = a.returns + (int64_t)net * bs * T;
+    float* __restrict__ adv = a.adv + (int64_t)net * bs * T;
+    float* __restrict__ msk = a.mask + (int64_t)net * bs * T;
+    float* __restrict__ vpr = a.value_preds + (int64_t)net * bs * T;
+    for (int b = (int)threadIdx.x; b < bs; b += (int)blockDim.x) {
+        const float* rw = a.reward + (int64_t)net * a.rw_s_net + (int64_t)b * a.rw_s_ep;
+        const uint8_t* tm = a.terminated + (int64_t)net * a.tm_s_net + (int64_t)b * a.tm_s_ep;
+        float gae = 0.f;
+        for (int t = T - 1; t >= 0; --t) {
+            const float m1 = 1.0f - (float)tm[(int64_t)(t + 1) * a.tm_s_t];
+            const float v0 = val[(int64_t)b * T1 + t], v1 = val[(int64_t)b * T1 + t + 1];
+            const float delta = rw[(int64_t)t * a.rw_s_t] + a.gamma * v1 * m1 - v0;
+            gae = delta + a.gamma * a.lam * m1 * gae;
+            const float r = gae + v0;
+            const float m0 = 1.0f - (float)tm[(int64_t)t * a.tm_s_t];
+            ret[(int64_t)b * T + t] = r;
+            msk[(int64_t)b * T + t] = m0;
+            vpr[(int64_t)b * T + t] = v0;
+            adv[(int64_t)b * T + t] = m0 == 0.0f ? 0.0f : r - v0;
+        }
+    }
+    __syncthreads();
+    const int n = bs * T;
+    float s = 0.f;
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) s += adv[i];
+    const float mean = block_sum_1024(s, s_part) / (float)n;
+    float q = 0.f;
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) { const float d = adv[i] - mean; q = fmaf(d, d, q); }
+    const float var = block_sum_1024(q, s_part) / (float)(n - 1);           // th.std_mean: unbiased
+    const float inv = 1.0f / (sqrtf(var) + 1e-5f);
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) adv[i] = (adv[i] - mean) * inv;
+}
+
+__device__ __forceinline__ float huber_q(float e, float d) {      // util.py:33-36 (one-sided)
+    const float ae = fabsf(e);
+    return (ae <= d ? e * e * 0.5f : 0.f) + (e > d ? d * (ae - d * 0.5f) : 0.f);
+}
+__device__ __forceinline__ float huber_dq(float e, float d) {
+    return (fabsf(e) <= d ? e : 0.f) + (e > d ? d : 0.f);
+}
+
+// ppo_update losses (ippo_learner.py:185-197, 128-159) and their gradients per row
+__global__ __launch_bounds__(1024) void ppo_loss_kernel(IplanPpoLossArgs a) {
+    __shared__ float s_part[16];
+    const int net = (int)blockIdx.x;
+    const int64_t o = (int64_t)net * a.row_stride;
+    const float* __restrict__ logp = a.logp + (int64_t)net * a.rows;
+    const float* __restrict__ val = a.values + (int64_t)net * a.rows;
+    const float* __restrict__ ent = a.entropy + (int64_t)net * a.rows;
+    float* __restrict__ g_lp = a.g_logp + (int64_t)net * a.rows;
+    float* __restrict__ g_v = a.g_values + (int64_t)net * a.rows;
+    const int n = a.rows;
+    float sm = 0.f;
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) sm += a.mask[o + i];
+    const float msum = block_sum_1024(sm, s_part);
+    float pol = 0.f, vls = 0.f, rat = 0.f, en = 0.f;
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
+        const float m = a.mask[o + i], ad = a.adv[o + i];
+        const float ratio = expf(logp[i] - a.old_logp[o + i]);
+        const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = ratio * ad, s2 = rc * ad;
+        pol -= fminf(s1, s2) * m;
+        const bool inside = ratio >= lo && ratio <= hi;
+        // th.min ties split evenly; inside the clip range both branches carry d/dratio = adv
+        float dr = 0.f;
+        if (s1 < s2) dr = ad;
+        else if (s1 == s2) dr = inside ? ad : 0.5f * ad;
+        g_lp[i] = -(m / msum) * dr * ratio;
+        rat += ratio;
+        en += ent[i];
+        const float v = val[i], vp = a.value_preds[o + i], rt = a.returns[o + i];
+        const float dv = v - vp;
+        const float vc = vp + fminf(fmaxf(dv, -a.clip), a.clip);
+        const float e1 = rt - v, e2 = rt - vc;
+        const float h1 = huber_q(e1, a.huber_delta), h2 = huber_q(e2, a.huber_delta);
+        vls += fmaxf(h1, h2) * m;
+        const float d1 = -huber_dq(e1, a.huber_delta);
+        const float d2 = (dv >= -a.clip && dv <= a.clip) ? -huber_dq(e2, a.huber_delta) : 0.f;
+        const float dvl = h1 > h2 ? d1 : (h2 > h1 ? d2 : 0.5f * (d1 + d2));
+        g_v[i] = a.value_loss_coef * (m / msum) * dvl;
+    }
+    pol = block_sum_1024(pol, s_part);
+    vls = block_sum_1024(vls, s_part);
+    rat = block_sum_1024(rat, s_part);
+    en = block_sum_1024(en, s_part);
+    if (threadIdx.x == 0) {
+        float* st = a.stats + (int64_t)net * 8;
+        st[0] = pol / msum;            // policy_loss
+        st[1] = vls / msum;            // value_loss
+        st[2] = rat / (float)n;        // imp_weights.mean()
+        st[3] = en / (float)n;         // dist_entropy (unmasked mean, act.py:164)
+        st[4] = msum;
+    }
+}
+
+}  // namespace iplan
+
+extern "C" int iplan_ppo_prepare(const IplanPpoPrepareArgs* a, iplan_stream_t stream) {
+    using namespace iplan;
+    if (!a || a->n_agents < 1 || a->bs < 1 || a->T < 1 || a->bs * a->T < 2 || !a->reward || !a->terminated ||
+        !a->values || !a->returns || !a->adv || !a->mask || !a->value_preds)
+        return fail(IPLAN_EINVAL, "iplan_ppo_prepare: bad arguments");
+    hipLaunchKernelGGL(ppo_prepare_kernel, dim3((unsigned)a->n_agents), dim3(1024), 0, (hipStream_t)stream, *a);
+    return check_launch("iplan_ppo_prepare");
+}
+
+extern "C" int iplan_ppo_loss(const IplanPpoLossArgs* a, iplan_stream_t stream) {
+    using namespace iplan;
+    if (!a || a->n_agents < 1 || a->rows < 1 || !a->logp || !a->entropy || !a->values || !a->old_logp || !a->adv ||
+        !a->value_preds || !a->returns || !a->mask || !a->g_logp || !a->g_values || !a->stats)
+        return fail(IPLAN_EINVAL, "iplan_ppo_loss: bad arguments");
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3((unsigned)a->n_agents), dim3(1024), 0, (hipStream_t)stream, *a);
+    return check_launch("iplan_ppo_loss");
+}

@@ -1,0 +1,274 @@
+"""IPPOLearner -- independent PPO over the decentralised controller (mirror of
+learners/ippo_learner.py:17-424).
+
+Same constructor, ``insert_episode_batch`` / ``train`` / ``save_models`` / ``load_models`` / ``lr_decay``
+contracts, same optimiser checkpoint files.  What differs is the execution plan:
+
+  * episodes are kept in ONE device-resident store ``[buffer_size, T+1, n_agents, ...]`` per field
+    (the reference keeps per-agent deques of per-episode tensors and ``th.cat``s them at train time);
+  * the reference trains agent after agent (15 epochs each); agents own private networks and
+    private data, so the updates are independent and here every PPO epoch is ONE fused
+    forward / loss / backward / clip+Adam launch sequence covering all agents, actors and critics;
+  * the ``[256, 91, F]`` input tensor of ``_build_inputs_ippo`` is never materialised -- the kernels
+    gather features from the stored fields; the ``randperm`` minibatch shuffle is dropped because
+    ``num_mini_batch == 1`` makes every epoch a full-batch step (row order only permutes a sum).
+
+Host code here is bookkeeping only: every number is produced by kernels in libiplan_hip.so.
+"""
+import copy
+
+import torch as th
+
+from .. import _lib as L
+from .. import ops
+from ..optim import FusedAdam, step_all
+from ..utils.mappo_utils.util import update_linear_schedule
+
+_STORE_KEYS = ("history", "attention_latent", "behavior_latent", "actions", "avail_actions", "reward",
+               "terminated", "rnn_states_actors", "rnn_states_critics", "actions_onehot", "obs", "state")
+
+
+class EpisodeStore:
+    """Device-resident stand-in for the n_agents ``SeparatedReplayBuffer`` deques
+    (utils/mappo_utils/separated_buffer.py:14-110): keeps the most recent ``buffer_size`` episodes
+    in insertion order."""
+
+    def __init__(self, args, device):
+        self.size = args.buffer_size
+        self.device = device
+        self.count = 0
+        self.data = {}
+
+    def insert(self, ep_batch, n_eps):
+        for key in _STORE_KEYS:
+            try:
+                src = ep_batch[key]
+            except (KeyError, ValueError):
+                continue
+            src = src[:n_eps]
+            if key not in self.data:
+                self.data[key] = th.zeros((self.size,) + tuple(src.shape[1:]), dtype=src.dtype, device=self.device)
+        over = self.count + n_eps - self.size
+        if over > 0:                                    # deque(maxlen) semantics: drop the oldest
+            keep = self.count - over
+            for v in self.data.values():
+                if keep > 0:
+                    v[:keep] = v[over:self.count].clone()
+            self.count = max(keep, 0)
+        take = min(n_eps, self.size)
+        for key, v in self.data.items():
+            v[self.count:self.count + take] = ep_batch[key][n_eps - take:n_eps].to(self.device)
+        self.count += take
+
+    def clear(self):
+        self.count = 0
+
+
+class _AgentBuffer:
+    """Per-agent view with the SeparatedReplayBuffer surface callers touch."""
+
+    def __init__(self, store, agent):
+        self.store, self.agent = store, agent
+
+    def can_sample(self):
+        return self.store.count == self.store.size
+
+    def clear_buffer(self):
+        self.store.clear()
+
+    def get_batch(self):
+        if not self.can_sample():
+            return None
+        d, i = self.store.data, self.agent
+        out = {"obs": d["obs"][:, :, i], "state": d["state"], "actions": d["actions"][:, :, i],
+               "actions_onehot": d["actions_onehot"][:, :, i], "rnn_states_actor": d["rnn_states_actors"][:, :, i],
+               "rnn_states_critic": d["rnn_states_critics"][:, :, i], "reward": d["reward"][:, :, i],
+               "terminated_masks": 1 - d["terminated"][:, :, i], "history": d["history"][:, :, i],
+               "available_actions": d["avail_actions"][:, :, i]}
+        for k in ("behavior_latent", "attention_latent"):
+            if k in d:
+                out[k] = d[k][:, :, i]
+        return out
+
+
+class IPPOLearner:
+    def __init__(self, mac, scheme, logger, args):
+        self.device = th.device("cuda" if args.use_cuda else "cpu")
+        self.args = args
+        self.lr = args.lr
+        self.critic_lr = args.critic_lr
+        self.use_linear_lr_decay = args.use_linear_lr_decay
+        self.optim_eps = args.optim_eps
+        self.weight_decay = args.weight_decay
+        self.tpdv = dict(dtype=th.float32, device=self.device)
+        self.n_agents = args.n_agents
+        self.t_max = args.t_max
+        self.episode_limit = args.episode_limit
+        self.batch_size_run = args.batch_size_run
+        self.batch_size = args.batch_size
+        self.mac = mac
+        self.state_shape = self.mac.input_scheme["state"]["vshape"]
+        self.obs_shape = self.mac.input_scheme["obs"]["vshape"]
+        self.n_actions = args.n_actions
+        self.logger = logger
+        self.log_prefix = args.log_prefix
+        self.log_stats_t = -self.args.learner_log_interval - 1
+
+        self.store = EpisodeStore(args, self.device)
+        self.buffers = [_AgentBuffer(self.store, i) for i in range(self.n_agents)]
+
+        self.clip_param = args.clip_param
+        self.ppo_epoch = args.ppo_epoch
+        self.num_mini_batch = args.num_mini_batch
+        self.data_chunk_length = args.data_chunk_length
+        self.value_loss_coef = args.value_loss_coef
+        self.entropy_coef = args.entropy_coef
+        self.max_grad_norm = args.max_grad_norm
+        self.huber_delta = args.huber_delta
+        self.gamma = args.gamma
+        self._use_gae = args.use_gae
+        self.gae_lambda = args.gae_lambda
+        self._use_max_grad_norm = args.use_max_grad_norm
+        if (args.num_mini_batch != 1 or not args.use_gae or not args.use_huber_loss or not args.use_clipped_value_loss
+                or not args.use_value_active_masks or not args.use_policy_active_masks):
+            raise NotImplementedError("iplan_amd implements the reference's shipped PPO configuration "
+                                      "(config/algs/ippo.yaml: 1 minibatch, GAE, clipped Huber value loss, active masks)")
+
+        self.actor_params = mac.parameters()
+        self.critic_params = mac.critic_parameters()
+        self.actor_optimizers = [FusedAdam([(mac.actor_arena, n)], lr=self.lr, eps=self.optim_eps,
+                                           weight_decay=self.weight_decay) for n in range(self.n_agents)]
+        self.critic_optimizers = [FusedAdam([(mac.critic_arena, n)], lr=self.critic_lr, eps=self.optim_eps,
+                                            weight_decay=self.weight_decay) for n in range(self.n_agents)]
+        self.last_train_info = None
+        self.dp = None          # optional iplan_amd.parallel.DataParallel (gradient / statistic all-reduce)
+
+    def lr_decay(self, episode, episodes):
+        for n in range(self.n_agents):
+            update_linear_schedule(self.actor_optimizers[n], episode, episodes, self.lr)
+            update_linear_schedule(self.critic_optimizers[n], episode, episodes, self.critic_lr)
+
+    def insert_episode_batch(self, ep_batch):
+        """learners/ippo_learner.py:96-126 -- one strided copy per field for all agents."""
+        self.store.insert(ep_batch, min(self.batch_size_run, ep_batch.batch_size))
+
+    # ------------------------------------------------------------------------------------------ train
+    def _feature_spec(self, T, T_phys, last):
+        a, d = self.args, self.store.data
+        srcs = []
+        for key, w in self.mac._widths():
+            t = d[key]                                     # [bs, T1, nA, N, w]
+            srcs.append((t, w, t.stride(2), t.stride(1)))
+        return ops.AcFeatureSpec(a.max_vehicle_num, srcs, n_actions=a.n_actions if a.obs_last_action else 0,
+                                 last_action=last, la_strides=(1, self.n_agents),
+                                 n_id=self.n_agents if a.obs_agent_id else 0, T=T, T_phys=T_phys)
+
+    def train(self, t_env):
+        """learners/ippo_learner.py:227-317."""
+        if not self.buffers[0].can_sample():
+            return
+        print("TRAINING IPPO")
+        if self.use_linear_lr_decay:
+            self.lr_decay(t_env, self.t_max)
+        a, d, nA = self.args, self.store.data, self.n_agents
+        mac = self.mac
+        bs, T = self.store.size, self.episode_limit
+        T1 = T + 1
+        dev = self.device
+        f32 = dict(dtype=th.float32, device=dev)
+        # last-action index per stored step: action[0] at t = 0, action[t-1] after (dcntrl_controller.py:107)
+        acts = d["actions"][..., 0]                                        # [bs, T1, nA]
+        last = th.cat([acts[:, :1], acts[:, :-1]], dim=1).to(th.int32).contiguous()
+        ha, hc = d["rnn_states_actors"], d["rnn_states_critics"]            # [bs, T1, nA, M]
+        hs = (ha.stride(2), ha.stride(1))
+        avail = d["avail_actions"]
+        if avail.dtype != th.int32:
+            avail = avail.to(th.int32)
+        av_s = (avail.stride(2), avail.stride(1))
+        actions = d["actions"]
+        act_s = (actions.stride(2), actions.stride(1))
+        n_act = a.n_actions
+
+        # compute_returns (:344-365): critic on every stored step, GAE, advantage normalisation (:273-279)
+        spec_all = self._feature_spec(T1, T1, last)
+        v_all = ops.ac_forward(None, mac.critic_arena, 1, spec_all, bs * T1, nA, h_critic=hc, h_strides=hs,
+                               ksplit=1, want_h=False)["values"]
+        rw, tm = d["reward"], d["terminated"]
+        pp = L.PpoPrepareArgs()
+        pp.n_agents, pp.bs, pp.T = nA, bs, T
+        pp.reward, pp.rw_s_net, pp.rw_s_ep, pp.rw_s_t = rw.data_ptr(), rw.stride(2), rw.stride(0), rw.stride(1)
+        assert tm.dtype == th.uint8
+        pp.terminated, pp.tm_s_net, pp.tm_s_ep, pp.tm_s_t = tm.data_ptr(), tm.stride(2), tm.stride(0), tm.stride(1)
+        pp.values, pp.gamma, pp.lam = v_all.data_ptr(), self.gamma, self.gae_lambda
+        returns, adv, mask, vpred = (th.empty(nA, bs * T, **f32) for _ in range(4))
+        pp.returns, pp.adv, pp.mask, pp.value_preds = returns.data_ptr(), adv.data_ptr(), mask.data_ptr(), vpred.data_ptr()
+        lib = L.get_lib()
+        stream = L.current_stream(dev)
+        lib.call("iplan_ppo_prepare", pp, stream)
+        if self.dp is not None:
+            raise NotImplementedError("advantage statistics across ranks: use parallel.DataParallel.train_ippo")
+
+        # generate_data (:368-424): the first batch_size * T rows
+        rows = self.batch_size * T
+        spec = self._feature_spec(T, T1, last)
+        fwd_kw = dict(h_actor=ha, h_critic=hc, h_strides=hs, avail=avail, avail_strides=av_s, mode=2,
+                      actions_in=actions, act_strides=act_s, n_actions=n_act, ksplit=1, want_h=False)
+        old_logp = ops.ac_forward(mac.actor_arena, None, 0, spec, rows, nA, **fwd_kw)["logp"]
+        if bs * T != rows:                                   # pad to the [nA, bs*T] stride of adv / returns
+            tmp = th.zeros(nA, bs * T, **f32)
+            tmp[:, :rows] = old_logp
+            old_logp = tmp
+
+        pl = L.PpoLossArgs()
+        pl.n_agents, pl.rows, pl.row_stride = nA, rows, bs * T
+        pl.old_logp, pl.adv, pl.value_preds = old_logp.data_ptr(), adv.data_ptr(), vpred.data_ptr()
+        pl.returns, pl.mask = returns.data_ptr(), mask.data_ptr()
+        pl.clip, pl.huber_delta, pl.value_loss_coef = self.clip_param, self.huber_delta, self.value_loss_coef
+        g_logp, g_v = th.empty(nA, rows, **f32), th.empty(nA, rows, **f32)
+        stats = th.zeros(self.ppo_epoch, nA, 8, **f32)
+        norms = th.zeros(self.ppo_epoch, 2, nA, **f32)
+        pl.g_logp, pl.g_values = g_logp.data_ptr(), g_v.data_ptr()
+        max_norm = self.max_grad_norm if self._use_max_grad_norm else None
+        for ep in range(self.ppo_epoch):
+            out = ops.ac_forward(mac.actor_arena, mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True, **fwd_kw)
+            pl.logp, pl.entropy, pl.values = out["logp"].data_ptr(), out["entropy"].data_ptr(), out["values"].data_ptr()
+            pl.stats = stats[ep].data_ptr()
+            lib.call("iplan_ppo_loss", pl, stream)
+            ops.ac_backward(out, mac.actor_arena, mac.critic_arena, g_logp=g_logp,
+                            g_entropy=-self.entropy_coef / rows, g_values=g_v)
+            if self.dp is not None:
+                self.dp.all_reduce_grads(mac.actor_arena, mac.critic_arena)
+            sq_a = step_all(self.actor_optimizers, max_norm)
+            norms[ep, 0] = sq_a[:, 0]
+            sq_c = step_all(self.critic_optimizers, max_norm)
+            norms[ep, 1] = sq_c[:, 0]
+        self.store.clear()
+
+        # train_info (:305-310): averages over agents x epochs -- ONE host read-back
+        st = stats.mean(dim=(0, 1)).cpu()
+        nr = norms.sqrt().mean(dim=(0, 2)).cpu() if max_norm is not None else th.zeros(2)
+        train_info = {"value_loss": float(st[1]), "policy_loss": float(st[0]), "dist_entropy": float(st[3]),
+                      "actor_grad_norm": float(nr[0]), "critic_grad_norm": float(nr[1]), "ratio": float(st[2])}
+        self.last_train_info = train_info
+        if t_env - self.log_stats_t >= self.args.learner_log_interval:
+            for k, v in train_info.items():
+                self.logger.log_stat(self.log_prefix + k, v, t_env)
+
+    # ------------------------------------------------------------------------------------------ misc
+    def cuda(self):
+        self.mac.cuda()
+
+    def save_models(self, path):
+        self.mac.save_models(path)
+        for i in range(self.n_agents):
+            th.save(self.actor_optimizers[i].state_dict(), "{}/actor_{}_opt.th".format(path, i))
+            th.save(self.critic_optimizers[i].state_dict(), "{}/critic_{}_opt.th".format(path, i))
+
+    def load_models(self, paths, load_optimisers=False):
+        self.mac.load_models(paths)
+        if load_optimisers:
+            if len(paths) == 1:
+                paths = [copy.copy(paths[0]) for _ in range(self.n_agents)]
+            for i in range(self.n_agents):
+                self.actor_optimizers[i].load_state_dict(th.load("{}/actor_{}_opt.th".format(paths[i], i), map_location="cpu"))
+                self.critic_optimizers[i].load_state_dict(th.load("{}/critic_{}_opt.th".format(paths[i], i), map_location="cpu"))

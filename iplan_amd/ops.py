@@ -202,6 +202,8 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
         out["saved"] = torch.empty(2, n_agents, rows, L.AC_SAVE_FLOATS, **f32)
         a.saved = out["saved"].data_ptr()
     lib.call("iplan_ac_fwd", a, L.current_stream(dev))
+    out["_args"] = a
+    out["_keep"] = (spec, h_actor, h_critic, avail, q_noise, actions_in)
     return out
 
 
@@ -265,3 +267,94 @@ class Wgrad:
             ws = workspace(dev, need)
             a.workspace, a.workspace_floats = ws.data_ptr(), ws.numel()
             lib.call("iplan_wgrad", a, stream)
+
+
+def _ac_wgrad(w, arena, head_names, saved, dsave, which, n_agents, rows, T, h, h_strides, T_phys, n_out, tiles, ln_part):
+    """Weight-gradient problems of the 64-wide layers of one arena (actor or critic)."""
+    M, SF, DS = L.AC_HIDDEN, L.AC_SAVE_FLOATS, L.AC_DSAVE_FLOATS
+    sv = saved[which]                     # [n_agents, rows, SF]
+    ds = dsave[which]                     # [n_agents, rows, DS]
+    dptr, sptr = ds.data_ptr(), sv.data_ptr()
+    dst = (rows * DS, DS, DS)
+    sst = (rows * SF, SF, SF)
+    off = arena.off
+    # head: dY = dhead, X = f3 (slot 9)
+    w.add(dptr + 4 * 6 * M, dst, n_out, rows, 1, x=sptr + 4 * 9 * M, x_strides=sst, K=M,
+          dw_off=off(head_names[0]), db_off=off(head_names[1]))
+    # GRU input weights: dgi = [dr, dz, dn_i] (cols 0..3M of the gate block), X = f2 (slot 3)
+    w.add(dptr + 4 * 2 * M, dst, 3 * M, rows, 1, x=sptr + 4 * 3 * M, x_strides=sst, K=M,
+          dw_off=off("rnn.rnn.weight_ih_l0"), db_off=off("rnn.rnn.bias_ih_l0"))
+    # GRU hidden weights: dgh = [dr, dz, dn_h], X = the stored hidden state of the row (episode layout)
+    n_ep = rows // T
+    assert n_ep * T == rows
+    w.add(dptr + 4 * 2 * M, (rows * DS, T * DS, DS), 3 * M, n_ep, T, x=h, x_strides=(h_strides[0], T_phys * h_strides[1], h_strides[1]),
+          K=M, dw_off=off("rnn.rnn.weight_hh_l0"), db_off=off("rnn.rnn.bias_hh_l0"), seg=(2 * M, 0, 3 * M))
+    # fc2: dY = dz2, X = f1 (slot 1)
+    w.add(dptr + 4 * M, dst, M, rows, 1, x=sptr + 4 * M, x_strides=sst, K=M,
+          dw_off=off("base.mlp.fc2.0.0.weight"), db_off=off("base.mlp.fc2.0.0.bias"))
+    # fc1 bias (S of the fc1 finalize)
+    w.add(dptr, dst, M, rows, 1, db_off=off("base.mlp.fc1.0.bias"))
+    # LayerNorm affine parameters: column sums of the per-tile partials
+    lp = ln_part[which]                   # [n_agents, tiles, 6M]
+    lst = (tiles * 6 * M, 6 * M, 6 * M)
+    for k, name in enumerate(("rnn.norm", "base.mlp.fc2.0.2", "base.mlp.fc1.2")):
+        w.add(lp.data_ptr() + 4 * (2 * k) * M, lst, M, tiles, 1, db_off=off(name + ".weight"))
+        w.add(lp.data_ptr() + 4 * (2 * k + 1) * M, lst, M, tiles, 1, db_off=off(name + ".bias"))
+    w._keep += [sv, ds, lp]
+
+
+def ac_backward(fwd, actor_arena, critic_arena, g_logp=None, g_entropy=0.0, g_values=None, lib=None):
+    """Backward of an ``ac_forward(..., mode=2, save=True)`` launch: fills the gradient arenas of the
+    nets that took part.  g_logp / g_values [n_agents, rows]; g_entropy: per-row tensor or a constant."""
+    lib = _lib(lib)
+    fa = fwd["_args"]
+    which, n_agents, rows = fa.which, fa.n_agents, fa.rows
+    spec, h_actor, h_critic = fwd["_keep"][0], fwd["_keep"][1], fwd["_keep"][2]
+    saved = fwd["saved"]
+    dev = saved.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    a = L.AcBwdArgs()
+    a.fwd = fa
+    if which != 1:
+        assert g_logp.shape == (n_agents, rows) and g_logp.is_contiguous()
+        a.g_logp = g_logp.data_ptr()
+        if torch.is_tensor(g_entropy):
+            assert g_entropy.shape == (n_agents, rows) and g_entropy.is_contiguous()
+            a.g_entropy = g_entropy.data_ptr()
+        else:
+            a.g_entropy_const = float(g_entropy)
+        a.actor_grad = actor_arena.grad.data_ptr()
+        a.actor_grad_s_net = actor_arena.grad.stride(0)
+    if which != 0:
+        assert g_values.shape == (n_agents, rows) and g_values.is_contiguous()
+        a.g_values = g_values.data_ptr()
+        a.critic_grad = critic_arena.grad.data_ptr()
+        a.critic_grad_s_net = critic_arena.grad.stride(0)
+    tiles = (rows + 15) // 16
+    dsave = torch.empty(2, n_agents, rows, L.AC_DSAVE_FLOATS, **f32)
+    ln_part = torch.empty(2, n_agents, tiles, L.AC_LNPART_FLOATS, **f32)
+    a.dsave, a.ln_part = dsave.data_ptr(), ln_part.data_ptr()
+    F = spec.F
+    Fpad = (F + 63) // 64 * 64
+    chunk_rows = max(256, ((rows + 31) // 32 + 15) // 16 * 16)
+    chunks = (rows + chunk_rows - 1) // chunk_rows
+    n_which = 2 if which == 2 else 1
+    g_part = workspace(dev, n_which * n_agents * chunks * L.AC_HIDDEN * Fpad, "fc1")
+    a.g_part, a.fc1_chunk_rows, a.fc1_chunks = g_part.data_ptr(), chunk_rows, chunks
+    stream = L.current_stream(dev)
+    lib.call("iplan_ac_bwd_tail", a, stream)
+    lib.call("iplan_ac_bwd_fc1", a, stream)
+    T, T_phys = spec.T, spec.T_phys
+    hs = (fa.hs_net, fa.hs_row)
+    if which != 1:
+        w = Wgrad(actor_arena.grad, n_agents)
+        _ac_wgrad(w, actor_arena, ("act.action_out.linear.weight", "act.action_out.linear.bias"), saved, dsave, 0,
+                  n_agents, rows, T, h_actor.data_ptr(), hs, T_phys, fa.actor.n_out, tiles, ln_part)
+        w.run(lib)
+    if which != 0:
+        w = Wgrad(critic_arena.grad, n_agents)
+        _ac_wgrad(w, critic_arena, ("v_out.weight", "v_out.bias"), saved, dsave, 1,
+                  n_agents, rows, T, h_critic.data_ptr(), hs, T_phys, 1, tiles, ln_part)
+        w.run(lib)
+    lib.call("iplan_ac_bwd_fc1_finalize", a, stream)
+    return dict(dsave=dsave, ln_part=ln_part)

@@ -1,0 +1,62 @@
+"""CPU (host-emulated kernel build): the learners through the reference's own API vs fixtures recorded
+from the real reference (tests/golden/*_train.pt, *_learn.pt; oracle/make_golden.py)."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from iplan_amd import _lib as L
+from iplan_amd import synth
+from tests.emu.emu_lib import get_emu_lib
+
+
+@pytest.fixture(autouse=True)
+def emu():
+    L.use_library_for_tests(get_emu_lib())
+    yield
+    L.use_library_for_tests(None)
+
+
+class RecLogger:
+    def __init__(self):
+        self.stats = {}
+
+    def log_stat(self, k, v, t):
+        self.stats[k] = float(v)
+
+
+def max_rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return (a - b).abs().max().item() / max(1.0, b.abs().max().item())
+
+
+def check_ippo_train(g, device):
+    from iplan_amd.controllers.dcntrl_controller import DcntrlMAC
+    from iplan_amd.learners.ippo_learner import IPPOLearner
+    args = SimpleNamespace(**dict(g["args"], use_cuda=(device != "cpu")))
+    scheme = synth.make_scheme(args)
+    mac = DcntrlMAC(scheme, {"agents": args.n_agents}, args)
+    for i in range(args.n_agents):
+        mac.agents[i].load_state_dict(g["pre"]["actors"][i])
+        mac.critics[i].load_state_dict(g["pre"]["critics"][i])
+    log = RecLogger()
+    learner = IPPOLearner(mac, scheme, log, args)
+    E = g["fields"]["history"].shape[0]
+    batch = synth.DictBatch(g["fields"], E, args.episode_limit + 1).to(device)
+    learner.insert_episode_batch(batch)
+    assert learner.buffers[0].can_sample()
+    learner.train(0)
+    assert not learner.buffers[0].can_sample()
+    for i in range(args.n_agents):
+        for name, mods in (("actors", mac.agents), ("critics", mac.critics)):
+            sd = mods[i].state_dict()
+            for k, ref in g["post"][name][i].items():
+                assert max_rel(sd[k], ref) < 2e-5, (name, i, k, max_rel(sd[k], ref))
+    for k, ref in g["stats"].items():
+        got = log.stats[k]
+        assert abs(got - ref) <= 2e-5 * max(1.0, abs(ref)), (k, got, ref)
+
+
+@pytest.mark.parametrize("tag", ["ippo_train", "ippo_train_mpe"])
+def test_ippo_train_emulated(golden, tag):
+    check_ippo_train(golden(tag), "cpu")
