@@ -74,15 +74,15 @@ enum {
     IPLAN_GAT_NPARAM
 };
 
-/* Activations kept for the backward pass (all [n_nets, B, ...] contiguous; NULL = inference). */
+/* Activations kept for the backward pass (contiguous; NULL = inference).  Rows are (b, i) = b*N + i. */
 typedef struct {
-    float* h_enc;   /* [n_nets,B,N,H]            ReLU(encoding(obs))                         */
-    float* gru;     /* [n_nets,B,2,N,N-1,5,H]    per pair-step and direction: h, r, z, n, hn */
-    float* qkv;     /* [n_nets,B,3,N,A]          q, k, v                                     */
-    float* soft;    /* [n_nets,B,N,N-1]          soft attention weights                      */
-    float* hard;    /* [n_nets,B,N,N-1]          gumbel-softmax class-1 weights              */
-    float* x;       /* [n_nets,B,N,A]            aggregated neighbour feature                */
-    float* cell;    /* [n_nets,B,N,4,A]          GRUCell r, z, n, hn                         */
+    float* h_enc;   /* [n_nets, B*N, H]              ReLU(encoding(obs))                          */
+    float* gru;     /* [n_nets, 2, B*N, N-1, 5H]     per direction and pair step: h, r, z, n, hn  */
+    float* qkv;     /* [n_nets, B*N, 3A]             q | k | v                                    */
+    float* soft;    /* [n_nets, B*N, N-1]            soft attention weights                       */
+    float* hard;    /* [n_nets, B*N, N-1]            gumbel-softmax class-1 weights               */
+    float* x;       /* [n_nets, B*N, A]              aggregated neighbour feature                 */
+    float* cell;    /* [n_nets, B*N, 4A]             GRUCell r, z, n, hn                          */
 } IplanGatSaved;
 
 typedef struct {
@@ -373,6 +373,29 @@ typedef struct {
 } IplanPpoLossArgs;
 
 int iplan_ppo_loss(const IplanPpoLossArgs* args, iplan_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward of GAT_Net.forward (autograd under loss.backward() at nova/prediction_policy.py:228) for
+ * every (net, env) scene in one launch: GRUCell', gated soft attention', gumbel gate', BPTT through
+ * the bidirectional pair GRU, node projections'.  Emits row-level pre-activation gradients; the
+ * weight gradients are iplan_wgrad contractions over them (host assembles the problem list).
+ * node_dy row layout (floats): ENC 0 (H) | DA_fwd 32 | DB_fwd 128 | DA_rev 224 | DB_rev 320 (3H each)
+ *                              | DQ 416 | DK 448 | DV 480 (A each) | CELL 512 (dr dz dn_i dn_h, 4A).
+ * hard_part row (per scene): [dir][tile<4][H] partial sums of dDelta * h, then sum(dDelta) at 8H.
+ */
+#define IPLAN_GAT_NODE_DY 640
+#define IPLAN_GAT_HARD_PART (8 * IPLAN_GAT_HIDDEN + 16)
+
+typedef struct {
+    IplanGatFwdArgs fwd;        /* descriptor of the forward launch (saved.* all non-NULL)           */
+    const float* g_out;         /* dLoss/d out, rows of A floats: (net,b,i)                          */
+    int64_t g_s_net, g_s_b;
+    float* dgru;                /* [n_nets, 2, B*N, N-1, 4H]   dr dz dn_i dn_h per pair step         */
+    float* node_dy;             /* [n_nets, B*N, IPLAN_GAT_NODE_DY]                                  */
+    float* hard_part;           /* [n_nets, B, IPLAN_GAT_HARD_PART]                                  */
+} IplanGatBwdArgs;
+
+int iplan_gat_bwd(const IplanGatBwdArgs* args, iplan_stream_t stream);
 
 #ifdef __cplusplus
 }

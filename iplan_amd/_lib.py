@@ -49,7 +49,7 @@ class IplanError(RuntimeError):
 
 # every entry point include/iplan_hip.h declares
 ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step", "iplan_wgrad",
-                "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_loss"]
+                "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_loss", "iplan_gat_bwd"]
 RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats"]      # non (args*, stream) signatures
 
 
@@ -244,3 +244,13 @@ class PpoLossArgs(C.Structure):
         ("clip", C.c_float), ("huber_delta", C.c_float), ("value_loss_coef", C.c_float),
         ("g_logp", fp), ("g_values", fp), ("stats", fp),
     ]
+
+
+# ---- GAT backward --------------------------------------------------------------------------------------
+GAT_NODE_DY = 640
+GAT_HARD_PART = 8 * 32 + 16
+
+
+class GatBwdArgs(C.Structure):
+    _fields_ = [("fwd", GatFwdArgs), ("g_out", fp), ("g_s_net", i64), ("g_s_b", i64),
+                ("dgru", fp), ("node_dy", fp), ("hard_part", fp)]

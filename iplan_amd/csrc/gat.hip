@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
                     for (int T = 0; T < 2; ++T) ac = mma_block(wfrag(Wm, GH, GH, GH, 16 * t, 16 * T), h[T], ac);
                     if (valid)
                         for (int q = 0; q < 4; ++q) dst[node][16 * t + 4 * g + q] = ac[q];
-                    if (sv.qkv) vstore(sv.qkv + ((sb * 3 + which) * N + node) * GH, valid, GH, t, ac);
+                    if (sv.qkv) vstore(sv.qkv + ((sb * N + node) * 3 + which) * GH, valid, GH, t, ac);
                 }
             }
         } else {
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
                 ac = relu4(ac);
                 if (valid)
                     for (int q = 0; q < 4; ++q) s_v[node][16 * t + 4 * g + q] = ac[q];
-                if (sv.qkv) vstore(sv.qkv + ((sb * 3 + 2) * N + node) * GH, valid, GH, t, ac);
+                if (sv.qkv) vstore(sv.qkv + ((sb * N + node) * 3 + 2) * GH, valid, GH, t, ac);
             }
         }
     }
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
             h0 = o0.h;
             h1 = o1.h;
             if (sv.gru) {
-                float* row = sv.gru + ((((sb * 2 + dir) * N + node) * (N - 1)) + s) * (5 * GH);
+                float* row = sv.gru + (((((int64_t)net * 2 + dir) * a.B + b) * N + node) * (N - 1) + s) * (5 * GH);
                 vstore(row, valid, GH, 0, o0.h);          vstore(row, valid, GH, 1, o1.h);
                 vstore(row + GH, valid, GH, 0, o0.r);     vstore(row + GH, valid, GH, 1, o1.r);
                 vstore(row + 2 * GH, valid, GH, 0, o0.z); vstore(row + 2 * GH, valid, GH, 1, o1.z);

@@ -60,17 +60,20 @@ def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None
     if save:
         H = A
         saved = dict(
-            h_enc=torch.empty(n_nets, B, N, H, device=dev),
-            gru=torch.empty(n_nets, B, 2, N, N - 1, 5, H, device=dev),
-            qkv=torch.empty(n_nets, B, 3, N, A, device=dev),
-            soft=torch.empty(n_nets, B, N, N - 1, device=dev),
-            hard=torch.empty(n_nets, B, N, N - 1, device=dev),
-            x=torch.empty(n_nets, B, N, A, device=dev),
-            cell=torch.empty(n_nets, B, N, 4, A, device=dev),
+            h_enc=torch.empty(n_nets, B * N, H, device=dev),
+            gru=torch.empty(n_nets, 2, B * N, N - 1, 5 * H, device=dev),
+            qkv=torch.empty(n_nets, B * N, 3 * A, device=dev),
+            soft=torch.empty(n_nets, B * N, N - 1, device=dev),
+            hard=torch.empty(n_nets, B * N, N - 1, device=dev),
+            x=torch.empty(n_nets, B * N, A, device=dev),
+            cell=torch.empty(n_nets, B * N, 4 * A, device=dev),
         )
         for k, v in saved.items():
             setattr(a.saved, k, v.data_ptr())
     lib.call("iplan_gat_fwd", a, L.current_stream(dev))
+    if saved is not None:
+        saved["_args"] = a
+        saved["_keep"] = (src0, src1, h_prev, noise, out)
     return out, saved
 
 
@@ -358,3 +361,70 @@ def ac_backward(fwd, actor_arena, critic_arena, g_logp=None, g_entropy=0.0, g_va
         w.run(lib)
     lib.call("iplan_ac_bwd_fc1_finalize", a, stream)
     return dict(dsave=dsave, ln_part=ln_part)
+
+
+def gat_backward(arena, saved, g_out, lib=None):
+    """Backward of a ``gat_forward(..., save=True)`` launch.  g_out [n_nets, B, N, A] (first two dims may
+    be strided).  Fills arena.grad (every GAT parameter of every net)."""
+    lib = _lib(lib)
+    fa = saved["_args"]
+    src0, src1, h_prev = saved["_keep"][0], saved["_keep"][1], saved["_keep"][2]
+    n_nets, B, N, d0, d1 = fa.n_nets, fa.B, fa.N, fa.d0, fa.d1
+    H = A = 32
+    dev = g_out.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    a = L.GatBwdArgs()
+    a.fwd = fa
+    a.g_out = g_out.data_ptr()
+    a.g_s_net, a.g_s_b = _nb_strides(g_out, N * A)
+    dgru = torch.empty(n_nets, 2, B * N, N - 1, 4 * H, **f32)
+    node_dy = torch.empty(n_nets, B * N, L.GAT_NODE_DY, **f32)
+    hard_part = torch.empty(n_nets, B, L.GAT_HARD_PART, **f32)
+    a.dgru, a.node_dy, a.hard_part = dgru.data_ptr(), node_dy.data_ptr(), hard_part.data_ptr()
+    lib.call("iplan_gat_bwd", a, L.current_stream(dev))
+
+    w = Wgrad(arena.grad, n_nets)
+    off = arena.off
+    DYW = L.GAT_NODE_DY
+    nd = node_dy.data_ptr()
+    nst = (B * N * DYW, N * DYW, DYW)                       # rows (b, i)
+    D = d0 + d1
+    # encoding: dY = ENC, X = [src0 || src1] rows
+    w.add(nd, nst, H, B, N, x=src0, x_strides=(src0.stride(0), src0.stride(1), d0), K=d0,
+          dw_off=off("encoding.weight"), dw_ld=D, db_off=off("encoding.bias"))
+    if d1 > 0:
+        w.add(nd, nst, H, B, N, x=src1, x_strides=(src1.stride(0), src1.stride(1), d1), K=d1,
+              dw_off=off("encoding.weight"), dw_ld=D, dw_col0=d0)
+    he = saved["h_enc"]
+    hst = (B * N * H, N * H, H)
+    gru = saved["gru"]
+    P1 = N - 1
+    for dr, sfx in ((0, ""), (1, "_reverse")):
+        # separable input projection: W_ih = [W_a | W_b]
+        w.add(nd + 4 * (32 + dr * 192), nst, 3 * H, B, N, x=he, x_strides=hst, K=H,
+              dw_off=off("hard_bi_GRU.weight_ih_l0" + sfx), dw_ld=2 * H, db_off=off("hard_bi_GRU.bias_ih_l0" + sfx))
+        w.add(nd + 4 * (128 + dr * 192), nst, 3 * H, B, N, x=he, x_strides=hst, K=H,
+              dw_off=off("hard_bi_GRU.weight_ih_l0" + sfx), dw_ld=2 * H, dw_col0=H)
+        # recurrent weights: pair level, previous state = the neighbouring pair step of the same ego
+        w.add(dgru.data_ptr() + 4 * dr * (B * N * P1 * 4 * H), (2 * B * N * P1 * 4 * H, P1 * 4 * H, 4 * H), 3 * H, B * N, P1,
+              x=gru.data_ptr() + 4 * dr * (B * N * P1 * 5 * H), x_strides=(2 * B * N * P1 * 5 * H, P1 * 5 * H, 5 * H), K=H,
+              dw_off=off("hard_bi_GRU.weight_hh_l0" + sfx), db_off=off("hard_bi_GRU.bias_hh_l0" + sfx),
+              seg=(2 * H, 0, 3 * H), x_shift=(1 if dr else -1))
+        # hard_encoding.weight[c][dr*H : (dr+1)*H] = -/+ sum dDelta * h  (per-scene partials from the kernel)
+        for c, sc in ((0, -1.0), (1, 1.0)):
+            w.add(hard_part.data_ptr() + 4 * dr * 4 * H, (B * L.GAT_HARD_PART, L.GAT_HARD_PART, H), H, B, 4,
+                  db_off=off("hard_encoding.weight") + c * 2 * H + dr * H, scale=sc)
+    for c, sc in ((0, -1.0), (1, 1.0)):
+        w.add(hard_part.data_ptr() + 4 * 8 * H, (B * L.GAT_HARD_PART, L.GAT_HARD_PART, L.GAT_HARD_PART), 1, B, 1,
+              db_off=off("hard_encoding.bias") + c, scale=sc)
+    w.add(nd + 4 * 416, nst, A, B, N, x=he, x_strides=hst, K=H, dw_off=off("q.weight"))
+    w.add(nd + 4 * 448, nst, A, B, N, x=he, x_strides=hst, K=H, dw_off=off("k.weight"))
+    w.add(nd + 4 * 480, nst, A, B, N, x=he, x_strides=hst, K=H, dw_off=off("v.weight"), db_off=off("v.bias"))
+    xs = saved["x"]
+    w.add(nd + 4 * 512, nst, 3 * A, B, N, x=xs, x_strides=(B * N * A, N * A, A), K=A,
+          dw_off=off("rnn.weight_ih"), db_off=off("rnn.bias_ih"))
+    w.add(nd + 4 * 512, nst, 3 * A, B, N, x=h_prev, x_strides=(h_prev.stride(0), h_prev.stride(1), A), K=A,
+          dw_off=off("rnn.weight_hh"), db_off=off("rnn.bias_hh"), seg=(2 * A, 0, 3 * A))
+    w._keep += [dgru, node_dy, hard_part, saved]
+    w.run(lib)
+    return dict(dgru=dgru, node_dy=node_dy, hard_part=hard_part)
