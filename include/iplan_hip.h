@@ -397,6 +397,49 @@ typedef struct {
 
 int iplan_gat_bwd(const IplanGatBwdArgs* args, iplan_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Prediction_Decoder.forward (nova/prediction_net.py:40-63; DecoderRNN :6-26) + the masked-L1 loss
+ * of Prediction_policy.learn (nova/prediction_policy.py:223-225), and their backward.
+ * Rows are (sample s, entity i) = s*N + i; hidden size == 32; d <= 16.
+ * Parameter tensors of DecoderRNN in state_dict order (also used by the behaviour decoder):
+ */
+enum {
+    IPLAN_DEC_LIN_W = 0,    /* decoder.linear.weight      [Hd, In]   */
+    IPLAN_DEC_LIN_B,        /* decoder.linear.bias        [Hd]       */
+    IPLAN_DEC_WIH,          /* decoder.rnn.weight_ih_l0   [3Hd, Hd]  */
+    IPLAN_DEC_WHH,          /* decoder.rnn.weight_hh_l0   [3Hd, Hd]  */
+    IPLAN_DEC_BIH,          /* decoder.rnn.bias_ih_l0     [3Hd]      */
+    IPLAN_DEC_BHH,          /* decoder.rnn.bias_hh_l0     [3Hd]      */
+    IPLAN_DEC_OUT_W,        /* decoder.out.weight         [d, Hd]    */
+    IPLAN_DEC_OUT_B,        /* decoder.out.bias           [d]        */
+    IPLAN_DEC_NPARAM
+};
+#define IPLAN_PDEC_SAVE 256   /* per (row, step): xin 0 (16) | u 16 | r 48 | z 80 | n 112 | hn 144 | h 176 | a 208 (32 each) | y 240 (16) */
+#define IPLAN_PDEC_DSAVE 176  /* per (row, step): dy 0 (16) | du 16 | dr 48 | dz 80 | dn_i 112 | dn_h 144 (32 each)                      */
+
+typedef struct {
+    int32_t n_nets, rows, N, P, d;
+    const float* x0;            /* [n_nets, rows, d]     current state (decoder input of step 0)        */
+    const float* h0;            /* [n_nets, rows, 32]    GAT output = initial hidden state              */
+    const float* target;        /* [n_nets, rows, P, d]  actual next states                             */
+    const float* mask;          /* [n_nets, rows / N]    per-sample mask                                */
+    const float* keep;          /* [n_nets, P, rows, 32] dropout keep flags {0,1}; NULL = no dropout    */
+    float drop_p;
+    const int32_t* teacher;     /* [n_nets, P] 1 = feed the actual state to the next step; NULL = never */
+    const float* params;
+    int64_t params_s_net;
+    int64_t off[IPLAN_DEC_NPARAM];
+    float* pred;                /* [n_nets, rows, P, d]                                                 */
+    float* saved;               /* [n_nets, rows, P, IPLAN_PDEC_SAVE]                                   */
+    float* loss_part;           /* [n_nets, ceil(rows/16)]                                              */
+    float* loss;                /* [n_nets]  sum|target-pred|*m / (sum m + 1e-10) * d * P               */
+    float* dsave;               /* backward: [n_nets, rows, P, IPLAN_PDEC_DSAVE]                        */
+    float* g_h0;                /* backward: [n_nets, rows, 32] dLoss/d h0                              */
+} IplanPdecArgs;
+
+int iplan_pdec_fwd(const IplanPdecArgs* args, iplan_stream_t stream);
+int iplan_pdec_bwd(const IplanPdecArgs* args, iplan_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

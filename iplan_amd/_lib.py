@@ -49,7 +49,8 @@ class IplanError(RuntimeError):
 
 # every entry point include/iplan_hip.h declares
 ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step", "iplan_wgrad",
-                "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_loss", "iplan_gat_bwd"]
+                "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_loss", "iplan_gat_bwd",
+                "iplan_pdec_fwd", "iplan_pdec_bwd"]
 RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats"]      # non (args*, stream) signatures
 
 
@@ -254,3 +255,18 @@ GAT_HARD_PART = 8 * 32 + 16
 class GatBwdArgs(C.Structure):
     _fields_ = [("fwd", GatFwdArgs), ("g_out", fp), ("g_s_net", i64), ("g_s_b", i64),
                 ("dgru", fp), ("node_dy", fp), ("hard_part", fp)]
+
+
+# ---- prediction decoder ------------------------------------------------------------------------------
+DEC_PARAM_ORDER = ["decoder.linear.weight", "decoder.linear.bias", "decoder.rnn.weight_ih_l0", "decoder.rnn.weight_hh_l0",
+                   "decoder.rnn.bias_ih_l0", "decoder.rnn.bias_hh_l0", "decoder.out.weight", "decoder.out.bias"]
+PDEC_SAVE, PDEC_DSAVE = 256, 176
+
+
+class PdecArgs(C.Structure):
+    _fields_ = [
+        ("n_nets", i32), ("rows", i32), ("N", i32), ("P", i32), ("d", i32),
+        ("x0", fp), ("h0", fp), ("target", fp), ("mask", fp), ("keep", fp), ("drop_p", C.c_float),
+        ("teacher", fp), ("params", fp), ("params_s_net", i64), ("off", i64 * len(DEC_PARAM_ORDER)),
+        ("pred", fp), ("saved", fp), ("loss_part", fp), ("loss", fp), ("dsave", fp), ("g_h0", fp),
+    ]

@@ -12,7 +12,7 @@ import torch
 
 from .. import ops
 from ..arena import ParamArena
-from ..optim import FusedAdam
+from ..optim import FusedAdam, step_all
 from .GAT_Net import GAT_Net, gumbel_noise
 from .prediction_net import Prediction_Decoder
 
@@ -84,6 +84,68 @@ class Prediction_policy:
         out, _ = ops.gat_forward(self.gat_arena, hist.permute(1, 0, 2, 3), lat, hid.permute(1, 0, 2, 3), noise)
         out = out.permute(1, 0, 2, 3)          # [E, nA, N, A] view
         return out.cpu().numpy() if as_np else out
+
+
+    # ---------------------------------------------------------------------------- learning
+    def _sample(self, n_thread, avail_len):
+        """The host-side random draws of one agent in the reference's order: the (episode, t) sample of
+        prediction_batch_wrapper (nova/prediction_policy.py:146) and the per-step teacher-forcing coin
+        of Prediction_Decoder.forward (nova/prediction_net.py:56; drawn even at ratio 0)."""
+        sel = np.random.choice(n_thread * avail_len, size=self.prediction_batch_size, replace=False)
+        coins = [np.random.random() < self.args.teacher_forcing_ratio for _ in range(self.pred_length)]
+        return sel, coins
+
+    def learn(self, batch, t_env, noise=None, keep=None):
+        """nova/prediction_policy.py:168-253 for all agents at once: sample -> fused GAT forward ->
+        decoder forward + masked L1 -> decoder backward -> GAT backward -> weight gradients ->
+        separate clip of the GAT and decoder groups -> Adam.  ``noise`` (gumbel, [nA, S, N, N-1, 2]) and
+        ``keep`` (dropout keep flags, [nA, P, S*N, A]) may be injected; by default they are drawn from
+        torch's generator on the device.  Returns the list of n_agents losses (numpy scalars)."""
+        a = self.args
+        dev = self.device
+        nA, N, S, P = self.n_agents, self.max_vehicle_num, self.prediction_batch_size, self.pred_length
+        history = batch["history"][:, :-1].to(device=dev, dtype=torch.float32)
+        attention = batch["attention_latent"][:, :-1].to(device=dev, dtype=torch.float32)
+        latent = batch["behavior_latent"][:, :-1].to(device=dev, dtype=torch.float32)
+        term = batch["terminated"][:, :-1].to(dev)
+        E, T = history.shape[:2]
+        d = history.shape[-1]
+        avail_len = T - P - 1
+        sels, coins = zip(*[self._sample(E, avail_len) for _ in range(nA)])
+        sel = torch.as_tensor(np.stack(sels), dtype=torch.long, device=dev)        # [nA, S]
+        bi, ti = sel // avail_len, sel % avail_len
+        ag = torch.arange(nA, device=dev)[:, None].expand(nA, S)
+        # gathers = data movement only (prediction_batch_wrapper, :123-164)
+        x0 = history[bi, ti, ag].contiguous()                                      # [nA, S, N, d]
+        att = attention[bi, ti, ag].contiguous()                                   # [nA, S, N, A]
+        lat = latent[bi, ti, ag].contiguous() if a.GAT_use_behavior else None
+        steps = ti[:, :, None] + 1 + torch.arange(P, device=dev)[None, None, :]
+        actual = history[bi[:, :, None], steps, ag[:, :, None]].permute(0, 1, 3, 2, 4).contiguous()   # [nA, S, N, P, d]
+        mask = term[bi, ti, ag, 0].to(torch.float32).contiguous()                  # [nA, S]  (polarity as the reference: :191)
+        if noise is None:
+            noise = gumbel_noise((nA, S, N, N - 1, 2), dev)
+        if keep is None and a.decoder_dropout > 0:
+            keep = torch.empty(nA, P, S * N, a.attention_dim, device=dev).bernoulli_(1.0 - a.decoder_dropout)
+        teacher = None
+        if any(any(c) for c in coins):
+            teacher = torch.as_tensor(np.array(coins, dtype=np.int32), device=dev).contiguous()
+        hid, saved = ops.gat_forward(self.gat_arena, x0, lat, att, noise, save=True)
+        fwd = ops.pdec_forward(self.dec_arena, x0.reshape(nA, S * N, d), hid.reshape(nA, S * N, -1),
+                               actual.reshape(nA, S * N, P, d), mask, N, keep=keep, drop_p=a.decoder_dropout, teacher=teacher)
+        g_h0 = ops.pdec_backward(self.dec_arena, fwd)
+        ops.gat_backward(self.gat_arena, saved, g_h0.reshape(nA, S, N, -1))
+        if getattr(self, "dp", None) is not None:
+            self.dp.all_reduce_grads(self.gat_arena, self.dec_arena)
+        sq = step_all(self.pred_optimizer, self.max_grad_norm if self._use_max_grad_norm else None)
+        host = torch.cat([fwd["loss"], sq.sqrt().reshape(-1)]).cpu()              # ONE host read-back
+        losses = host[:nA].numpy()
+        norms = host[nA:].reshape(nA, 2)
+        train_info = {"prediction_loss": float(losses.sum()), "pred_encoder_grad_norm": float(norms[:, 0].sum()),
+                      "pred_decoder_grad_norm": float(norms[:, 1].sum())}
+        if t_env - self.log_stats_t >= self.args.learner_log_interval:
+            for k, v in train_info.items():
+                self.logger.log_stat(self.log_prefix + k, v, t_env)
+        return [np.asarray(x) for x in losses]
 
     # ---------------------------------------------------------------------------- checkpoints
     def save_models(self, path):

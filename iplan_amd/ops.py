@@ -428,3 +428,66 @@ def gat_backward(arena, saved, g_out, lib=None):
     w._keep += [dgru, node_dy, hard_part, saved]
     w.run(lib)
     return dict(dgru=dgru, node_dy=node_dy, hard_part=hard_part)
+
+
+# ---- prediction decoder --------------------------------------------------------------------------------
+def pdec_forward(arena, x0, h0, target, mask, N, keep=None, drop_p=0.0, teacher=None, lib=None):
+    """Prediction_Decoder.forward + masked-L1 loss for all nets.  x0 [n_nets, rows, d], h0 [n_nets, rows, 32],
+    target [n_nets, rows, P, d], mask [n_nets, rows // N], keep [n_nets, P, rows, 32] or None, teacher int32
+    [n_nets, P] or None.  Returns dict(pred, loss [n_nets], saved, ...)."""
+    lib = _lib(lib)
+    n_nets, rows, d = x0.shape
+    P = target.shape[2]
+    dev = x0.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    for t in (x0, h0, target, mask):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    assert h0.shape == (n_nets, rows, 32) and target.shape == (n_nets, rows, P, d) and mask.shape == (n_nets, rows // N)
+    a = L.PdecArgs()
+    a.n_nets, a.rows, a.N, a.P, a.d = n_nets, rows, N, P, d
+    a.x0, a.h0, a.target, a.mask = x0.data_ptr(), h0.data_ptr(), target.data_ptr(), mask.data_ptr()
+    if keep is not None:
+        assert keep.shape == (n_nets, P, rows, 32) and keep.is_contiguous() and keep.dtype == torch.float32
+        a.keep = keep.data_ptr()
+    a.drop_p = drop_p
+    if teacher is not None:
+        assert teacher.dtype == torch.int32 and teacher.shape == (n_nets, P) and teacher.is_contiguous()
+        a.teacher = teacher.data_ptr()
+    a.params, a.params_s_net = arena.data.data_ptr(), arena.net_stride
+    for i, k in enumerate(L.DEC_PARAM_ORDER):
+        a.off[i] = arena.off(k)
+    tiles = (rows + 15) // 16
+    out = dict(pred=torch.empty(n_nets, rows, P, d, **f32), saved=torch.empty(n_nets, rows, P, L.PDEC_SAVE, **f32),
+               loss_part=torch.empty(n_nets, tiles, **f32), loss=torch.empty(n_nets, **f32))
+    a.pred, a.saved, a.loss_part, a.loss = (out[k].data_ptr() for k in ("pred", "saved", "loss_part", "loss"))
+    lib.call("iplan_pdec_fwd", a, L.current_stream(dev))
+    out["_args"] = a
+    out["_keep"] = (x0, h0, target, mask, keep, teacher)
+    return out
+
+
+def pdec_backward(arena, fwd, lib=None):
+    """Backward of pdec_forward's loss (d loss = 1 per net): fills arena.grad, returns dLoss/dh0 [n_nets, rows, 32]."""
+    lib = _lib(lib)
+    a = fwd["_args"]
+    n_nets, rows, P, d = a.n_nets, a.rows, a.P, a.d
+    h0 = fwd["_keep"][1]
+    dev = h0.device
+    dsave = torch.empty(n_nets, rows, P, L.PDEC_DSAVE, dtype=torch.float32, device=dev)
+    g_h0 = torch.empty(n_nets, rows, 32, dtype=torch.float32, device=dev)
+    a.dsave, a.g_h0 = dsave.data_ptr(), g_h0.data_ptr()
+    lib.call("iplan_pdec_bwd", a, L.current_stream(dev))
+    SV, DS, H = L.PDEC_SAVE, L.PDEC_DSAVE, 32
+    sv, dp = fwd["saved"].data_ptr(), dsave.data_ptr()
+    sst, dst = (rows * P * SV, P * SV, SV), (rows * P * DS, P * DS, DS)
+    off = arena.off
+    w = Wgrad(arena.grad, n_nets)
+    w.add(dp, dst, d, rows, P, x=sv + 4 * 208, x_strides=sst, K=H, dw_off=off("decoder.out.weight"), db_off=off("decoder.out.bias"))
+    w.add(dp + 4 * 48, dst, 3 * H, rows, P, x=sv + 4 * 16, x_strides=sst, K=H,
+          dw_off=off("decoder.rnn.weight_ih_l0"), db_off=off("decoder.rnn.bias_ih_l0"))
+    w.add(dp + 4 * 48, dst, 3 * H, rows, P, x=sv + 4 * 176, x_strides=sst, K=H, x_shift=-1, x0=h0, x0_strides=(rows * H, H),
+          dw_off=off("decoder.rnn.weight_hh_l0"), db_off=off("decoder.rnn.bias_hh_l0"), seg=(2 * H, 0, 3 * H))
+    w.add(dp + 4 * 16, dst, H, rows, P, x=sv, x_strides=sst, K=d, dw_off=off("decoder.linear.weight"), db_off=off("decoder.linear.bias"))
+    w._keep += [dsave, fwd]
+    w.run(lib)
+    return g_h0

@@ -60,3 +60,33 @@ def check_ippo_train(g, device):
 @pytest.mark.parametrize("tag", ["ippo_train", "ippo_train_mpe"])
 def test_ippo_train_emulated(golden, tag):
     check_ippo_train(golden(tag), "cpu")
+
+
+def check_prediction_learn(g, device):
+    import numpy as np
+    from iplan_amd.nova.prediction_policy import Prediction_policy
+    args = SimpleNamespace(**dict(g["args"], use_cuda=(device != "cpu")))
+    pol = Prediction_policy(args, RecLogger())
+    nA, N, S, P = args.n_agents, args.max_vehicle_num, args.pred_batch_size, args.pred_length
+    for i in range(nA):
+        pol.pred_GAT[i].load_state_dict(g["pre"]["gat"][i])
+        pol.pred_decoder[i].load_state_dict(g["pre"]["dec"][i])
+    E = g["fields"]["history"].shape[0]
+    batch = synth.DictBatch(g["fields"], E, args.episode_limit + 1).to(device)
+    noise = torch.stack([x.reshape(S, N, N - 1, 2) for x in g["gumbel"]]).to(device)
+    keep = torch.stack([torch.stack([g["dropout"][i * P + p].reshape(S * N, -1) for p in range(P)]) for i in range(nA)]).to(device)
+    np.random.seed(g["np_seed"])
+    losses = pol.learn(batch, 0, noise=noise, keep=keep.float().contiguous())
+    for i in range(nA):
+        assert abs(float(losses[i]) - g["losses"][i]) <= 1e-5 * max(1.0, abs(g["losses"][i])), (i, losses[i], g["losses"][i])
+        for name, mods, arena in (("gat", pol.pred_GAT, pol.gat_arena), ("dec", pol.pred_decoder, pol.dec_arena)):
+            for k, ref in g["clipped"][name][i].items():
+                got = arena.grad_of(i, k).cpu()
+                assert max_rel(got, ref) < 2e-5, ("clipped grad", name, i, k, max_rel(got, ref))
+            sd = mods[i].state_dict()
+            for k, ref in g["post"][name][i].items():
+                assert max_rel(sd[k], ref) < 1e-6, ("post", name, i, k, max_rel(sd[k], ref))
+
+
+def test_prediction_learn_emulated(golden):
+    check_prediction_learn(golden("prediction_learn"), "cpu")
