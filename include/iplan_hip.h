@@ -440,6 +440,51 @@ typedef struct {
 int iplan_pdec_fwd(const IplanPdecArgs* args, iplan_stream_t stream);
 int iplan_pdec_bwd(const IplanPdecArgs* args, iplan_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Behavior_policy.learn, soft update (nova/stable_behavior_policy.py:161-279): the whole episode of
+ * every (env, entity) chain of every agent-net in one forward and one backward launch.
+ * Encoder parameters: IPLAN_ENC_* (EncoderRNN); decoder parameters: IPLAN_DEC_* of
+ * behavior_decoder[i].decoder (DecoderRNN, input d + Z, hidden 64).  rows = E * N, J = T - 1 - L.
+ * Per-step records (floats):
+ *   saved_dec  x 0 (16) | latent 16 (16) | u 32 | r 96 | z 160 | n 224 | hn 288 | h 352 | a 416 (64 each) | y 480 (16)
+ *   saved_enc  u 0 | r 32 | z 64 | n 96 | hn 128 | h 160 (32 each)
+ *   dsave_dec  dy 0 (16) | du 16 | dr 80 | dz 144 | dn_i 208 | dn_h 272 (64 each)
+ *   dsave_enc  du 0 | dr 32 | dz 64 | dn_i 96 | dn_h 128 (32 each)
+ */
+#define IPLAN_BEH_SAVE_DEC 496
+#define IPLAN_BEH_SAVE_ENC 192
+#define IPLAN_BEH_SAVE_LAT 16
+#define IPLAN_BEH_DSAVE_DEC 336
+#define IPLAN_BEH_DSAVE_ENC 160
+#define IPLAN_BEH_DSAVE_LAT 16
+
+typedef struct {
+    int32_t n_nets, E, N, T, L, d, Z;  /* T = stored steps used (= episode_limit)                      */
+    const float* hist;          /* x(net,e,t,i,c) = hist[net*h_s_net + e*h_s_e + t*h_s_t + i*d + c]     */
+    int64_t h_s_net, h_s_e, h_s_t;
+    const float* mask;          /* [n_nets, E, T] loss mask (env-dependent polarity applied by caller)  */
+    const uint8_t* keep;        /* [n_nets, J, rows, L, 64] dropout keep flags; NULL = drawn in-kernel  */
+    uint64_t seed;              /* seed of the in-kernel counter-based Bernoulli draw                   */
+    float drop_p, coef, thres;  /* decoder_dropout, soft_update_coef, thres_small_variation             */
+    const float* enc_params;
+    int64_t enc_s_net;
+    int64_t enc_off[IPLAN_ENC_NPARAM];
+    const float* dec_params;
+    int64_t dec_s_net;
+    int64_t dec_off[IPLAN_DEC_NPARAM];
+    float* saved_dec;           /* [n_nets, rows, J, L, IPLAN_BEH_SAVE_DEC]                             */
+    float* saved_enc;           /* [n_nets, rows, J, L, IPLAN_BEH_SAVE_ENC]                             */
+    float* saved_lat;           /* [n_nets, rows, J, IPLAN_BEH_SAVE_LAT]  softmax output of window j    */
+    float* loss_part;           /* [n_nets, ceil(rows/16), 2]                                           */
+    float* loss;                /* [n_nets, 2]  behaviour error, stability error                        */
+    float* dsave_dec;           /* backward: [n_nets, rows, J, L, IPLAN_BEH_DSAVE_DEC]                  */
+    float* dsave_enc;           /* backward: [n_nets, rows, J, L, IPLAN_BEH_DSAVE_ENC]                  */
+    float* dsave_lat;           /* backward: [n_nets, rows, J, IPLAN_BEH_DSAVE_LAT]  d(latent logits)   */
+} IplanBehArgs;
+
+int iplan_beh_fwd(const IplanBehArgs* args, iplan_stream_t stream);
+int iplan_beh_bwd(const IplanBehArgs* args, iplan_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,7 +50,7 @@ class IplanError(RuntimeError):
 # every entry point include/iplan_hip.h declares
 ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step", "iplan_wgrad",
                 "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_loss", "iplan_gat_bwd",
-                "iplan_pdec_fwd", "iplan_pdec_bwd"]
+                "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd"]
 RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats"]      # non (args*, stream) signatures
 
 
@@ -269,4 +269,22 @@ class PdecArgs(C.Structure):
         ("x0", fp), ("h0", fp), ("target", fp), ("mask", fp), ("keep", fp), ("drop_p", C.c_float),
         ("teacher", fp), ("params", fp), ("params_s_net", i64), ("off", i64 * len(DEC_PARAM_ORDER)),
         ("pred", fp), ("saved", fp), ("loss_part", fp), ("loss", fp), ("dsave", fp), ("g_h0", fp),
+    ]
+
+
+# ---- behaviour learning ------------------------------------------------------------------------------
+BEH_SAVE_DEC, BEH_SAVE_ENC, BEH_SAVE_LAT = 496, 192, 16
+BEH_DSAVE_DEC, BEH_DSAVE_ENC, BEH_DSAVE_LAT = 336, 160, 16
+
+
+class BehArgs(C.Structure):
+    _fields_ = [
+        ("n_nets", i32), ("E", i32), ("N", i32), ("T", i32), ("L", i32), ("d", i32), ("Z", i32),
+        ("hist", fp), ("h_s_net", i64), ("h_s_e", i64), ("h_s_t", i64),
+        ("mask", fp), ("keep", fp), ("seed", C.c_uint64),
+        ("drop_p", C.c_float), ("coef", C.c_float), ("thres", C.c_float),
+        ("enc_params", fp), ("enc_s_net", i64), ("enc_off", i64 * len(ENC_PARAM_ORDER)),
+        ("dec_params", fp), ("dec_s_net", i64), ("dec_off", i64 * len(DEC_PARAM_ORDER)),
+        ("saved_dec", fp), ("saved_enc", fp), ("saved_lat", fp), ("loss_part", fp), ("loss", fp),
+        ("dsave_dec", fp), ("dsave_enc", fp), ("dsave_lat", fp),
     ]

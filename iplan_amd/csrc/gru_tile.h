@@ -86,6 +86,15 @@ __device__ __forceinline__ GruGrads gru_gates_bwd(f32x4 dh, f32x4 r, f32x4 z, f3
     return o;
 }
 
+// Same as dense_tile with the input tiles taken from x[0..KT) against weight columns k0 + 16*T
+// (lets the backward contract [dr | dz | dn_h] out of a [dr | dz | dn_i | dn_h] register array).
+template <int KT>
+__device__ __forceinline__ f32x4 dense_tile_k(const float* __restrict__ sW, int ld, int o0, int k0,
+                                              const f32x4* __restrict__ x, f32x4 acc) {
+    for (int T = 0; T < KT; ++T) acc = mma_block(wfrag_lds(sW, ld, o0, k0 + 16 * T), x[T], acc);
+    return acc;
+}
+
 // One GRU step with LDS-resident weights.  HT = H/16 hidden tiles, XT = input tiles.
 // sWih: [3H x ldi], sWhh: [3H x ldh], sbih/sbhh: [3H].  h is updated in place; when `keep` is
 // non-null the gate activations (r, z, n, hn) of every tile are returned for the backward pass.

@@ -21,6 +21,21 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// dynamic LDS of a kernel (the host-emulated test build has no `extern __shared__`)
+#ifdef IPLAN_HOST_EMULATION
+#define IPLAN_DYN_LDS(name) float* name = iplan_emu::dyn_lds()
+#else
+#define IPLAN_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) float name[]
+#endif
+
+// Scheduling fence: keeps the compiler from hoisting the next tile's LDS fragment reads above the
+// current tile's MFMA chain (which otherwise blows the register budget in the 64-wide GRU kernels).
+#ifdef IPLAN_HOST_EMULATION
+#define IPLAN_SCHED_FENCE() do {} while (0)
+#else
+#define IPLAN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace iplan {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }

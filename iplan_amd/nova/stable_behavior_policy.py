@@ -7,7 +7,7 @@ import torch
 
 from .. import ops
 from ..arena import ParamArena
-from ..optim import FusedAdam
+from ..optim import FusedAdam, step_all
 from .behavior_net import Behavior_Latent_Decoder, EncoderRNN
 from .prediction_policy import _as_dev
 
@@ -73,6 +73,49 @@ class Behavior_policy:
         if as_np:
             return lat.cpu().numpy(), hL
         return lat, hL
+
+
+    # ---------------------------------------------------------------------------- learning
+    def learn(self, batch, t_env, keep=None):
+        """nova/stable_behavior_policy.py:161-279 for all agents at once: ONE persistent forward launch
+        walks every (env, entity) chain through the T-1-L windows (decoder + encoder GRUs, soft latent
+        update, masked L1), ONE backward launch does the BPTT, then weight-gradient contractions,
+        separate clipping of the encoder and decoder groups and Adam.  ``keep`` (uint8 dropout keep flags
+        [nA, J, E*N, L, 64]) may be injected; by default the kernel draws them from a counter-based
+        generator seeded from torch's RNG.  Returns (behavior_loss, stability_loss, total_loss) lists."""
+        a = self.args
+        dev = self.device
+        if self.behavior_variation_penalty != 0:
+            raise NotImplementedError("iplan_amd implements iPLAN's shipped behavior_variation_penalty = 0 "
+                                      "(the stability term is reported, not differentiated)")
+        history = batch["history"][:, :-1].to(device=dev, dtype=torch.float32)     # [E, T, nA, N, d]
+        term = batch["terminated"][:, :-1].to(dev)                                 # [E, T, nA, 1]
+        # mask polarity is env dependent in the reference (:190-193)
+        mask = (1 - term[..., 0]) if a.env == "MPE" else term[..., 0]
+        mask = mask.permute(2, 0, 1).to(torch.float32).contiguous()                # [nA, E, T]
+        hist = history.permute(2, 0, 1, 3, 4)                                       # [nA, E, T, N, d] view
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if keep is None else 0
+        fwd = ops.beh_forward(self.enc_arena, self.dec_arena, hist, mask, self.max_history_len, self.latent_dim,
+                              self.soft_update_coef, self.thres_small_variation, a.decoder_dropout, keep=keep, seed=seed)
+        ops.beh_backward(self.enc_arena, self.dec_arena, fwd)
+        if getattr(self, "dp", None) is not None:
+            self.dp.all_reduce_grads(self.enc_arena, self.dec_arena)
+        sq = step_all(self.behavior_optimizer, self.max_grad_norm if self._use_max_grad_norm else None)
+        nA = self.n_agents
+        host = torch.cat([fwd["loss"].reshape(-1), sq.sqrt().reshape(-1)]).cpu()    # ONE host read-back
+        loss = host[:2 * nA].reshape(nA, 2).numpy()
+        norms = host[2 * nA:].reshape(nA, 2)
+        beh = [np.asarray(loss[i, 0]) for i in range(nA)]
+        stab = [np.asarray(loss[i, 1]) for i in range(nA)]
+        total = [np.asarray(loss[i, 0] + self.behavior_variation_penalty * loss[i, 1]) for i in range(nA)]
+        train_info = {"behavior_loss": float(loss[:, 0].sum()), "stability_loss": float(loss[:, 1].sum()),
+                      "behavior_total": float(sum(float(t) for t in total)),
+                      "behavior_encoder_grad_norm": float(norms[:, 0].sum()),
+                      "behavior_decoder_grad_norm": float(norms[:, 1].sum())}
+        if t_env - self.log_stats_t >= self.args.learner_log_interval:
+            for k, v in train_info.items():
+                self.logger.log_stat(self.log_prefix + k, v, t_env)
+        return beh, stab, total
 
     # ---------------------------------------------------------------------------- checkpoints
     def save_models(self, path):

@@ -491,3 +491,93 @@ def pdec_backward(arena, fwd, lib=None):
     w._keep += [dsave, fwd]
     w.run(lib)
     return g_h0
+
+
+# ---- behaviour learning ---------------------------------------------------------------------------------
+def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p, keep=None, seed=0, lib=None):
+    """Forward of Behavior_policy.learn for all nets.  hist [n_nets, E, T, N, d] (first three dims may be
+    strided), mask [n_nets, E, T] contiguous, keep uint8 [n_nets, J, E*N, L, 64] or None (in-kernel draw from
+    ``seed``).  Returns dict(loss [n_nets, 2] = (behaviour, stability), saved...)."""
+    lib = _lib(lib)
+    n_nets, E, T, N, d = hist.shape
+    assert hist.dtype == torch.float32 and hist.stride(4) == 1 and hist.stride(3) == d
+    assert mask.shape == (n_nets, E, T) and mask.is_contiguous() and mask.dtype == torch.float32
+    dev = hist.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    J = T - 1 - L_win
+    rows = E * N
+    a = L.BehArgs()
+    a.n_nets, a.E, a.N, a.T, a.L, a.d, a.Z = n_nets, E, N, T, L_win, d, Z
+    a.hist, a.h_s_net, a.h_s_e, a.h_s_t = hist.data_ptr(), hist.stride(0), hist.stride(1), hist.stride(2)
+    a.mask = mask.data_ptr()
+    if keep is not None:
+        assert keep.dtype == torch.uint8 and keep.shape == (n_nets, J, rows, L_win, 64) and keep.is_contiguous()
+        a.keep = keep.data_ptr()
+    a.seed, a.drop_p, a.coef, a.thres = seed, drop_p, coef, thres
+    a.enc_params, a.enc_s_net = enc_arena.data.data_ptr(), enc_arena.net_stride
+    for i, k in enumerate(L.ENC_PARAM_ORDER):
+        a.enc_off[i] = enc_arena.off(k)
+    a.dec_params, a.dec_s_net = dec_arena.data.data_ptr(), dec_arena.net_stride
+    for i, k in enumerate(L.DEC_PARAM_ORDER):
+        a.dec_off[i] = dec_arena.off(k)
+    tiles = (rows + 15) // 16
+    out = dict(saved_dec=torch.empty(n_nets, rows, J, L_win, L.BEH_SAVE_DEC, **f32),
+               saved_enc=torch.empty(n_nets, rows, J, L_win, L.BEH_SAVE_ENC, **f32),
+               saved_lat=torch.empty(n_nets, rows, J, L.BEH_SAVE_LAT, **f32),
+               loss_part=torch.empty(n_nets, tiles, 2, **f32), loss=torch.empty(n_nets, 2, **f32))
+    for k in ("saved_dec", "saved_enc", "saved_lat", "loss_part", "loss"):
+        setattr(a, k, out[k].data_ptr())
+    lib.call("iplan_beh_fwd", a, L.current_stream(dev))
+    out["_args"] = a
+    out["_keep"] = (hist, mask, keep)
+    return out
+
+
+def beh_backward(enc_arena, dec_arena, fwd, lib=None):
+    """BPTT of beh_forward's behaviour loss (behavior_variation_penalty == 0): fills both gradient arenas."""
+    lib = _lib(lib)
+    a = fwd["_args"]
+    n_nets, E, N, T, Lw, d, Z = a.n_nets, a.E, a.N, a.T, a.L, a.d, a.Z
+    J, rows = T - 1 - Lw, E * N
+    dev = fwd["loss"].device
+    f32 = dict(dtype=torch.float32, device=dev)
+    dd = torch.empty(n_nets, rows, J, Lw, L.BEH_DSAVE_DEC, **f32)
+    de = torch.empty(n_nets, rows, J, Lw, L.BEH_DSAVE_ENC, **f32)
+    dl = torch.empty(n_nets, rows, J, L.BEH_DSAVE_LAT, **f32)
+    a.dsave_dec, a.dsave_enc, a.dsave_lat = dd.data_ptr(), de.data_ptr(), dl.data_ptr()
+    lib.call("iplan_beh_bwd", a, L.current_stream(dev))
+    SD, SE, DD, DE = L.BEH_SAVE_DEC, L.BEH_SAVE_ENC, L.BEH_DSAVE_DEC, L.BEH_DSAVE_ENC
+    n_in = J * Lw
+    sd, se = fwd["saved_dec"].data_ptr(), fwd["saved_enc"].data_ptr()
+    sd_st, se_st = (rows * n_in * SD, n_in * SD, SD), (rows * n_in * SE, n_in * SE, SE)
+    dd_st, de_st = (rows * n_in * DD, n_in * DD, DD), (rows * n_in * DE, n_in * DE, DE)
+    H, R = 64, 32
+    off = dec_arena.off
+    w = Wgrad(dec_arena.grad, n_nets)
+    w.add(dd.data_ptr(), dd_st, d, rows, n_in, x=sd + 4 * 416, x_strides=sd_st, K=H,
+          dw_off=off("decoder.out.weight"), db_off=off("decoder.out.bias"))
+    w.add(dd.data_ptr() + 4 * 80, dd_st, 3 * H, rows, n_in, x=sd + 4 * 32, x_strides=sd_st, K=H,
+          dw_off=off("decoder.rnn.weight_ih_l0"), db_off=off("decoder.rnn.bias_ih_l0"))
+    w.add(dd.data_ptr() + 4 * 80, dd_st, 3 * H, rows, n_in, x=sd + 4 * 352, x_strides=sd_st, K=H, x_shift=-1,
+          dw_off=off("decoder.rnn.weight_hh_l0"), db_off=off("decoder.rnn.bias_hh_l0"), seg=(2 * H, 0, 3 * H))
+    # input Linear, split by source column block: [x_t | latent]
+    w.add(dd.data_ptr() + 4 * 16, dd_st, H, rows, n_in, x=sd, x_strides=sd_st, K=d, dw_ld=d + Z,
+          dw_off=off("decoder.linear.weight"), db_off=off("decoder.linear.bias"))
+    w.add(dd.data_ptr() + 4 * 16, dd_st, H, rows, n_in, x=sd + 4 * 16, x_strides=sd_st, K=Z, dw_ld=d + Z, dw_col0=d,
+          dw_off=off("decoder.linear.weight"))
+    w._keep += [dd, fwd]
+    w.run(lib)
+    off = enc_arena.off
+    w = Wgrad(enc_arena.grad, n_nets)
+    w.add(de.data_ptr() + 4 * 32, de_st, 3 * R, rows, n_in, x=se, x_strides=se_st, K=R,
+          dw_off=off("rnn.weight_ih_l0"), db_off=off("rnn.bias_ih_l0"))
+    w.add(de.data_ptr() + 4 * 32, de_st, 3 * R, rows, n_in, x=se + 4 * 160, x_strides=se_st, K=R, x_shift=-1,
+          dw_off=off("rnn.weight_hh_l0"), db_off=off("rnn.bias_hh_l0"), seg=(2 * R, 0, 3 * R))
+    w.add(de.data_ptr(), de_st, R, rows, n_in, x=sd, x_strides=sd_st, K=d, dw_off=off("linear.weight"), db_off=off("linear.bias"))
+    # latent head: one row per (chain, window); X = encoder hidden after the window's last step
+    w.add(dl.data_ptr(), (rows * J * L.BEH_DSAVE_LAT, J * L.BEH_DSAVE_LAT, L.BEH_DSAVE_LAT), Z, rows, J,
+          x=se + 4 * ((Lw - 1) * SE + 160), x_strides=(rows * n_in * SE, n_in * SE, Lw * SE), K=R,
+          dw_off=off("out.weight"), db_off=off("out.bias"))
+    w._keep += [de, dl, fwd]
+    w.run(lib)
+    return dict(dsave_dec=dd, dsave_enc=de, dsave_lat=dl)

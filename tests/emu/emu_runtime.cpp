@@ -11,6 +11,11 @@ Fiber* g_cur = nullptr;
 static constexpr size_t kStack = 192 * 1024;
 static std::vector<std::unique_ptr<char[]>> g_stacks;
 
+float* dyn_lds() {
+    static std::vector<float> buf(40960 + 64);
+    return reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(buf.data()) + 63) & ~uintptr_t(63));
+}
+
 static void trampoline() {
     Block* b = g_block;
     b->body();

@@ -40,6 +40,7 @@ typedef void* hipStream_t;
 typedef int hipError_t;
 enum { hipSuccess = 0 };
 inline hipError_t hipGetLastError() { return hipSuccess; }
+typedef uint8_t __emu_u8;
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
@@ -89,6 +90,7 @@ inline void wave_sync() {
 }
 
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+float* dyn_lds();   // 160 KiB scratch standing in for a kernel's dynamic LDS (workgroups run one at a time)
 
 }  // namespace iplan_emu
 
