@@ -5,12 +5,16 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Workload = BASELINE.json configs[2]: Heterogeneous-Highway chaotic, full iPLAN (Behaviour + GAT +
-soft update), 5 agents, 32 parallel envs per GPU (configs[3] = the same sharded over 8 GPUs, weak
-scaling), synthetic observation tensors already resident in HBM.
-One "step" = one training cycle of the reference loop (run_ippo.py:261-332): buffer_size/E rollouts
-of E envs x 90 steps (per vector step: select_actions_ippo, GAT_latent_update, latent_update,
-episode-buffer writes), after every rollout Behavior_policy.learn + Prediction_policy.learn +
-insert_episode_batch, and one IPPOLearner.train (15 PPO epochs) when the 256-episode buffer fills.
+soft update), 5 agents, 32 parallel envs per GPU (configs[3] = the same sharded over the GPUs of a
+node: weak scaling, 32 envs per rank, PPO / prediction / behaviour gradients all-reduced over RCCL),
+synthetic observation tensors already resident in HBM (the simulators cannot be
+installed offline; env.step and observation_wrapper are outside the hot path).
+
+One "step" = one full training cycle of the reference loop (run_ippo.py:261-285): buffer_size / E
+rollouts of E envs x 90 steps (per vector step: select_actions_ippo, GAT_latent_update,
+latent_update, episode-buffer writes), after every rollout insert_episode_batch +
+Behavior_policy.learn + Prediction_policy.learn, and IPPOLearner.train (15 PPO epochs over 255 x 90
+rows per agent) when the 256-episode buffer fills.  Nothing is skipped inside the timed region.
 value = env transitions processed by all ranks / max-over-ranks wall time.
 """
 import argparse
@@ -26,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 from iplan_amd.config import default_args  # noqa: E402
 
-FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32
+FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32, dense)
 
 
 def gat_algorithmic_flops(n_nets, B, N, D, H=32, A=32):
@@ -35,73 +39,124 @@ def gat_algorithmic_flops(n_nets, B, N, D, H=32, A=32):
     return n_nets * (V * (2 * D * H + 24 * H * H + 6 * H * A + 12 * A * A) + P * (12 * H * H + 8 * H + 4 * A))
 
 
-def cpu_baseline(args, E, budget_s=20.0):
-    """The oracle (a CPU port of the reference arithmetic) timed on this host's cores on a bounded
-    sample of the same workload.  Reported beside the GPU number, never mixed into it."""
+def cpu_baseline(args, E):
+    """The oracle (CPU port of the reference arithmetic, kind "port") timed on this host's cores on a
+    BOUNDED sample of the same workload: a few rollout vector steps at full width plus one
+    Behaviour / Prediction / PPO learner pass on a reduced number of envs / rows, each scaled to
+    seconds per env-step and summed.  Reported beside the GPU number, never mixed into it."""
     from oracle import iplan_oracle as O
     from iplan_amd import synth
-    # intra-op threads: the reference's hot path is thousands of tiny ATen ops; beyond ~16 threads the
-    # fork/join overhead dominates (with 256 threads on the GPU box's 2 x 64-core EPYC one vector step
-    # took minutes), so the baseline uses min(host cores, 16) threads and says so in `cores`.
+    from iplan_amd.modules.agents.ippo_actor import R_Actor
+    from iplan_amd.modules.critics.ippo_critic import R_Critic
+    from iplan_amd.nova.GAT_Net import GAT_Net
+    from iplan_amd.nova.behavior_net import Behavior_Latent_Decoder, EncoderRNN
+    from iplan_amd.nova.prediction_net import Prediction_Decoder
+    # intra-op threads: the path is thousands of small ATen ops; beyond ~16 threads fork/join overhead
+    # dominates (with all 256 hardware threads of the GPU box one vector step took minutes)
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    nA, N, d, Z, A, L = args.n_agents, args.max_vehicle_num, args.obs_shape_single, args.latent_dim, args.attention_dim, args.max_history_len
-    from iplan_amd.harness import SyntheticLoop
-    cargs = default_args("highway", use_cuda=False)
-    # parameters: random init of the same architectures (state_dict layout of the reference)
-    from iplan_amd.nova.GAT_Net import GAT_Net
-    from iplan_amd.nova.behavior_net import EncoderRNN
-    from iplan_amd.modules.agents.ippo_actor import R_Actor
-    from iplan_amd.modules.critics.ippo_critic import R_Critic
-    sd = lambda m: {k: v.detach() for k, v in m.state_dict().items()}  # noqa: E731
-    gat = [sd(GAT_Net(d + Z, cargs)) for _ in range(nA)]
+    ca = default_args("highway", use_cuda=False)
+    nA, N, d, Z, A, L, T = ca.n_agents, ca.max_vehicle_num, ca.obs_shape_single, ca.latent_dim, ca.attention_dim, ca.max_history_len, ca.episode_limit
+    sd = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}  # noqa: E731
+    req = lambda p: {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in p.items()}  # noqa: E731
+    gat = [sd(GAT_Net(d + Z, ca)) for _ in range(nA)]
     enc = [sd(EncoderRNN(d, 32, Z, 1)) for _ in range(nA)]
-    F = N * (d + A + Z) + args.n_actions + nA
-    act = [sd(R_Actor(F, cargs)) for _ in range(nA)]
-    cri = [sd(R_Critic(F, cargs)) for _ in range(nA)]
-    hist, window = synth.rollout_step_inputs(cargs, E, 0)
+    bdec = sd(Behavior_Latent_Decoder(d + Z, 64, 1, d, 0.1))
+    pdec = sd(Prediction_Decoder(d, A, 1, d, ca.pred_length, 0.1, 0))
+    F = N * (d + A + Z) + ca.n_actions + nA
+    act = [sd(R_Actor(F, ca)) for _ in range(nA)]
+    cri = [sd(R_Critic(F, ca)) for _ in range(nA)]
+    hist, window = synth.rollout_step_inputs(ca, E, 0)
     hist, window = torch.as_tensor(hist, dtype=torch.float32), torch.as_tensor(window, dtype=torch.float32)
-    att = torch.zeros(E, nA, N, A)
-    lat = torch.full((E, nA, N, Z), 1.0 / Z)
-    eh = torch.zeros(E, 1, nA, N, 32)
+    st = dict(att=torch.zeros(E, nA, N, A), lat=torch.full((E, nA, N, Z), 1.0 / Z), eh=torch.zeros(E, 1, nA, N, 32))
     ha = torch.zeros(E, nA, 64)
 
     def vector_step():
-        nonlocal att, lat, eh
         with torch.no_grad():
             new_att = []
             for i in range(nA):
                 noise = O.gumbel_noise_like_reference(E * N * (N - 1))
-                new_att.append(O.gat_forward(gat[i], torch.cat([hist[:, i], lat[:, i]], -1), att[:, i].reshape(E * N, A), noise).reshape(E, N, A))
-            att = torch.stack(new_att, 1)
-            lat, eh = O.latent_update(enc, window, eh, lat, cargs.soft_update_coef)
-            x = O.build_inputs_rollout(hist, att, lat, torch.zeros(E, nA, args.n_actions), nA)
+                new_att.append(O.gat_forward(gat[i], torch.cat([hist[:, i], st["lat"][:, i]], -1),
+                                             st["att"][:, i].reshape(E * N, A), noise).reshape(E, N, A))
+            st["att"] = torch.stack(new_att, 1)
+            st["lat"], st["eh"] = O.latent_update(enc, window, st["eh"], st["lat"], ca.soft_update_coef)
+            x = O.build_inputs_rollout(hist, st["att"], st["lat"], torch.zeros(E, nA, ca.n_actions), nA)
             for i in range(nA):
                 O.actor_logits(act[i], x[:, i], ha[:, i])
                 O.critic_value(cri[i], x[:, i], ha[:, i])
+
+    def timed(fn, budget, max_n=50):
+        fn()
+        t0, n = time.time(), 0
+        while n < 1 or (time.time() - t0 < budget and n < max_n):
+            fn()
+            n += 1
+        return (time.time() - t0) / n, n
+
+    t_vec, n_vec = timed(vector_step, 6.0)
+    # Behaviour learn: one agent, Eb envs, full episode, forward + backward
+    Eb = 2
+    f = synth.make_episode_fields(ca, Eb, seed=1, terminated_p=0.5)
+
+    def beh_learn():
+        ep, dp = req(enc[0]), req(bdec)
+        _, _, loss = O.behavior_learn_loss(ep, dp, f["history"][:, :-1, 0], f["terminated"][:, :-1, 0, 0].float(), L,
+                                           ca.soft_update_coef, None, 0.0)
+        loss.backward()
     t0 = time.time()
-    vector_step()                                   # warm-up (first call pays one-time init)
-    warm = time.time() - t0
-    budget_s = max(2.0, min(budget_s, 60.0 - warm))
+    beh_learn()
+    t_beh = time.time() - t0
+    # Prediction learn: one agent, full sample count
+    S = ca.pred_batch_size
+    gen = torch.Generator().manual_seed(2)
+    obs = synth.make_history(gen, (S,), N, d)
+    lat = torch.softmax(torch.randn(S, N, Z, generator=gen), -1)
+    att = torch.randn(S, N, 1, A, generator=gen) * 0.1
+    actual = synth.make_history(gen, (S, N), ca.pred_length, d)
+
+    def pred_learn():
+        gp, dp = req(gat[0]), req(pdec)
+        noise = O.gumbel_noise_like_reference(S * N * (N - 1))
+        loss, _ = O.prediction_loss(gp, dp, obs.unsqueeze(2), att, lat.unsqueeze(2), actual, torch.ones_like(actual), noise,
+                                    None, 0.0, ca.pred_length)
+        loss.backward()
     t0 = time.time()
-    n = 0
-    while n < 1 or (time.time() - t0 < budget_s and n < 200):
-        vector_step()
-        n += 1
-    dt = time.time() - t0
-    return dict(value=n * E / dt, unit="env-steps/s", cores=cores, kind="port",
-                sample=f"{n} rollout vector steps (E={E}, 5 agents x 55 entities: GAT_latent_update + latent_update + "
-                       f"select_actions) of the oracle in {dt:.1f}s; learners not included in this sample")
+    pred_learn()
+    t_pred = time.time() - t0
+    # PPO: one agent, one epoch (actor + critic forward/backward) on Rp rows
+    Rp = 2048
+    xr = torch.randn(Rp, F)
+    hr = torch.randn(Rp, 64) * 0.1
+    ar = torch.randint(0, ca.n_actions, (Rp, 1))
+
+    def ppo_epoch():
+        ap, cp = req(act[0]), req(cri[0])
+        lp, ent = O.actor_evaluate(ap, xr, hr, ar)
+        v, _ = O.critic_value(cp, xr, hr)
+        (lp.sum() + ent).backward()
+        v.sum().backward()
+    t0 = time.time()
+    ppo_epoch()
+    t_ppo = time.time() - t0
+    per_step = (t_vec / E                                                  # rollout inference
+                + nA * t_beh / (Eb * T)                                    # Behavior_policy.learn
+                + nA * t_pred / (E * T)                                    # Prediction_policy.learn (once per rollout)
+                + nA * ca.ppo_epoch * t_ppo / Rp * (ca.batch_size / ca.buffer_size))   # IPPOLearner.train
+    return dict(value=1.0 / per_step, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"oracle on {cores} threads: {n_vec} rollout vector steps at E={E} ({t_vec:.2f}s each); Behaviour learn fwd+bwd "
+                       f"1 agent x {Eb} envs x full episode ({t_beh:.1f}s); Prediction learn fwd+bwd 1 agent x {S} samples ({t_pred:.1f}s); "
+                       f"one PPO epoch 1 agent x {Rp} rows ({t_ppo:.2f}s); each scaled to s/env-step and summed")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--envs", type=int, default=32, help="parallel envs per GPU (config 3: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rollout-only", action="store_true", help="diagnostic: time rollout inference without the learners")
     opt = ap.parse_args()
     if os.environ.get("IPLAN_BENCH_WATCHDOG"):
         import faulthandler
@@ -111,47 +166,53 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=dev)
 
     args = default_args("highway", use_cuda=True, batch_size_run=opt.envs)
     E = opt.envs
     from iplan_amd.harness import SyntheticLoop
     loop = SyntheticLoop(args, E, seed=1234 + rank, device=dev)
-    rollouts_per_step = max(1, args.buffer_size // (E * world)) if False else max(1, args.buffer_size // E)
+    if world > 1:
+        from iplan_amd.parallel import DataParallel
+        DataParallel(dist.group.WORLD).attach(loop)
+    rollouts_per_step = max(1, args.buffer_size // E)
 
-    gat_ms = []
+    import contextlib
+    import io
 
-    def one_step(timed):
-        for _ in range(rollouts_per_step):
-            loop.rollout()
+    def one_step():
+        with contextlib.redirect_stdout(io.StringIO()):            # the reference prints "TRAINING IPPO"
+            for _ in range(rollouts_per_step):
+                if opt.rollout_only:
+                    loop.rollout()
+                else:
+                    loop.cycle()
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(opt.warmup):
-        one_step(False)
+        one_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(opt.steps):
-        one_step(True)
+        one_step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        import torch.distributed as dist
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-
     env_steps = opt.steps * rollouts_per_step * E * args.episode_limit * world
 
-    # dominant kernel: fused GAT forward -- live HIP-event timing on the launch stream
+    # dominant kernel of the rollout (profiles/): fused GAT forward -- live HIP-event timing on the launch stream
     from iplan_amd import ops
     from iplan_amd.nova.GAT_Net import gumbel_noise
     nA, N, d, Z, A = args.n_agents, args.max_vehicle_num, args.obs_shape_single, args.latent_dim, args.attention_dim
@@ -179,10 +240,11 @@ def main():
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": opt.steps,
             "warmup": opt.warmup, "ms_per_step": dt / opt.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Highway chaotic full iPLAN, 5 agents x 55 entities, "
-                                   f"{E} envs/GPU x 90 steps; ROLLOUT INFERENCE ONLY in this build "
-                                   "(learners not yet in the timed region)",
-                       "envs_per_gpu": E, "rollouts_per_step": rollouts_per_step},
+            "config": {"workload": "Highway chaotic full iPLAN (Behaviour + GAT + soft update), 5 agents x 55 entities, "
+                                   f"{E} envs/GPU x 90 steps; step = {rollouts_per_step} rollouts, each followed by "
+                                   "insert + Behavior_policy.learn + Prediction_policy.learn, then IPPOLearner.train "
+                                   "(15 epochs x 255 x 90 rows x 5 agents)" + (" [ROLLOUT ONLY diagnostic]" if opt.rollout_only else ""),
+                       "envs_per_gpu": E, "rollouts_per_step": rollouts_per_step, "env_steps_per_step": rollouts_per_step * E * args.episode_limit},
             "roofline": {"kernel": "gat_fwd_kernel", "bound": "mfma", "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": None, "us_per_launch": gat_s * 1e6, "algorithmic_gflop_per_launch": flops / 1e9},
@@ -191,7 +253,6 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args, E)
         print(json.dumps(line))
     if world > 1:
-        import torch.distributed as dist
         dist.destroy_process_group()
 
 

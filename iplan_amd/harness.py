@@ -8,6 +8,7 @@ import torch
 
 from . import synth
 from .controllers.dcntrl_controller import DcntrlMAC
+from .learners.ippo_learner import IPPOLearner
 from .nova.prediction_policy import Prediction_policy
 from .nova.stable_behavior_policy import Behavior_policy
 
@@ -29,7 +30,8 @@ class SyntheticLoop:
         self.mac = DcntrlMAC(self.scheme, {"agents": args.n_agents}, args)
         self.prediction = Prediction_policy(args, self.logger) if args.GAT_enable else None
         self.behavior = Behavior_policy(args, self.logger) if args.Behavior_enable else None
-        self.learner = None
+        self.learner = IPPOLearner(self.mac, self.scheme, self.logger, args)
+        self.t_env = 0
         gen = torch.Generator().manual_seed(seed + 1)
         T1, nA, N = args.episode_limit + 1, args.n_agents, args.max_vehicle_num
         d, L = args.obs_shape_single, args.max_history_len
@@ -100,3 +102,18 @@ class SyntheticLoop:
             D["rnn_states_actors"][:, t + 1] = ha_new[0]
             D["rnn_states_critics"][:, t + 1] = hc_new[0]
         return batch
+
+    def cycle(self):
+        """One iteration of run_ippo.run_sequential's loop (run_ippo.py:261-285): rollout -> insert ->
+        Behavior_policy.learn -> Prediction_policy.learn -> IPPOLearner.train (acts when the buffer is
+        full).  Warm-up gates (Behavior_warmup / GAT_warmup) are treated as already passed: the timed
+        workload is the steady state.  Returns the number of env transitions produced."""
+        batch = self.rollout()
+        self.t_env += self.E * self.args.episode_limit
+        self.learner.insert_episode_batch(batch)
+        if self.behavior is not None:
+            self.behavior.learn(batch, self.t_env)
+        if self.prediction is not None:
+            self.prediction.learn(batch, self.t_env)
+        self.learner.train(self.t_env)
+        return self.E * self.args.episode_limit

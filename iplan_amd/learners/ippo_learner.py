@@ -205,9 +205,6 @@ class IPPOLearner:
         lib = L.get_lib()
         stream = L.current_stream(dev)
         lib.call("iplan_ppo_prepare", pp, stream)
-        if self.dp is not None:
-            raise NotImplementedError("advantage statistics across ranks: use parallel.DataParallel.train_ippo")
-
         # generate_data (:368-424): the first batch_size * T rows
         rows = self.batch_size * T
         spec = self._feature_spec(T, T1, last)

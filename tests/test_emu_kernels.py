@@ -150,3 +150,24 @@ def test_harness_rollout_emulated():
     for t in range(1, 4):
         assert (sums[:, t] - (1 - 0.9 ** t)).abs().max() < 1e-5
     assert batch["actions"].max() < args.n_actions
+
+
+def test_harness_full_cycle_emulated(capsys):
+    """rollout -> insert -> behaviour learn -> prediction learn -> PPO train, end to end (tiny dims)."""
+    from iplan_amd.config import default_args
+    from iplan_amd.harness import SyntheticLoop
+    args = default_args("highway", use_cuda=False, max_vehicle_num=4, n_agents=2, episode_limit=14, batch_size_run=2,
+                        buffer_size=2, batch_size=1, ppo_epoch=2, pred_batch_size=4, max_history_len=3)
+    loop = SyntheticLoop(args, 2, seed=0, device="cpu")
+    before = [p.detach().clone() for p in loop.mac.agents[0].parameters()]
+    enc_before = loop.behavior.enc_arena.data.clone()
+    gat_before = loop.prediction.gat_arena.data.clone()
+    n = loop.cycle()
+    assert n == 2 * 14
+    assert loop.learner.last_train_info is not None and not loop.learner.buffers[0].can_sample()
+    assert any((a - b).abs().max() > 0 for a, b in zip(before, loop.mac.agents[0].parameters()))
+    assert (loop.behavior.enc_arena.data - enc_before).abs().max() > 0
+    assert (loop.prediction.gat_arena.data - gat_before).abs().max() > 0
+    for arena in (loop.mac.actor_arena, loop.mac.critic_arena, loop.behavior.enc_arena, loop.behavior.dec_arena,
+                  loop.prediction.gat_arena, loop.prediction.dec_arena):
+        assert torch.isfinite(arena.data).all()
