@@ -79,3 +79,4 @@ class _SingleNetView:
         self.names = arena.names
         self.shapes = arena.shapes
         self.size = arena.size
+        self.trainable = arena.trainable

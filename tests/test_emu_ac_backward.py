@@ -71,3 +71,56 @@ def test_actor_critic_backward_matches_autograd():
                 ref = prm[k].grad if prm[k].grad is not None else torch.zeros_like(prm[k])
                 err = (got.double() - ref).abs().max().item()
                 assert err <= 1e-5 * ref.abs().max().item() + 1e-12, (name, i, k, err, ref.abs().max().item())
+
+
+def test_module_level_autograd():
+    """R_Actor.evaluate_actions / R_Critic.forward / GAT_Net.forward called as plain nn.Modules under
+    autograd (the way the reference's learner calls them) give the oracle's gradients."""
+    from iplan_amd.modules.agents.ippo_actor import R_Actor
+    from iplan_amd.modules.critics.ippo_critic import R_Critic
+    from iplan_amd.nova.GAT_Net import GAT_Net
+    args = default_args("highway", use_cuda=False, max_vehicle_num=3, n_agents=2)
+    torch.manual_seed(11)
+    F, R = 40, 19
+    actor, critic = R_Actor(F, args), R_Critic(F, args)
+    x = torch.randn(R, 1, F)
+    h = torch.randn(1, R, 64) * 0.1
+    act = torch.randint(0, 5, (R, 1, 1))
+    avail = torch.ones(R, 1, 5, dtype=torch.int32)
+    avail[::3, 0, 2] = 0
+    ap = {k: v.detach().clone().double().requires_grad_(v.requires_grad) for k, v in actor.state_dict(keep_vars=True).items()}
+    cp = {k: v.detach().clone().double().requires_grad_(v.requires_grad) for k, v in critic.state_dict(keep_vars=True).items()}
+    logp, ent = actor.evaluate_actions(x, h, act, avail)
+    w = torch.randn(R, 1)
+    ((logp * w).sum() - 0.3 * ent).backward()
+    v, _ = critic(x, h)
+    (v.reshape(-1) * w.reshape(-1)).sum().backward()
+    lp, en = O.actor_evaluate(ap, x[:, 0].double(), h[0].double(), act.reshape(R, 1), avail.reshape(R, 5))
+    ((lp * w.double()).sum() - 0.3 * en).backward()
+    vv, _ = O.critic_value(cp, x[:, 0].double(), h[0].double())
+    (vv[:, 0] * w.reshape(-1).double()).sum().backward()
+    for mod, prm in ((actor, ap), (critic, cp)):
+        for k, p in mod.named_parameters():
+            if prm[k].grad is None:
+                continue
+            err = (p.grad.double() - prm[k].grad).abs().max().item()
+            assert err <= 1e-5 * prm[k].grad.abs().max().item() + 1e-12, (k, err)
+    # second backward accumulates (torch semantics)
+    g1 = actor.base.mlp.fc1[0].bias.grad.clone()
+    logp, ent = actor.evaluate_actions(x, h, act, avail)
+    ((logp * w).sum() - 0.3 * ent).backward()
+    assert torch.allclose(actor.base.mlp.fc1[0].bias.grad, 2 * g1, rtol=1e-5, atol=1e-8)
+    # GAT module
+    N, D, B = 3, 13, 2
+    net = GAT_Net(D, args)
+    obs, hp = torch.rand(B, N, D), torch.randn(B * N, 32) * 0.1
+    noise = O.gumbel_noise_like_reference(B * N * (N - 1))
+    gout = torch.randn(B * N, 32)
+    out = net(obs, hp, noise=noise)
+    (out * gout).sum().backward()
+    gp = {k: v.detach().clone().double().requires_grad_(True) for k, v in net.state_dict().items()}
+    o64 = O.gat_forward(gp, obs.double(), hp.double(), noise.double())
+    (o64 * gout.double()).sum().backward()
+    for k, p in net.named_parameters():
+        err = (p.grad.double() - gp[k].grad).abs().max().item()
+        assert err <= 2e-5 * gp[k].grad.abs().max().item() + 1e-10, (k, err)
