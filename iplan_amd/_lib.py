@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libiplan_hip.so")
+LIB_PATH = os.environ.get("IPLAN_HIP_LIB", os.path.join(_HERE, "libiplan_hip.so"))   # override = kernel A/B experiments
 
 GAT_NPARAM = 20
 GAT_PARAM_ORDER = [

@@ -18,29 +18,108 @@ namespace iplan {
 constexpr int AM = IPLAN_AC_HIDDEN;    // 64
 constexpr int AT = AM / 16;            // 4 tiles
 
-struct FeatCursor {
-    // Streams features c0, c0+1, c0+2, c0+3 of one row (c0 % 4 == 0).
-    const IplanAcFeatures* f;
-    int net;
-    int64_t pr;
-    int W, NW;
-    int last;
-    __device__ __forceinline__ float at(int c) const {
-        if (c < NW) {
-            const int i = c / W, k = c - i * W;
-            if (k < f->w[0]) return f->src[0][(int64_t)net * f->s_net[0] + pr * f->s_row[0] + (int64_t)i * f->w[0] + k];
-            if (k < f->w[0] + f->w[1])
-                return f->src[1][(int64_t)net * f->s_net[1] + pr * f->s_row[1] + (int64_t)i * f->w[1] + (k - f->w[0])];
-            return f->src[2][(int64_t)net * f->s_net[2] + pr * f->s_row[2] + (int64_t)i * f->w[2] + (k - f->w[0] - f->w[1])];
-        }
-        c -= NW;
-        if (c < f->n_actions) return c == last ? 1.0f : 0.0f;
-        c -= f->n_actions;
-        if (c < f->n_id) return c == net ? 1.0f : 0.0f;
-        return 0.0f;
-    }
+// ---- K order of the fc1 contraction ---------------------------------------------------------------
+// The reference lays the F input features out entity-major ([hist_i || att_i || beh_i] per entity,
+// then the one-hots).  An MFMA contraction may visit K in any order as long as A (weights) and B
+// (features) agree, so the kernels use a SOURCE-major order: block s = the row's contiguous vector of
+// source s (N * w_s floats, padded to a multiple of 16), then one block for the one-hots.  Feature
+// loads are then plain 16-byte vector loads from the episode-buffer fields (no per-element index
+// math), and the matching weight / LayerNorm columns are  e*W + off_s + k  -- 4 consecutive columns
+// whenever w_s % 4 == 0 (attention 32, behaviour 8), per-element otherwise (history 5).
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ f32x4 ldu4(const float* __restrict__ p) { return *reinterpret_cast<const f32x4_u*>(p); }
+
+struct KMap {
+    int kt0[5];        // first k-tile of block 0..3, and the total
+    int len[4];        // valid entries of each block
+    int w[3], off[3];
+    int W, NW, n_actions, n_id;
 };
 
+__device__ __forceinline__ KMap make_kmap(const IplanAcFeatures& ft) {
+    KMap k;
+    k.W = ft.w[0] + ft.w[1] + ft.w[2];
+    k.NW = ft.N * k.W;
+    k.n_actions = ft.n_actions;
+    k.n_id = ft.n_id;
+    int t = 0, off = 0;
+    for (int s = 0; s < 3; ++s) {
+        k.w[s] = ft.w[s];
+        k.off[s] = off;
+        off += ft.w[s];
+        k.len[s] = ft.N * ft.w[s];
+        k.kt0[s] = t;
+        t += (k.len[s] + 15) / 16;
+    }
+    k.len[3] = ft.n_actions + ft.n_id;
+    k.kt0[3] = t;
+    t += (k.len[3] + 15) / 16;
+    k.kt0[4] = t;
+    return k;
+}
+
+struct KTile {
+    int s;             // block
+    int f0;            // first in-block index of this lane's 4 entries
+    int nv;            // how many of the 4 are real (0..4)
+    int c[4];          // their feature columns in the reference's layout
+    bool contig;       // c[q] == c[0] + q
+};
+
+__device__ __forceinline__ KTile ktile(const KMap& k, int T) {
+    KTile o;
+    const int g = lane_id() >> 4;
+    o.s = T >= k.kt0[3] ? 3 : (T >= k.kt0[2] ? 2 : (T >= k.kt0[1] ? 1 : 0));
+    o.f0 = 16 * (T - k.kt0[o.s]) + 4 * g;
+    const int rem = k.len[o.s] - o.f0;
+    o.nv = rem >= 4 ? 4 : (rem > 0 ? rem : 0);
+    if (o.s == 3) {
+        for (int q = 0; q < 4; ++q) o.c[q] = k.NW + o.f0 + q;
+        o.contig = true;
+    } else {
+        const int w = k.w[o.s];
+        if ((w & 3) == 0) {
+            const int e = o.f0 / w;
+            const int c0 = e * k.W + k.off[o.s] + (o.f0 - e * w);
+            for (int q = 0; q < 4; ++q) o.c[q] = c0 + q;
+            o.contig = true;
+        } else {
+            for (int q = 0; q < 4; ++q) {
+                const int f = o.f0 + q, e = f / w;
+                o.c[q] = e * k.W + k.off[o.s] + (f - e * w);
+            }
+            o.contig = false;
+        }
+    }
+    return o;
+}
+
+// this lane's 4 raw features of one row for a k-tile
+__device__ __forceinline__ f32x4 kfeat(const KMap& k, const KTile& kt, const float* const (&src)[3], bool valid, int last, int net) {
+    f32x4 v = splat4(0.f);
+    if (!valid || kt.nv == 0) return v;
+    if (kt.s < 3) {
+        const float* p = src[kt.s] + kt.f0;
+        if (kt.nv == 4) v = ldu4(p);
+        else for (int q = 0; q < 4; ++q) if (q < kt.nv) v[q] = p[q];
+    } else {
+        for (int q = 0; q < 4; ++q) {
+            const int idx = kt.f0 + q;
+            if (q < kt.nv) v[q] = idx < k.n_actions ? (idx == last ? 1.0f : 0.0f) : (idx - k.n_actions == net ? 1.0f : 0.0f);
+        }
+    }
+    return v;
+}
+
+// 4 entries of a per-feature vector (LayerNorm gamma / beta, or one row of fc1.weight) at the tile's columns
+__device__ __forceinline__ f32x4 kcols(const KTile& kt, const float* __restrict__ vec) {
+    f32x4 v = splat4(0.f);
+    if (kt.nv == 4 && kt.contig) return ldu4(vec + kt.c[0]);
+    for (int q = 0; q < 4; ++q) if (q < kt.nv) v[q] = vec[kt.c[q]];
+    return v;
+}
+
+template <int RT>
 __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     __shared__ float s_red[8][16];
     __shared__ __attribute__((aligned(16))) f32x4 s_acc[8][AT][64];
@@ -51,72 +130,112 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     const float* __restrict__ P = nw.params + (int64_t)net * nw.params_s_net;
     const IplanAcFeatures& ft = a.feat;
     const int l = lane_id(), w = wave_id(), n = l & 15, g = l >> 4;
-    const int ks = a.ksplit;
+    const int ks = RT == 1 ? a.ksplit : 1;
     const int groups = 8 / ks;
     const int part = w % ks;
-    const int tile = (int)blockIdx.x * groups + w / ks;
-    const int r = tile * 16 + n;
-    const bool valid = r < a.rows;
-    const int64_t pr = valid ? (int64_t)(r / ft.T) * ft.T_phys + (r % ft.T) : 0;
-    const int W = ft.w[0] + ft.w[1] + ft.w[2];
-    const int F = ft.N * W + ft.n_actions + ft.n_id;
-    const int KT = (F + 15) / 16;
+    const KMap km = make_kmap(ft);
+    const int F = km.NW + km.n_actions + km.n_id;
+    const int KT = km.kt0[4];
     const int T_lo = (int)((int64_t)KT * part / ks), T_hi = (int)((int64_t)KT * (part + 1) / ks);
 
-    FeatCursor cur;
-    cur.f = &ft; cur.net = net; cur.pr = pr; cur.W = W; cur.NW = ft.N * W;
-    cur.last = (valid && ft.n_actions > 0 && ft.last_action) ? ft.last_action[(int64_t)net * ft.la_s_net + pr * ft.la_s_row] : -1;
+    int rr[RT], last[RT];
+    bool vld[RT];
+    int64_t prr[RT];
+    const float* src[RT][3];
+    for (int t = 0; t < RT; ++t) {
+        const int tile = ((int)blockIdx.x * groups + w / ks) * RT + t;
+        rr[t] = tile * 16 + n;
+        vld[t] = rr[t] < a.rows;
+        prr[t] = vld[t] ? (int64_t)(rr[t] / ft.T) * ft.T_phys + (rr[t] % ft.T) : 0;
+        for (int s = 0; s < 3; ++s)
+            src[t][s] = ft.w[s] > 0 ? ft.src[s] + (int64_t)net * ft.s_net[s] + prr[t] * ft.s_row[s] : nullptr;
+        last[t] = (vld[t] && ft.n_actions > 0 && ft.last_action) ? ft.last_action[(int64_t)net * ft.la_s_net + prr[t] * ft.la_s_row] : -1;
+    }
 
-    // ---- LayerNorm(F) statistics, two passes (mean, then centred second moment)
-    float s = 0.f;
-    if (valid)
-        for (int T = T_lo; T < T_hi; ++T)
-            for (int q = 0; q < 4; ++q) { const int c = 16 * T + 4 * g + q; if (c < F) s += cur.at(c); }
-    s = group_sum(s);
-    if (g == 0) s_red[w][n] = s;
-    __syncthreads();
-    float mu = 0.f;
-    for (int p2 = 0; p2 < ks; ++p2) mu += s_red[(w / ks) * ks + p2][n];
-    mu /= (float)F;
-    __syncthreads();
-    float v2 = 0.f;
-    if (valid)
-        for (int T = T_lo; T < T_hi; ++T)
-            for (int q = 0; q < 4; ++q) { const int c = 16 * T + 4 * g + q; if (c < F) { const float d = cur.at(c) - mu; v2 = fmaf(d, d, v2); } }
-    v2 = group_sum(v2);
-    if (g == 0) s_red[w][n] = v2;
-    __syncthreads();
-    float var = 0.f;
-    for (int p2 = 0; p2 < ks; ++p2) var += s_red[(w / ks) * ks + p2][n];
-    const float rstd = 1.0f / sqrtf(var / (float)F + 1e-5f);
+    // ---- LayerNorm(F) statistics, two passes (mean, then centred second moment) over L2-resident rows
+    float mu[RT], rstd[RT];
+    {
+        float s[RT];
+        for (int t = 0; t < RT; ++t) s[t] = 0.f;
+        for (int T = T_lo; T < T_hi; ++T) {
+            const KTile kt = ktile(km, T);
+            for (int t = 0; t < RT; ++t) {
+                const f32x4 x = kfeat(km, kt, src[t], vld[t], last[t], net);
+                s[t] += (x[0] + x[1]) + (x[2] + x[3]);
+            }
+        }
+        for (int t = 0; t < RT; ++t) s[t] = group_sum(s[t]);
+        if (ks > 1) {
+            if (g == 0) s_red[w][n] = s[0];
+            __syncthreads();
+            float m = 0.f;
+            for (int p2 = 0; p2 < ks; ++p2) m += s_red[(w / ks) * ks + p2][n];
+            s[0] = m;
+            __syncthreads();
+        }
+        for (int t = 0; t < RT; ++t) mu[t] = s[t] / (float)F;
+        float v2[RT];
+        for (int t = 0; t < RT; ++t) v2[t] = 0.f;
+        for (int T = T_lo; T < T_hi; ++T) {
+            const KTile kt = ktile(km, T);
+            for (int t = 0; t < RT; ++t) {
+                const f32x4 x = kfeat(km, kt, src[t], vld[t], last[t], net);
+                for (int q = 0; q < 4; ++q)
+                    if (q < kt.nv) { const float d = x[q] - mu[t]; v2[t] = fmaf(d, d, v2[t]); }
+            }
+        }
+        for (int t = 0; t < RT; ++t) v2[t] = group_sum(v2[t]);
+        if (ks > 1) {
+            if (g == 0) s_red[w][n] = v2[0];
+            __syncthreads();
+            float m = 0.f;
+            for (int p2 = 0; p2 < ks; ++p2) m += s_red[(w / ks) * ks + p2][n];
+            v2[0] = m;
+        }
+        for (int t = 0; t < RT; ++t) rstd[t] = 1.0f / sqrtf(v2[t] / (float)F + 1e-5f);
+    }
 
-    // ---- fc1 contraction over this wave's share of F
+    // ---- fc1 contraction over this wave's share of K
     const float* fnw = P + nw.off[IPLAN_AC_FN_W];
     const float* fnb = P + nw.off[IPLAN_AC_FN_B];
     const float* W1 = P + nw.off[IPLAN_AC_FC1_W];
-    f32x4 acc[AT];
-    for (int t = 0; t < AT; ++t) acc[t] = splat4(0.f);
+    f32x4 accs[RT][AT];
+    for (int t = 0; t < RT; ++t)
+        for (int o = 0; o < AT; ++o) accs[t][o] = splat4(0.f);
     for (int T = T_lo; T < T_hi; ++T) {
-        f32x4 x = splat4(0.f);
-        for (int q = 0; q < 4; ++q) {
-            const int c = 16 * T + 4 * g + q;
-            if (valid && c < F) x[q] = (cur.at(c) - mu) * rstd * fnw[c] + fnb[c];
+        const KTile kt = ktile(km, T);
+        const f32x4 gm = kcols(kt, fnw), bt = kcols(kt, fnb);
+        f32x4 xn[RT];
+        for (int t = 0; t < RT; ++t) {
+            const f32x4 x = kfeat(km, kt, src[t], vld[t], last[t], net);
+            for (int q = 0; q < 4; ++q) xn[t][q] = (vld[t] && q < kt.nv) ? (x[q] - mu[t]) * rstd[t] * gm[q] + bt[q] : 0.f;
         }
-        for (int t = 0; t < AT; ++t) acc[t] = mma_block(wfrag(W1, F, AM, F, 16 * t, 16 * T), x, acc[t]);
+        for (int o = 0; o < AT; ++o) {
+            const f32x4 wf = kcols(kt, W1 + (int64_t)(16 * o + n) * F);
+            for (int t = 0; t < RT; ++t) accs[t][o] = mma_block(wf, xn[t], accs[t][o]);
+        }
     }
     if (ks > 1) {
-        for (int t = 0; t < AT; ++t) s_acc[w][t][l] = acc[t];
+        for (int t = 0; t < AT; ++t) s_acc[w][t][l] = accs[0][t];
         __syncthreads();
         if (part == 0) {
             for (int t = 0; t < AT; ++t) {
                 f32x4 sum = s_acc[w][t][l];
                 for (int p2 = 1; p2 < ks; ++p2) sum += s_acc[w + p2][t][l];
-                acc[t] = sum;
+                accs[0][t] = sum;
             }
         }
     }
     if (part != 0) return;
 
+  for (int rt = 0; rt < RT; ++rt) {
+    const int r = rr[rt];
+    const bool valid = vld[rt];
+    const int64_t pr = prr[rt];
+    const float mu_ = mu[rt], rstd_ = rstd[rt];
+    f32x4 acc[AT];
+    for (int t = 0; t < AT; ++t) acc[t] = accs[rt][t];
+    if (RT > 1 && (r - n) >= a.rows) break;                       // whole row tile beyond the end
     // ---- 64-wide tail, one wave per row tile
     float* sv = a.saved ? a.saved + (((int64_t)which * a.n_agents + net) * a.rows + (valid ? r : 0)) * IPLAN_AC_SAVE_FLOATS : nullptr;
     float mu1, rs1, mu2, rs2, mu3, rs3;
@@ -176,7 +295,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         for (int t = 0; t < AT; ++t) vstore(sv + 9 * AM, valid, AM, t, hnew[t]);      // f3
         if (valid && g == 0) {
             float* st = sv + 10 * AM;
-            st[0] = mu; st[1] = rstd; st[2] = mu1; st[3] = rs1; st[4] = mu2; st[5] = rs2; st[6] = mu3; st[7] = rs3;
+            st[0] = mu_; st[1] = rstd_; st[2] = mu1; st[3] = rs1; st[4] = mu2; st[5] = rs2; st[6] = mu3; st[7] = rs3;
         }
     }
     // ---- head
@@ -185,7 +304,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     const int64_t orow = (int64_t)net * a.rows + (valid ? r : 0);
     if (which == 1) {
         if (valid && g == 0 && a.values) a.values[orow] = lg[0];
-        return;
+        continue;
     }
     // masked categorical (distributions.py:64-68, act.py:81-83,159-164)
     f32x4 x;
@@ -248,6 +367,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         if (a.logp) a.logp[orow] = sel;
         if (a.entropy) a.entropy[orow] = ent;
     }
+  }   // row tiles
 }
 
 }  // namespace iplan
@@ -264,8 +384,12 @@ extern "C" int iplan_ac_fwd(const IplanAcFwdArgs* a, iplan_stream_t stream) {
     if (a->which != 1 && a->mode == 1 && !a->q_noise) return fail(IPLAN_EINVAL, "iplan_ac_fwd: mode 1 needs q_noise");
     if (a->which != 1 && a->mode == 2 && !a->actions_in) return fail(IPLAN_EINVAL, "iplan_ac_fwd: mode 2 needs actions_in");
     const int tiles = (a->rows + 15) / 16;
-    const int groups = 8 / a->ksplit;
-    dim3 grid((unsigned)((tiles + groups - 1) / groups), (unsigned)a->n_agents, a->which == 2 ? 2u : 1u);
-    hipLaunchKernelGGL(ac_fwd_kernel, grid, dim3(512), 0, (hipStream_t)stream, *a);
+    if (a->ksplit == 8) {
+        dim3 grid((unsigned)tiles, (unsigned)a->n_agents, a->which == 2 ? 2u : 1u);
+        hipLaunchKernelGGL(ac_fwd_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, *a);
+    } else {
+        dim3 grid((unsigned)((tiles + 15) / 16), (unsigned)a->n_agents, a->which == 2 ? 2u : 1u);   // 8 waves x 2 row tiles
+        hipLaunchKernelGGL(ac_fwd_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, *a);
+    }
     return check_launch("iplan_ac_fwd");
 }

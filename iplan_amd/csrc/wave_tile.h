@@ -53,8 +53,22 @@ __device__ __forceinline__ f32x4 splat4(float v) {
     return r;
 }
 
+// Gate non-linearities.  Default: the hardware transcendental pipe (v_exp_f32 = 2^x, v_rcp_f32, both
+// ~1 ulp), 4-5 VALU instructions per value instead of the ~25-40 of libm's expf/tanhf -- the gate math
+// is otherwise co-dominant with the MFMA chain in every GRU step.  Absolute error <= ~2e-7, the same
+// size as fp32 round-off of the reference itself (parity tests run on these).  -DIPLAN_EXACT_GATES
+// restores libm.
+#ifdef IPLAN_EXACT_GATES
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) { return tanhf(x); }
+#else
+__device__ __forceinline__ float sigmoid_f(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanh_f(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.8853900817779268f * x) + 1.0f);
+}
+#endif
 
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     f32x4 r;

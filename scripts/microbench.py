@@ -1,0 +1,90 @@
+"""Per-piece timings of the hot path at BASELINE.json config 3 (E = 32, 5 agents x 55 entities), HIP events
+around the host-level calls.  Usage: python scripts/microbench.py [piece ...]   (default: all)"""
+import contextlib
+import io
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from iplan_amd import ops  # noqa: E402
+from iplan_amd.config import default_args  # noqa: E402
+from iplan_amd.harness import SyntheticLoop  # noqa: E402
+from iplan_amd.nova.GAT_Net import gumbel_noise  # noqa: E402
+
+E = int(os.environ.get("MB_ENVS", "32"))
+args = default_args("highway", use_cuda=True, batch_size_run=E)
+dev = torch.device("cuda")
+loop = SyntheticLoop(args, E, seed=0, device=dev)
+nA, N, d, Z, A = args.n_agents, args.max_vehicle_num, args.obs_shape_single, args.latent_dim, args.attention_dim
+want = set(sys.argv[1:])
+
+
+def tm(name, fn, n=10, warm=2):
+    if want and name.split(":")[0] not in want:
+        return
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{name:34s} gpu {e0.elapsed_time(e1) / n:9.3f} ms   wall {(time.perf_counter() - t0) / n * 1e3:9.3f} ms", flush=True)
+
+
+hist = loop.obs_sets[0]["hist"][0].permute(1, 0, 2, 3)
+lat = torch.softmax(torch.randn(nA, E, N, Z, device=dev), -1)
+hid = torch.randn(nA, E, N, A, device=dev) * 0.1
+noise = gumbel_noise((nA, E, N, N - 1, 2), dev)
+out = torch.empty(nA, E, N, A, device=dev)
+tm("gat_fwd", lambda: ops.gat_forward(loop.prediction.gat_arena, hist, lat, hid, noise, out=out), n=50)
+
+window = loop.obs_sets[0]["hist"][0:10].permute(1, 2, 3, 0, 4).contiguous()
+eh = torch.zeros(E, 1, nA, N, 32, device=dev)
+lat_e = lat.permute(1, 0, 2, 3).contiguous()
+tm("enc_fwd", lambda: loop.behavior.latent_update(window, eh, lat_e), n=50)
+
+with contextlib.redirect_stdout(io.StringIO()):
+    batch = loop.rollout()
+tm("select_actions", lambda: loop.mac.select_actions_ippo(batch, 3, test_mode=False, as_numpy=False), n=50)
+tm("rollout", lambda: loop.rollout(), n=2, warm=1)
+tm("behavior_learn", lambda: loop.behavior.learn(batch, 0), n=3, warm=1)
+tm("prediction_learn", lambda: loop.prediction.learn(batch, 0), n=5, warm=1)
+
+
+def ppo():
+    while not loop.learner.buffers[0].can_sample():
+        loop.learner.insert_episode_batch(batch)
+    with contextlib.redirect_stdout(io.StringIO()):
+        loop.learner.train(0)
+
+
+tm("ppo_train", ppo, n=2, warm=1)
+
+if not want or "ac_train_parts" in want:
+    # the pieces of one PPO epoch
+    while not loop.learner.buffers[0].can_sample():
+        loop.learner.insert_episode_batch(batch)
+    L = loop.learner
+    dd = L.store.data
+    T = args.episode_limit
+    acts = dd["actions"][..., 0]
+    last = torch.cat([acts[:, :1], acts[:, :-1]], dim=1).to(torch.int32).contiguous()
+    spec = L._feature_spec(T, T + 1, last)
+    ha, hc = dd["rnn_states_actors"], dd["rnn_states_critics"]
+    avail = dd["avail_actions"]
+    rows = args.batch_size * T
+    kw = dict(h_actor=ha, h_critic=hc, h_strides=(ha.stride(2), ha.stride(1)), avail=avail, avail_strides=(avail.stride(2), avail.stride(1)),
+              mode=2, actions_in=dd["actions"], act_strides=(dd["actions"].stride(2), dd["actions"].stride(1)), n_actions=5, ksplit=1, want_h=False)
+    want = set()
+    tm("ac_fwd_train(infer)", lambda: ops.ac_forward(loop.mac.actor_arena, loop.mac.critic_arena, 2, spec, rows, nA, **kw), n=5)
+    tm("ac_fwd_train(save)", lambda: ops.ac_forward(loop.mac.actor_arena, loop.mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True, **kw), n=5)
+    fo = ops.ac_forward(loop.mac.actor_arena, loop.mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True, **kw)
+    g1 = torch.randn(nA, rows, device=dev)
+    tm("ac_backward(all)", lambda: ops.ac_backward(fo, loop.mac.actor_arena, loop.mac.critic_arena, g_logp=g1, g_entropy=-1e-6, g_values=g1), n=5)

@@ -147,6 +147,8 @@ inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; 
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 inline float __expf(float x) { return expf(x); }
+inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline float __logf(float x) { return logf(x); }
 inline float __frcp_rn(float x) { return 1.0f / x; }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
