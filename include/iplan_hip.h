@@ -126,7 +126,7 @@ enum {
 
 typedef struct {
     int32_t n_nets, B, N, L, d, Z;
-    const float* x;            /* window (net,b,i) at x + net*x_s_net + b*x_s_b + i*L*d, [L][d] */
+    const float* x;            /* window element (net,b,i,t,c) at x + net*x_s_net + b*x_s_b + i*x_s_i + t*x_s_t + c */
     int64_t x_s_net, x_s_b;
     const float* h0;           /* carried hidden, rows of 32 floats */
     int64_t h0_s_net, h0_s_b;
@@ -140,6 +140,8 @@ typedef struct {
     const float* params;
     int64_t params_s_net;
     int64_t off[IPLAN_ENC_NPARAM];
+    int64_t x_s_i, x_s_t;      /* 0, 0 = the contiguous default (L*d, d); lets a sliding window over a time-major
+                                  observation log be read in place                                          */
 } IplanEncFwdArgs;
 
 int iplan_enc_fwd(const IplanEncFwdArgs* args, iplan_stream_t stream);
@@ -196,6 +198,8 @@ typedef struct {
     int64_t la_s_net, la_s_row;
     int32_t n_id;               /* width of the agent-id one-hot (0 = obs_agent_id False); hot index = net */
     int32_t T, T_phys;          /* logical / physical steps per episode (equal when rows are contiguous) */
+    const int64_t* last_action64; /* alternative to last_action: int64 indices read in place (e.g. EpisodeBatch "actions"), */
+    int64_t la64_s_net, la64_s_row; /* last_action64[net*la64_s_net + pr*la64_s_row]; used when last_action == NULL      */
 } IplanAcFeatures;
 
 typedef struct {
@@ -224,6 +228,18 @@ typedef struct {
     float* values;              /* [n_agents, rows] */
     /* activations for the backward pass, [2, n_agents, rows, IPLAN_AC_SAVE_FLOATS] (NULL = inference) */
     float* saved;
+    /* optional strided destinations (all-zero strides = the contiguous defaults above) so that a rollout step
+     * writes straight into the episode buffer: h_*_out rows at net*ho_s_net + r*ho_s_row, actions_out at
+     * net*ao_s_net + r*ao_s_row, and the action's one-hot (n_actions floats) at onehot_out + net*oh_s_net + r*oh_s_row */
+    int64_t ho_s_net, ho_s_row;
+    int64_t ao_s_net, ao_s_row;
+    float* onehot_out;
+    int64_t oh_s_net, oh_s_row;
+    /* LayerNorm(F) statistics (mean, rstd) per (net, physical row): the features do not change across PPO
+     * epochs, so they are computed once (mode 1 = compute + store) and re-read (mode 2); mode 0 = private.   */
+    float* ln_stats;
+    int64_t ln_stats_s_net;
+    int32_t ln_stats_mode;
 } IplanAcFwdArgs;
 
 int iplan_ac_fwd(const IplanAcFwdArgs* args, iplan_stream_t stream);

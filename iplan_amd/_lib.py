@@ -131,6 +131,7 @@ class EncFwdArgs(C.Structure):
         ("latent_out", fp), ("lo_s_net", i64), ("lo_s_b", i64),
         ("one_minus_c", C.c_float), ("c", C.c_float),
         ("params", fp), ("params_s_net", i64), ("off", i64 * len(ENC_PARAM_ORDER)),
+        ("x_s_i", i64), ("x_s_t", i64),
     ]
 
 
@@ -158,6 +159,7 @@ class AcFeatures(C.Structure):
         ("N", i32), ("w", i32 * 3), ("src", fp * 3), ("s_net", i64 * 3), ("s_row", i64 * 3),
         ("n_actions", i32), ("last_action", fp), ("la_s_net", i64), ("la_s_row", i64),
         ("n_id", i32), ("T", i32), ("T_phys", i32),
+        ("last_action64", fp), ("la64_s_net", i64), ("la64_s_row", i64),
     ]
 
 
@@ -172,6 +174,9 @@ class AcFwdArgs(C.Structure):
         ("actions_in", fp), ("act_s_net", i64), ("act_s_row", i64),
         ("actions_out", fp), ("logp", fp), ("entropy", fp), ("probs", fp),
         ("values", fp), ("saved", fp),
+        ("ho_s_net", i64), ("ho_s_row", i64), ("ao_s_net", i64), ("ao_s_row", i64),
+        ("onehot_out", fp), ("oh_s_net", i64), ("oh_s_row", i64),
+        ("ln_stats", fp), ("ln_stats_s_net", i64), ("ln_stats_mode", i32),
     ]
 
 

@@ -52,11 +52,14 @@ class DcntrlMAC:
         t = t.to(self.device) if t.device != self.device else t
         return t if dtype is None or t.dtype == dtype else t.to(dtype)
 
-    def select_actions_ippo(self, ep_batch, t_ep, test_mode=False, q_noise=None, as_numpy=True):
+    def select_actions_ippo(self, ep_batch, t_ep, test_mode=False, q_noise=None, as_numpy=True, write_back=False):
         """One fused launch: features gathered in place from ``ep_batch`` at ``t_ep``, all agents,
         actor + critic (controllers/dcntrl_controller.py:27-58).  Returns the reference's 5-tuple
         (values [E,nA], actions [E,nA], list of nA logp [E,1], rnn_states_actors [1,E,nA,M],
-        rnn_states_critics [1,E,nA,M]); numpy for the array items unless ``as_numpy=False``."""
+        rnn_states_critics [1,E,nA,M]); numpy for the array items unless ``as_numpy=False``.
+        ``write_back=True`` (device-resident rollouts): the kernel additionally writes the actions, their
+        one-hot and the new GRU states straight into ``ep_batch`` (actions / actions_onehot at ``t_ep``, rnn
+        states at ``t_ep + 1``), i.e. the ``EpisodeBatch.update`` of ippo_parallel_runner.py:260-266."""
         a = self.args
         nA, N, M = self.n_agents, a.max_vehicle_num, a.rnn_hidden_dim
         E = ep_batch.batch_size
@@ -68,8 +71,8 @@ class DcntrlMAC:
         last = None
         la_strides = (0, 0)
         if a.obs_last_action and t_ep > 0:
-            last = self._dev(ep_batch["actions"])[:, t_ep - 1, :, 0].to(th.int32).contiguous()   # [E, nA]
-            la_strides = (1, nA)
+            last = self._dev(ep_batch["actions"])[:, t_ep - 1, :, 0]             # [E, nA] int64 view, read in place
+            la_strides = (last.stride(1), last.stride(0))
         spec = ops.AcFeatureSpec(N, sources, n_actions=a.n_actions if a.obs_last_action else 0,
                                  last_action=last, la_strides=la_strides,
                                  n_id=nA if a.obs_agent_id else 0, T=E, T_phys=E)
@@ -82,15 +85,28 @@ class DcntrlMAC:
         assert ha.stride() == hc.stride()
         if not test_mode and q_noise is None:
             q_noise = th.empty(nA, E, a.n_actions, dtype=th.float32, device=self.device).exponential_()
+        wb = {}
+        if write_back:
+            ha_n = ep_batch["rnn_states_actors"][:, t_ep + 1]             # [E, nA, M] views
+            hc_n = ep_batch["rnn_states_critics"][:, t_ep + 1]
+            act_n = ep_batch["actions"][:, t_ep, :, 0]
+            oh_n = ep_batch["actions_onehot"][:, t_ep]
+            assert ha_n.stride() == hc_n.stride()
+            wb = dict(h_out=(ha_n, hc_n, (ha_n.stride(1), ha_n.stride(0))),
+                      actions_out=(act_n, (act_n.stride(1), act_n.stride(0))),
+                      onehot_out=(oh_n, (oh_n.stride(1), oh_n.stride(0))))
         o = ops.ac_forward(self.actor_arena, self.critic_arena, 2, spec, E, nA, h_actor=ha, h_critic=hc,
                            h_strides=(ha.stride(1), ha.stride(0)), avail=avail,
                            avail_strides=(avail.stride(1), avail.stride(0)),
-                           mode=0 if test_mode else 1, q_noise=q_noise, n_actions=a.n_actions)
+                           mode=0 if test_mode else 1, q_noise=q_noise, n_actions=a.n_actions, **wb)
         values = o["values"].t()                                          # [E, nA]
-        actions = o["actions"].t()
         logps = [o["logp"][i].reshape(E, 1) for i in range(nA)]
-        ha_new = o["h_actor"].permute(1, 0, 2).unsqueeze(0)               # [1, E, nA, M]
-        hc_new = o["h_critic"].permute(1, 0, 2).unsqueeze(0)
+        if write_back:
+            actions, ha_new, hc_new = act_n, ha_n.unsqueeze(0), hc_n.unsqueeze(0)
+        else:
+            actions = o["actions"].t()
+            ha_new = o["h_actor"].permute(1, 0, 2).unsqueeze(0)           # [1, E, nA, M]
+            hc_new = o["h_critic"].permute(1, 0, 2).unsqueeze(0)
         if as_numpy:
             return (values.cpu().numpy(), actions.cpu().numpy(), logps,
                     ha_new.cpu().numpy(), hc_new.cpu().numpy())

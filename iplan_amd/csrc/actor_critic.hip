@@ -149,12 +149,24 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         prr[t] = vld[t] ? (int64_t)(rr[t] / ft.T) * ft.T_phys + (rr[t] % ft.T) : 0;
         for (int s = 0; s < 3; ++s)
             src[t][s] = ft.w[s] > 0 ? ft.src[s] + (int64_t)net * ft.s_net[s] + prr[t] * ft.s_row[s] : nullptr;
-        last[t] = (vld[t] && ft.n_actions > 0 && ft.last_action) ? ft.last_action[(int64_t)net * ft.la_s_net + prr[t] * ft.la_s_row] : -1;
+        last[t] = -1;
+        if (vld[t] && ft.n_actions > 0) {
+            if (ft.last_action) last[t] = ft.last_action[(int64_t)net * ft.la_s_net + prr[t] * ft.la_s_row];
+            else if (ft.last_action64) last[t] = (int)ft.last_action64[(int64_t)net * ft.la64_s_net + prr[t] * ft.la64_s_row];
+        }
     }
 
     // ---- LayerNorm(F) statistics, two passes (mean, then centred second moment) over L2-resident rows
     float mu[RT], rstd[RT];
-    {
+    if (a.ln_stats_mode == 2) {
+        for (int t = 0; t < RT; ++t) {
+            mu[t] = 0.f; rstd[t] = 0.f;
+            if (vld[t]) {
+                const float* st = a.ln_stats + (int64_t)net * a.ln_stats_s_net + prr[t] * 2;
+                mu[t] = st[0]; rstd[t] = st[1];
+            }
+        }
+    } else {
         float s[RT];
         for (int t = 0; t < RT; ++t) s[t] = 0.f;
         for (int T = T_lo; T < T_hi; ++T) {
@@ -192,7 +204,13 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
             for (int p2 = 0; p2 < ks; ++p2) m += s_red[(w / ks) * ks + p2][n];
             v2[0] = m;
         }
-        for (int t = 0; t < RT; ++t) rstd[t] = 1.0f / sqrtf(v2[t] / (float)F + 1e-5f);
+        for (int t = 0; t < RT; ++t) {
+            rstd[t] = 1.0f / sqrtf(v2[t] / (float)F + 1e-5f);
+            if (a.ln_stats_mode == 1 && vld[t] && g == 0 && part == 0) {
+                float* st = a.ln_stats + (int64_t)net * a.ln_stats_s_net + prr[t] * 2;
+                st[0] = mu[t]; st[1] = rstd[t];
+            }
+        }
     }
 
     // ---- fc1 contraction over this wave's share of K
@@ -287,7 +305,8 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     }
     float* hout = which ? a.h_critic_out : a.h_actor_out;
     if (hout) {
-        float* orow = hout + ((int64_t)net * a.rows + (valid ? r : 0)) * AM;
+        float* orow = a.ho_s_row ? hout + (int64_t)net * a.ho_s_net + (int64_t)(valid ? r : 0) * a.ho_s_row
+                                 : hout + ((int64_t)net * a.rows + (valid ? r : 0)) * AM;
         for (int t = 0; t < AT; ++t) vstore(orow, valid, AM, t, hnew[t]);
     }
     layer_norm_tiles<AT>(hnew, P + nw.off[IPLAN_AC_LN3_W], P + nw.off[IPLAN_AC_LN3_B], &mu3, &rs3);
@@ -350,7 +369,13 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         int o = __shfl_xor(cand, 16); cand = o < cand ? o : cand;
         o = __shfl_xor(cand, 32); cand = o < cand ? o : cand;
         action = cand;
-        if (valid && g == 0 && a.actions_out) a.actions_out[orow] = (int64_t)action;
+        if (valid && g == 0 && a.actions_out) {
+            if (a.ao_s_row) a.actions_out[(int64_t)net * a.ao_s_net + (int64_t)r * a.ao_s_row] = (int64_t)action;
+            else a.actions_out[orow] = (int64_t)action;
+        }
+        if (valid && a.onehot_out)
+            for (int q = 0; q < 4; ++q)
+                if (4 * g + q < n_out) a.onehot_out[(int64_t)net * a.oh_s_net + (int64_t)r * a.oh_s_row + 4 * g + q] = (4 * g + q == action) ? 1.0f : 0.0f;
     }
     float sel = 0.f, ent = 0.f;
     for (int q = 0; q < 4; ++q) {

@@ -284,7 +284,10 @@ __global__ __launch_bounds__(64) void ac_fc1_wgrad_kernel(IplanAcBwdArgs a) {
                 if (rv && cr.kind != 3) {
                     if (cr.kind == 0) x = cr.base[pr * cr.s_row];
                     else if (cr.kind == 1) {
-                        if (last == -1 && ft.last_action) last = ft.last_action[(int64_t)net * ft.la_s_net + pr * ft.la_s_row];
+                        if (last == -1) {
+                            if (ft.last_action) last = ft.last_action[(int64_t)net * ft.la_s_net + pr * ft.la_s_row];
+                            else if (ft.last_action64) last = (int)ft.last_action64[(int64_t)net * ft.la64_s_net + pr * ft.la64_s_row];
+                        }
                         x = (cr.idx == last) ? 1.0f : 0.0f;
                     } else x = cr.cval;
                     x = (x - mu) * rstd;

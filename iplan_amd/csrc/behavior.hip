@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void enc_fwd_kernel(IplanEncFwdArgs a) {
     const int row = ((int)blockIdx.x * 4 + wave_id()) * 16 + (l & 15);
     const bool valid = row < rows;
     const int b = valid ? row / a.N : 0, i = valid ? row % a.N : 0;
-    const float* xrow = a.x + (int64_t)net * a.x_s_net + (int64_t)b * a.x_s_b + (int64_t)i * a.L * a.d;
+    const int64_t xs_i = a.x_s_i ? a.x_s_i : (int64_t)a.L * a.d, xs_t = a.x_s_t ? a.x_s_t : (int64_t)a.d;
+    const float* xrow = a.x + (int64_t)net * a.x_s_net + (int64_t)b * a.x_s_b + (int64_t)i * xs_i;
     f32x4 h[2];
     {
         const float* hrow = a.h0 + (int64_t)net * a.h0_s_net + (int64_t)b * a.h0_s_b + (int64_t)i * ER;
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void enc_fwd_kernel(IplanEncFwdArgs a) {
     }
     for (int t = 0; t < a.L; ++t) {
         f32x4 x[1];
-        x[0] = vload(xrow + t * a.d, valid, a.d, 0);
+        x[0] = vload(xrow + t * xs_t, valid, a.d, 0);
         f32x4 u[2];
         u[0] = relu4(dense_tile<1>(s_lin, 20, 0, x, bfrag_lds(s_blin, 0)));
         u[1] = relu4(dense_tile<1>(s_lin, 20, 16, x, bfrag_lds(s_blin, 1)));

@@ -63,7 +63,10 @@ class SyntheticLoop:
 
     @torch.no_grad()
     def rollout(self):
-        """One vectorised episode of E envs x T steps (ippo_parallel_runner.py:105-281 order of calls)."""
+        """One vectorised episode of E envs x T steps (ippo_parallel_runner.py:105-281 order of calls).
+        Device resident: the three fused launches of a vector step read their inputs from, and write their
+        outputs into, the episode-buffer tensors in place; the per-step random draws (gumbel noise of the hard
+        attention, the exponential race of the action sampling) are drawn for the whole rollout in two launches."""
         a, E = self.args, self.E
         T, nA, N, L = a.episode_limit, a.n_agents, a.max_vehicle_num, a.max_history_len
         dev = self.device
@@ -71,36 +74,28 @@ class SyntheticLoop:
         self._rollouts += 1
         batch = self.new_batch()
         D = batch.data
-        att = torch.zeros(E, nA, N, a.attention_dim, device=dev)
-        lat = torch.zeros(E, nA, N, a.latent_dim, device=dev)
-        eh = torch.zeros(E, 1, nA, N, a.encoder_rnn_dim, device=dev)
-        ha = torch.zeros(E, nA, a.rnn_hidden_dim, device=dev)
-        hc = torch.zeros(E, nA, a.rnn_hidden_dim, device=dev)
-        hist_all = obs["hist"]
-        single = hist_all[L - 1]
+        hist_all = obs["hist"]                                         # [T1 + L - 1, E, nA, N, d] time-major "environment"
+        # what env.step + EpisodeBatch.update would deliver step by step, copied once
+        D["history"].copy_(hist_all[L - 1:L + T].permute(1, 0, 2, 3, 4))
+        D["reward"][:, :T].copy_(obs["reward"][:T].permute(1, 0, 2, 3))
+        D["terminated"][:, :T].copy_(obs["terminated"][:T].permute(1, 0, 2, 3))
+        eh = torch.zeros(2, E, 1, nA, N, a.encoder_rnn_dim, device=dev)   # ping-pong encoder hidden state
         if self.prediction is not None:
-            att = self.prediction.GAT_latent_update(single, att, lat)
-        D["history"][:, 0] = single
-        D["attention_latent"][:, 0] = att
-        D["behavior_latent"][:, 0] = lat
+            from .nova.GAT_Net import gumbel_noise
+            noise = gumbel_noise((T + 1, nA, E, N, N - 1, 2), dev)
+            self.prediction.GAT_latent_update(D["history"][:, 0], D["attention_latent"][:, 0], D["behavior_latent"][:, 0],
+                                              noise=noise[T], out=D["attention_latent"][:, 0])
+        q_all = torch.empty(T, nA, E, a.n_actions, device=dev).exponential_()
         for t in range(T):
-            _, actions, _, ha_new, hc_new = self.mac.select_actions_ippo(batch, t, test_mode=False, as_numpy=False)
-            D["actions"][:, t, :, 0] = actions
-            D["actions_onehot"][:, t].zero_().scatter_(-1, actions.unsqueeze(-1), 1.0)
+            self.mac.select_actions_ippo(batch, t, test_mode=False, q_noise=q_all[t], as_numpy=False, write_back=True)
             # env.step would run here; its outputs are the pre-generated tensors
-            single = hist_all[L + t]
             if self.prediction is not None:
-                att = self.prediction.GAT_latent_update(single, att, lat)
+                self.prediction.GAT_latent_update(D["history"][:, t + 1], D["attention_latent"][:, t], D["behavior_latent"][:, t],
+                                                  noise=noise[t], out=D["attention_latent"][:, t + 1])
             if self.behavior is not None:
-                window = hist_all[t + 1:t + 1 + L].permute(1, 2, 3, 0, 4)          # [E, nA, N, L, d] view
-                lat, eh = self.behavior.latent_update(window.contiguous(), eh, lat)
-            D["reward"][:, t] = obs["reward"][t]
-            D["terminated"][:, t] = obs["terminated"][t]
-            D["history"][:, t + 1] = single
-            D["attention_latent"][:, t + 1] = att
-            D["behavior_latent"][:, t + 1] = lat
-            D["rnn_states_actors"][:, t + 1] = ha_new[0]
-            D["rnn_states_critics"][:, t + 1] = hc_new[0]
+                window = hist_all[t + 1:t + 1 + L].permute(1, 2, 3, 0, 4)           # [E, nA, N, L, d] sliding view, read in place
+                self.behavior.latent_update(window, eh[t & 1], D["behavior_latent"][:, t],
+                                            out_latent=D["behavior_latent"][:, t + 1], out_hidden=eh[(t + 1) & 1][:, 0])
         return batch
 
     def cycle(self):

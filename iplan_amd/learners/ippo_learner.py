@@ -191,8 +191,11 @@ class IPPOLearner:
 
         # compute_returns (:344-365): critic on every stored step, GAE, advantage normalisation (:273-279)
         spec_all = self._feature_spec(T1, T1, last)
+        # LayerNorm(F) statistics of every stored row: the features are fixed during train(), so this pass
+        # computes them once and all 1 + 15 x 2 later passes re-use them
+        ln_stats = th.empty(nA, bs * T1, 2, **f32)
         v_all = ops.ac_forward(None, mac.critic_arena, 1, spec_all, bs * T1, nA, h_critic=hc, h_strides=hs,
-                               ksplit=1, want_h=False)["values"]
+                               ksplit=1, want_h=False, ln_stats=ln_stats, ln_stats_mode=1)["values"]
         rw, tm = d["reward"], d["terminated"]
         pp = L.PpoPrepareArgs()
         pp.n_agents, pp.bs, pp.T = nA, bs, T
@@ -209,7 +212,8 @@ class IPPOLearner:
         rows = self.batch_size * T
         spec = self._feature_spec(T, T1, last)
         fwd_kw = dict(h_actor=ha, h_critic=hc, h_strides=hs, avail=avail, avail_strides=av_s, mode=2,
-                      actions_in=actions, act_strides=act_s, n_actions=n_act, ksplit=1, want_h=False)
+                      actions_in=actions, act_strides=act_s, n_actions=n_act, ksplit=1, want_h=False,
+                      ln_stats=ln_stats, ln_stats_mode=2)
         old_logp = ops.ac_forward(mac.actor_arena, None, 0, spec, rows, nA, **fwd_kw)["logp"]
         if bs * T != rows:                                   # pad to the [nA, bs*T] stride of adv / returns
             tmp = th.zeros(nA, bs * T, **f32)

@@ -68,10 +68,12 @@ class Prediction_policy:
                       weight_decay=self.weight_decay) for i in range(self.n_agents)]
 
     # ---------------------------------------------------------------------------- rollout
-    def GAT_latent_update(self, history_single, encoder_hidden, behavior_latent=None, noise=None):
+    def GAT_latent_update(self, history_single, encoder_hidden, behavior_latent=None, noise=None, out=None):
         """history_single [E,nA,N,d], encoder_hidden [E,nA,N,A], behavior_latent [E,nA,N,Z] ->
         attention latent [E,nA,N,A]  (nova/prediction_policy.py:92-118).
-        numpy in -> numpy out (drop-in for ParallelRunner); device tensors in -> device tensor out."""
+        numpy in -> numpy out (drop-in for ParallelRunner); device tensors in -> device tensor out.
+        ``noise``: pre-drawn gumbel samples [nA,E,N,N-1,2]; ``out``: optional [E,nA,N,A] destination view
+        (e.g. ``batch["attention_latent"][:, t + 1]``) the kernel writes in place."""
         as_np = isinstance(history_single, np.ndarray)
         hist = _as_dev(history_single, self.device)
         hid = _as_dev(encoder_hidden, self.device)
@@ -81,7 +83,8 @@ class Prediction_policy:
             lat = _as_dev(behavior_latent, self.device).permute(1, 0, 2, 3)
         if noise is None:
             noise = gumbel_noise((nA, E, N, N - 1, 2), self.device)
-        out, _ = ops.gat_forward(self.gat_arena, hist.permute(1, 0, 2, 3), lat, hid.permute(1, 0, 2, 3), noise)
+        out, _ = ops.gat_forward(self.gat_arena, hist.permute(1, 0, 2, 3), lat, hid.permute(1, 0, 2, 3), noise,
+                                 out=None if out is None else out.permute(1, 0, 2, 3))
         out = out.permute(1, 0, 2, 3)          # [E, nA, N, A] view
         return out.cpu().numpy() if as_np else out
 

@@ -77,9 +77,11 @@ def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None
     return out, saved
 
 
-def enc_forward(arena, x, h0, prev_latent, coef, Z, lib=None):
-    """EncoderRNN + soft update for all nets.  x [n_nets,B,N,L,d], h0 [n_nets,B,N,R],
-    prev_latent [n_nets,B,N,Z] or None (first two dims may be strided views).
+def enc_forward(arena, x, h0, prev_latent, coef, Z, out_lat=None, out_h=None, lib=None):
+    """EncoderRNN + soft update for all nets.  x [n_nets,B,N,L,d] (any strides as long as the last dim is
+    contiguous: a sliding window over a time-major observation log is read in place), h0 [n_nets,B,N,R],
+    prev_latent [n_nets,B,N,Z] or None (first two dims may be strided views).  ``out_lat`` / ``out_h``:
+    optional destinations of the same logical shapes (e.g. views into the episode buffer).
     Returns (latent [n_nets,B,N,Z], hL [n_nets,B,N,R])."""
     lib = _lib(lib)
     n_nets, B, N, Lw, d = x.shape
@@ -87,17 +89,18 @@ def enc_forward(arena, x, h0, prev_latent, coef, Z, lib=None):
     dev = x.device
     a = L.EncFwdArgs()
     a.n_nets, a.B, a.N, a.L, a.d, a.Z = n_nets, B, N, Lw, d, Z
+    assert x.dtype == torch.float32 and x.stride(4) == 1
     a.x = x.data_ptr()
-    a.x_s_net, a.x_s_b = _nb_strides(x, N * Lw * d)
+    a.x_s_net, a.x_s_b, a.x_s_i, a.x_s_t = x.stride(0), x.stride(1), x.stride(2), x.stride(3)
     a.h0 = h0.data_ptr()
     a.h0_s_net, a.h0_s_b = _nb_strides(h0, N * R)
-    hL = torch.empty(n_nets, B, N, R, dtype=torch.float32, device=dev)
+    hL = out_h if out_h is not None else torch.empty(n_nets, B, N, R, dtype=torch.float32, device=dev)
     a.hL = hL.data_ptr()
     a.hL_s_net, a.hL_s_b = _nb_strides(hL, N * R)
     if prev_latent is not None:
         a.prev_latent = prev_latent.data_ptr()
         a.pl_s_net, a.pl_s_b = _nb_strides(prev_latent, N * Z)
-    lat = torch.empty(n_nets, B, N, Z, dtype=torch.float32, device=dev)
+    lat = out_lat if out_lat is not None else torch.empty(n_nets, B, N, Z, dtype=torch.float32, device=dev)
     a.latent_out = lat.data_ptr()
     a.lo_s_net, a.lo_s_b = _nb_strides(lat, N * Z)
     a.one_minus_c = 1.0 - coef
@@ -116,6 +119,7 @@ class AcFeatureSpec:
     only referenced (kept alive) -- the kernel reads them in place."""
 
     def __init__(self, N, sources, n_actions=0, last_action=None, la_strides=(0, 0), n_id=0, T=1, T_phys=1):
+        """last_action: int32 (or int64, read in place) tensor of hot indices (-1 = all zeros), or None."""
         self.N, self.sources, self.n_actions = N, sources, n_actions
         self.last_action, self.la_strides, self.n_id, self.T, self.T_phys = last_action, la_strides, n_id, T, T_phys
 
@@ -134,9 +138,13 @@ class AcFeatureSpec:
                 f.w[k], f.src[k], f.s_net[k], f.s_row[k] = 0, None, 0, 0
         f.n_actions = self.n_actions
         if self.last_action is not None:
-            assert self.last_action.dtype == torch.int32
-            f.last_action = self.last_action.data_ptr()
-            f.la_s_net, f.la_s_row = self.la_strides
+            if self.last_action.dtype == torch.int64:
+                f.last_action64 = self.last_action.data_ptr()
+                f.la64_s_net, f.la64_s_row = self.la_strides
+            else:
+                assert self.last_action.dtype == torch.int32
+                f.last_action = self.last_action.data_ptr()
+                f.la_s_net, f.la_s_row = self.la_strides
         f.n_id = self.n_id
         f.T, f.T_phys = self.T, self.T_phys
 
@@ -152,9 +160,13 @@ def _fill_acnet(dst, arena, order, n_out):
 def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=None, h_critic=None,
                h_strides=(0, 0), avail=None, avail_strides=(0, 0), mode=0, q_noise=None, actions_in=None,
                act_strides=(0, 0), n_actions=5, ksplit=None, save=False, want_probs=False, want_entropy=False,
-               want_h=True, lib=None):
+               want_h=True, h_out=None, actions_out=None, onehot_out=None, ln_stats=None, ln_stats_mode=0, lib=None):
     """Fused actor (which=0) / critic (1) / both (2) forward for all agents.
-    Returns a dict with the requested outputs, each laid out [n_agents, rows, ...]."""
+    Returns a dict with the requested outputs, each laid out [n_agents, rows, ...].
+    Optional in-place destinations (rollout: write straight into the episode buffer):
+      h_out = (actor_tensor, critic_tensor, (s_net, s_row));  actions_out = (int64 tensor, (s_net, s_row));
+      onehot_out = (float tensor, (s_net, s_row)).
+    ln_stats [n_agents, n_physical_rows, 2] with ln_stats_mode 1 (compute + store) / 2 (re-use)."""
     lib = _lib(lib)
     dev = (actor_arena if which != 1 else critic_arena).data.device
     a = L.AcFwdArgs()
@@ -166,7 +178,9 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
     if which != 1:
         _fill_acnet(a.actor, actor_arena, L.ACTOR_PARAM_ORDER, n_actions)
         a.h_actor = h_actor.data_ptr()
-        if want_h:
+        if h_out is not None:
+            a.h_actor_out = h_out[0].data_ptr()
+        elif want_h:
             out["h_actor"] = torch.empty(n_agents, rows, L.AC_HIDDEN, **f32)
             a.h_actor_out = out["h_actor"].data_ptr()
         if avail is not None:
@@ -181,9 +195,17 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
             assert actions_in.dtype == torch.int64
             a.actions_in = actions_in.data_ptr()
             a.act_s_net, a.act_s_row = act_strides
+        elif actions_out is not None:
+            assert actions_out[0].dtype == torch.int64
+            a.actions_out = actions_out[0].data_ptr()
+            a.ao_s_net, a.ao_s_row = actions_out[1]
         else:
             out["actions"] = torch.empty(n_agents, rows, dtype=torch.int64, device=dev)
             a.actions_out = out["actions"].data_ptr()
+        if onehot_out is not None and mode != 2:
+            assert onehot_out[0].dtype == torch.float32
+            a.onehot_out = onehot_out[0].data_ptr()
+            a.oh_s_net, a.oh_s_row = onehot_out[1]
         out["logp"] = torch.empty(n_agents, rows, **f32)
         a.logp = out["logp"].data_ptr()
         if want_entropy:
@@ -195,18 +217,25 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
     if which != 0:
         _fill_acnet(a.critic, critic_arena, L.CRITIC_PARAM_ORDER, 1)
         a.h_critic = h_critic.data_ptr()
-        if want_h:
+        if h_out is not None:
+            a.h_critic_out = h_out[1].data_ptr()
+        elif want_h:
             out["h_critic"] = torch.empty(n_agents, rows, L.AC_HIDDEN, **f32)
             a.h_critic_out = out["h_critic"].data_ptr()
         out["values"] = torch.empty(n_agents, rows, **f32)
         a.values = out["values"].data_ptr()
     a.hs_net, a.hs_row = h_strides
+    if h_out is not None:
+        a.ho_s_net, a.ho_s_row = h_out[2]
+    if ln_stats is not None and ln_stats_mode:
+        assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.shape[0] == n_agents and ln_stats.shape[2] == 2
+        a.ln_stats, a.ln_stats_s_net, a.ln_stats_mode = ln_stats.data_ptr(), ln_stats.stride(0), ln_stats_mode
     if save:
         out["saved"] = torch.empty(2, n_agents, rows, L.AC_SAVE_FLOATS, **f32)
         a.saved = out["saved"].data_ptr()
     lib.call("iplan_ac_fwd", a, L.current_stream(dev))
     out["_args"] = a
-    out["_keep"] = (spec, h_actor, h_critic, avail, q_noise, actions_in)
+    out["_keep"] = (spec, h_actor, h_critic, avail, q_noise, actions_in, h_out, actions_out, onehot_out, ln_stats)
     return out
 
 

@@ -162,6 +162,9 @@ def test_harness_full_cycle_emulated(capsys):
     before = [p.detach().clone() for p in loop.mac.agents[0].parameters()]
     enc_before = loop.behavior.enc_arena.data.clone()
     gat_before = loop.prediction.gat_arena.data.clone()
+    for o in loop.obs_sets:
+        # Highway polarity: the prediction / behaviour loss mask IS `terminated`, PPO's is 1 - terminated
+        o["terminated"].copy_((torch.rand(o["terminated"].shape) < 0.5).to(torch.uint8))
     n = loop.cycle()
     assert n == 2 * 14
     assert loop.learner.last_train_info is not None and not loop.learner.buffers[0].can_sample()
