@@ -102,6 +102,8 @@ typedef struct {
     int64_t off[IPLAN_GAT_NPARAM];
     float tau;                /* 0.01 (nova/GAT_Net.py:93)                                  */
     IplanGatSaved saved;      /* all-NULL for inference                                     */
+    int64_t* phase_clocks;    /* optional profiling aid: [n_nets*B, 5] wall_clock64 at kernel entry and after each
+                                 of the 4 phases (written by thread 0 of each workgroup); NULL = off          */
 } IplanGatFwdArgs;
 
 int iplan_gat_fwd(const IplanGatFwdArgs* args, iplan_stream_t stream);

@@ -39,7 +39,7 @@ class GatFwdArgs(C.Structure):
         ("h_prev", fp), ("h_s_net", i64), ("h_s_b", i64),
         ("out", fp), ("out_s_net", i64), ("out_s_b", i64),
         ("noise", fp), ("params", fp), ("params_s_net", i64),
-        ("off", i64 * GAT_NPARAM), ("tau", C.c_float), ("saved", GatSaved),
+        ("off", i64 * GAT_NPARAM), ("tau", C.c_float), ("saved", GatSaved), ("phase_clocks", fp),
     ]
 
 

@@ -49,6 +49,8 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
     const bool valid = node < N;
     const int64_t sb = (int64_t)net * a.B + b;
     const IplanGatSaved& sv = a.saved;
+    int64_t* clk = a.phase_clocks ? a.phase_clocks + (int64_t)blockIdx.x * 5 : nullptr;
+    if (clk && threadIdx.x == 0) clk[0] = IPLAN_CLOCK();
 
     const float* bih = P + a.off[dir ? IPLAN_GAT_R_BIH : IPLAN_GAT_F_BIH];
     const float* bhh = P + a.off[dir ? IPLAN_GAT_R_BHH : IPLAN_GAT_F_BHH];
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
         }
     }
     __syncthreads();
+    if (clk && threadIdx.x == 0) clk[1] = IPLAN_CLOCK();
 
     // ---------------------------------------------------------------- phase 2: hard-attention bi-GRU
     if (tile_live) {
@@ -131,29 +134,50 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
             for (int T = 0; T < 2; ++T) whh[t][T] = wfrag(Whh, GH, 3 * GH, GH, 16 * t, 16 * T);
         const f32x4 bhn0 = bfrag(bhh, 3 * GH, 4), bhn1 = bfrag(bhh, 3 * GH, 5);
         const float* Wh = P + a.off[IPLAN_GAT_HARD_W];                           // [2][2H]
-        const f32x4 wl00 = bfrag(Wh + dir * GH, GH, 0), wl01 = bfrag(Wh + dir * GH, GH, 1);
-        const f32x4 wl10 = bfrag(Wh + 2 * GH + dir * GH, GH, 0), wl11 = bfrag(Wh + 2 * GH + dir * GH, GH, 1);
+        // hard-attention logits as a 7th MFMA chain: A = hard_encoding.weight[:, dir*H:(dir+1)*H] (2 real rows),
+        // B = the hidden state -> class c of chain n lands in lane (n, g = 0), register c.  The chain runs one
+        // step behind (it contracts the SAME h operand the recurrent chains use), so it rides along in the
+        // round-robin issue order instead of costing cross-lane reductions on the critical path.
+        f32x4 wl[2];
+        for (int T = 0; T < 2; ++T) wl[T] = wfrag(Wh, 2 * GH, 2, 2 * GH, 0, dir * GH + 16 * T);
         f32x4 h0 = splat4(0.f), h1 = splat4(0.f);
-        for (int it = 0; it < N - 1; ++it) {
+        auto brow = [&](int it) -> const float* {
             const int s = dir ? (N - 2 - it) : it;
             int j = s + (s >= node ? 1 : 0);
             if (j > N - 1) j = N - 1;
-            const float* Bj = &s_B[dir][j][4 * g];
-            f32x4 pr0 = areg[0] + *reinterpret_cast<const f32x4*>(Bj);
-            f32x4 pr1 = areg[1] + *reinterpret_cast<const f32x4*>(Bj + 16);
-            f32x4 pz0 = areg[2] + *reinterpret_cast<const f32x4*>(Bj + 32);
-            f32x4 pz1 = areg[3] + *reinterpret_cast<const f32x4*>(Bj + 48);
-            const f32x4 gn0 = areg[4] + *reinterpret_cast<const f32x4*>(Bj + 64);
-            const f32x4 gn1 = areg[5] + *reinterpret_cast<const f32x4*>(Bj + 80);
-            f32x4 hn0 = bhn0, hn1 = bhn1;
-            pr0 = mma_block(whh[0][0], h0, pr0); pr0 = mma_block(whh[0][1], h1, pr0);
-            pr1 = mma_block(whh[1][0], h0, pr1); pr1 = mma_block(whh[1][1], h1, pr1);
-            pz0 = mma_block(whh[2][0], h0, pz0); pz0 = mma_block(whh[2][1], h1, pz0);
-            pz1 = mma_block(whh[3][0], h0, pz1); pz1 = mma_block(whh[3][1], h1, pz1);
-            hn0 = mma_block(whh[4][0], h0, hn0); hn0 = mma_block(whh[4][1], h1, hn0);
-            hn1 = mma_block(whh[5][0], h0, hn1); hn1 = mma_block(whh[5][1], h1, hn1);
-            const GruGates o0 = gru_gates(pr0, pz0, gn0, hn0, h0);
-            const GruGates o1 = gru_gates(pr1, pz1, gn1, hn1, h1);
+            return &s_B[dir][j][4 * g];
+        };
+        f32x4 bc[6], bn[6];
+        {
+            const float* Bj = brow(0);
+            for (int t = 0; t < 6; ++t) bc[t] = *reinterpret_cast<const f32x4*>(Bj + 16 * t);
+        }
+        int s_prev = 0;
+        for (int it = 0; it < N - 1; ++it) {
+            const int s = dir ? (N - 2 - it) : it;
+            if (it + 1 < N - 1) {                                   // next step's W_b h_j rows: issued now, consumed next iteration
+                const float* Bj = brow(it + 1);
+                for (int t = 0; t < 6; ++t) bn[t] = *reinterpret_cast<const f32x4*>(Bj + 16 * t);
+            }
+            f32x4 acc[7];
+            acc[0] = areg[0]; acc[1] = areg[1]; acc[2] = areg[2]; acc[3] = areg[3];
+            acc[4] = bhn0; acc[5] = bhn1; acc[6] = splat4(0.f);
+            // 7 independent accumulator chains issued round-robin: consecutive MFMAs never depend on each other
+            for (int T = 0; T < 2; ++T) {
+                const f32x4 hb = T ? h1 : h0;
+                for (int q = 0; q < 4; ++q) {
+                    for (int c = 0; c < 6; ++c) acc[c] = mfma4(whh[c][T][q], hb[q], acc[c]);
+                    acc[6] = mfma4(wl[T][q], hb[q], acc[6]);
+                }
+            }
+            if (it > 0 && g == 0 && valid) {                        // logits of the previous step
+                s_pl[dir][node][s_prev][0] = acc[6][0];
+                s_pl[dir][node][s_prev][1] = acc[6][1];
+            }
+            const f32x4 pr0 = acc[0] + bc[0], pr1 = acc[1] + bc[1], pz0 = acc[2] + bc[2], pz1 = acc[3] + bc[3];
+            const f32x4 gn0 = areg[4] + bc[4], gn1 = areg[5] + bc[5];
+            const GruGates o0 = gru_gates(pr0, pz0, gn0, acc[4], h0);
+            const GruGates o1 = gru_gates(pr1, pz1, gn1, acc[5], h1);
             h0 = o0.h;
             h1 = o1.h;
             if (sv.gru) {
@@ -164,20 +188,21 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
                 vstore(row + 3 * GH, valid, GH, 0, o0.n); vstore(row + 3 * GH, valid, GH, 1, o1.n);
                 vstore(row + 4 * GH, valid, GH, 0, o0.hn); vstore(row + 4 * GH, valid, GH, 1, o1.hn);
             }
-            float p0 = 0.f, p1 = 0.f;
-            for (int q = 0; q < 4; ++q) {
-                p0 = fmaf(wl00[q], h0[q], p0); p0 = fmaf(wl01[q], h1[q], p0);
-                p1 = fmaf(wl10[q], h0[q], p1); p1 = fmaf(wl11[q], h1[q], p1);
-            }
-            p0 = group_sum(p0);
-            p1 = group_sum(p1);
+            s_prev = s;
+            for (int t = 0; t < 6; ++t) bc[t] = bn[t];
+        }
+        {   // logits of the last step
+            f32x4 la = splat4(0.f);
+            la = mma_block(wl[0], h0, la);
+            la = mma_block(wl[1], h1, la);
             if (g == 0 && valid) {
-                s_pl[dir][node][s][0] = p0;
-                s_pl[dir][node][s][1] = p1;
+                s_pl[dir][node][s_prev][0] = la[0];
+                s_pl[dir][node][s_prev][1] = la[1];
             }
         }
     }
     __syncthreads();
+    if (clk && threadIdx.x == 0) clk[2] = IPLAN_CLOCK();
 
     // ---------------------------------------------------------------- phase 3: gated soft attention
     {
@@ -221,6 +246,7 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
         }
     }
     __syncthreads();
+    if (clk && threadIdx.x == 0) clk[3] = IPLAN_CLOCK();
 
     // ---------------------------------------------------------------- phase 4: output GRUCell
     if (tile_live) {
@@ -259,6 +285,10 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
             vstore(row + 2 * GH, valid, GH, t, o.n);
             vstore(row + 3 * GH, valid, GH, t, o.hn);
         }
+    }
+    if (clk) {
+        __syncthreads();
+        if (threadIdx.x == 0) clk[4] = IPLAN_CLOCK();
     }
 }
 

@@ -31,6 +31,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Scheduling fence: keeps the compiler from hoisting the next tile's LDS fragment reads above the
 // current tile's MFMA chain (which otherwise blows the register budget in the 64-wide GRU kernels).
 #ifdef IPLAN_HOST_EMULATION
+#define IPLAN_CLOCK() ((int64_t)0)
+#else
+#define IPLAN_CLOCK() ((int64_t)wall_clock64())
+#endif
+#ifdef IPLAN_HOST_EMULATION
 #define IPLAN_SCHED_FENCE() do {} while (0)
 #else
 #define IPLAN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)

@@ -50,15 +50,25 @@ __device__ __forceinline__ int ocol(const IplanWgradProblem& p, int o) {
     return o < p.seg_split ? p.seg_c0 + o : p.seg_c1 + (o - p.seg_split);
 }
 
-// grid: (virtual chunk, job, problem * n_nets + net); block: 64 (one wave)
-__global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a) {
-    const int pi = (int)blockIdx.z / a.n_nets, net = (int)blockIdx.z % a.n_nets;
+// grid: (problem * max_jobs + job, virtual chunk, net); block: 64 (one wave).  The (problem, job) index varies
+// fastest so that the waves that read the same rows (other tile jobs of a problem, and the other problems of a
+// launch -- a GRU's W_ih / W_hh share their dY rows) are dispatched together and meet in L2 / the Infinity Cache.
+//
+// Data path per 16-row block: every lane fetches ONE 16-byte piece of each operand tile (row = lane/4, 4
+// consecutive columns: 64 contiguous bytes per row, whole cache lines across neighbouring tiles), the 16x16 tiles
+// are parked in LDS and read back in MFMA operand order (lane (i, g), sub-step s: element [4s+g][i]; with a
+// 16-float row pitch the two 32-lane halves of a ds_read_b32 hit disjoint banks).  The next block's global loads
+// are in flight while the current block's 64 MFMAs run.
+__global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a, int max_jobs) {
+    __shared__ __attribute__((aligned(16))) float s_t[2][WG_TO + WG_TK][256];
+    const int pi = (int)blockIdx.x / max_jobs, job = (int)blockIdx.x % max_jobs, net = (int)blockIdx.z;
     const IplanWgradProblem& p = a.p[pi];
     const WgradGeom gm = wgrad_geom(p);
-    const int vc = (int)blockIdx.x, job = (int)blockIdx.y;
+    const int vc = (int)blockIdx.y;
     if (vc >= gm.vchunks || job >= gm.jobs) return;
     const int og = job / gm.n_kg, kg = job % gm.n_kg;
-    const int l = lane_id(), i = l & 15, g = l >> 4;
+    const int l = lane_id(), i = l & 15, g = l >> 4;       // MFMA role
+    const int lr = l >> 2, lc = 4 * (l & 3);               // loader role: row of the block, first of 4 columns
     const int ot0 = og * WG_TO, kt0 = kg * WG_TK;
     const int not_ = imin(WG_TO, gm.OT - ot0), nkt = gm.KT > 0 ? imin(WG_TK, gm.KT - kt0) : 0;
     const bool want_bias = (kg == 0);
@@ -73,41 +83,82 @@ __global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a) {
         bacc[t] = splat4(0.f);
         for (int u = 0; u < WG_TK; ++u) acc[t][u] = splat4(0.f);
     }
-    int ocols[WG_TO];
-    bool ovalid[WG_TO];
+    // loader-side column bookkeeping: this lane's 4 columns of every tile
+    int acol[WG_TO], anv[WG_TO], bcol[WG_TK], bnv[WG_TK];
+    bool avec[WG_TO], bvec[WG_TK];
+    const bool dy_al = ((p.dy_s_outer | p.dy_s_inner | p.dy_s_net) & 3) == 0 && ((((size_t)p.dy) & 15) == 0);
+    const bool x_al = ((p.x_s_outer | p.x_s_inner | p.x_s_net | p.x0_s_outer | p.x0_s_net) & 3) == 0 &&
+                      ((((size_t)p.x) & 15) == 0) && ((((size_t)p.x0) & 15) == 0);
     for (int t = 0; t < WG_TO; ++t) {
-        const int o = (ot0 + t) * 16 + i;
-        ovalid[t] = t < not_ && o < p.O;
-        ocols[t] = ovalid[t] ? ocol(p, o) : 0;
+        const int o = (ot0 + t) * 16 + lc;
+        const int rem = p.O - o;
+        anv[t] = t < not_ ? (rem >= 4 ? 4 : (rem > 0 ? rem : 0)) : 0;
+        acol[t] = anv[t] > 0 ? ocol(p, o) : 0;
+        avec[t] = anv[t] == 4 && ocol(p, o + 3) == acol[t] + 3 && dy_al && (acol[t] & 3) == 0;
+    }
+    for (int u = 0; u < WG_TK; ++u) {
+        const int k = (kt0 + u) * 16 + lc;
+        const int rem = p.K - k;
+        bnv[u] = u < nkt ? (rem >= 4 ? 4 : (rem > 0 ? rem : 0)) : 0;
+        bcol[u] = p.x_col0 + k;
+        bvec[u] = bnv[u] == 4 && x_al && (bcol[u] & 3) == 0;
     }
     const int64_t r_lo = (int64_t)vc * gm.vrows;
     const int64_t r_hi = gm.rows < r_lo + gm.vrows ? gm.rows : r_lo + gm.vrows;
-    for (int64_t rb = r_lo; rb < r_hi; rb += 16) {
+    // (outer, inner) of the row this lane loads, advanced by 16 rows per block (no division in the loop)
+    int o_s, i_s;
+    {
+        const int64_t r = r_lo + lr;
+        o_s = (int)(r / p.n_inner);
+        i_s = (int)(r - (int64_t)o_s * p.n_inner);
+    }
+    const int adv_o = 16 / p.n_inner, adv_i = 16 % p.n_inner;
+
+    struct Regs { f32x4 av[WG_TO]; f32x4 bv[WG_TK]; };
+    auto fetch = [&](int64_t rb, Regs& o) {
+        const int64_t r = rb + lr;
+        const bool rv = r < r_hi;
+        const int64_t outer = o_s;
+        const int inner = i_s;
+        o_s += adv_o;
+        i_s += adv_i;
+        if (i_s >= p.n_inner) { i_s -= p.n_inner; o_s += 1; }
+        const float* dyr = dy + outer * p.dy_s_outer + (int64_t)inner * p.dy_s_inner;
+        for (int t = 0; t < WG_TO; ++t) {
+            f32x4 v = splat4(0.f);
+            if (rv && anv[t] > 0) {
+                if (avec[t]) v = *reinterpret_cast<const f32x4*>(dyr + acol[t]);
+                else for (int q = 0; q < 4; ++q) if (q < anv[t]) v[q] = dyr[ocol(p, (ot0 + t) * 16 + lc + q)];
+            }
+            o.av[t] = v;
+        }
+        const float* xr = nullptr;
+        if (rv && nkt > 0) {
+            const int xi = inner + p.x_shift;
+            if (xi >= 0 && xi < p.n_inner) xr = x + outer * p.x_s_outer + (int64_t)xi * p.x_s_inner;
+            else if (x0) xr = x0 + outer * p.x0_s_outer - p.x_col0;
+        }
+        for (int u = 0; u < WG_TK; ++u) {
+            f32x4 v = splat4(0.f);
+            if (xr && bnv[u] > 0) {
+                if (bvec[u]) v = *reinterpret_cast<const f32x4*>(xr + bcol[u]);
+                else for (int q = 0; q < 4; ++q) if (q < bnv[u]) v[q] = xr[bcol[u] + q];
+            }
+            o.bv[u] = v;
+        }
+    };
+    auto park = [&](const Regs& o, int buf) {
+        for (int t = 0; t < WG_TO; ++t)
+            if (t < not_) *reinterpret_cast<f32x4*>(&s_t[buf][t][lr * 16 + lc]) = o.av[t];
+        for (int u = 0; u < WG_TK; ++u)
+            if (u < nkt) *reinterpret_cast<f32x4*>(&s_t[buf][WG_TO + u][lr * 16 + lc]) = o.bv[u];
+    };
+    auto contract = [&](int buf) {
         for (int s = 0; s < 4; ++s) {
-            const int64_t r = rb + 4 * s + g;
-            const bool rv = r < r_hi;
-            int64_t outer = 0;
-            int inner = 0;
-            if (rv) {
-                outer = r / p.n_inner;
-                inner = (int)(r - outer * p.n_inner);
-            }
-            float av[WG_TO];
-            const float* dyr = dy + outer * p.dy_s_outer + (int64_t)inner * p.dy_s_inner;
-            for (int t = 0; t < WG_TO; ++t) av[t] = (rv && ovalid[t]) ? dyr[ocols[t]] : 0.f;
-            float bv[WG_TK];
-            if (nkt > 0) {
-                const int xi = inner + p.x_shift;
-                const float* xr = nullptr;
-                if (rv) {
-                    if (xi >= 0 && xi < p.n_inner) xr = x + outer * p.x_s_outer + (int64_t)xi * p.x_s_inner + p.x_col0;
-                    else if (x0) xr = x0 + outer * p.x0_s_outer;
-                }
-                for (int u = 0; u < WG_TK; ++u) {
-                    const int k = (kt0 + u) * 16 + i;
-                    bv[u] = (xr && u < nkt && k < p.K) ? xr[k] : 0.f;
-                }
-            }
+            const int e = (4 * s + g) * 16 + i;
+            float av[WG_TO], bv[WG_TK];
+            for (int t = 0; t < WG_TO; ++t) av[t] = t < not_ ? s_t[buf][t][e] : 0.f;
+            for (int u = 0; u < WG_TK; ++u) bv[u] = u < nkt ? s_t[buf][WG_TO + u][e] : 0.f;
             for (int t = 0; t < WG_TO; ++t) {
                 if (t < not_) {
                     for (int u = 0; u < WG_TK; ++u)
@@ -116,6 +167,16 @@ __global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a) {
                 }
             }
         }
+    };
+    Regs rg;
+    fetch(r_lo, rg);
+    int buf = 0;
+    for (int64_t rb = r_lo; rb < r_hi; rb += 16) {
+        park(rg, buf);
+        if (rb + 16 < r_hi) fetch(rb + 16, rg);            // next block's global loads fly during the MFMAs below
+        __syncthreads();                                    // one wave per workgroup: orders the LDS hand-off
+        contract(buf);
+        buf ^= 1;
     }
     // partial tile layout: part[vc][o (OT*16)][KT*16 + 1]; D layout: lane (col j = i, row = 4g + q)
     float* __restrict__ part = a.workspace + p.ws_off + ((int64_t)net * gm.vchunks + vc) * gm.part_floats;
@@ -187,8 +248,8 @@ extern "C" int iplan_wgrad(IplanWgradArgs* a, iplan_stream_t stream) {
         return fail(IPLAN_EINVAL, "iplan_wgrad: workspace too small (%lld floats needed, %lld given)", (long long)off,
                     (long long)a->workspace_floats);
     const unsigned z = (unsigned)(a->n_problems * a->n_nets);
-    hipLaunchKernelGGL(wgrad_partial_kernel, dim3((unsigned)max_vc, (unsigned)max_jobs, z), dim3(64), 0,
-                       (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(wgrad_partial_kernel, dim3((unsigned)(a->n_problems * max_jobs), (unsigned)max_vc, (unsigned)a->n_nets),
+                       dim3(64), 0, (hipStream_t)stream, *a, max_jobs);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((max_elems + 255) / 256), z), dim3(256), 0,
                        (hipStream_t)stream, *a);
     return check_launch("iplan_wgrad");

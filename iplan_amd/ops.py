@@ -27,7 +27,7 @@ def _nb_strides(t, inner):
     return t.stride(0), t.stride(1)
 
 
-def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None, lib=None):
+def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None, phase_clocks=None, lib=None):
     """GAT_Net.forward for all nets.  src0 [n_nets,B,N,d0], src1 [n_nets,B,N,d1] or None,
     h_prev [n_nets,B,N,A] (first two dims may be arbitrarily strided views), noise
     [n_nets,B,N,N-1,2] contiguous.  Returns (out [n_nets,B,N,A], saved dict or None)."""
@@ -56,6 +56,9 @@ def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None
     for i, k in enumerate(L.GAT_PARAM_ORDER):
         a.off[i] = arena.off(k)
     a.tau = tau
+    if phase_clocks is not None:
+        assert phase_clocks.dtype == torch.int64 and phase_clocks.numel() >= n_nets * B * 5
+        a.phase_clocks = phase_clocks.data_ptr()
     saved = None
     if save:
         H = A

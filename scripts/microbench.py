@@ -88,3 +88,12 @@ if not want or "ac_train_parts" in want:
     fo = ops.ac_forward(loop.mac.actor_arena, loop.mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True, **kw)
     g1 = torch.randn(nA, rows, device=dev)
     tm("ac_backward(all)", lambda: ops.ac_backward(fo, loop.mac.actor_arena, loop.mac.critic_arena, g_logp=g1, g_entropy=-1e-6, g_values=g1), n=5)
+
+if "gat_phases" in set(sys.argv[1:]):
+    clk = torch.zeros(nA * E, 5, dtype=torch.int64, device=dev)
+    ops.gat_forward(loop.prediction.gat_arena, hist, lat, hid, noise, out=out, phase_clocks=clk)
+    torch.cuda.synchronize()
+    c = clk.cpu().double()
+    d = (c[:, 1:] - c[:, :-1])
+    print("gat phases (wall_clock64 ticks, 100 MHz => x10 ns): mean per WG", d.mean(0).tolist(), "max", d.max(0).values.tolist())
+    print("kernel span ticks:", float(c[:, 4].max() - c[:, 0].min()), "first-start spread", float(c[:, 0].max() - c[:, 0].min()))

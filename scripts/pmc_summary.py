@@ -1,0 +1,22 @@
+"""Average PMC counter values per kernel from rocprofv3 --pmc csv outputs (one sub-directory per pass)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+for f in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True)):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if not k.startswith("iplan::") and "iplan" not in k:
+            continue
+        a = agg[k][r["Counter_Name"]]
+        a[0] += float(r["Counter_Value"])
+        a[1] += 1
+for k in sorted(agg):
+    print(k)
+    for c in sorted(agg[k]):
+        s, n = agg[k][c]
+        print(f"    {c:32s} avg/dispatch {s / n:16.1f}   (n={n})")
