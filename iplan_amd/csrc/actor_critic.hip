@@ -259,14 +259,14 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     float mu1, rs1, mu2, rs2, mu3, rs3;
     f32x4 f[AT];
     for (int t = 0; t < AT; ++t) {
-        f[t] = relu4(acc[t] + bfrag(P + nw.off[IPLAN_AC_FC1_B], AM, t));
+        f[t] = relu4(acc[t] + bfrag_a(P + nw.off[IPLAN_AC_FC1_B], t));
         if (sv) vstore(sv, valid, AM, t, f[t]);                       // a1
     }
     layer_norm_tiles<AT>(f, P + nw.off[IPLAN_AC_LN1_W], P + nw.off[IPLAN_AC_LN1_B], &mu1, &rs1);
     if (sv) for (int t = 0; t < AT; ++t) vstore(sv + AM, valid, AM, t, f[t]);   // f1
     f32x4 f2[AT];
     for (int t = 0; t < AT; ++t) {
-        f2[t] = relu4(dense_tile_g<AT>(P + nw.off[IPLAN_AC_FC2_W], AM, AM, AM, 16 * t, f, bfrag(P + nw.off[IPLAN_AC_FC2_B], AM, t)));
+        f2[t] = relu4(dense_tile_ga<AT>(P + nw.off[IPLAN_AC_FC2_W], AM, AM, 16 * t, f, bfrag_a(P + nw.off[IPLAN_AC_FC2_B], t)));
         if (sv) vstore(sv + 2 * AM, valid, AM, t, f2[t]);             // a2
     }
     layer_norm_tiles<AT>(f2, P + nw.off[IPLAN_AC_LN2_W], P + nw.off[IPLAN_AC_LN2_B], &mu2, &rs2);
@@ -282,16 +282,16 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         const float* bi = P + nw.off[IPLAN_AC_BIH];
         const float* bh = P + nw.off[IPLAN_AC_BHH];
         for (int t = 0; t < AT; ++t) {
-            f32x4 prr = bfrag(bi, 3 * AM, t) + bfrag(bh, 3 * AM, t);
-            f32x4 pz = bfrag(bi, 3 * AM, AT + t) + bfrag(bh, 3 * AM, AT + t);
-            f32x4 gn = bfrag(bi, 3 * AM, 2 * AT + t);
-            f32x4 hn = bfrag(bh, 3 * AM, 2 * AT + t);
-            prr = dense_tile_g<AT>(Wi, AM, 3 * AM, AM, 16 * t, f2, prr);
-            prr = dense_tile_g<AT>(Wh, AM, 3 * AM, AM, 16 * t, h, prr);
-            pz = dense_tile_g<AT>(Wi, AM, 3 * AM, AM, AM + 16 * t, f2, pz);
-            pz = dense_tile_g<AT>(Wh, AM, 3 * AM, AM, AM + 16 * t, h, pz);
-            gn = dense_tile_g<AT>(Wi, AM, 3 * AM, AM, 2 * AM + 16 * t, f2, gn);
-            hn = dense_tile_g<AT>(Wh, AM, 3 * AM, AM, 2 * AM + 16 * t, h, hn);
+            f32x4 prr = bfrag_a(bi, t) + bfrag_a(bh, t);
+            f32x4 pz = bfrag_a(bi, AT + t) + bfrag_a(bh, AT + t);
+            f32x4 gn = bfrag_a(bi, 2 * AT + t);
+            f32x4 hn = bfrag_a(bh, 2 * AT + t);
+            prr = dense_tile_ga<AT>(Wi, AM, 3 * AM, 16 * t, f2, prr);
+            prr = dense_tile_ga<AT>(Wh, AM, 3 * AM, 16 * t, h, prr);
+            pz = dense_tile_ga<AT>(Wi, AM, 3 * AM, AM + 16 * t, f2, pz);
+            pz = dense_tile_ga<AT>(Wh, AM, 3 * AM, AM + 16 * t, h, pz);
+            gn = dense_tile_ga<AT>(Wi, AM, 3 * AM, 2 * AM + 16 * t, f2, gn);
+            hn = dense_tile_ga<AT>(Wh, AM, 3 * AM, 2 * AM + 16 * t, h, hn);
             const GruGates o = gru_gates(prr, pz, gn, hn, h[t]);
             hnew[t] = o.h;
             if (sv) {
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     }
     // ---- head
     const int n_out = nw.n_out;
-    const f32x4 lg = dense_tile_g<AT>(P + nw.off[IPLAN_AC_HEAD_W], AM, n_out, AM, 0, hnew, bfrag(P + nw.off[IPLAN_AC_HEAD_B], n_out, 0));
+    const f32x4 lg = dense_tile_ga<AT>(P + nw.off[IPLAN_AC_HEAD_W], AM, n_out, 0, hnew, bfrag(P + nw.off[IPLAN_AC_HEAD_B], n_out, 0));
     const int64_t orow = (int64_t)net * a.rows + (valid ? r : 0);
     if (which == 1) {
         if (valid && g == 0 && a.values) a.values[orow] = lg[0];

@@ -25,7 +25,7 @@ __device__ __forceinline__ void ln_bwd_tiles(f32x4 (&dy)[BT], const f32x4 (&xhat
     float s1 = 0.f, s2 = 0.f;
     f32x4 dxh[BT];
     for (int t = 0; t < BT; ++t) {
-        const f32x4 gm = bfrag(gamma, BM, t);
+        const f32x4 gm = bfrag_a(gamma, t);
         for (int q = 0; q < 4; ++q) {
             dgam[t][q] = dy[t][q] * xhat[t][q];
             dbet[t][q] = dy[t][q];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
         if (valid && g == 0) dhead[0][0] = a.g_values[orow];
     } else {
         // recompute the masked categorical exactly as the forward does (distributions.py:64-68)
-        const f32x4 lg = dense_tile_g<BT>(P + nw.off[IPLAN_AC_HEAD_W], BM, n_out, BM, 0, f3, bfrag(P + nw.off[IPLAN_AC_HEAD_B], n_out, 0));
+        const f32x4 lg = dense_tile_ga<BT>(P + nw.off[IPLAN_AC_HEAD_W], BM, n_out, 0, f3, bfrag(P + nw.off[IPLAN_AC_HEAD_B], n_out, 0));
         f32x4 x;
         bool masked[4];
         float m = -INFINITY;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
             vstore(ds + 5 * BM, valid, BM, t, o.dnh);
         }
     }
-    for (int t = 0; t < BT; ++t) d[t] = dense_tile_gt<3 * BT>(P + nw.off[IPLAN_AC_WIH], BM, 3 * BM, BM, 16 * t, dg, splat4(0.f));
+    for (int t = 0; t < BT; ++t) d[t] = dense_tile_gta<3 * BT>(P + nw.off[IPLAN_AC_WIH], BM, 16 * t, dg, splat4(0.f));
     // ---- f2 = LN2(a2), a2 = ReLU(fc2(f1))
     {
         f32x4 xh[BT], a2[BT];
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
     }
     {
         f32x4 df1[BT];
-        for (int t = 0; t < BT; ++t) df1[t] = dense_tile_gt<BT>(P + nw.off[IPLAN_AC_FC2_W], BM, BM, BM, 16 * t, d, splat4(0.f));
+        for (int t = 0; t < BT; ++t) df1[t] = dense_tile_gta<BT>(P + nw.off[IPLAN_AC_FC2_W], BM, 16 * t, d, splat4(0.f));
         for (int t = 0; t < BT; ++t) d[t] = df1[t];
     }
     // ---- f1 = LN1(a1), a1 = ReLU(fc1(LN_F(x)))

@@ -93,8 +93,8 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
             if (t < 4) ac += bfrag(bhh, 3 * GH, t);          // r,z gates: both biases sit outside r*(.)
             f32x4 bc = splat4(0.f);
             for (int T = 0; T < 2; ++T) {
-                ac = mma_block(wfrag(Wih, 2 * GH, 3 * GH, 2 * GH, 16 * t, 16 * T), h[T], ac);
-                bc = mma_block(wfrag(Wih, 2 * GH, 3 * GH, 2 * GH, 16 * t, GH + 16 * T), h[T], bc);
+                ac = mma_block(wfrag_a(Wih, 2 * GH, 3 * GH, 16 * t, 16 * T), h[T], ac);
+                bc = mma_block(wfrag_a(Wih, 2 * GH, 3 * GH, 16 * t, GH + 16 * T), h[T], bc);
             }
             areg[t] = ac;
             if (valid) *reinterpret_cast<f32x4*>(&s_B[dir][node][16 * t + 4 * g]) = bc;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
                 float (*dst)[QST] = which ? s_k : s_q;
                 for (int t = 0; t < 2; ++t) {
                     f32x4 ac = splat4(0.f);
-                    for (int T = 0; T < 2; ++T) ac = mma_block(wfrag(Wm, GH, GH, GH, 16 * t, 16 * T), h[T], ac);
+                    for (int T = 0; T < 2; ++T) ac = mma_block(wfrag_a(Wm, GH, GH, 16 * t, 16 * T), h[T], ac);
                     if (valid)
                         for (int q = 0; q < 4; ++q) dst[node][16 * t + 4 * g + q] = ac[q];
                     if (sv.qkv) vstore(sv.qkv + ((sb * N + node) * 3 + which) * GH, valid, GH, t, ac);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
             const float* Wm = P + a.off[IPLAN_GAT_V_W];
             for (int t = 0; t < 2; ++t) {
                 f32x4 ac = bfrag(P + a.off[IPLAN_GAT_V_B], GH, t);
-                for (int T = 0; T < 2; ++T) ac = mma_block(wfrag(Wm, GH, GH, GH, 16 * t, 16 * T), h[T], ac);
+                for (int T = 0; T < 2; ++T) ac = mma_block(wfrag_a(Wm, GH, GH, 16 * t, 16 * T), h[T], ac);
                 ac = relu4(ac);
                 if (valid)
                     for (int q = 0; q < 4; ++q) s_v[node][16 * t + 4 * g + q] = ac[q];
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
         const float* Whh = P + a.off[dir ? IPLAN_GAT_R_WHH : IPLAN_GAT_F_WHH];   // [3H][H]
         f32x4 whh[6][2];
         for (int t = 0; t < 6; ++t)
-            for (int T = 0; T < 2; ++T) whh[t][T] = wfrag(Whh, GH, 3 * GH, GH, 16 * t, 16 * T);
+            for (int T = 0; T < 2; ++T) whh[t][T] = wfrag_a(Whh, GH, 3 * GH, 16 * t, 16 * T);
         const f32x4 bhn0 = bfrag(bhh, 3 * GH, 4), bhn1 = bfrag(bhh, 3 * GH, 5);
         const float* Wh = P + a.off[IPLAN_GAT_HARD_W];                           // [2][2H]
         // hard-attention logits as a 7th MFMA chain: A = hard_encoding.weight[:, dir*H:(dir+1)*H] (2 real rows),
@@ -268,12 +268,12 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
         f32x4 gn = bfrag(bi, 3 * GH, 4 + t);
         f32x4 hn = bfrag(bc, 3 * GH, 4 + t);
         for (int T = 0; T < 2; ++T) {
-            pr = mma_block(wfrag(Wi, GH, 3 * GH, GH, 16 * t, 16 * T), x[T], pr);
-            pr = mma_block(wfrag(Wc, GH, 3 * GH, GH, 16 * t, 16 * T), hp[T], pr);
-            pz = mma_block(wfrag(Wi, GH, 3 * GH, GH, GH + 16 * t, 16 * T), x[T], pz);
-            pz = mma_block(wfrag(Wc, GH, 3 * GH, GH, GH + 16 * t, 16 * T), hp[T], pz);
-            gn = mma_block(wfrag(Wi, GH, 3 * GH, GH, 2 * GH + 16 * t, 16 * T), x[T], gn);
-            hn = mma_block(wfrag(Wc, GH, 3 * GH, GH, 2 * GH + 16 * t, 16 * T), hp[T], hn);
+            pr = mma_block(wfrag_a(Wi, GH, 3 * GH, 16 * t, 16 * T), x[T], pr);
+            pr = mma_block(wfrag_a(Wc, GH, 3 * GH, 16 * t, 16 * T), hp[T], pr);
+            pz = mma_block(wfrag_a(Wi, GH, 3 * GH, GH + 16 * t, 16 * T), x[T], pz);
+            pz = mma_block(wfrag_a(Wc, GH, 3 * GH, GH + 16 * t, 16 * T), hp[T], pz);
+            gn = mma_block(wfrag_a(Wi, GH, 3 * GH, 2 * GH + 16 * t, 16 * T), x[T], gn);
+            hn = mma_block(wfrag_a(Wc, GH, 3 * GH, 2 * GH + 16 * t, 16 * T), hp[T], hn);
         }
         const GruGates o = gru_gates(pr, pz, gn, hn, hp[t]);
         float* orow = a.out + (int64_t)net * a.out_s_net + (int64_t)b * a.out_s_b + (int64_t)node * GH;

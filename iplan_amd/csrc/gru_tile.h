@@ -57,6 +57,24 @@ __device__ __forceinline__ f32x4 dense_tile_g(const float* __restrict__ W, int l
     return acc;
 }
 
+// Aligned fast paths (see wfrag_a / wfrag_ta): arena tensors are 16-byte aligned and the 32/64-wide layers have
+// ld % 4 == 0 and whole 16-column tiles.
+template <int KT>
+__device__ __forceinline__ f32x4 dense_tile_ga(const float* __restrict__ W, int ld, int rows, int o0,
+                                               const f32x4 (&x)[KT], f32x4 acc) {
+    f32x4 wf[KT];
+    for (int T = 0; T < KT; ++T) wf[T] = wfrag_a(W, ld, rows, o0, 16 * T);
+    for (int T = 0; T < KT; ++T) acc = mma_block(wf[T], x[T], acc);
+    return acc;
+}
+template <int KT>
+__device__ __forceinline__ f32x4 dense_tile_gta(const float* __restrict__ W, int ld, int o0, const f32x4 (&x)[KT], f32x4 acc) {
+    f32x4 wf[KT];
+    for (int T = 0; T < KT; ++T) wf[T] = wfrag_ta(W, ld, o0, 16 * T);
+    for (int T = 0; T < KT; ++T) acc = mma_block(wf[T], x[T], acc);
+    return acc;
+}
+
 // acc += (W^T x)[o0 .. o0+15]: W row-major [rows x cols], x has `rows` entries in KT tiles
 // (backward-data of a dense layer: dx = W^T dy).
 template <int KT>
@@ -137,7 +155,7 @@ __device__ __forceinline__ void layer_norm_tiles(f32x4 (&v)[DT], const float* __
         for (int k = 0; k < 4; ++k) { const float d = v[t][k] - mu; q = fmaf(d, d, q); }
     const float rstd = 1.0f / sqrtf(group_sum(q) * inv + 1e-5f);
     for (int t = 0; t < DT; ++t) {
-        const f32x4 gm = bfrag(gamma, 16 * DT, t), bt = bfrag(beta, 16 * DT, t);
+        const f32x4 gm = bfrag_a(gamma, t), bt = bfrag_a(beta, t);
         for (int k = 0; k < 4; ++k) v[t][k] = (v[t][k] - mu) * rstd * gm[k] + bt[k];
     }
     if (mean_out) *mean_out = mu;

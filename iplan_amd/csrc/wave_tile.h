@@ -102,6 +102,32 @@ __device__ __forceinline__ f32x4 wfrag(const float* __restrict__ W, int ld, int 
     return v;
 }
 
+// Fast path of wfrag for the common case -- base 16-byte aligned, ld % 4 == 0, the 16 columns k0..k0+15 inside the
+// matrix: ONE unconditional 16-byte load (rows past the end are clamped and zeroed by a select), so the compiler is
+// free to batch many fragment loads instead of serialising load -> wait -> MFMA through alignment branches.
+__device__ __forceinline__ f32x4 wfrag_a(const float* __restrict__ W, int ld, int rows, int o0, int k0) {
+    const int l = lane_id();
+    const int r = o0 + (l & 15);
+    const int rc = r < rows ? r : rows - 1;
+    f32x4 v = *reinterpret_cast<const f32x4*>(W + (size_t)rc * ld + k0 + 4 * (l >> 4));
+    if (r >= rows) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    return v;
+}
+
+// Same for the transposed fragment (full tiles only: rows k0..k0+15 and columns o0..o0+15 exist).
+__device__ __forceinline__ f32x4 wfrag_ta(const float* __restrict__ W, int ld, int o0, int k0) {
+    const int l = lane_id();
+    const float* p = W + (size_t)(k0 + 4 * (l >> 4)) * ld + o0 + (l & 15);
+    f32x4 v;
+    v[0] = p[0]; v[1] = p[ld]; v[2] = p[2 * ld]; v[3] = p[3 * ld];
+    return v;
+}
+
+// Bias tile when 16 t + 15 < dim and b is 16-byte aligned.
+__device__ __forceinline__ f32x4 bfrag_a(const float* __restrict__ b, int t) {
+    return *reinterpret_cast<const f32x4*>(b + 16 * t + 4 * (lane_id() >> 4));
+}
+
 // Fragment of the TRANSPOSE of a row-major [rows x cols] matrix: lane (m,g) gets
 // W[k0+4g+q][o0+m], q<4  (A operand of  y = W^T x).
 __device__ __forceinline__ f32x4 wfrag_t(const float* __restrict__ W, int ld, int rows, int cols,
