@@ -39,9 +39,12 @@ __device__ __forceinline__ float chain_sum_b(float v) {
 // counter-based Bernoulli(1-p) keep flag (used when no mask tensor is injected): same value in the
 // forward and the backward launch for the same (seed, element index)
 __device__ __forceinline__ float keep_flag(uint64_t seed, uint64_t idx, float p) {
-    uint64_t x = idx * 0x9E3779B97F4A7C15ull + seed;
-    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 32;
-    const float u = (float)(x >> 40) * (1.0f / 16777216.0f);
+    // murmur3-style 32-bit finaliser over (element index, seed): two 32-bit multiplies per flag
+    uint32_t x = (uint32_t)idx ^ ((uint32_t)(idx >> 32) * 0x9E3779B9u) ^ (uint32_t)seed;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    x ^= (uint32_t)(seed >> 32);
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+    const float u = (float)(x >> 8) * (1.0f / 16777216.0f);
     return u >= p ? 1.0f : 0.0f;
 }
 
@@ -247,8 +250,8 @@ __global__ __launch_bounds__(64) void beh_loss_kernel(IplanBehArgs a) {
 
 __global__ __launch_bounds__(256) void beh_bwd_kernel(IplanBehArgs a) {
     IPLAN_DYN_LDS(smem);
-    constexpr int TLD = 3 * DHd + 4;                        // 196
-    constexpr int TLE = 3 * EHd + 4;                        // 100
+    constexpr int TLD = 3 * DHd + 8;                        // 200: ld % 16 == 8 -> conflict-free ds_read_b128 fragments
+    constexpr int TLE = 3 * EHd + 8;                        // 104
     float* s_dwihT = smem;                                  // [64][196]   W_ih^T
     float* s_dwhhT = s_dwihT + DHd * TLD;                   // [64][196]
     float* s_doutT = s_dwhhT + DHd * TLD;                   // [64][20]    W_out^T (cols = d)
@@ -290,10 +293,48 @@ __global__ __launch_bounds__(256) void beh_bwd_kernel(IplanBehArgs a) {
     const int64_t grow = (int64_t)net * rows + (valid ? row : 0);
     const float inv_keep = 1.0f / (1.0f - a.drop_p);
 
+    // Everything one backward step reads from HBM (the forward's record of that step, the loss target, the mask
+    // and the dropout flags).  The NEXT step's record is fetched while the current step computes: with one wave
+    // per SIMD nothing else hides the ~2 us HBM latency, and the un-prefetched kernel spent half its cycles in
+    // s_waitcnt (profiles/).
+    struct StepIn {
+        f32x4 e_r[ET], e_z[ET], e_n[ET], e_hn[ET], e_hp[ET];
+        f32x4 d_r[DT], d_z[DT], d_n[DT], d_hn[DT], d_hp[DT];
+        f32x4 d_y, d_nx;
+        float m;
+    };
+    auto load_step = [&](int j, int t, StepIn& o) {
+        const int64_t step = (grow * J + j) * a.L + t;
+        const bool first = (j == 0 && t == 0);
+        const float* se = a.saved_enc + step * SVE;
+        const float* sd = a.saved_dec + step * SVD;
+        for (int T = 0; T < ET; ++T) {
+            o.e_r[T] = vload(se + SE_R, valid, EHd, T);
+            o.e_z[T] = vload(se + SE_Z, valid, EHd, T);
+            o.e_n[T] = vload(se + SE_N, valid, EHd, T);
+            o.e_hn[T] = vload(se + SE_HN, valid, EHd, T);
+            o.e_hp[T] = vload(se - SVE + SE_H, valid && !first, EHd, T);
+        }
+        for (int T = 0; T < DT; ++T) {
+            o.d_r[T] = vload(sd + SD_R, valid, DHd, T);
+            o.d_z[T] = vload(sd + SD_Z, valid, DHd, T);
+            o.d_n[T] = vload(sd + SD_N, valid, DHd, T);
+            o.d_hn[T] = vload(sd + SD_HN, valid, DHd, T);
+            o.d_hp[T] = vload(sd - SVD + SD_H, valid && !first, DHd, T);
+        }
+        o.d_y = vload(sd + SD_Y, valid, 16, 0);
+        o.d_nx = vload(hrow + (int64_t)(j + 1 + t) * a.h_s_t, valid, a.d, 0);
+        o.m = valid ? mrow[j + 1 + t] : 0.f;
+    };
+
     f32x4 dhd[DT], dhe[ET], dlat;
     for (int t = 0; t < DT; ++t) dhd[t] = splat4(0.f);
     for (int t = 0; t < ET; ++t) dhe[t] = splat4(0.f);
     dlat = splat4(0.f);
+    StepIn cur;
+    load_step(J - 1, a.L - 1, cur);
+    f32x4 hcur[DT];                                     // decoder h of the current step (= h_prev of the step just done)
+    for (int T = 0; T < DT; ++T) hcur[T] = vload(a.saved_dec + ((grow * J + (J - 1)) * a.L + (a.L - 1)) * SVD + SD_H, valid, DHd, T);
     for (int j = J - 1; j >= 0; --j) {
         const float scale = (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS) / (float)J;
         // ---- soft update + latent head backward
@@ -313,83 +354,89 @@ __global__ __launch_bounds__(256) void beh_bwd_kernel(IplanBehArgs a) {
         }
         for (int t = a.L - 1; t >= 0; --t) {
             const int64_t step = (grow * J + j) * a.L + t;
-            const bool first = (j == 0 && t == 0);
-            // ---- encoder step backward
-            {
-                const float* se = a.saved_enc + step * SVE;
-                float* de = a.dsave_enc + step * DSE;
-                f32x4 dg[4 * ET], dd[ET];                  // [dr | dz | dn_i | dn_h]
-                for (int T = 0; T < ET; ++T) {
-                    const GruGrads o = gru_gates_bwd(dhe[T], vload(se + SE_R, valid, EHd, T), vload(se + SE_Z, valid, EHd, T),
-                                                     vload(se + SE_N, valid, EHd, T), vload(se + SE_HN, valid, EHd, T),
-                                                     vload(se - SVE + SE_H, valid && !first, EHd, T));
-                    vstore(de + DE_DR, valid, EHd, T, o.dr);
-                    vstore(de + DE_DZ, valid, EHd, T, o.dz);
-                    vstore(de + DE_DNI, valid, EHd, T, o.dni);
-                    vstore(de + DE_DNH, valid, EHd, T, o.dnh);
-                    dg[T] = o.dr; dg[ET + T] = o.dz; dg[2 * ET + T] = o.dni; dg[3 * ET + T] = o.dnh;
-                    dd[T] = o.dh_direct;
-                }
-                for (int T = 0; T < ET; ++T) {
-                    const f32x4 du = dense_tile_k<3 * ET>(s_ewihT, TLE, 16 * T, 0, dg, splat4(0.f));
-                    const f32x4 u = vload(se + SE_U, valid, EHd, T);
-                    f32x4 dup;
-                    for (int q = 0; q < 4; ++q) dup[q] = u[q] > 0.f ? du[q] : 0.f;
-                    vstore(de + DE_DU, valid, EHd, T, dup);
-                    dhe[T] = dense_tile_k<ET>(s_ewhhT, TLE, 16 * T, 2 * EHd, dg + 3 * ET,
-                                              dense_tile_k<2 * ET>(s_ewhhT, TLE, 16 * T, 0, dg, dd[T]));
-                }
+            float* de = a.dsave_enc + step * DSE;
+            float* dd_ = a.dsave_dec + step * DSD;
+            // ReLU inputs of the two input Linears: needed only after the first MFMA products, loaded here so their
+            // latency hides behind part A
+            f32x4 eu[ET], du_[DT];
+            for (int T = 0; T < ET; ++T) eu[T] = vload(a.saved_enc + step * SVE + SE_U, valid, EHd, T);
+            for (int T = 0; T < DT; ++T) du_[T] = vload(a.saved_dec + step * SVD + SD_U, valid, DHd, T);
+            // ---- part A: everything lane-local that consumes the step's record
+            f32x4 eg[4 * ET], edd[ET];                     // encoder [dr | dz | dn_i | dn_h], direct path
+            for (int T = 0; T < ET; ++T) {
+                const GruGrads o = gru_gates_bwd(dhe[T], cur.e_r[T], cur.e_z[T], cur.e_n[T], cur.e_hn[T], cur.e_hp[T]);
+                vstore(de + DE_DR, valid, EHd, T, o.dr);
+                vstore(de + DE_DZ, valid, EHd, T, o.dz);
+                vstore(de + DE_DNI, valid, EHd, T, o.dni);
+                vstore(de + DE_DNH, valid, EHd, T, o.dnh);
+                eg[T] = o.dr; eg[ET + T] = o.dz; eg[2 * ET + T] = o.dni; eg[3 * ET + T] = o.dnh;
+                edd[T] = o.dh_direct;
             }
-            // ---- decoder step backward
-            {
-                const float* sd = a.saved_dec + step * SVD;
-                float* dd_ = a.dsave_dec + step * DSD;
-                const f32x4 y = vload(sd + SD_Y, valid, 16, 0);
-                const f32x4 nx = vload(hrow + (int64_t)(j + 1 + t) * a.h_s_t, valid, a.d, 0);
-                const float m = valid ? mrow[j + 1 + t] : 0.f;
-                f32x4 dy[1];
+            f32x4 dy[1];
+            for (int q = 0; q < 4; ++q) {
+                float v = 0.f;
+                if (valid && 4 * g + q < a.d) {
+                    const float er = cur.d_nx[q] - cur.d_y[q];
+                    v = -((er > 0.f) ? 1.0f : (er < 0.f ? -1.0f : 0.0f)) * cur.m * scale;
+                }
+                dy[0][q] = v;
+            }
+            vstore(dd_ + DD_DY, valid, 16, 0, dy[0]);
+            f32x4 dg[4 * DT], ddir[DT];                    // decoder [dr | dz | dn_i | dn_h]
+            for (int T = 0; T < DT; ++T) {
+                const f32x4 da = dense_tile<1>(s_doutT, 20, 16 * T, dy, splat4(0.f));
+                const f32x4 km = keep_tile(a, net, j, row, t, T, valid, rows);
+                f32x4 dht;
                 for (int q = 0; q < 4; ++q) {
-                    float v = 0.f;
-                    if (valid && 4 * g + q < a.d) {
-                        const float er = nx[q] - y[q];
-                        v = -((er > 0.f) ? 1.0f : (er < 0.f ? -1.0f : 0.0f)) * m * scale;
-                    }
-                    dy[0][q] = v;
+                    const float th = tanh_f(hcur[T][q]);
+                    dht[q] = fmaf(da[q] * km[q] * inv_keep, 1.0f - th * th, dhd[T][q]);
                 }
-                vstore(dd_ + DD_DY, valid, 16, 0, dy[0]);
-                f32x4 dg[4 * DT], ddir[DT];                // [dr | dz | dn_i | dn_h]
-                for (int T = 0; T < DT; ++T) {
-                    const f32x4 da = dense_tile<1>(s_doutT, 20, 16 * T, dy, splat4(0.f));
-                    const f32x4 hs = vload(sd + SD_H, valid, DHd, T);
-                    const f32x4 km = keep_tile(a, net, j, row, t, T, valid, rows);
-                    f32x4 dht;
-                    for (int q = 0; q < 4; ++q) {
-                        const float th = tanh_f(hs[q]);
-                        dht[q] = fmaf(da[q] * km[q] * inv_keep, 1.0f - th * th, dhd[T][q]);
-                    }
-                    const GruGrads o = gru_gates_bwd(dht, vload(sd + SD_R, valid, DHd, T), vload(sd + SD_Z, valid, DHd, T),
-                                                     vload(sd + SD_N, valid, DHd, T), vload(sd + SD_HN, valid, DHd, T),
-                                                     vload(sd - SVD + SD_H, valid && !first, DHd, T));
-                    vstore(dd_ + DD_DR, valid, DHd, T, o.dr);
-                    vstore(dd_ + DD_DZ, valid, DHd, T, o.dz);
-                    vstore(dd_ + DD_DNI, valid, DHd, T, o.dni);
-                    vstore(dd_ + DD_DNH, valid, DHd, T, o.dnh);
-                    dg[T] = o.dr; dg[DT + T] = o.dz; dg[2 * DT + T] = o.dni; dg[3 * DT + T] = o.dnh;
-                    ddir[T] = o.dh_direct;
-                }
-                f32x4 dup[DT];
-                for (int T = 0; T < DT; ++T) {
-                    const f32x4 du = dense_tile_k<3 * DT>(s_dwihT, TLD, 16 * T, 0, dg, splat4(0.f));
-                    const f32x4 u = vload(sd + SD_U, valid, DHd, T);
-                    for (int q = 0; q < 4; ++q) dup[T][q] = u[q] > 0.f ? du[q] : 0.f;
-                    vstore(dd_ + DD_DU, valid, DHd, T, dup[T]);
-                    IPLAN_SCHED_FENCE();
-                    dhd[T] = dense_tile_k<DT>(s_dwhhT, TLD, 16 * T, 2 * DHd, dg + 3 * DT,
-                                              dense_tile_k<2 * DT>(s_dwhhT, TLD, 16 * T, 0, dg, ddir[T]));
-                    IPLAN_SCHED_FENCE();
-                }
-                dlat = dense_tile<DT>(s_dlatT, DLD, 0, dup, dlat);       // through the tiled latent input
+                const GruGrads o = gru_gates_bwd(dht, cur.d_r[T], cur.d_z[T], cur.d_n[T], cur.d_hn[T], cur.d_hp[T]);
+                vstore(dd_ + DD_DR, valid, DHd, T, o.dr);
+                vstore(dd_ + DD_DZ, valid, DHd, T, o.dz);
+                vstore(dd_ + DD_DNI, valid, DHd, T, o.dni);
+                vstore(dd_ + DD_DNH, valid, DHd, T, o.dnh);
+                dg[T] = o.dr; dg[DT + T] = o.dz; dg[2 * DT + T] = o.dni; dg[3 * DT + T] = o.dnh;
+                ddir[T] = o.dh_direct;
+                hcur[T] = cur.d_hp[T];                     // h_{t-1}: the next step's "current" hidden state
             }
+            // ---- the record is consumed: fetch the next step's while the transposed-weight products below run
+            IPLAN_SCHED_FENCE();
+            if (t > 0) load_step(j, t - 1, cur);
+            else if (j > 0) load_step(j - 1, a.L - 1, cur);
+            IPLAN_SCHED_FENCE();
+            // ---- part B: backward-data products on MFMA (all output tiles of a product share the B operand)
+            {
+                const int oe[ET] = {0, 16};
+                f32x4 du[ET];
+                for (int T = 0; T < ET; ++T) du[T] = splat4(0.f);
+                dense_multi<ET, 3 * ET>(s_ewihT, TLE, oe, 0, eg, du);                       // W_ih^T [dr dz dn_i]
+                for (int T = 0; T < ET; ++T) {
+                    f32x4 dup;
+                    for (int q = 0; q < 4; ++q) dup[q] = eu[T][q] > 0.f ? du[T][q] : 0.f;
+                    vstore(de + DE_DU, valid, EHd, T, dup);
+                    dhe[T] = edd[T];
+                }
+                dense_multi<ET, 2 * ET>(s_ewhhT, TLE, oe, 0, eg, dhe);                      // W_hh^T [dr dz | dn_h]
+                dense_multi<ET, ET>(s_ewhhT, TLE, oe, 2 * EHd, eg + 3 * ET, dhe);
+            }
+            f32x4 dup[DT];
+            {
+                const int od[DT] = {0, 16, 32, 48};
+                f32x4 du[DT];
+                for (int T = 0; T < DT; ++T) du[T] = splat4(0.f);
+                dense_multi<DT, 3 * DT>(s_dwihT, TLD, od, 0, dg, du);
+                for (int T = 0; T < DT; ++T) {
+                    for (int q = 0; q < 4; ++q) dup[T][q] = du_[T][q] > 0.f ? du[T][q] : 0.f;
+                    vstore(dd_ + DD_DU, valid, DHd, T, dup[T]);
+                    dhd[T] = ddir[T];
+                }
+                IPLAN_SCHED_FENCE();
+                dense_multi<DT, 2 * DT>(s_dwhhT, TLD, od, 0, dg, dhd);
+                dense_multi<DT, DT>(s_dwhhT, TLD, od, 2 * DHd, dg + 3 * DT, dhd);
+                IPLAN_SCHED_FENCE();
+            }
+            dlat = dense_tile<DT>(s_dlatT, DLD, 0, dup, dlat);       // through the tiled latent input
         }
     }
 }
@@ -428,7 +475,7 @@ extern "C" int iplan_beh_bwd(const IplanBehArgs* a, iplan_stream_t stream) {
     if (int rc = check_beh(a, "iplan_beh_bwd")) return rc;
     if (!a->dsave_dec || !a->dsave_enc || !a->dsave_lat) return fail(IPLAN_EINVAL, "iplan_beh_bwd: dsave buffers missing");
     const int tiles = (a->E * a->N + 15) / 16;
-    const size_t lds = sizeof(float) * (2 * DHd * (3 * DHd + 4) + DHd * 20 + 16 * DLD + 2 * EHd * (3 * EHd + 4) + EHd * 20);
+    const size_t lds = sizeof(float) * (2 * DHd * (3 * DHd + 8) + DHd * 20 + 16 * DLD + 2 * EHd * (3 * EHd + 8) + EHd * 20);
 #ifndef IPLAN_HOST_EMULATION
     hipFuncSetAttribute(reinterpret_cast<const void*>(beh_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif

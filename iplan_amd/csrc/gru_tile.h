@@ -113,6 +113,25 @@ __device__ __forceinline__ f32x4 dense_tile_k(const float* __restrict__ sW, int 
     return acc;
 }
 
+// NA output tiles that share one B operand (x, KT tiles), weights in LDS: acc[a] += W[o0[a].., k0..] x.
+// The NA accumulator chains are issued round-robin (consecutive MFMAs never depend on each other: the
+// 16x16x4 fp32 MFMA has 40 cycles of dependent latency against a 32-cycle issue) and the next k-tile's fragments
+// are read from LDS while the current k-tile's MFMAs issue (LDS latency off the critical path).
+template <int NA, int KT>
+__device__ __forceinline__ void dense_multi(const float* __restrict__ sW, int ld, const int (&o0)[NA], int k0,
+                                            const f32x4* __restrict__ x, f32x4 (&acc)[NA]) {
+    f32x4 f[NA], fn[NA];
+    for (int a = 0; a < NA; ++a) f[a] = wfrag_lds(sW, ld, o0[a], k0);
+    for (int T = 0; T < KT; ++T) {
+        if (T + 1 < KT)
+            for (int a = 0; a < NA; ++a) fn[a] = wfrag_lds(sW, ld, o0[a], k0 + 16 * (T + 1));
+        for (int q = 0; q < 4; ++q)
+            for (int a = 0; a < NA; ++a) acc[a] = mfma4(f[a][q], x[T][q], acc[a]);
+        if (T + 1 < KT)
+            for (int a = 0; a < NA; ++a) f[a] = fn[a];
+    }
+}
+
 // One GRU step with LDS-resident weights.  HT = H/16 hidden tiles, XT = input tiles.
 // sWih: [3H x ldi], sWhh: [3H x ldh], sbih/sbhh: [3H].  h is updated in place; when `keep` is
 // non-null the gate activations (r, z, n, hn) of every tile are returned for the backward pass.
@@ -124,17 +143,17 @@ __device__ __forceinline__ void gru_step_lds(const float* __restrict__ sWih, int
     constexpr int H = 16 * HT;
     f32x4 hnew[HT];
     for (int t = 0; t < HT; ++t) {
-        f32x4 pr = bfrag_lds(sbih, t) + bfrag_lds(sbhh, t);
-        f32x4 pz = bfrag_lds(sbih, HT + t) + bfrag_lds(sbhh, HT + t);
-        f32x4 gn = bfrag_lds(sbih, 2 * HT + t);
-        f32x4 hn = bfrag_lds(sbhh, 2 * HT + t);
-        pr = dense_tile<XT>(sWih, ldi, 16 * t, x, pr);
-        pr = dense_tile<HT>(sWhh, ldh, 16 * t, h, pr);
-        pz = dense_tile<XT>(sWih, ldi, H + 16 * t, x, pz);
-        pz = dense_tile<HT>(sWhh, ldh, H + 16 * t, h, pz);
-        gn = dense_tile<XT>(sWih, ldi, 2 * H + 16 * t, x, gn);
-        hn = dense_tile<HT>(sWhh, ldh, 2 * H + 16 * t, h, hn);
-        const GruGates o = gru_gates(pr, pz, gn, hn, h[t]);
+        const int rows[3] = {16 * t, H + 16 * t, 2 * H + 16 * t};            // r, z, n gate rows of this hidden tile
+        f32x4 ai[3], ah[3];
+        ai[0] = bfrag_lds(sbih, t) + bfrag_lds(sbhh, t);
+        ai[1] = bfrag_lds(sbih, HT + t) + bfrag_lds(sbhh, HT + t);
+        ai[2] = bfrag_lds(sbih, 2 * HT + t);
+        dense_multi<3, XT>(sWih, ldi, rows, 0, x, ai);                        // W_ih x: pre_r, pre_z, gi_n
+        ah[0] = ai[0];
+        ah[1] = ai[1];
+        ah[2] = bfrag_lds(sbhh, 2 * HT + t);
+        dense_multi<3, HT>(sWhh, ldh, rows, 0, h, ah);                        // + W_hh h: pre_r, pre_z, gh_n
+        const GruGates o = gru_gates(ah[0], ah[1], ai[2], ah[2], h[t]);
         hnew[t] = o.h;
         if (keep) keep[t] = o;
     }
