@@ -242,6 +242,8 @@ typedef struct {
     float* ln_stats;
     int64_t ln_stats_s_net;
     int32_t ln_stats_mode;
+    int64_t* phase_clocks;      /* optional profiling aid: wall_clock64 of workgroup (0,0,0) at entry, after the
+                                   LayerNorm statistics, after the fc1 contraction, at the end of the tail; NULL = off */
 } IplanAcFwdArgs;
 
 int iplan_ac_fwd(const IplanAcFwdArgs* args, iplan_stream_t stream);

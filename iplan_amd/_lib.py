@@ -176,7 +176,7 @@ class AcFwdArgs(C.Structure):
         ("values", fp), ("saved", fp),
         ("ho_s_net", i64), ("ho_s_row", i64), ("ao_s_net", i64), ("ao_s_row", i64),
         ("onehot_out", fp), ("oh_s_net", i64), ("oh_s_row", i64),
-        ("ln_stats", fp), ("ln_stats_s_net", i64), ("ln_stats_mode", i32),
+        ("ln_stats", fp), ("ln_stats_s_net", i64), ("ln_stats_mode", i32), ("phase_clocks", fp),
     ]
 
 

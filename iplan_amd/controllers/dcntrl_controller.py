@@ -52,7 +52,7 @@ class DcntrlMAC:
         t = t.to(self.device) if t.device != self.device else t
         return t if dtype is None or t.dtype == dtype else t.to(dtype)
 
-    def select_actions_ippo(self, ep_batch, t_ep, test_mode=False, q_noise=None, as_numpy=True, write_back=False):
+    def select_actions_ippo(self, ep_batch, t_ep, test_mode=False, q_noise=None, as_numpy=True, write_back=False, phase_clocks=None):
         """One fused launch: features gathered in place from ``ep_batch`` at ``t_ep``, all agents,
         actor + critic (controllers/dcntrl_controller.py:27-58).  Returns the reference's 5-tuple
         (values [E,nA], actions [E,nA], list of nA logp [E,1], rnn_states_actors [1,E,nA,M],
@@ -98,7 +98,7 @@ class DcntrlMAC:
         o = ops.ac_forward(self.actor_arena, self.critic_arena, 2, spec, E, nA, h_actor=ha, h_critic=hc,
                            h_strides=(ha.stride(1), ha.stride(0)), avail=avail,
                            avail_strides=(avail.stride(1), avail.stride(0)),
-                           mode=0 if test_mode else 1, q_noise=q_noise, n_actions=a.n_actions, **wb)
+                           mode=0 if test_mode else 1, q_noise=q_noise, n_actions=a.n_actions, phase_clocks=phase_clocks, **wb)
         values = o["values"].t()                                          # [E, nA]
         logps = [o["logp"][i].reshape(E, 1) for i in range(nA)]
         if write_back:

@@ -133,10 +133,14 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     const int ks = RT == 1 ? a.ksplit : 1;
     const int groups = 8 / ks;
     const int part = w % ks;
+    const bool clk = a.phase_clocks && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
+    if (clk) a.phase_clocks[0] = IPLAN_CLOCK();
     const KMap km = make_kmap(ft);
     const int F = km.NW + km.n_actions + km.n_id;
     const int KT = km.kt0[4];
-    const int T_lo = (int)((int64_t)KT * part / ks), T_hi = (int)((int64_t)KT * (part + 1) / ks);
+    // k-tiles are dealt round-robin to the ks cooperating waves (tile T belongs to wave T % ks): the slow tiles
+    // (the gathered history block) are spread evenly instead of landing on one straggler wave
+    const int T_lo = part, T_hi = KT, T_st = ks;
 
     int rr[RT], last[RT];
     bool vld[RT];
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     } else {
         float s[RT];
         for (int t = 0; t < RT; ++t) s[t] = 0.f;
-        for (int T = T_lo; T < T_hi; ++T) {
+        for (int T = T_lo; T < T_hi; T += T_st) {
             const KTile kt = ktile(km, T);
             for (int t = 0; t < RT; ++t) {
                 const f32x4 x = kfeat(km, kt, src[t], vld[t], last[t], net);
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         for (int t = 0; t < RT; ++t) mu[t] = s[t] / (float)F;
         float v2[RT];
         for (int t = 0; t < RT; ++t) v2[t] = 0.f;
-        for (int T = T_lo; T < T_hi; ++T) {
+        for (int T = T_lo; T < T_hi; T += T_st) {
             const KTile kt = ktile(km, T);
             for (int t = 0; t < RT; ++t) {
                 const f32x4 x = kfeat(km, kt, src[t], vld[t], last[t], net);
@@ -213,6 +217,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         }
     }
 
+    if (clk) a.phase_clocks[1] = IPLAN_CLOCK();
     // ---- fc1 contraction over this wave's share of K
     const float* fnw = P + nw.off[IPLAN_AC_FN_W];
     const float* fnb = P + nw.off[IPLAN_AC_FN_B];
@@ -220,17 +225,83 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     f32x4 accs[RT][AT];
     for (int t = 0; t < RT; ++t)
         for (int o = 0; o < AT; ++o) accs[t][o] = splat4(0.f);
-    for (int T = T_lo; T < T_hi; ++T) {
-        const KTile kt = ktile(km, T);
-        const f32x4 gm = kcols(kt, fnw), bt = kcols(kt, fnb);
+    // Software pipeline: the operands of k-tile T + PF are requested while k-tile T's MFMAs issue.  The weight rows
+    // (636 KB per net) and the feature rows come from L2 / HBM with ~1-2 us latency; un-pipelined, every k-tile paid
+    // that latency in full (profiles/: 2.1 us per k-tile in the rollout variant).
+    struct KOps {
+        KTile kt;
+        f32x4 gm, bt, x[RT], wf[AT];
+    };
+    auto kload = [&](int T, KOps& o) {
+        o.kt = ktile(km, T);
+        o.gm = kcols(o.kt, fnw);
+        o.bt = kcols(o.kt, fnb);
+        for (int t = 0; t < RT; ++t) o.x[t] = kfeat(km, o.kt, src[t], vld[t], last[t], net);
+        for (int oo = 0; oo < AT; ++oo) o.wf[oo] = kcols(o.kt, W1 + (int64_t)(16 * oo + n) * F);
+    };
+    auto kmma = [&](const KOps& o) {
         f32x4 xn[RT];
-        for (int t = 0; t < RT; ++t) {
-            const f32x4 x = kfeat(km, kt, src[t], vld[t], last[t], net);
-            for (int q = 0; q < 4; ++q) xn[t][q] = (vld[t] && q < kt.nv) ? (x[q] - mu[t]) * rstd[t] * gm[q] + bt[q] : 0.f;
+        for (int t = 0; t < RT; ++t)
+            for (int q = 0; q < 4; ++q)
+                xn[t][q] = (vld[t] && q < o.kt.nv) ? (o.x[t][q] - mu[t]) * rstd[t] * o.gm[q] + o.bt[q] : 0.f;
+        for (int oo = 0; oo < AT; ++oo)
+            for (int t = 0; t < RT; ++t) accs[t][oo] = mma_block(o.wf[oo], xn[t], accs[t][oo]);
+    };
+    // Fast tiles: whole 16-column tiles inside a source block whose width is a multiple of 4 (attention 32,
+    // behaviour 8: 137 of the 157 k-tiles at Highway chaotic).  Their operand fetch has NO per-lane control flow --
+    // one unaligned 16-byte load per operand -- so the ring below really keeps PF k-tiles of loads in flight (with
+    // divergent branches around the loads the compiler has to drain vmcnt at every join).
+    struct FOps {
+        f32x4 gm, bt, x[RT], wf[AT];
+    };
+    auto fload = [&](int T, int s, FOps& o) {
+        const int wS = km.w[s];
+        const int f0 = 16 * (T - km.kt0[s]) + 4 * g;
+        const int e = f0 / wS;
+        const int c0 = e * km.W + km.off[s] + (f0 - e * wS);
+        o.gm = ldu4(fnw + c0);
+        o.bt = ldu4(fnb + c0);
+        for (int t = 0; t < RT; ++t) o.x[t] = ldu4(src[t][s] + f0);
+        for (int oo = 0; oo < AT; ++oo) o.wf[oo] = ldu4(W1 + (int64_t)(16 * oo + n) * F + c0);
+    };
+    auto fmma = [&](const FOps& o) {
+        f32x4 xn[RT];
+        for (int t = 0; t < RT; ++t)
+            for (int q = 0; q < 4; ++q) xn[t][q] = vld[t] ? (o.x[t][q] - mu[t]) * rstd[t] * o.gm[q] + o.bt[q] : 0.f;
+        for (int oo = 0; oo < AT; ++oo)
+            for (int t = 0; t < RT; ++t) accs[t][oo] = mma_block(o.wf[oo], xn[t], accs[t][oo]);
+    };
+    constexpr int PF = 3;
+    for (int s = 0; s < 4; ++s) {
+        // this wave's tiles of block s: T in [b_lo, b_hi) with T % T_st == part; the fast ones are below f_hi
+        const int b_end = imin(T_hi, km.kt0[s + 1]);
+        int b_lo = km.kt0[s] + ((part - km.kt0[s]) % T_st + T_st) % T_st;           // first owned tile of the block
+        if (b_lo >= b_end) continue;
+        int f_hi = b_lo;
+        if (s < 3 && (km.w[s] & 3) == 0 && src[0][s] != nullptr) f_hi = imin(b_end, km.kt0[s] + km.len[s] / 16);
+        int T_slow = b_lo;
+        if (f_hi > b_lo) {
+            FOps ring[PF];
+            for (int i = 0; i < PF; ++i)
+                if (b_lo + i * T_st < f_hi) fload(b_lo + i * T_st, s, ring[i]);
+            IPLAN_SCHED_FENCE();                            // keep the prefetches where they are: the scheduler would
+            int T = b_lo;                                   // otherwise sink every load next to its use
+            for (; T < f_hi; T += PF * T_st) {
+                for (int i = 0; i < PF; ++i) {
+                    if (T + i * T_st < f_hi) {
+                        fmma(ring[i]);
+                        IPLAN_SCHED_FENCE();
+                        if (T + (i + PF) * T_st < f_hi) fload(T + (i + PF) * T_st, s, ring[i]);
+                        IPLAN_SCHED_FENCE();
+                    }
+                }
+            }
+            T_slow = b_lo + ((f_hi - b_lo + T_st - 1) / T_st) * T_st;              // first owned tile at or past f_hi
         }
-        for (int o = 0; o < AT; ++o) {
-            const f32x4 wf = kcols(kt, W1 + (int64_t)(16 * o + n) * F);
-            for (int t = 0; t < RT; ++t) accs[t][o] = mma_block(wf, xn[t], accs[t][o]);
+        for (int T = T_slow; T < b_end; T += T_st) {        // ragged / gathered / one-hot tiles
+            KOps o;
+            kload(T, o);
+            kmma(o);
         }
     }
     if (ks > 1) {
@@ -244,6 +315,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
             }
         }
     }
+    if (clk) a.phase_clocks[2] = IPLAN_CLOCK();
     if (part != 0) return;
 
   for (int rt = 0; rt < RT; ++rt) {
@@ -393,6 +465,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         if (a.entropy) a.entropy[orow] = ent;
     }
   }   // row tiles
+    if (clk) a.phase_clocks[3] = IPLAN_CLOCK();
 }
 
 }  // namespace iplan

@@ -163,7 +163,7 @@ def _fill_acnet(dst, arena, order, n_out):
 def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=None, h_critic=None,
                h_strides=(0, 0), avail=None, avail_strides=(0, 0), mode=0, q_noise=None, actions_in=None,
                act_strides=(0, 0), n_actions=5, ksplit=None, save=False, want_probs=False, want_entropy=False,
-               want_h=True, h_out=None, actions_out=None, onehot_out=None, ln_stats=None, ln_stats_mode=0, lib=None):
+               want_h=True, h_out=None, actions_out=None, onehot_out=None, ln_stats=None, ln_stats_mode=0, phase_clocks=None, lib=None):
     """Fused actor (which=0) / critic (1) / both (2) forward for all agents.
     Returns a dict with the requested outputs, each laid out [n_agents, rows, ...].
     Optional in-place destinations (rollout: write straight into the episode buffer):
@@ -233,6 +233,8 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
     if ln_stats is not None and ln_stats_mode:
         assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.shape[0] == n_agents and ln_stats.shape[2] == 2
         a.ln_stats, a.ln_stats_s_net, a.ln_stats_mode = ln_stats.data_ptr(), ln_stats.stride(0), ln_stats_mode
+    if phase_clocks is not None:
+        a.phase_clocks = phase_clocks.data_ptr()
     if save:
         out["saved"] = torch.empty(2, n_agents, rows, L.AC_SAVE_FLOATS, **f32)
         a.saved = out["saved"].data_ptr()

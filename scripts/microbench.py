@@ -97,3 +97,11 @@ if "gat_phases" in set(sys.argv[1:]):
     d = (c[:, 1:] - c[:, :-1])
     print("gat phases (wall_clock64 ticks, 100 MHz => x10 ns): mean per WG", d.mean(0).tolist(), "max", d.max(0).values.tolist())
     print("kernel span ticks:", float(c[:, 4].max() - c[:, 0].min()), "first-start spread", float(c[:, 0].max() - c[:, 0].min()))
+
+if "ac_phases" in set(sys.argv[1:]):
+    clk = torch.zeros(4, dtype=torch.int64, device=dev)
+    for _ in range(3):
+        loop.mac.select_actions_ippo(batch, 3, test_mode=False, as_numpy=False, phase_clocks=clk)
+    torch.cuda.synchronize()
+    c = clk.cpu().double()
+    print("ac_fwd (rollout) phases of WG 0, x10 ns: stats, contraction, tail =", (c[1:] - c[:-1]).tolist())
