@@ -18,6 +18,8 @@ rows per agent) when the 256-episode buffer fills.  Nothing is skipped inside th
 value = env transitions processed by all ranks / max-over-ranks wall time.
 """
 import argparse
+import contextlib
+import io
 import json
 import os
 import sys
@@ -31,6 +33,12 @@ sys.path.insert(0, ROOT)
 from iplan_amd.config import default_args  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32, dense)
+# HBM bytes per launch from the committed PMC passes (profiles/r01*_pmc_*.txt), keyed by (kernel, envs per GPU):
+# (2 * FETCH_SIZE + WRITE_SIZE) KiB -> bytes.  Counters cannot be collected from inside bench.py; None = not profiled.
+PMC_TRAFFIC_BYTES = {
+    ("beh_bwd_kernel", 32): int((2 * 9662384.5 + 14045465.5) * 1024),
+    ("gat_fwd_kernel", 32): int((2 * 5031.8 + 1100.0) * 1024),
+}
 
 
 def gat_algorithmic_flops(n_nets, B, N, D, H=32, A=32):
@@ -181,9 +189,6 @@ def main():
         DataParallel(dist.group.WORLD).attach(loop)
     rollouts_per_step = max(1, args.buffer_size // E)
 
-    import contextlib
-    import io
-
     def one_step():
         with contextlib.redirect_stdout(io.StringIO()):            # the reference prints "TRAINING IPPO"
             for _ in range(rollouts_per_step):
@@ -212,27 +217,55 @@ def main():
         dt = float(tt.item())
     env_steps = opt.steps * rollouts_per_step * E * args.episode_limit * world
 
-    # dominant kernel of the rollout (profiles/): fused GAT forward -- live HIP-event timing on the launch stream
+    # ---- roofline of the dominant kernels, timed live with HIP events on the launch stream (torch's current stream)
+    from iplan_amd import _lib as L
     from iplan_amd import ops
     from iplan_amd.nova.GAT_Net import gumbel_noise
     nA, N, d, Z, A = args.n_agents, args.max_vehicle_num, args.obs_shape_single, args.latent_dim, args.attention_dim
+    lib = L.get_lib()
+
+    def event_time(fn, iters, warm=2):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters / 1e3
+
+    # (1) beh_bwd_kernel -- BPTT of Behavior_policy.learn, the largest single share of a training cycle (profiles/)
+    with contextlib.redirect_stdout(io.StringIO()):
+        batch = loop.rollout()
+    hist_b = batch["history"][:, :-1].permute(2, 0, 1, 3, 4)
+    mask_b = batch["terminated"][:, :-1, :, 0].permute(2, 0, 1).to(torch.float32).contiguous()
+    fwd = ops.beh_forward(loop.behavior.enc_arena, loop.behavior.dec_arena, hist_b, mask_b, args.max_history_len, Z,
+                          args.soft_update_coef, args.thres_small_variation, args.decoder_dropout, seed=1)
+    ba = fwd["_args"]
+    T_b, Lw = args.episode_limit, args.max_history_len
+    J = T_b - 1 - Lw
+    rows_b = E * N
+    dsv = [torch.empty(nA, rows_b, J, Lw, w_, device=dev) for w_ in (L.BEH_DSAVE_DEC, L.BEH_DSAVE_ENC)]
+    dsl = torch.empty(nA, rows_b, J, L.BEH_DSAVE_LAT, device=dev)
+    ba.dsave_dec, ba.dsave_enc, ba.dsave_lat = dsv[0].data_ptr(), dsv[1].data_ptr(), dsl.data_ptr()
+    stream = L.current_stream(dev)
+    bwd_s = event_time(lambda: lib.call("iplan_beh_bwd", ba, stream), iters=3, warm=1)
+    R_, Hd = args.encoder_rnn_dim, args.decoder_rnn_dim
+    # decoder V*L*(2(d+Z)*64 + 12*64^2 + 2*64*d) per window + encoder V*(L*(2dR + 12R^2) + 2RZ);
+    # the backward-data pass (this kernel) is 1x the forward FLOPs, the weight-gradient pass (wgrad) the other 1x
+    flops_b = nA * rows_b * J * (Lw * (2 * (d + Z) * Hd + 12 * Hd * Hd + 2 * Hd * d) + Lw * (2 * d * R_ + 12 * R_ * R_) + 2 * R_ * Z)
+    del fwd, dsv, dsl
+    torch.cuda.empty_cache()
+
+    # (2) gat_fwd_kernel -- dominant kernel of the rollout
     hist = loop.obs_sets[0]["hist"][0].permute(1, 0, 2, 3)
     lat = torch.softmax(torch.randn(nA, E, N, Z, device=dev), -1)
     hid = torch.randn(nA, E, N, A, device=dev) * 0.1
     noise = gumbel_noise((nA, E, N, N - 1, 2), dev)
     out = torch.empty(nA, E, N, A, device=dev)
-    for _ in range(3):
-        ops.gat_forward(loop.prediction.gat_arena, hist, lat, hid, noise, out=out)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    iters = 20
-    e0.record()
-    for _ in range(iters):
-        ops.gat_forward(loop.prediction.gat_arena, hist, lat, hid, noise, out=out)
-    e1.record()
-    torch.cuda.synchronize()
-    gat_s = e0.elapsed_time(e1) / iters / 1e3
+    gat_s = event_time(lambda: ops.gat_forward(loop.prediction.gat_arena, hist, lat, hid, noise, out=out), iters=20, warm=3)
     flops = gat_algorithmic_flops(nA, E, N, d + Z)
-    achieved = flops / gat_s / 1e12
 
     if rank == 0:
         line = {
@@ -245,9 +278,20 @@ def main():
                                    "insert + Behavior_policy.learn + Prediction_policy.learn, then IPPOLearner.train "
                                    "(15 epochs x 255 x 90 rows x 5 agents)" + (" [ROLLOUT ONLY diagnostic]" if opt.rollout_only else ""),
                        "envs_per_gpu": E, "rollouts_per_step": rollouts_per_step, "env_steps_per_step": rollouts_per_step * E * args.episode_limit},
-            "roofline": {"kernel": "gat_fwd_kernel", "bound": "mfma", "achieved": achieved,
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "us_per_launch": gat_s * 1e6, "algorithmic_gflop_per_launch": flops / 1e9},
+            "roofline": {"kernel": "beh_bwd_kernel", "bound": "mfma", "achieved": flops_b / bwd_s / 1e12,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops_b / bwd_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         # HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB) of the rocprofv3 --pmc passes committed in
+                         # profiles/ (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); measured at this exact shape
+                         "traffic": PMC_TRAFFIC_BYTES.get(("beh_bwd_kernel", E)), "us_per_launch": bwd_s * 1e6,
+                         "algorithmic_gflop_per_launch": flops_b / 1e9,
+                         "note": "BPTT of Behavior_policy.learn (5 nets x E*55 chains x 79 windows x 10 steps); launched "
+                                 f"{rollouts_per_step}x per step"},
+            "roofline_others": [
+                {"kernel": "gat_fwd_kernel", "bound": "mfma", "achieved": flops / gat_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
+                 "unit": "TFLOP/s", "frac": flops / gat_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                 "traffic": PMC_TRAFFIC_BYTES.get(("gat_fwd_kernel", E)), "us_per_launch": gat_s * 1e6,
+                 "algorithmic_gflop_per_launch": flops / 1e9,
+                 "note": f"rollout GAT_latent_update, launched {rollouts_per_step * (args.episode_limit + 1)}x per step"}],
         }
         if not opt.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, E)

@@ -500,6 +500,13 @@ typedef struct {
     float* dsave_dec;           /* backward: [n_nets, rows, J, L, IPLAN_BEH_DSAVE_DEC]                  */
     float* dsave_enc;           /* backward: [n_nets, rows, J, L, IPLAN_BEH_DSAVE_ENC]                  */
     float* dsave_lat;           /* backward: [n_nets, rows, J, IPLAN_BEH_DSAVE_LAT]  d(latent logits)   */
+    /* single-window decoder mode = Behavior_Latent_Decoder.forward (nova/behavior_net.py:55-69): set T = L + 2 (one
+     * window) and pass the window, latent and hidden state explicitly; the encoder and the loss are skipped.     */
+    const float* win;           /* [n_nets, rows, L, d] or NULL                                          */
+    const float* lat_in;        /* [n_nets, rows, Z]                                                     */
+    const float* hd_in;         /* [n_nets, rows, 64]                                                    */
+    float* pred_out;            /* [n_nets, rows, L, d]                                                  */
+    float* hd_out;              /* [n_nets, rows, 64]                                                    */
 } IplanBehArgs;
 
 int iplan_beh_fwd(const IplanBehArgs* args, iplan_stream_t stream);

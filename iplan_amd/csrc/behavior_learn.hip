@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void beh_fwd_kernel(IplanBehArgs a) {
     const bool valid = row < rows;
     const int e = valid ? row / a.N : 0, ent = valid ? row % a.N : 0;
     const int J = a.T - 1 - a.L;
-    const float* __restrict__ hrow = a.hist + (int64_t)net * a.h_s_net + (int64_t)e * a.h_s_e + (int64_t)ent * a.d;
-    const float* __restrict__ mrow = a.mask + ((int64_t)net * a.E + e) * a.T;
+    const float* __restrict__ hrow = a.hist ? a.hist + (int64_t)net * a.h_s_net + (int64_t)e * a.h_s_e + (int64_t)ent * a.d : nullptr;
+    const float* __restrict__ mrow = a.mask ? a.mask + ((int64_t)net * a.E + e) * a.T : nullptr;
     const int64_t grow = (int64_t)net * rows + (valid ? row : 0);
     const float inv_keep = 1.0f / (1.0f - a.drop_p);
 
@@ -141,15 +141,20 @@ __global__ __launch_bounds__(256) void beh_fwd_kernel(IplanBehArgs a) {
     for (int t = 0; t < DT; ++t) hd[t] = splat4(0.f);
     for (int t = 0; t < ET; ++t) he[t] = splat4(0.f);
     lat = splat4(0.f);
+    const bool dec_only = a.win != nullptr;                  // Behavior_Latent_Decoder.forward on an explicit window
+    if (dec_only) {
+        lat = vload(a.lat_in + grow * a.Z, valid, a.Z, 0);
+        for (int t = 0; t < DT; ++t) hd[t] = vload(a.hd_in + grow * DHd, valid, DHd, t);
+    }
     float beh = 0.f, stab = 0.f;
     for (int j = 0; j < J; ++j) {
-        const float scale = (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS);
+        const float scale = dec_only ? 0.f : (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS);
         float err = 0.f;
         f32x4 zproj[DT], lat1[1];
         lat1[0] = lat;
         for (int T = 0; T < DT; ++T) zproj[T] = dense_tile<1>(s_dlinz, 20, 16 * T, lat1, bfrag_lds(s_db, T));
         for (int t = 0; t < a.L; ++t) {
-            const f32x4 xt = window_x(a, hrow, j, t, valid);
+            const f32x4 xt = dec_only ? vload(a.win + (grow * a.L + t) * a.d, valid, a.d, 0) : window_x(a, hrow, j, t, valid);
             // ---- decoder step (behavior_net.py:39-45, 55-69)
             float* sd = a.saved_dec + ((grow * J + j) * a.L + t) * SVD;
             f32x4 x1[1];
@@ -177,6 +182,10 @@ __global__ __launch_bounds__(256) void beh_fwd_kernel(IplanBehArgs a) {
             }
             const f32x4 y = dense_tile<DT>(s_dout, DLD, 0, act, bfrag_lds(s_db + 448, 0));
             vstore(sd + SD_Y, valid, 16, 0, y);
+            if (dec_only) {
+                vstore(a.pred_out + (grow * a.L + t) * a.d, valid, a.d, 0, y);
+                continue;
+            }
             // masked L1 against the next window, stability vs the current one (:226, 233-240)
             const f32x4 nx = vload(hrow + (int64_t)(j + 1 + t) * a.h_s_t, valid, a.d, 0);
             const float m = valid ? mrow[j + 1 + t] : 0.f;
@@ -206,6 +215,10 @@ __global__ __launch_bounds__(256) void beh_fwd_kernel(IplanBehArgs a) {
                 vstore(se + SE_HN, valid, EHd, T, ke[T].hn);
                 vstore(se + SE_H, valid, EHd, T, he[T]);
             }
+        }
+        if (dec_only) {
+            for (int t = 0; t < DT; ++t) vstore(a.hd_out + grow * DHd, valid, DHd, t, hd[t]);
+            return;
         }
         beh = fmaf(err, scale, beh);
         // latent head + soft update (:223-230)
@@ -446,7 +459,13 @@ static int check_beh(const IplanBehArgs* a, const char* what) {
     if (a->n_nets < 1 || a->E < 1 || a->N < 1 || a->L < 1 || a->T - 1 - a->L < 1 || a->d < 1 || a->Z < 1 ||
         a->d + a->Z > 16 || a->Z > 16)
         return fail(IPLAN_EINVAL, "%s: unsupported dims E=%d N=%d T=%d L=%d d=%d Z=%d", what, a->E, a->N, a->T, a->L, a->d, a->Z);
-    if (!a->hist || !a->mask || !a->enc_params || !a->dec_params || !a->saved_dec || !a->saved_enc || !a->saved_lat)
+    if (a->win) {
+        if (!a->lat_in || !a->hd_in || !a->pred_out || !a->hd_out || a->T != a->L + 2 || !a->saved_dec)
+            return fail(IPLAN_EINVAL, "%s: single-window decoder mode needs lat_in, hd_in, pred_out, hd_out, saved_dec and T == L + 2", what);
+    } else if (!a->hist || !a->mask || !a->saved_enc || !a->saved_lat) {
+        return fail(IPLAN_EINVAL, "%s: null tensor pointer", what);
+    }
+    if (!a->enc_params || !a->dec_params || !a->saved_dec)
         return fail(IPLAN_EINVAL, "%s: null tensor pointer", what);
     if (a->drop_p < 0.f || a->drop_p >= 1.f) return fail(IPLAN_EINVAL, "%s: dropout p=%f", what, a->drop_p);
     return IPLAN_OK;
@@ -457,7 +476,7 @@ static int check_beh(const IplanBehArgs* a, const char* what) {
 extern "C" int iplan_beh_fwd(const IplanBehArgs* a, iplan_stream_t stream) {
     using namespace iplan;
     if (int rc = check_beh(a, "iplan_beh_fwd")) return rc;
-    if (!a->loss_part || !a->loss) return fail(IPLAN_EINVAL, "iplan_beh_fwd: loss buffers missing");
+    if (!a->win && (!a->loss_part || !a->loss)) return fail(IPLAN_EINVAL, "iplan_beh_fwd: loss buffers missing");
     const int tiles = (a->E * a->N + 15) / 16;
     const size_t lds = sizeof(float) * (2 * 3 * DHd * DLD + 2 * DHd * 20 + 16 * DLD + 2 * 3 * EHd * ELDB + EHd * 20 + 16 * ELDB +
                                         (64 + 192 + 192 + 16) + (32 + 96 + 96 + 16));
@@ -466,7 +485,7 @@ extern "C" int iplan_beh_fwd(const IplanBehArgs* a, iplan_stream_t stream) {
 #endif
     hipLaunchKernelGGL(beh_fwd_kernel, dim3((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets), dim3(256), lds,
                        (hipStream_t)stream, *a);
-    hipLaunchKernelGGL(beh_loss_kernel, dim3((unsigned)a->n_nets), dim3(64), 0, (hipStream_t)stream, *a);
+    if (!a->win) hipLaunchKernelGGL(beh_loss_kernel, dim3((unsigned)a->n_nets), dim3(64), 0, (hipStream_t)stream, *a);
     return check_launch("iplan_beh_fwd");
 }
 

@@ -255,6 +255,86 @@ class IPPOLearner:
             for k, v in train_info.items():
                 self.logger.log_stat(self.log_prefix + k, v, t_env)
 
+    # ------------------------------------------------------------------ reference-shaped single-agent methods
+    # The fused train() above is the production path.  The methods below keep the reference's per-agent,
+    # per-minibatch surface (learners/ippo_learner.py:128-225, 344-424) for callers that drive PPO themselves;
+    # they run the same kernels through the module-level autograd Functions.
+    def compute_returns(self, agent_id, obs_all, rewards, terminated, rnn_state_critic_all):
+        """learners/ippo_learner.py:344-365.  obs_all [bs,T+1,F] (assembled), rewards [bs,T,1], terminated =
+        the reference's ``terminated_masks`` (1 - terminated) [bs,T+1,1] -> returns [bs,T,1]."""
+        bs, T = rewards.shape[0], rewards.shape[1]
+        with th.no_grad():
+            v_all = self.mac.get_value_ippo(agent_id, obs_all, rnn_state_critic_all).reshape(1, bs * (T + 1)).contiguous()
+        rw = rewards.to(**self.tpdv).reshape(bs, T).contiguous()
+        tm = (1 - terminated.to(self.device).reshape(bs, T + 1).to(th.float32)).to(th.uint8).contiguous()
+        pp = L.PpoPrepareArgs()
+        pp.n_agents, pp.bs, pp.T = 1, bs, T
+        pp.reward, pp.rw_s_net, pp.rw_s_ep, pp.rw_s_t = rw.data_ptr(), 0, T, 1
+        pp.terminated, pp.tm_s_net, pp.tm_s_ep, pp.tm_s_t = tm.data_ptr(), 0, T + 1, 1
+        pp.values, pp.gamma, pp.lam = v_all.data_ptr(), self.gamma, self.gae_lambda
+        outs = [th.empty(1, bs * T, **self.tpdv) for _ in range(4)]
+        pp.returns, pp.adv, pp.mask, pp.value_preds = (o.data_ptr() for o in outs)
+        L.get_lib().call("iplan_ppo_prepare", pp, L.current_stream(self.device))
+        return outs[0].reshape(bs, T, 1)
+
+    def _losses(self, logp, entropy_rows, values, old_logp, adv, value_preds, returns, mask):
+        """One iplan_ppo_loss launch for a single agent: (stats [8], dLoss/dlogp [R], d(value_loss)/dvalue [R])."""
+        R = values.numel()
+        f = lambda t: t.detach().to(**self.tpdv).reshape(1, R).contiguous()  # noqa: E731
+        pl = L.PpoLossArgs()
+        pl.n_agents, pl.rows, pl.row_stride = 1, R, R
+        ts = [f(t) for t in (logp, entropy_rows, values, old_logp, adv, value_preds, returns, mask)]
+        (pl.logp, pl.entropy, pl.values, pl.old_logp, pl.adv, pl.value_preds, pl.returns, pl.mask) = (t.data_ptr() for t in ts)
+        pl.clip, pl.huber_delta, pl.value_loss_coef = self.clip_param, self.huber_delta, 1.0
+        g_lp, g_v, stats = th.empty(1, R, **self.tpdv), th.empty(1, R, **self.tpdv), th.zeros(1, 8, **self.tpdv)
+        pl.g_logp, pl.g_values, pl.stats = g_lp.data_ptr(), g_v.data_ptr(), stats.data_ptr()
+        L.get_lib().call("iplan_ppo_loss", pl, L.current_stream(self.device))
+        return stats[0], g_lp[0], g_v[0]
+
+    def cal_value_loss(self, values, value_preds_batch, return_batch, terminated_batch):
+        """learners/ippo_learner.py:128-159 (clipped one-sided Huber, masked mean) -- differentiable w.r.t. ``values``."""
+        return _ValueLoss.apply(self, values, value_preds_batch, return_batch, terminated_batch)
+
+    def generate_data(self, obs, rnn_states_actor, rnn_states_critic, actions, returns, terminated, action_log_probs,
+                      advantages, available_actions, value_preds, num_mini_batch=None, mini_batch_size=None):
+        """learners/ippo_learner.py:368-424: shuffled minibatches over the first batch_size * episode_limit rows
+        (index plumbing only)."""
+        n = self.batch_size * self.episode_limit
+        if mini_batch_size is None:
+            mini_batch_size = n // num_mini_batch
+        rand = th.randperm(n)
+        flat = lambda t: t.reshape(-1, *t.shape[2:])  # noqa: E731
+        obs, ha, hc = flat(obs), flat(rnn_states_actor), flat(rnn_states_critic)
+        actions = actions.reshape(-1, actions.shape[-1])
+        if available_actions is not None:
+            available_actions = available_actions[:-1].reshape(-1, available_actions.shape[-1])
+        vp, rt, tm = value_preds.reshape(-1, 1), returns.reshape(-1, 1), terminated.reshape(-1, 1)
+        lp, adv = action_log_probs.reshape(-1, action_log_probs.shape[-1]), advantages.reshape(-1, 1)
+        for i in range(num_mini_batch):
+            idx = rand[i * mini_batch_size:(i + 1) * mini_batch_size].to(self.device)
+            yield (obs[idx], ha[idx], hc[idx], actions[idx], vp[idx], rt[idx], tm[idx], lp[idx], adv[idx],
+                   None if available_actions is None else available_actions[idx])
+
+    def ppo_update(self, agent_id, obs_batch, rnn_states_actor_batch, rnn_states_critic_batch, actions_batch,
+                   value_preds_batch, return_batch, terminated_batch, old_action_log_probs_batch, adv_targ,
+                   available_actions_batch, update_actor=True):
+        """learners/ippo_learner.py:161-225 for one agent and one minibatch."""
+        logp, ent = self.mac.eval_action_ippo(agent_id, obs_batch, actions_batch, available_actions_batch, rnn_states_actor_batch)
+        values = self.mac.get_value_ippo(agent_id, obs_batch, rnn_states_critic_batch)
+        policy_loss, ratio_mean = _PolicyLoss.apply(self, logp, old_action_log_probs_batch, adv_targ, terminated_batch)
+        max_norm = self.max_grad_norm if self._use_max_grad_norm else None
+        self.actor_optimizers[agent_id].zero_grad()
+        if update_actor:
+            (policy_loss - ent * self.entropy_coef).backward()
+        self.actor_optimizers[agent_id].step(max_norm=max_norm)
+        actor_grad_norm = self.actor_optimizers[agent_id].grad_norms()[0]
+        value_loss = self.cal_value_loss(values, value_preds_batch, return_batch, terminated_batch)
+        self.critic_optimizers[agent_id].zero_grad()
+        (value_loss * self.value_loss_coef).backward()
+        self.critic_optimizers[agent_id].step(max_norm=max_norm)
+        critic_grad_norm = self.critic_optimizers[agent_id].grad_norms()[0]
+        return value_loss, critic_grad_norm, policy_loss, ent, actor_grad_norm, ratio_mean
+
     # ------------------------------------------------------------------------------------------ misc
     def cuda(self):
         self.mac.cuda()
@@ -273,3 +353,34 @@ class IPPOLearner:
             for i in range(self.n_agents):
                 self.actor_optimizers[i].load_state_dict(th.load("{}/actor_{}_opt.th".format(paths[i], i), map_location="cpu"))
                 self.critic_optimizers[i].load_state_dict(th.load("{}/critic_{}_opt.th".format(paths[i], i), map_location="cpu"))
+
+
+class _ValueLoss(th.autograd.Function):
+    @staticmethod
+    def forward(ctx, learner, values, value_preds, returns, mask):
+        z = th.zeros_like(values)
+        stats, _, g_v = learner._losses(z, z, values, z, z, value_preds, returns, mask)
+        ctx.save_for_backward(g_v.reshape(values.shape))
+        return stats[1].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (g_v,) = ctx.saved_tensors
+        return None, g * g_v, None, None, None
+
+
+class _PolicyLoss(th.autograd.Function):
+    """(policy_loss, mean importance weight) of learners/ippo_learner.py:185-197."""
+
+    @staticmethod
+    def forward(ctx, learner, logp, old_logp, adv, mask):
+        z = th.zeros_like(logp)
+        stats, g_lp, _ = learner._losses(logp, z, z, old_logp, adv, z, z, mask)
+        ctx.save_for_backward(g_lp.reshape(logp.shape))
+        ctx.mark_non_differentiable(stats)
+        return stats[0].clone(), stats[2].clone()
+
+    @staticmethod
+    def backward(ctx, g, _g_ratio):
+        (g_lp,) = ctx.saved_tensors
+        return None, g * g_lp, None, None, None

@@ -65,4 +65,25 @@ class DecoderRNN(nn.Module):
 class Behavior_Latent_Decoder(_ArenaModule):
     def __init__(self, input_size, hidden_size, num_layers, output_size, dropout=0.5):
         super().__init__()
+        if hidden_size != 64:
+            raise NotImplementedError("behaviour decoder kernels are built for decoder_rnn_dim = 64")
+        self.output_size, self.hidden_size, self.p = output_size, hidden_size, dropout
         self.decoder = DecoderRNN(input_size, hidden_size, output_size, num_layers, dropout)
+        self._enc_stub = None
+
+    def forward(self, curr_history, prev_latent, hidden, keep=None):
+        """curr_history [E,N,L,d], prev_latent [E,N,Z], hidden [1,E*N,64] -> (pred [E*N,L,d], hidden [1,E*N,64])
+        (nova/behavior_net.py:55-69; inference of one window -- training goes through Behavior_policy.learn).
+        Dropout is active in train() mode, as in the reference (which never switches these modules to eval)."""
+        E, N, Lw, d = curr_history.shape
+        dev = curr_history.device
+        arena = self._single(dev)
+        if self._enc_stub is None or self._enc_stub.data.device != torch.device(dev):
+            # the fused kernel stages the encoder weights too; the single-window mode never uses them
+            self._enc_stub = ParamArena([EncoderRNN(d, 32, prev_latent.shape[-1], 1)], dev)
+        p = self.p if self.training else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0 and keep is None) else 0
+        pred, hout = ops.bdec_forward(self._enc_stub, arena, curr_history.float().reshape(1, E * N, Lw, d).contiguous(),
+                                      prev_latent.float().reshape(1, E * N, -1).contiguous(),
+                                      hidden.float().reshape(1, E * N, self.hidden_size).contiguous(), drop_p=p, keep=keep, seed=seed)
+        return pred[0], hout

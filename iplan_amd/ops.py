@@ -615,3 +615,34 @@ def beh_backward(enc_arena, dec_arena, fwd, lib=None):
     w._keep += [de, dl, fwd]
     w.run(lib)
     return dict(dsave_dec=dd, dsave_enc=de, dsave_lat=dl)
+
+
+def bdec_forward(enc_arena, dec_arena, window, latent, hidden, drop_p=0.0, keep=None, seed=0, lib=None):
+    """Behavior_Latent_Decoder.forward on one explicit window for all nets (single-window mode of iplan_beh_fwd).
+    window [n_nets, rows, L, d], latent [n_nets, rows, Z], hidden [n_nets, rows, 64] -> (pred [n_nets, rows, L, d],
+    new hidden [n_nets, rows, 64])."""
+    lib = _lib(lib)
+    n_nets, rows, Lw, d = window.shape
+    Z = latent.shape[-1]
+    dev = window.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    for t in (window, latent, hidden):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    a = L.BehArgs()
+    a.n_nets, a.E, a.N, a.T, a.L, a.d, a.Z = n_nets, rows, 1, Lw + 2, Lw, d, Z
+    a.win, a.lat_in, a.hd_in = window.data_ptr(), latent.data_ptr(), hidden.data_ptr()
+    pred, hout = torch.empty(n_nets, rows, Lw, d, **f32), torch.empty(n_nets, rows, 64, **f32)
+    saved = torch.empty(n_nets, rows, 1, Lw, L.BEH_SAVE_DEC, **f32)
+    a.pred_out, a.hd_out, a.saved_dec = pred.data_ptr(), hout.data_ptr(), saved.data_ptr()
+    if keep is not None:
+        assert keep.dtype == torch.uint8 and keep.shape == (n_nets, 1, rows, Lw, 64) and keep.is_contiguous()
+        a.keep = keep.data_ptr()
+    a.seed, a.drop_p, a.coef, a.thres = seed, drop_p, 0.0, 0.0
+    a.enc_params, a.enc_s_net = enc_arena.data.data_ptr(), enc_arena.net_stride
+    for i, k in enumerate(L.ENC_PARAM_ORDER):
+        a.enc_off[i] = enc_arena.off(k)
+    a.dec_params, a.dec_s_net = dec_arena.data.data_ptr(), dec_arena.net_stride
+    for i, k in enumerate(L.DEC_PARAM_ORDER):
+        a.dec_off[i] = dec_arena.off(k)
+    lib.call("iplan_beh_fwd", a, L.current_stream(dev))
+    return pred, hout

@@ -122,3 +122,47 @@ def check_behavior_learn(g, device):
 
 def test_behavior_learn_emulated(golden):
     check_behavior_learn(golden("behavior_learn"), "cpu")
+
+
+def test_ippo_reference_shaped_methods_emulated(golden):
+    """compute_returns / generate_data / ppo_update (the reference's per-agent surface) reproduce the fused train():
+    replaying the golden run agent by agent, epoch by epoch, lands on the reference's post-train parameters."""
+    from iplan_amd.controllers.dcntrl_controller import DcntrlMAC
+    from iplan_amd.learners.ippo_learner import IPPOLearner
+    from oracle import iplan_oracle as O
+    g = golden("ippo_train_mpe")
+    args = SimpleNamespace(**dict(g["args"], use_cuda=False))
+    scheme = synth.make_scheme(args)
+    mac = DcntrlMAC(scheme, {"agents": args.n_agents}, args)
+    for i in range(args.n_agents):
+        mac.agents[i].load_state_dict(g["pre"]["actors"][i])
+        mac.critics[i].load_state_dict(g["pre"]["critics"][i])
+    learner = IPPOLearner(mac, scheme, RecLogger(), args)
+    f = g["fields"]
+    E, T = f["history"].shape[0], args.episode_limit
+    learner.insert_episode_batch(synth.DictBatch(f, E, T + 1))
+    torch.manual_seed(0)
+    for agent_id in range(args.n_agents):
+        batch = learner.buffers[agent_id].get_batch()
+        obs_all = mac._build_inputs_ippo(agent_id, batch, batch["actions_onehot"])
+        rewards, term_all = batch["reward"][:, :-1], batch["terminated_masks"]
+        returns = learner.compute_returns(agent_id, obs_all, rewards, term_all, batch["rnn_states_critic"])
+        ref_x = O.build_inputs_train(agent_id, f["history"][:, :, agent_id], None, None, f["actions_onehot"][:, :, agent_id],
+                                     args.n_agents, False, False)
+        assert max_rel(obs_all, ref_x) < 1e-6
+        obs, term = obs_all[:, :-1], term_all[:, :-1].float()
+        with torch.no_grad():
+            values = mac.get_value_ippo(agent_id, obs, batch["rnn_states_critic"][:, :-1])
+            adv = O.normalise_advantages(returns, values, term)          # host-side check of the kernel's advantage path
+            old_logp, _ = mac.eval_action_ippo(agent_id, obs, batch["actions"][:, :-1], batch["available_actions"][:, :-1],
+                                               batch["rnn_states_actor"][:, :-1])
+        for _ in range(args.ppo_epoch):
+            for sample in learner.generate_data(obs, batch["rnn_states_actor"][:, :-1], batch["rnn_states_critic"][:, :-1],
+                                                batch["actions"][:, :-1], returns, term, old_logp, adv,
+                                                batch["available_actions"][:, :-1], values, args.num_mini_batch):
+                learner.ppo_update(agent_id, *sample)
+    for i in range(args.n_agents):
+        for name, mods in (("actors", mac.agents), ("critics", mac.critics)):
+            sd = mods[i].state_dict()
+            for k, ref in g["post"][name][i].items():
+                assert max_rel(sd[k], ref) < 3e-5, (name, i, k, max_rel(sd[k], ref))

@@ -26,3 +26,8 @@ def test_library_loaded_is_the_hip_build():
     from iplan_amd import _lib
     lib = _lib.get_lib()
     assert lib.c._name.endswith("libiplan_hip.so")
+
+
+def test_decoder_modules_match_reference(golden):
+    from tests.test_emu_kernels import check_decoder_modules
+    check_decoder_modules(golden, "cuda")
