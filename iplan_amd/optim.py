@@ -111,7 +111,9 @@ class FusedAdam(torch.optim.Optimizer):
         state = {}
         if self._steps > 0:
             for idx, (trainable, m, v) in enumerate(self._param_moments()):
-                if trainable:
+                # torch.optim.Adam only creates state for parameters that ever received a gradient (the unused
+                # `fc_h` template layer of MLPLayer never does): here that is "second moment still all zero"
+                if trainable and bool((v != 0).any()):
                     state[idx] = {"step": torch.tensor(float(self._steps)), "exp_avg": m.detach().clone(),
                                   "exp_avg_sq": v.detach().clone()}
         g = dict(self.param_groups[0])

@@ -542,8 +542,39 @@ def main():
     golden_rollout_step()
     golden_ippo_train(70, "highway")
     golden_ippo_train(80, "mpe_easy")
+    golden_checkpoint()
     print("all golden fixtures written to", GOLD)
 
 
 if __name__ == "__main__":
     main()
+
+
+def golden_checkpoint():
+    """Known-answer test on the reference's OWN shipped checkpoints: trained IPPO actor /
+    critic + Adam state of baselines/QMIX/marl_results/MPE/models/ippo_highway__seed=112358_03-12-23-44-17/40
+    loaded into the reference classes (input dim 85), one forward on seeded inputs."""
+    from modules.agents.ippo_actor import R_Actor
+    from modules.critics.ippo_critic import R_Critic
+    print("checkpoint fixture")
+    root = os.path.join(REF, "baselines", "QMIX", "marl_results", "MPE", "models",
+                        "ippo_highway__seed=112358_03-12-23-44-17", "40")
+    args = default_args("highway", use_cuda=False)
+    actor, critic = R_Actor(85, args), R_Critic(85, args)
+    a_sd = torch.load(os.path.join(root, "agent_0.th"), map_location="cpu")
+    c_sd = torch.load(os.path.join(root, "critic_0.th"), map_location="cpu")
+    a_opt = torch.load(os.path.join(root, "actor_0_opt.th"), map_location="cpu")
+    print(actor.load_state_dict(a_sd), critic.load_state_dict(c_sd))
+    opt = torch.optim.Adam(actor.parameters(), lr=args.lr, eps=args.optim_eps)
+    opt.load_state_dict(a_opt)
+    gen = torch.Generator().manual_seed(90)
+    B = 9
+    x = torch.randn(B, 1, 85, generator=gen)
+    h = torch.randn(1, B, 64, generator=gen) * 0.1
+    avail = torch.ones(B, 1, 5)
+    avail[::2, 0, 3] = 0
+    with torch.no_grad():
+        act, logp, h_a = actor(x, h, avail, deterministic=True)
+        val, h_c = critic(x, h)
+    torch.save(dict(actor=a_sd, critic=c_sd, actor_opt=a_opt, x=x, h=h, avail=avail, actions=act, logp=logp, h_actor=h_a,
+                    values=val, h_critic=h_c), os.path.join(GOLD, "checkpoint_fixture.pt"))

@@ -199,3 +199,43 @@ def check_decoder_modules(golden, device):
 
 def test_decoder_module_forwards_emulated(golden):
     check_decoder_modules(golden, "cpu")
+
+
+def check_reference_checkpoint(golden, device, tmp_path):
+    """The reference's own shipped checkpoint files (trained IPPO actor / critic / Adam state, input dim 85) load
+    into the mirrored classes key for key, give the reference's outputs, and round-trip through save/load."""
+    from iplan_amd.config import default_args
+    from iplan_amd.modules.agents.ippo_actor import R_Actor
+    from iplan_amd.modules.critics.ippo_critic import R_Critic
+    from iplan_amd.arena import ParamArena
+    from iplan_amd.optim import FusedAdam
+    g = golden("checkpoint_fixture")
+    args = default_args("highway", use_cuda=(device != "cpu"))
+    actor, critic = R_Actor(85, args), R_Critic(85, args)
+    assert list(actor.state_dict().keys()) == list(g["actor"].keys())
+    assert list(critic.state_dict().keys()) == list(g["critic"].keys())
+    assert str(actor.load_state_dict(g["actor"])) == "<All keys matched successfully>"
+    assert str(critic.load_state_dict(g["critic"])) == "<All keys matched successfully>"
+    with torch.no_grad():
+        act, logp, h_a = actor(g["x"].to(device), g["h"].to(device), g["avail"].to(device), deterministic=True)
+        val, h_c = critic(g["x"].to(device), g["h"].to(device))
+    assert torch.equal(act.cpu(), g["actions"])
+    assert rel_err(logp.cpu(), g["logp"]) < 1e-5 and rel_err(h_a.cpu(), g["h_actor"]) < 1e-5
+    assert rel_err(val.cpu(), g["values"]) < 1e-5 and rel_err(h_c.cpu(), g["h_critic"]) < 1e-5
+    # optimiser state in torch.optim.Adam's file format
+    arena = ParamArena([actor], device)
+    opt = FusedAdam([(arena, 0)], lr=args.lr, eps=args.optim_eps)
+    opt.load_state_dict(g["actor_opt"])
+    sd = opt.state_dict()
+    assert set(sd["state"].keys()) == set(g["actor_opt"]["state"].keys())
+    for k, st in g["actor_opt"]["state"].items():
+        assert float(sd["state"][k]["step"]) == float(st["step"])
+        assert torch.equal(sd["state"][k]["exp_avg"].cpu(), st["exp_avg"]) and torch.equal(sd["state"][k]["exp_avg_sq"].cpu(), st["exp_avg_sq"])
+    torch.save(actor.state_dict(), tmp_path / "agent_0.th")
+    back = torch.load(tmp_path / "agent_0.th", map_location="cpu")
+    for k, v in g["actor"].items():
+        assert torch.equal(back[k].cpu(), v), k
+
+
+def test_reference_checkpoint_emulated(golden, tmp_path):
+    check_reference_checkpoint(golden, "cpu", tmp_path)

@@ -31,3 +31,8 @@ def test_library_loaded_is_the_hip_build():
 def test_decoder_modules_match_reference(golden):
     from tests.test_emu_kernels import check_decoder_modules
     check_decoder_modules(golden, "cuda")
+
+
+def test_reference_checkpoint_matches(golden, tmp_path):
+    from tests.test_emu_kernels import check_reference_checkpoint
+    check_reference_checkpoint(golden, "cuda", tmp_path)
