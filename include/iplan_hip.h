@@ -507,6 +507,10 @@ typedef struct {
     const float* hd_in;         /* [n_nets, rows, 64]                                                    */
     float* pred_out;            /* [n_nets, rows, L, d]                                                  */
     float* hd_out;              /* [n_nets, rows, 64]                                                    */
+    /* hard = 1: the iPLAN-Hard ablation (nova/behavior_policy.py:119-215): non-overlapping windows
+     * (window j = steps j*L .. j*L+L-1, J = T/L - 1), the latent is REPLACED by the encoder output, one global
+     * normaliser sum(mask[:, :J*L]) for the whole loss and the mask taken at the window's own steps.            */
+    int32_t hard;
 } IplanBehArgs;
 
 int iplan_beh_fwd(const IplanBehArgs* args, iplan_stream_t stream);

@@ -292,5 +292,5 @@ class BehArgs(C.Structure):
         ("dec_params", fp), ("dec_s_net", i64), ("dec_off", i64 * len(DEC_PARAM_ORDER)),
         ("saved_dec", fp), ("saved_enc", fp), ("saved_lat", fp), ("loss_part", fp), ("loss", fp),
         ("dsave_dec", fp), ("dsave_enc", fp), ("dsave_lat", fp),
-        ("win", fp), ("lat_in", fp), ("hd_in", fp), ("pred_out", fp), ("hd_out", fp),
+        ("win", fp), ("lat_in", fp), ("hd_in", fp), ("pred_out", fp), ("hd_out", fp), ("hard", i32),
     ]

@@ -36,6 +36,12 @@ __device__ __forceinline__ float chain_sum_b(float v) {
     return v;
 }
 
+// window geometry: soft update = sliding windows (stride 1, right-aligned zero padding), hard update = blocks
+__device__ __forceinline__ int beh_windows(const IplanBehArgs& a) { return a.hard ? a.T / a.L - 1 : a.T - 1 - a.L; }
+__device__ __forceinline__ int beh_x_step(const IplanBehArgs& a, int j, int t) { return a.hard ? j * a.L + t : j - (a.L - 1) + t; }
+__device__ __forceinline__ int beh_y_step(const IplanBehArgs& a, int j, int t) { return a.hard ? (j + 1) * a.L + t : j + 1 + t; }
+__device__ __forceinline__ int beh_m_step(const IplanBehArgs& a, int j, int t) { return a.hard ? j * a.L + t : j + 1 + t; }
+
 // counter-based Bernoulli(1-p) keep flag (used when no mask tensor is injected): same value in the
 // forward and the backward launch for the same (seed, element index)
 __device__ __forceinline__ float keep_flag(uint64_t seed, uint64_t idx, float p) {
@@ -50,7 +56,7 @@ __device__ __forceinline__ float keep_flag(uint64_t seed, uint64_t idx, float p)
 
 __device__ __forceinline__ f32x4 keep_tile(const IplanBehArgs& a, int net, int j, int row, int t, int T, bool valid, int rows) {
     const int l = lane_id(), g = l >> 4;
-    const int64_t base = ((((int64_t)net * (a.T - 1 - a.L) + j) * rows + row) * a.L + t) * DHd + 16 * T + 4 * g;
+    const int64_t base = ((((int64_t)net * beh_windows(a) + j) * rows + row) * a.L + t) * DHd + 16 * T + 4 * g;
     f32x4 k = splat4(0.f);
     if (!valid) return k;
     if (a.keep) {
@@ -66,17 +72,20 @@ __device__ __forceinline__ f32x4 keep_tile(const IplanBehArgs& a, int net, int j
 // sum of the mask over the window's target steps (all envs), times N * d  (mask_over_next_traj.sum())
 __device__ __forceinline__ float window_mask_sum(const IplanBehArgs& a, int net, int j) {
     float s = 0.f;
-    const int cnt = a.E * a.L;
+    // hard update: ONE normaliser over all windows (nova/behavior_policy.py:185-187)
+    const int span = a.hard ? beh_windows(a) * a.L : a.L;
+    const int first = a.hard ? 0 : j + 1;
+    const int cnt = a.E * span;
     for (int i = lane_id(); i < cnt; i += 64) {
-        const int e = i / a.L, t = i - e * a.L;
-        s += a.mask[((int64_t)net * a.E + e) * a.T + j + 1 + t];
+        const int e = i / span, t = i - e * span;
+        s += a.mask[((int64_t)net * a.E + e) * a.T + first + t];
     }
     return wave_sum(s) * (float)(a.N * a.d);
 }
 
 // x_t of window j for this lane's chain: history[e, j-(L-1)+t] or zeros (right-aligned window)
 __device__ __forceinline__ f32x4 window_x(const IplanBehArgs& a, const float* __restrict__ hrow, int j, int t, bool valid) {
-    const int st = j - (a.L - 1) + t;
+    const int st = beh_x_step(a, j, t);
     return vload(hrow + (int64_t)(st < 0 ? 0 : st) * a.h_s_t, valid && st >= 0, a.d, 0);
 }
 
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256) void beh_fwd_kernel(IplanBehArgs a) {
     const int row = tile * 16 + n;
     const bool valid = row < rows;
     const int e = valid ? row / a.N : 0, ent = valid ? row % a.N : 0;
-    const int J = a.T - 1 - a.L;
+    const int J = beh_windows(a);
     const float* __restrict__ hrow = a.hist ? a.hist + (int64_t)net * a.h_s_net + (int64_t)e * a.h_s_e + (int64_t)ent * a.d : nullptr;
     const float* __restrict__ mrow = a.mask ? a.mask + ((int64_t)net * a.E + e) * a.T : nullptr;
     const int64_t grow = (int64_t)net * rows + (valid ? row : 0);
@@ -187,8 +196,8 @@ __global__ __launch_bounds__(256) void beh_fwd_kernel(IplanBehArgs a) {
                 continue;
             }
             // masked L1 against the next window, stability vs the current one (:226, 233-240)
-            const f32x4 nx = vload(hrow + (int64_t)(j + 1 + t) * a.h_s_t, valid, a.d, 0);
-            const float m = valid ? mrow[j + 1 + t] : 0.f;
+            const f32x4 nx = vload(hrow + (int64_t)beh_y_step(a, j, t) * a.h_s_t, valid, a.d, 0);
+            const float m = valid ? mrow[beh_m_step(a, j, t)] : 0.f;
             float d2 = 0.f;
             for (int q = 0; q < 4; ++q) {
                 if (4 * g + q < a.d) {
@@ -235,9 +244,9 @@ __global__ __launch_bounds__(256) void beh_fwd_kernel(IplanBehArgs a) {
         f32x4 nl;
         for (int q = 0; q < 4; ++q) nl[q] = ex[q] / ss;
         vstore(a.saved_lat + (grow * J + j) * SVL, valid, 16, 0, nl);
-        for (int q = 0; q < 4; ++q) lat[q] = (1.0f - a.coef) * lat[q] + nl[q] * a.coef;
+        for (int q = 0; q < 4; ++q) lat[q] = a.hard ? nl[q] : (1.0f - a.coef) * lat[q] + nl[q] * a.coef;
     }
-    beh = chain_sum_b(group_sum(beh)) / (float)J;
+    beh = chain_sum_b(group_sum(beh)) / (a.hard ? 1.0f : (float)J);
     stab = chain_sum_b(group_sum(stab)) / (float)a.E / (float)a.L / (float)J;
     if (l == 0) {
         a.loss_part[((int64_t)net * tiles + tile) * 2] = beh;
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(256) void beh_bwd_kernel(IplanBehArgs a) {
     const int row = tile * 16 + n;
     const bool valid = row < rows;
     const int e = valid ? row / a.N : 0, ent = valid ? row % a.N : 0;
-    const int J = a.T - 1 - a.L;
+    const int J = beh_windows(a);
     const float* __restrict__ hrow = a.hist + (int64_t)net * a.h_s_net + (int64_t)e * a.h_s_e + (int64_t)ent * a.d;
     const float* __restrict__ mrow = a.mask + ((int64_t)net * a.E + e) * a.T;
     const int64_t grow = (int64_t)net * rows + (valid ? row : 0);
@@ -336,8 +345,8 @@ __global__ __launch_bounds__(256) void beh_bwd_kernel(IplanBehArgs a) {
             o.d_hp[T] = vload(sd - SVD + SD_H, valid && !first, DHd, T);
         }
         o.d_y = vload(sd + SD_Y, valid, 16, 0);
-        o.d_nx = vload(hrow + (int64_t)(j + 1 + t) * a.h_s_t, valid, a.d, 0);
-        o.m = valid ? mrow[j + 1 + t] : 0.f;
+        o.d_nx = vload(hrow + (int64_t)beh_y_step(a, j, t) * a.h_s_t, valid, a.d, 0);
+        o.m = valid ? mrow[beh_m_step(a, j, t)] : 0.f;
     };
 
     f32x4 dhd[DT], dhe[ET], dlat;
@@ -349,18 +358,19 @@ __global__ __launch_bounds__(256) void beh_bwd_kernel(IplanBehArgs a) {
     f32x4 hcur[DT];                                     // decoder h of the current step (= h_prev of the step just done)
     for (int T = 0; T < DT; ++T) hcur[T] = vload(a.saved_dec + ((grow * J + (J - 1)) * a.L + (a.L - 1)) * SVD + SD_H, valid, DHd, T);
     for (int j = J - 1; j >= 0; --j) {
-        const float scale = (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS) / (float)J;
+        const float scale = (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS) / (a.hard ? 1.0f : (float)J);
         // ---- soft update + latent head backward
         f32x4 dlog[1];
         {
             const f32x4 nl = vload(a.saved_lat + (grow * J + j) * SVL, valid, 16, 0);
             float s = 0.f;
             f32x4 dnew;
-            for (int q = 0; q < 4; ++q) { dnew[q] = a.coef * dlat[q]; s = fmaf(nl[q], dnew[q], s); }
+            const float cn = a.hard ? 1.0f : a.coef, ck = a.hard ? 0.0f : 1.0f - a.coef;
+            for (int q = 0; q < 4; ++q) { dnew[q] = cn * dlat[q]; s = fmaf(nl[q], dnew[q], s); }
             s = group_sum(s);
             for (int q = 0; q < 4; ++q) {
                 dlog[0][q] = nl[q] * (dnew[q] - s);
-                dlat[q] *= (1.0f - a.coef);
+                dlat[q] *= ck;
             }
             vstore(a.dsave_lat + (grow * J + j) * DSL, valid, 16, 0, dlog[0]);
             for (int T = 0; T < ET; ++T) dhe[T] = dense_tile<1>(s_eoutT, 20, 16 * T, dlog, dhe[T]);
@@ -456,7 +466,7 @@ __global__ __launch_bounds__(256) void beh_bwd_kernel(IplanBehArgs a) {
 
 static int check_beh(const IplanBehArgs* a, const char* what) {
     if (!a) return fail(IPLAN_EINVAL, "%s: null args", what);
-    if (a->n_nets < 1 || a->E < 1 || a->N < 1 || a->L < 1 || a->T - 1 - a->L < 1 || a->d < 1 || a->Z < 1 ||
+    if (a->n_nets < 1 || a->E < 1 || a->N < 1 || a->L < 1 || (a->hard ? a->T / a->L - 1 : a->T - 1 - a->L) < 1 || a->d < 1 || a->Z < 1 ||
         a->d + a->Z > 16 || a->Z > 16)
         return fail(IPLAN_EINVAL, "%s: unsupported dims E=%d N=%d T=%d L=%d d=%d Z=%d", what, a->E, a->N, a->T, a->L, a->d, a->Z);
     if (a->win) {
@@ -481,7 +491,7 @@ extern "C" int iplan_beh_fwd(const IplanBehArgs* a, iplan_stream_t stream) {
     const size_t lds = sizeof(float) * (2 * 3 * DHd * DLD + 2 * DHd * 20 + 16 * DLD + 2 * 3 * EHd * ELDB + EHd * 20 + 16 * ELDB +
                                         (64 + 192 + 192 + 16) + (32 + 96 + 96 + 16));
 #ifndef IPLAN_HOST_EMULATION
-    hipFuncSetAttribute(reinterpret_cast<const void*>(beh_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
     hipLaunchKernelGGL(beh_fwd_kernel, dim3((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets), dim3(256), lds,
                        (hipStream_t)stream, *a);
@@ -496,7 +506,7 @@ extern "C" int iplan_beh_bwd(const IplanBehArgs* a, iplan_stream_t stream) {
     const int tiles = (a->E * a->N + 15) / 16;
     const size_t lds = sizeof(float) * (2 * DHd * (3 * DHd + 8) + DHd * 20 + 16 * DLD + 2 * EHd * (3 * EHd + 8) + EHd * 20);
 #ifndef IPLAN_HOST_EMULATION
-    hipFuncSetAttribute(reinterpret_cast<const void*>(beh_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
     hipLaunchKernelGGL(beh_bwd_kernel, dim3((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets), dim3(256), lds,
                        (hipStream_t)stream, *a);

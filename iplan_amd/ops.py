@@ -528,7 +528,7 @@ def pdec_backward(arena, fwd, lib=None):
 
 
 # ---- behaviour learning ---------------------------------------------------------------------------------
-def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p, keep=None, seed=0, lib=None):
+def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p, keep=None, seed=0, hard=False, lib=None):
     """Forward of Behavior_policy.learn for all nets.  hist [n_nets, E, T, N, d] (first three dims may be
     strided), mask [n_nets, E, T] contiguous, keep uint8 [n_nets, J, E*N, L, 64] or None (in-kernel draw from
     ``seed``).  Returns dict(loss [n_nets, 2] = (behaviour, stability), saved...)."""
@@ -538,10 +538,11 @@ def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p,
     assert mask.shape == (n_nets, E, T) and mask.is_contiguous() and mask.dtype == torch.float32
     dev = hist.device
     f32 = dict(dtype=torch.float32, device=dev)
-    J = T - 1 - L_win
+    J = (T // L_win - 1) if hard else (T - 1 - L_win)
     rows = E * N
     a = L.BehArgs()
     a.n_nets, a.E, a.N, a.T, a.L, a.d, a.Z = n_nets, E, N, T, L_win, d, Z
+    a.hard = 1 if hard else 0
     a.hist, a.h_s_net, a.h_s_e, a.h_s_t = hist.data_ptr(), hist.stride(0), hist.stride(1), hist.stride(2)
     a.mask = mask.data_ptr()
     if keep is not None:
@@ -572,7 +573,7 @@ def beh_backward(enc_arena, dec_arena, fwd, lib=None):
     lib = _lib(lib)
     a = fwd["_args"]
     n_nets, E, N, T, Lw, d, Z = a.n_nets, a.E, a.N, a.T, a.L, a.d, a.Z
-    J, rows = T - 1 - Lw, E * N
+    J, rows = ((T // Lw - 1) if a.hard else (T - 1 - Lw)), E * N
     dev = fwd["loss"].device
     f32 = dict(dtype=torch.float32, device=dev)
     dd = torch.empty(n_nets, rows, J, Lw, L.BEH_DSAVE_DEC, **f32)

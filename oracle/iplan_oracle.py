@@ -411,3 +411,36 @@ def adam_step(p, g, m, v, step, lr, eps, b1=0.9, b2=0.999):
     bc2 = 1 - b2 ** step
     denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
     p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+# ----------------------------------------------------------------------------------------------
+# iPLAN-Hard ablation: Behavior_policy.learn with hard latent updates (nova/behavior_policy.py:119-215)
+# ----------------------------------------------------------------------------------------------
+def behavior_hard_learn_loss(enc_p, dec_p, history, mask, L, drop_masks, drop_p):
+    """history [E,T,N,d] (already [:, :-1]), mask [E,T] (polarity applied), drop_masks [J, E*N, L, Hd].
+    Non-overlapping blocks of L steps; block j+1 is predicted from block j and the latent encoded from
+    blocks <= j-1; the latent is replaced (not blended); ONE normaliser over all J*L masked steps, and the
+    mask is taken at the CURRENT block's steps (:145-150, 181-187)."""
+    E, T, N, d = history.shape
+    Z = enc_p["out.weight"].shape[0]
+    R = enc_p["rnn.weight_hh_l0"].shape[1]
+    Hd = dec_p["decoder.rnn.weight_hh_l0"].shape[1]
+    dp = strip_prefix(dec_p, "decoder.")
+    nh = T // L
+    J = nh - 1
+    blocks = history[:, :nh * L].reshape(E, nh, L, N, d)
+    latent = torch.zeros(E, N, Z, dtype=history.dtype)
+    eh = torch.zeros(E * N, R, dtype=history.dtype)
+    dh = torch.zeros(E * N, Hd, dtype=history.dtype)
+    preds = []
+    for j in range(J):
+        curr = blocks[:, j].permute(0, 2, 1, 3)                                    # [E,N,L,d]
+        dec_in = torch.cat([curr, latent[:, :, None, :].expand(E, N, L, Z)], dim=-1)
+        pred, dh = decoder_forward(dp, dec_in.reshape(E * N, L, d + Z), dh, None if drop_masks is None else drop_masks[j], drop_p)
+        preds.append(pred.reshape(E, N, L, d).permute(0, 2, 1, 3))               # [E,L,N,d]
+        _, eh, latent = encoder_forward(enc_p, curr.reshape(E * N, L, d), eh)
+        latent = latent.reshape(E, N, Z)
+    nxt = blocks[:, 1:].reshape(E, J * L, N, d)
+    pred = torch.stack(preds, 1).reshape(E, J * L, N, d)
+    m = mask[:, :J * L].to(history.dtype)[:, :, None, None].expand(E, J * L, N, d)
+    return (torch.abs(nxt - pred) * m).sum() / (m.sum() + EPS) * d * N

@@ -543,6 +543,7 @@ def main():
     golden_ippo_train(70, "highway")
     golden_ippo_train(80, "mpe_easy")
     golden_checkpoint()
+    golden_behavior_hard_learn()
     print("all golden fixtures written to", GOLD)
 
 
@@ -578,3 +579,42 @@ def golden_checkpoint():
         val, h_c = critic(x, h)
     torch.save(dict(actor=a_sd, critic=c_sd, actor_opt=a_opt, x=x, h=h, avail=avail, actions=act, logp=logp, h_actor=h_a,
                     values=val, h_critic=h_c), os.path.join(GOLD, "checkpoint_fixture.pt"))
+
+
+def golden_behavior_hard_learn(seed=55):
+    """iPLAN-Hard ablation (nova/behavior_policy.py)."""
+    from nova.behavior_policy import Behavior_policy
+    print("behavior learn (hard update)")
+    args = small_args(max_vehicle_num=5, n_agents=2, episode_limit=25, batch_size_run=3, max_history_len=5)
+    E = 3
+    torch.manual_seed(seed)
+    pol = Behavior_policy(args, NullLogger())
+    batch, fields = ref_episode_batch(args, E, seed + 1, 0.8)
+    pre = dict(enc=[sd(m) for m in pol.behavior_encoder], dec=[sd(m) for m in pol.behavior_decoder])
+    patch()
+    torch.manual_seed(seed + 2)
+    bl = pol.learn(batch, 0)
+    drops = [d.clone() for d in REC["dropout"]]
+    unpatch()
+    post = dict(enc=[sd(m) for m in pol.behavior_encoder], dec=[sd(m) for m in pol.behavior_decoder])
+    clipped = dict(enc=[{k: v.grad.clone() for k, v in m.named_parameters()} for m in pol.behavior_encoder],
+                   dec=[{k: v.grad.clone() for k, v in m.named_parameters()} for m in pol.behavior_decoder])
+    hist = fields["history"][:, :-1]
+    term = fields["terminated"][:, :-1]
+    L = args.max_history_len
+    J = hist.shape[1] // L - 1
+    for i in range(args.n_agents):
+        ep, dp = req(pre["enc"][i]), req(pre["dec"][i])
+        masks = torch.stack(drops[i * J:(i + 1) * J])
+        loss = O.behavior_hard_learn_loss(ep, dp, hist[:, :, i], term[:, :, i, 0], L, masks, args.decoder_dropout)
+        check(f"agent{i} hard behavior loss", loss, bl[i], 1e-5)
+        loss.backward()
+        O.clip_grad_norm([ep[k].grad for k in ep], args.max_grad_norm)
+        O.clip_grad_norm([dp[k].grad for k in dp], args.max_grad_norm)
+        for k in ep:
+            check(f"agent{i} clipped grad enc.{k}", ep[k].grad, clipped["enc"][i][k], 2e-4)
+        for k in dp:
+            check(f"agent{i} clipped grad dec.{k}", dp[k].grad, clipped["dec"][i][k], 2e-4)
+    torch.save(dict(args=vars(args), fields=fields, pre=pre, post=post, clipped=clipped,
+                    behavior_loss=[float(x) for x in bl], dropout=drops),
+               os.path.join(GOLD, "behavior_hard_learn.pt"))

@@ -166,3 +166,31 @@ def test_ippo_reference_shaped_methods_emulated(golden):
             sd = mods[i].state_dict()
             for k, ref in g["post"][name][i].items():
                 assert max_rel(sd[k], ref) < 3e-5, (name, i, k, max_rel(sd[k], ref))
+
+
+def check_behavior_hard_learn(g, device):
+    from iplan_amd.nova.behavior_policy import Behavior_policy
+    args = SimpleNamespace(**dict(g["args"], use_cuda=(device != "cpu")))
+    pol = Behavior_policy(args, RecLogger())
+    nA, Lw = args.n_agents, args.max_history_len
+    for i in range(nA):
+        pol.behavior_encoder[i].load_state_dict(g["pre"]["enc"][i])
+        pol.behavior_decoder[i].load_state_dict(g["pre"]["dec"][i])
+    E = g["fields"]["history"].shape[0]
+    J = args.episode_limit // Lw - 1
+    batch = synth.DictBatch(g["fields"], E, args.episode_limit + 1).to(device)
+    keep = torch.stack([torch.stack(g["dropout"][i * J:(i + 1) * J]) for i in range(nA)])
+    bl = pol.learn(batch, 0, keep=keep.to(torch.uint8).contiguous().to(device))
+    for i in range(nA):
+        assert abs(float(bl[i]) - g["behavior_loss"][i]) <= 1e-5 * max(1.0, abs(g["behavior_loss"][i])), (i, bl[i])
+        for name, mods, arena in (("enc", pol.behavior_encoder, pol.enc_arena), ("dec", pol.behavior_decoder, pol.dec_arena)):
+            for k, ref in g["clipped"][name][i].items():
+                err = (arena.grad_of(i, k).cpu().double() - ref.double()).abs().max().item()
+                assert err <= 2e-5 * ref.abs().max().item() + 1e-9, ("clipped grad", name, i, k, err)
+            sd = mods[i].state_dict()
+            for k, ref in g["post"][name][i].items():
+                assert max_rel(sd[k], ref) < 1e-6, ("post", name, i, k)
+
+
+def test_behavior_hard_learn_emulated(golden):
+    check_behavior_hard_learn(golden("behavior_hard_learn"), "cpu")

@@ -25,3 +25,8 @@ def test_behavior_learn_matches_reference(golden):
 def test_gat_backward_matches_reference(golden, tag):
     from tests.test_emu_gat_backward import check_gat_backward
     check_gat_backward(golden("gat_" + tag), "cuda")
+
+
+def test_behavior_hard_learn_matches_reference(golden):
+    from tests.test_emu_learners import check_behavior_hard_learn
+    check_behavior_hard_learn(golden("behavior_hard_learn"), "cuda")

@@ -55,3 +55,17 @@ def test_behavior_learn_loss_matches_reference(golden):
 def test_huber_is_one_sided():
     e = torch.tensor([-20.0, -5.0, 5.0, 20.0])
     assert torch.allclose(O.huber_loss(e, 10.0), torch.tensor([0.0, 12.5, 12.5, 150.0]))
+
+
+def test_behavior_hard_learn_loss_matches_reference(golden):
+    g = golden("behavior_hard_learn")
+    a = g["args"]
+    hist = g["fields"]["history"][:, :-1]
+    term = g["fields"]["terminated"][:, :-1]
+    L = a["max_history_len"]
+    J = hist.shape[1] // L - 1
+    for i in range(a["n_agents"]):
+        masks = torch.stack(g["dropout"][i * J:(i + 1) * J])
+        loss = O.behavior_hard_learn_loss(g["pre"]["enc"][i], g["pre"]["dec"][i], hist[:, :, i], term[:, :, i, 0], L,
+                                          masks, a["decoder_dropout"])
+        assert close(loss, g["behavior_loss"][i])
