@@ -160,7 +160,7 @@ def cpu_baseline(args, E):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--envs", type=int, default=32, help="parallel envs per GPU (config 3: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -86,16 +86,36 @@ class SyntheticLoop:
             self.prediction.GAT_latent_update(D["history"][:, 0], D["attention_latent"][:, 0], D["behavior_latent"][:, 0],
                                               noise=noise[T], out=D["attention_latent"][:, 0])
         q_all = torch.empty(T, nA, E, a.n_actions, device=dev).exponential_()
+        # The instant-incentive (GAT) and behavioural-incentive (encoder) updates of a step are independent of each
+        # other (both read the PREVIOUS latents), and the GAT launch leaves 96 of the 256 CUs idle (one scene per
+        # workgroup): the encoder runs beside it on a second HIP stream, joined before the next action selection.
+        two_streams = torch.device(dev).type == "cuda" and self.prediction is not None and self.behavior is not None
+        if two_streams:
+            main = torch.cuda.current_stream(dev)
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(dev)
+                self._ev = (torch.cuda.Event(), torch.cuda.Event())
+            side, (ev_go, ev_done) = self._side, self._ev
         for t in range(T):
             self.mac.select_actions_ippo(batch, t, test_mode=False, q_noise=q_all[t], as_numpy=False, write_back=True)
             # env.step would run here; its outputs are the pre-generated tensors
+            if two_streams:
+                ev_go.record(main)
             if self.prediction is not None:
                 self.prediction.GAT_latent_update(D["history"][:, t + 1], D["attention_latent"][:, t], D["behavior_latent"][:, t],
                                                   noise=noise[t], out=D["attention_latent"][:, t + 1])
             if self.behavior is not None:
                 window = hist_all[t + 1:t + 1 + L].permute(1, 2, 3, 0, 4)           # [E, nA, N, L, d] sliding view, read in place
-                self.behavior.latent_update(window, eh[t & 1], D["behavior_latent"][:, t],
-                                            out_latent=D["behavior_latent"][:, t + 1], out_hidden=eh[(t + 1) & 1][:, 0])
+                if two_streams:
+                    side.wait_event(ev_go)
+                    with torch.cuda.stream(side):
+                        self.behavior.latent_update(window, eh[t & 1], D["behavior_latent"][:, t],
+                                                    out_latent=D["behavior_latent"][:, t + 1], out_hidden=eh[(t + 1) & 1][:, 0])
+                        ev_done.record(side)
+                    main.wait_event(ev_done)
+                else:
+                    self.behavior.latent_update(window, eh[t & 1], D["behavior_latent"][:, t],
+                                                out_latent=D["behavior_latent"][:, t + 1], out_hidden=eh[(t + 1) & 1][:, 0])
         return batch
 
     def cycle(self):
@@ -106,9 +126,39 @@ class SyntheticLoop:
         batch = self.rollout()
         self.t_env += self.E * self.args.episode_limit
         self.learner.insert_episode_batch(batch)
+        dev = torch.device(self.device)
+        if dev.type != "cuda":
+            if self.behavior is not None:
+                self.behavior.learn(batch, self.t_env)
+            if self.prediction is not None:
+                self.prediction.learn(batch, self.t_env)
+            self.learner.train(self.t_env)
+            return self.E * self.args.episode_limit
+        # The three learners of a cycle touch disjoint parameter sets and only READ the episode data, and the
+        # behaviour kernels occupy 138 of the 256 CUs: prediction learning and the PPO update are enqueued on two
+        # side streams beside them and joined before the next rollout.  Values are identical to running them one
+        # after another; only the host read-backs are deferred to the join.
+        main = torch.cuda.current_stream(dev)
+        if getattr(self, "_lstreams", None) is None:
+            self._lstreams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        fins = []
+        ev = torch.cuda.Event()
+        ev.record(main)
+        for strm, fn in zip(self._lstreams, (
+                (lambda: self.prediction.learn(batch, self.t_env, defer=True)) if self.prediction is not None else None,
+                lambda: self.learner.train(self.t_env, defer=True))):
+            if fn is None:
+                continue
+            strm.wait_event(ev)
+            with torch.cuda.stream(strm):
+                f = fn()
+                done = torch.cuda.Event()
+                done.record(strm)
+            fins.append((f, done))
         if self.behavior is not None:
             self.behavior.learn(batch, self.t_env)
-        if self.prediction is not None:
-            self.prediction.learn(batch, self.t_env)
-        self.learner.train(self.t_env)
+        for f, done in fins:
+            main.wait_event(done)
+            if f is not None:
+                f()
         return self.E * self.args.episode_limit

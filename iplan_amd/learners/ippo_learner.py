@@ -163,8 +163,9 @@ class IPPOLearner:
                                  last_action=last, la_strides=(1, self.n_agents),
                                  n_id=self.n_agents if a.obs_agent_id else 0, T=T, T_phys=T_phys)
 
-    def train(self, t_env):
-        """learners/ippo_learner.py:227-317."""
+    def train(self, t_env, defer=False):
+        """learners/ippo_learner.py:227-317.  ``defer=True``: enqueue everything on the current stream and return a
+        ``finish()`` callable that does the single host read-back + logging (None when the buffer is not full)."""
         if not self.buffers[0].can_sample():
             return
         print("TRAINING IPPO")
@@ -246,14 +247,19 @@ class IPPOLearner:
         self.store.clear()
 
         # train_info (:305-310): averages over agents x epochs -- ONE host read-back
-        st = stats.mean(dim=(0, 1)).cpu()
-        nr = norms.sqrt().mean(dim=(0, 2)).cpu() if max_norm is not None else th.zeros(2)
-        train_info = {"value_loss": float(st[1]), "policy_loss": float(st[0]), "dist_entropy": float(st[3]),
-                      "actor_grad_norm": float(nr[0]), "critic_grad_norm": float(nr[1]), "ratio": float(st[2])}
-        self.last_train_info = train_info
-        if t_env - self.log_stats_t >= self.args.learner_log_interval:
-            for k, v in train_info.items():
-                self.logger.log_stat(self.log_prefix + k, v, t_env)
+        st_d = stats.mean(dim=(0, 1))
+        nr_d = norms.sqrt().mean(dim=(0, 2)) if max_norm is not None else th.zeros(2, device=dev)
+
+        def finish():
+            st, nr = st_d.cpu(), nr_d.cpu()
+            train_info = {"value_loss": float(st[1]), "policy_loss": float(st[0]), "dist_entropy": float(st[3]),
+                          "actor_grad_norm": float(nr[0]), "critic_grad_norm": float(nr[1]), "ratio": float(st[2])}
+            self.last_train_info = train_info
+            if t_env - self.log_stats_t >= self.args.learner_log_interval:
+                for k, v in train_info.items():
+                    self.logger.log_stat(self.log_prefix + k, v, t_env)
+            return train_info
+        return finish if defer else (finish() and None)
 
     # ------------------------------------------------------------------ reference-shaped single-agent methods
     # The fused train() above is the production path.  The methods below keep the reference's per-agent,

@@ -98,12 +98,14 @@ class Prediction_policy:
         coins = [np.random.random() < self.args.teacher_forcing_ratio for _ in range(self.pred_length)]
         return sel, coins
 
-    def learn(self, batch, t_env, noise=None, keep=None):
+    def learn(self, batch, t_env, noise=None, keep=None, defer=False):
         """nova/prediction_policy.py:168-253 for all agents at once: sample -> fused GAT forward ->
         decoder forward + masked L1 -> decoder backward -> GAT backward -> weight gradients ->
         separate clip of the GAT and decoder groups -> Adam.  ``noise`` (gumbel, [nA, S, N, N-1, 2]) and
         ``keep`` (dropout keep flags, [nA, P, S*N, A]) may be injected; by default they are drawn from
-        torch's generator on the device.  Returns the list of n_agents losses (numpy scalars)."""
+        torch's generator on the device.  Returns the list of n_agents losses (numpy scalars); with ``defer=True``
+        everything is enqueued on the current stream and a ``finish()`` callable is returned instead (it does the
+        single host read-back and the logging), so independent learners can overlap on separate streams."""
         a = self.args
         dev = self.device
         nA, N, S, P = self.n_agents, self.max_vehicle_num, self.prediction_batch_size, self.pred_length
@@ -140,15 +142,19 @@ class Prediction_policy:
         if getattr(self, "dp", None) is not None:
             self.dp.all_reduce_grads(self.gat_arena, self.dec_arena)
         sq = step_all(self.pred_optimizer, self.max_grad_norm if self._use_max_grad_norm else None)
-        host = torch.cat([fwd["loss"], sq.sqrt().reshape(-1)]).cpu()              # ONE host read-back
-        losses = host[:nA].numpy()
-        norms = host[nA:].reshape(nA, 2)
-        train_info = {"prediction_loss": float(losses.sum()), "pred_encoder_grad_norm": float(norms[:, 0].sum()),
-                      "pred_decoder_grad_norm": float(norms[:, 1].sum())}
-        if t_env - self.log_stats_t >= self.args.learner_log_interval:
-            for k, v in train_info.items():
-                self.logger.log_stat(self.log_prefix + k, v, t_env)
-        return [np.asarray(x) for x in losses]
+        stats = torch.cat([fwd["loss"], sq.sqrt().reshape(-1)])
+
+        def finish():
+            host = stats.cpu()                                                      # ONE host read-back
+            losses = host[:nA].numpy()
+            norms = host[nA:].reshape(nA, 2)
+            train_info = {"prediction_loss": float(losses.sum()), "pred_encoder_grad_norm": float(norms[:, 0].sum()),
+                          "pred_decoder_grad_norm": float(norms[:, 1].sum())}
+            if t_env - self.log_stats_t >= self.args.learner_log_interval:
+                for k, v in train_info.items():
+                    self.logger.log_stat(self.log_prefix + k, v, t_env)
+            return [np.asarray(x) for x in losses]
+        return finish if defer else finish()
 
     # ---------------------------------------------------------------------------- checkpoints
     def save_models(self, path):

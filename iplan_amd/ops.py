@@ -249,8 +249,10 @@ _WORKSPACES = {}
 
 
 def workspace(device, floats, tag="wgrad"):
-    """Grow-only scratch buffer per (device, tag) -- owned by torch's caching allocator."""
-    key = (str(device), tag)
+    """Grow-only scratch buffer per (device, current stream, tag) -- owned by torch's caching allocator.  Keyed by
+    stream because independent learners may run concurrently on different HIP streams."""
+    sid = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+    key = (str(device), sid, tag)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < floats:
         buf = torch.empty(max(int(floats), 1), dtype=torch.float32, device=device)
