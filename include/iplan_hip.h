@@ -337,7 +337,7 @@ typedef struct {
     const float* g_values;      /* [n_agents, rows] dLoss/dvalue                                         */
     float* dsave;               /* [2, n_agents, rows, IPLAN_AC_DSAVE_FLOATS]                            */
     float* ln_part;             /* [2, n_agents, ceil(rows/16), IPLAN_AC_LNPART_FLOATS]                  */
-    float* g_part;              /* [2, n_agents, fc1_chunks, 64, Fpad] partial G tiles (Fpad = ceil(F/64)*64) */
+    float* g_part;              /* [2, n_agents, fc1_chunks, 64, Kpad] partial G tiles, Kpad = iplan_ac_kpad()  */
     int32_t fc1_chunk_rows;     /* rows per chunk, multiple of 16                                        */
     int32_t fc1_chunks;
     float* actor_grad;          /* gradient arenas (fc1.weight, feature_norm.* are written by finalize)  */
@@ -345,6 +345,7 @@ typedef struct {
     int64_t actor_grad_s_net, critic_grad_s_net;
 } IplanAcBwdArgs;
 
+int iplan_ac_kpad(const IplanAcFeatures* feat);   /* padded length of the kernels' source-major feature order */
 int iplan_ac_bwd_tail(const IplanAcBwdArgs* args, iplan_stream_t stream);
 int iplan_ac_bwd_fc1(const IplanAcBwdArgs* args, iplan_stream_t stream);
 int iplan_ac_bwd_fc1_finalize(const IplanAcBwdArgs* args, iplan_stream_t stream);

@@ -13,6 +13,7 @@
 //      gradients:  dW1 = gamma*G + beta*S,  dgamma = sum_m W1*G,  dbeta = sum_m W1*S  (S = db1).
 #include "api_util.h"
 #include "gru_tile.h"
+#include "ac_kmap.h"
 
 namespace iplan {
 
@@ -210,99 +211,103 @@ __global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// G[m][c] = sum_r dz1[r][m] * xhat[r][c]   (xhat = (x - mu_r) * rstd_r, LN(F) without its affine part)
-// grid: (column group of 64, row chunk, which * n_agents + net); one wave per workgroup.
-struct ColRef {
-    int kind;                 // 0 source load, 1 last-action one-hot, 2 constant, 3 padding (xhat = 0)
-    const float* base;
-    int64_t s_row;
-    int idx;
-    float cval;
-};
-
+// G[m][kb] = sum_r dz1[r][m] * xhat[r][kb]   (xhat = (x - mu_r) * rstd_r, LN(F) without its affine part), with the
+// feature axis in the SOURCE-MAJOR K order of ac_kmap.h, so the feature operand is read with plain 16-byte loads
+// from the episode-buffer fields.  Same data path as wgrad.hip: per 16-row block every lane fetches one 16-byte
+// piece of each 16x16 operand tile (row = lane / 4), the tiles are parked in LDS and read back in MFMA operand
+// order, and the next block's loads fly during the current block's 64 MFMAs.
+// grid: (group of 4 k-tiles, row chunk, which * n_agents + net); one wave per workgroup.
 __global__ __launch_bounds__(64) void ac_fc1_wgrad_kernel(IplanAcBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_t[2][8][256];
     const IplanAcFwdArgs& fa = a.fwd;
     const IplanAcFeatures& ft = fa.feat;
     const int nz = (int)blockIdx.z;
     const int which_i = nz / fa.n_agents, net = nz % fa.n_agents;
     const int which = fa.which == 2 ? which_i : fa.which;
-    const int l = lane_id(), i = l & 15, g = l >> 4;
-    const int W = ft.w[0] + ft.w[1] + ft.w[2];
-    const int NW = ft.N * W;
-    const int F = NW + ft.n_actions + ft.n_id;
-    const int Fpad = (F + 63) / 64 * 64;
-    const int c0 = (int)blockIdx.x * 64;
+    const int l = lane_id(), i = l & 15, g = l >> 4;           // MFMA role
+    const int lr = l >> 2, lc = 4 * (l & 3);                   // loader role
+    const KMap km = make_kmap(ft);
+    const int KT = km.kt0[4], Kpad = KT * 16;
+    const int T0 = (int)blockIdx.x * 4;
+    const int nkt = imin(4, KT - T0);
     const int chunk = (int)blockIdx.y;
     const int64_t r_lo = (int64_t)chunk * a.fc1_chunk_rows;
     const int64_t r_hi = r_lo + a.fc1_chunk_rows < fa.rows ? r_lo + a.fc1_chunk_rows : fa.rows;
-
-    ColRef col[4];
-    for (int u = 0; u < 4; ++u) {
-        int c = c0 + 16 * u + i;
-        ColRef& cr = col[u];
-        cr.base = nullptr; cr.s_row = 0; cr.idx = 0; cr.cval = 0.f;
-        if (c >= F) { cr.kind = 3; continue; }
-        if (c < NW) {
-            const int e = c / W;
-            int k = c - e * W, s = 0;
-            if (k >= ft.w[0]) { k -= ft.w[0]; s = 1; if (k >= ft.w[1]) { k -= ft.w[1]; s = 2; } }
-            cr.kind = 0;
-            cr.base = ft.src[s] + (int64_t)net * ft.s_net[s] + (int64_t)e * ft.w[s] + k;
-            cr.s_row = ft.s_row[s];
-            continue;
-        }
-        c -= NW;
-        if (c < ft.n_actions) { cr.kind = 1; cr.idx = c; continue; }
-        c -= ft.n_actions;
-        cr.kind = 2;
-        cr.cval = (c == net) ? 1.0f : 0.0f;
-    }
     const int64_t sbase = ((int64_t)which * fa.n_agents + net) * fa.rows;
+
+    // per-tile loader bookkeeping (wave-uniform class: fast = whole tile inside a source block of width % 4 == 0)
+    KTile kt[4];
+    bool fast[4];
+    for (int u = 0; u < 4; ++u) {
+        kt[u] = ktile_at(km, imin(T0 + u, KT - 1), lc);
+        const int s = kt[u].s;
+        fast[u] = u < nkt && s < 3 && (km.w[s] & 3) == 0 && 16 * (T0 + u - km.kt0[s]) + 16 <= km.len[s];
+    }
     f32x4 acc[BT][4];
     for (int t = 0; t < BT; ++t)
         for (int u = 0; u < 4; ++u) acc[t][u] = splat4(0.f);
-    for (int64_t rb = r_lo; rb < r_hi; rb += 16) {
+
+    struct Regs { f32x4 av[BT]; f32x4 bv[4]; };
+    auto fetch = [&](int64_t rb, Regs& o) {
+        const int64_t r = rb + lr;
+        const bool rv = r < r_hi;
+        const int64_t rc = rv ? r : r_lo;
+        const int64_t pr = (rc / ft.T) * ft.T_phys + (rc % ft.T);
+        const float* dz = a.dsave + (sbase + rc) * IPLAN_AC_DSAVE_FLOATS;
+        for (int t = 0; t < BT; ++t) {
+            o.av[t] = *reinterpret_cast<const f32x4*>(dz + 16 * t + lc);
+            if (!rv) o.av[t] = splat4(0.f);
+        }
+        const float* st = fa.saved + (sbase + rc) * IPLAN_AC_SAVE_FLOATS + 10 * BM;
+        const float mu = st[0], rstd = st[1];
+        const float* src[3];
+        for (int s = 0; s < 3; ++s) src[s] = ft.w[s] > 0 ? ft.src[s] + (int64_t)net * ft.s_net[s] + pr * ft.s_row[s] : nullptr;
+        int last = -1;
+        if (ft.n_actions > 0) {
+            if (ft.last_action) last = ft.last_action[(int64_t)net * ft.la_s_net + pr * ft.la_s_row];
+            else if (ft.last_action64) last = (int)ft.last_action64[(int64_t)net * ft.la64_s_net + pr * ft.la64_s_row];
+        }
+        for (int u = 0; u < 4; ++u) {
+            f32x4 x = splat4(0.f);
+            int nv = 0;
+            if (u < nkt) {
+                if (fast[u]) { x = ldu4(src[kt[u].s] + kt[u].f0); nv = 4; }
+                else { x = kfeat(km, kt[u], src, true, last, net); nv = kt[u].nv; }
+            }
+            for (int q = 0; q < 4; ++q) x[q] = (rv && q < nv) ? (x[q] - mu) * rstd : 0.f;
+            o.bv[u] = x;
+        }
+    };
+    auto park = [&](const Regs& o, int buf) {
+        for (int t = 0; t < BT; ++t) *reinterpret_cast<f32x4*>(&s_t[buf][t][lr * 16 + lc]) = o.av[t];
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(&s_t[buf][4 + u][lr * 16 + lc]) = o.bv[u];
+    };
+    auto contract = [&](int buf) {
         for (int s = 0; s < 4; ++s) {
-            const int64_t r = rb + 4 * s + g;
-            const bool rv = r < r_hi;
+            const int e = (4 * s + g) * 16 + i;
             float av[BT], bv[4];
-            float mu = 0.f, rstd = 0.f;
-            int64_t pr = 0;
-            if (rv) {
-                const float* st = fa.saved + (sbase + r) * IPLAN_AC_SAVE_FLOATS + 10 * BM;
-                mu = st[0]; rstd = st[1];
-                pr = (r / ft.T) * ft.T_phys + (r % ft.T);
-                const float* dz = a.dsave + (sbase + r) * IPLAN_AC_DSAVE_FLOATS;
-                for (int t = 0; t < BT; ++t) av[t] = dz[16 * t + i];
-            } else {
-                for (int t = 0; t < BT; ++t) av[t] = 0.f;
-            }
-            int last = -1;
-            for (int u = 0; u < 4; ++u) {
-                float x = 0.f;
-                const ColRef& cr = col[u];
-                if (rv && cr.kind != 3) {
-                    if (cr.kind == 0) x = cr.base[pr * cr.s_row];
-                    else if (cr.kind == 1) {
-                        if (last == -1) {
-                            if (ft.last_action) last = ft.last_action[(int64_t)net * ft.la_s_net + pr * ft.la_s_row];
-                            else if (ft.last_action64) last = (int)ft.last_action64[(int64_t)net * ft.la64_s_net + pr * ft.la64_s_row];
-                        }
-                        x = (cr.idx == last) ? 1.0f : 0.0f;
-                    } else x = cr.cval;
-                    x = (x - mu) * rstd;
-                }
-                bv[u] = x;
-            }
+            for (int t = 0; t < BT; ++t) av[t] = s_t[buf][t][e];
+            for (int u = 0; u < 4; ++u) bv[u] = s_t[buf][4 + u][e];
             for (int t = 0; t < BT; ++t)
                 for (int u = 0; u < 4; ++u) acc[t][u] = mfma4(av[t], bv[u], acc[t][u]);
         }
+    };
+    Regs rg;
+    fetch(r_lo, rg);
+    int buf = 0;
+    for (int64_t rb = r_lo; rb < r_hi; rb += 16) {
+        park(rg, buf);
+        if (rb + 16 < r_hi) fetch(rb + 16, rg);
+        __syncthreads();
+        contract(buf);
+        buf ^= 1;
     }
-    float* part = a.g_part + (((int64_t)which_i * fa.n_agents + net) * a.fc1_chunks + chunk) * (int64_t)BM * Fpad;
+    float* part = a.g_part + (((int64_t)which_i * fa.n_agents + net) * a.fc1_chunks + chunk) * (int64_t)BM * Kpad;
     for (int t = 0; t < BT; ++t)
         for (int q = 0; q < 4; ++q) {
             const int m = 16 * t + 4 * g + q;
-            for (int u = 0; u < 4; ++u) part[(int64_t)m * Fpad + c0 + 16 * u + i] = acc[t][u][q];
+            for (int u = 0; u < 4; ++u)
+                if (u < nkt) part[(int64_t)m * Kpad + (T0 + u) * 16 + i] = acc[t][u][q];
         }
 }
 
@@ -315,19 +320,20 @@ __global__ __launch_bounds__(256) void ac_fc1_finalize_kernel(IplanAcBwdArgs a) 
     const IplanAcNet& nw = which ? fa.critic : fa.actor;
     const float* __restrict__ P = nw.params + (int64_t)net * nw.params_s_net;
     float* __restrict__ G = (which ? a.critic_grad : a.actor_grad) + (int64_t)net * (which ? a.critic_grad_s_net : a.actor_grad_s_net);
-    const int W = ft.w[0] + ft.w[1] + ft.w[2];
-    const int F = ft.N * W + ft.n_actions + ft.n_id;
-    const int Fpad = (F + 63) / 64 * 64;
+    const KMap km = make_kmap(ft);
+    const int F = km.NW + km.n_actions + km.n_id;
+    const int Kpad = km.kt0[4] * 16;
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (c >= F) return;
+    const int kb = korder_of_column(km, c);
     const float gam = P[nw.off[IPLAN_AC_FN_W] + c], bet = P[nw.off[IPLAN_AC_FN_B] + c];
     const float* __restrict__ W1 = P + nw.off[IPLAN_AC_FC1_W];
     const float* __restrict__ S = G + nw.off[IPLAN_AC_FC1_B];
-    const float* __restrict__ part = a.g_part + ((int64_t)which_i * fa.n_agents + net) * a.fc1_chunks * (int64_t)BM * Fpad;
+    const float* __restrict__ part = a.g_part + ((int64_t)which_i * fa.n_agents + net) * a.fc1_chunks * (int64_t)BM * Kpad;
     float dgam = 0.f, dbet = 0.f;
     for (int m = 0; m < BM; ++m) {
         float gsum = 0.f;
-        for (int k = 0; k < a.fc1_chunks; ++k) gsum += part[((int64_t)k * BM + m) * Fpad + c];
+        for (int k = 0; k < a.fc1_chunks; ++k) gsum += part[((int64_t)k * BM + m) * Kpad + kb];
         const float w = W1[(int64_t)m * F + c], s = S[m];
         G[nw.off[IPLAN_AC_FC1_W] + (int64_t)m * F + c] = fmaf(gam, gsum, bet * s);
         dgam = fmaf(w, gsum, dgam);
@@ -350,6 +356,14 @@ static int check_bwd_args(const IplanAcBwdArgs* a, const char* what) {
 
 }  // namespace iplan
 
+// padded length of the source-major K order (multiple of 16): N*w_s rounded up per source, then the one-hots
+extern "C" int iplan_ac_kpad(const IplanAcFeatures* ft) {
+    int t = 0;
+    for (int s = 0; s < 3; ++s) t += (ft->N * ft->w[s] + 15) / 16;
+    t += (ft->n_actions + ft->n_id + 15) / 16;
+    return t * 16;
+}
+
 extern "C" int iplan_ac_bwd_tail(const IplanAcBwdArgs* a, iplan_stream_t stream) {
     using namespace iplan;
     if (int rc = check_bwd_args(a, "iplan_ac_bwd_tail")) return rc;
@@ -367,10 +381,8 @@ extern "C" int iplan_ac_bwd_fc1(const IplanAcBwdArgs* a, iplan_stream_t stream) 
         (int64_t)a->fc1_chunks * a->fc1_chunk_rows < a->fwd.rows)
         return fail(IPLAN_EINVAL, "iplan_ac_bwd_fc1: bad chunking (%d chunks x %d rows for %d rows)", a->fc1_chunks,
                     a->fc1_chunk_rows, a->fwd.rows);
-    const IplanAcFeatures& ft = a->fwd.feat;
-    const int F = ft.N * (ft.w[0] + ft.w[1] + ft.w[2]) + ft.n_actions + ft.n_id;
     const unsigned nw = a->fwd.which == 2 ? 2u : 1u;
-    dim3 grid((unsigned)((F + 63) / 64), (unsigned)a->fc1_chunks, nw * (unsigned)a->fwd.n_agents);
+    dim3 grid((unsigned)((iplan_ac_kpad(&a->fwd.feat) / 16 + 3) / 4), (unsigned)a->fc1_chunks, nw * (unsigned)a->fwd.n_agents);
     hipLaunchKernelGGL(ac_fc1_wgrad_kernel, grid, dim3(64), 0, (hipStream_t)stream, *a);
     return check_launch("iplan_ac_bwd_fc1");
 }

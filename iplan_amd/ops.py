@@ -373,8 +373,7 @@ def ac_backward(fwd, actor_arena, critic_arena, g_logp=None, g_entropy=0.0, g_va
     dsave = torch.empty(2, n_agents, rows, L.AC_DSAVE_FLOATS, **f32)
     ln_part = torch.empty(2, n_agents, tiles, L.AC_LNPART_FLOATS, **f32)
     a.dsave, a.ln_part = dsave.data_ptr(), ln_part.data_ptr()
-    F = spec.F
-    Fpad = (F + 63) // 64 * 64
+    Fpad = int(lib.c.iplan_ac_kpad(C.byref(fa.feat)))
     chunk_rows = max(256, ((rows + 31) // 32 + 15) // 16 * 16)
     chunks = (rows + chunk_rows - 1) // chunk_rows
     n_which = 2 if which == 2 else 1
