@@ -36,8 +36,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md (v
 # HBM bytes per launch from the committed PMC passes (profiles/r01*_pmc_*.txt), keyed by (kernel, envs per GPU):
 # (2 * FETCH_SIZE + WRITE_SIZE) KiB -> bytes.  Counters cannot be collected from inside bench.py; None = not profiled.
 PMC_TRAFFIC_BYTES = {
-    ("beh_bwd_kernel", 32): int((2 * 9662384.5 + 14045465.5) * 1024),
-    ("gat_fwd_kernel", 32): int((2 * 5031.8 + 1100.0) * 1024),
+    ("beh_bwd_kernel", 32): int((2 * 9357943.3 + 14332591.4) * 1024),    # profiles/r01c_pmc_gat_fwd_behaviour_learn.txt
+    ("gat_fwd_kernel", 32): int((2 * 5037.5 + 1100.0) * 1024),
 }
 
 
