@@ -474,10 +474,12 @@ int iplan_pdec_bwd(const IplanPdecArgs* args, iplan_stream_t stream);
  */
 #define IPLAN_BEH_SAVE_DEC 496
 #define IPLAN_BEH_SAVE_ENC 192
-#define IPLAN_BEH_SAVE_LAT 16
+#define IPLAN_BEH_SAVE_LAT 32        /* per (row, window): softmax output 0 (16) | latent used by the decoder 16 (16) */
 #define IPLAN_BEH_DSAVE_DEC 336
 #define IPLAN_BEH_DSAVE_ENC 160
 #define IPLAN_BEH_DSAVE_LAT 16
+#define IPLAN_BEH_ENC_PART 7408       /* per-wave encoder weight-gradient partial: W_ih 0 | W_hh 3072 | b_ih 6144 | b_hh 6240
+                                         | lin.W [32][16] 6336 | lin.b 6848 | out.W [16][32] 6880 | out.b 7392          */
 
 typedef struct {
     int32_t n_nets, E, N, T, L, d, Z;  /* T = stored steps used (= episode_limit)                      */
@@ -499,8 +501,9 @@ typedef struct {
     float* loss_part;           /* [n_nets, ceil(rows/16), 2]                                           */
     float* loss;                /* [n_nets, 2]  behaviour error, stability error                        */
     float* dsave_dec;           /* backward: [n_nets, rows, J, L, IPLAN_BEH_DSAVE_DEC]                  */
-    float* dsave_enc;           /* backward: [n_nets, rows, J, L, IPLAN_BEH_DSAVE_ENC]                  */
-    float* dsave_lat;           /* backward: [n_nets, rows, J, IPLAN_BEH_DSAVE_LAT]  d(latent logits)   */
+    float* dsave_enc;           /* unused since the encoder accumulates its weight gradients in-kernel  */
+    float* dsave_lat;           /* backward: [n_nets, rows, J, IPLAN_BEH_DSAVE_LAT] d(loss)/d(latent_j) through
+                                   the decoder inputs of window j (decoder BPTT -> encoder BPTT hand-off) */
     /* single-window decoder mode = Behavior_Latent_Decoder.forward (nova/behavior_net.py:55-69): set T = L + 2 (one
      * window) and pass the window, latent and hidden state explicitly; the encoder and the loss are skipped.     */
     const float* win;           /* [n_nets, rows, L, d] or NULL                                          */
@@ -512,6 +515,12 @@ typedef struct {
      * (window j = steps j*L .. j*L+L-1, J = T/L - 1), the latent is REPLACED by the encoder output, one global
      * normaliser sum(mask[:, :J*L]) for the whole loss and the mask taken at the window's own steps.            */
     int32_t hard;
+    float* enc_part;            /* backward: [n_nets, ceil(rows/16), IPLAN_BEH_ENC_PART] per-wave partials */
+    float* enc_grad;            /* backward: encoder gradient arena (written at enc_off[])               */
+    int64_t enc_grad_s_net;
+    int32_t bwd_phase;          /* iplan_beh_bwd: 0 = decoder then encoder, 1 = decoder BPTT only, 2 = encoder BPTT only
+                                   (lets the host run the encoder's BPTT on a second stream beside the decoder's
+                                   weight-gradient contractions; phase 2 needs phase 1's dsave_lat)               */
 } IplanBehArgs;
 
 int iplan_beh_fwd(const IplanBehArgs* args, iplan_stream_t stream);

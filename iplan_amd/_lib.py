@@ -278,7 +278,8 @@ class PdecArgs(C.Structure):
 
 
 # ---- behaviour learning ------------------------------------------------------------------------------
-BEH_SAVE_DEC, BEH_SAVE_ENC, BEH_SAVE_LAT = 496, 192, 16
+BEH_SAVE_DEC, BEH_SAVE_ENC, BEH_SAVE_LAT = 496, 192, 32
+BEH_ENC_PART = 7408
 BEH_DSAVE_DEC, BEH_DSAVE_ENC, BEH_DSAVE_LAT = 336, 160, 16
 
 
@@ -293,4 +294,5 @@ class BehArgs(C.Structure):
         ("saved_dec", fp), ("saved_enc", fp), ("saved_lat", fp), ("loss_part", fp), ("loss", fp),
         ("dsave_dec", fp), ("dsave_enc", fp), ("dsave_lat", fp),
         ("win", fp), ("lat_in", fp), ("hd_in", fp), ("pred_out", fp), ("hd_out", fp), ("hard", i32),
+        ("enc_part", fp), ("enc_grad", fp), ("enc_grad_s_net", i64), ("bwd_phase", i32),
     ]

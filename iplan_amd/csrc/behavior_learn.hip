@@ -3,13 +3,18 @@
 //
 // A chain is one (env, entity) row of one agent-net.  Chains never interact (the only coupling is the
 // mask normaliser of the loss, which depends on the mask alone), so a wave owns 16 chains for the
-// entire episode: for every window j < T-1-L it runs
-//      decoder:  y_t, h^d = Linear(Dropout(tanh(GRU64(ReLU(Linear([x_t || latent])), h^d))))   t < L
+// entire episode; for every window j it runs
 //      encoder:  h^e = GRU32(ReLU(Linear(x_t)), h^e)  t < L;  latent <- (1-c) latent + c softmax(Linear(h^e))
-// with both hidden states and the latent carried from window to window in registers (D layout of
-// wave_tile.h), weights resident in LDS (140 KB), ~5 100 MFMAs per window.  The forward streams the
-// activations BPTT needs; the backward walks the 2 x 790 GRU steps in reverse and streams the
-// row-level pre-activation gradients that wgrad.hip contracts into weight gradients.
+//      decoder:  y_t, h^d = Linear(Dropout(tanh(GRU64(ReLU(Linear([x_t || latent])), h^d))))   t < L
+// The data flow between the two is one-way and tiny: the decoder only consumes the per-window latent, the
+// encoder's backward only consumes the decoder's per-window d(loss)/d(latent).  So the two chains are four
+// kernels, each with only its own weights in LDS:
+//   beh_enc_fwd  (all windows; light, several waves per SIMD)  -> latents per window, encoder records
+//   beh_dec_fwd  (416 MFMAs per step, one wave per SIMD, 129 KB of LDS weights) -> loss, decoder records
+//   beh_dec_bwd  BPTT of the decoder; streams row gradients for wgrad.hip and d(loss)/d(latent_j)
+//   beh_enc_bwd  BPTT of the encoder with its weight gradients accumulated IN the kernel (H = 32: the
+//                24 accumulator tiles fit in registers; operands are turned through LDS each step)
+// hidden states and the latent are carried from window to window in registers (D layout of wave_tile.h).
 #include "api_util.h"
 #include "gru_tile.h"
 
@@ -17,8 +22,8 @@ namespace iplan {
 
 constexpr int DHd = 64, DT = 4;          // decoder_rnn_dim
 constexpr int EHd = 32, ET = 2;          // encoder_rnn_dim
-constexpr int DLD = DHd + 4;             // LDS leading dims (ld % 4 == 0, bank-staggered)
-constexpr int ELDB = EHd + 4;
+constexpr int DLD = DHd + 8;             // LDS leading dims: ld % 16 == 8 -> conflict-free ds_read_b128 fragment reads
+constexpr int ELDB = EHd + 8;
 constexpr int SVD = IPLAN_BEH_SAVE_DEC, SVE = IPLAN_BEH_SAVE_ENC, SVL = IPLAN_BEH_SAVE_LAT;
 constexpr int DSD = IPLAN_BEH_DSAVE_DEC, DSE = IPLAN_BEH_DSAVE_ENC, DSL = IPLAN_BEH_DSAVE_LAT;
 constexpr float BEPS = 1e-10f;
@@ -89,134 +94,72 @@ __device__ __forceinline__ f32x4 window_x(const IplanBehArgs& a, const float* __
     return vload(hrow + (int64_t)(st < 0 ? 0 : st) * a.h_s_t, valid && st >= 0, a.d, 0);
 }
 
-__global__ __launch_bounds__(256) void beh_fwd_kernel(IplanBehArgs a) {
-    IPLAN_DYN_LDS(smem);
-    float* s_dwih = smem;                                   // [192][DLD]
-    float* s_dwhh = s_dwih + 3 * DHd * DLD;                 // [192][DLD]
-    float* s_dlin = s_dwhh + 3 * DHd * DLD;                 // [64][20]   W_lin[:, :d]
-    float* s_dlinz = s_dlin + DHd * 20;                     // [64][20]   W_lin[:, d:d+Z]
-    float* s_dout = s_dlinz + DHd * 20;                     // [16][DLD]
-    float* s_ewih = s_dout + 16 * DLD;                      // [96][ELDB]
-    float* s_ewhh = s_ewih + 3 * EHd * ELDB;
-    float* s_elin = s_ewhh + 3 * EHd * ELDB;                // [32][20]
-    float* s_eout = s_elin + EHd * 20;                      // [16][ELDB]
-    float* s_db = s_eout + 16 * ELDB;                       // dec biases: lin 64 | ih 192 | hh 192 | out 16
-    float* s_eb = s_db + 64 + 192 + 192 + 16;               // enc biases: lin 32 | ih 96 | hh 96 | out 16
+// ------------------------------------------------------------------------------------------------------------
+// shared prologue of the four kernels
+struct BehChain {
+    int net, rows, tiles, tile, row, e, ent, J, n, g;
+    bool valid;
+    const float* hrow;
+    const float* mrow;
+    int64_t grow;
+};
+__device__ __forceinline__ bool beh_chain(const IplanBehArgs& a, BehChain& c) {
+    const int l = lane_id();
+    c.n = l & 15;
+    c.g = l >> 4;
+    c.net = (int)blockIdx.y;
+    c.rows = a.E * a.N;
+    c.tiles = (c.rows + 15) / 16;
+    c.tile = (int)blockIdx.x * 4 + wave_id();
+    c.row = c.tile * 16 + c.n;
+    c.valid = c.tile < c.tiles && c.row < c.rows;
+    c.e = c.valid ? c.row / a.N : 0;
+    c.ent = c.valid ? c.row % a.N : 0;
+    c.J = beh_windows(a);
+    c.hrow = a.hist ? a.hist + (int64_t)c.net * a.h_s_net + (int64_t)c.e * a.h_s_e + (int64_t)c.ent * a.d : nullptr;
+    c.mrow = a.mask ? a.mask + ((int64_t)c.net * a.E + c.e) * a.T : nullptr;
+    c.grow = (int64_t)c.net * c.rows + (c.valid ? c.row : 0);
+    return c.tile < c.tiles;
+}
 
-    const int net = (int)blockIdx.y;
-    const float* __restrict__ PD = a.dec_params + (int64_t)net * a.dec_s_net;
-    const float* __restrict__ PE = a.enc_params + (int64_t)net * a.enc_s_net;
-    const int din = a.d + a.Z;
-    stage_matrix(s_dwih, DLD, 3 * DHd, PD + a.dec_off[IPLAN_DEC_WIH], 3 * DHd, DHd);
-    stage_matrix(s_dwhh, DLD, 3 * DHd, PD + a.dec_off[IPLAN_DEC_WHH], 3 * DHd, DHd);
-    {   // split the input Linear by source: columns [0, d) act on x_t, [d, d+Z) on the latent
-        const float* Wl = PD + a.dec_off[IPLAN_DEC_LIN_W];
-        for (int idx = (int)threadIdx.x; idx < DHd * 20; idx += (int)blockDim.x) {
-            const int m = idx / 20, c = idx - m * 20;
-            s_dlin[idx] = c < a.d ? Wl[(int64_t)m * din + c] : 0.f;
-            s_dlinz[idx] = c < a.Z ? Wl[(int64_t)m * din + a.d + c] : 0.f;
-        }
-    }
-    stage_matrix(s_dout, DLD, 16, PD + a.dec_off[IPLAN_DEC_OUT_W], a.d, DHd);
-    stage_matrix(s_ewih, ELDB, 3 * EHd, PE + a.enc_off[IPLAN_ENC_WIH], 3 * EHd, EHd);
-    stage_matrix(s_ewhh, ELDB, 3 * EHd, PE + a.enc_off[IPLAN_ENC_WHH], 3 * EHd, EHd);
-    stage_matrix(s_elin, 20, EHd, PE + a.enc_off[IPLAN_ENC_LIN_W], EHd, a.d);
-    stage_matrix(s_eout, ELDB, 16, PE + a.enc_off[IPLAN_ENC_OUT_W], a.Z, EHd);
-    stage_vector(s_db, 64, PD + a.dec_off[IPLAN_DEC_LIN_B], 64);
-    stage_vector(s_db + 64, 192, PD + a.dec_off[IPLAN_DEC_BIH], 192);
-    stage_vector(s_db + 256, 192, PD + a.dec_off[IPLAN_DEC_BHH], 192);
-    stage_vector(s_db + 448, 16, PD + a.dec_off[IPLAN_DEC_OUT_B], a.d);
-    stage_vector(s_eb, 32, PE + a.enc_off[IPLAN_ENC_LIN_B], 32);
-    stage_vector(s_eb + 32, 96, PE + a.enc_off[IPLAN_ENC_BIH], 96);
-    stage_vector(s_eb + 128, 96, PE + a.enc_off[IPLAN_ENC_BHH], 96);
-    stage_vector(s_eb + 224, 16, PE + a.enc_off[IPLAN_ENC_OUT_B], a.Z);
+// ------------------------------------------------------------------------------------------------------------
+// encoder forward over the whole episode: records per step (saved_enc) and per window (saved_lat)
+__global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_wih[3 * EHd * ELDB];
+    __shared__ __attribute__((aligned(16))) float s_whh[3 * EHd * ELDB];
+    __shared__ __attribute__((aligned(16))) float s_lin[EHd * 24];
+    __shared__ __attribute__((aligned(16))) float s_out[16 * ELDB];
+    __shared__ __attribute__((aligned(16))) float s_b[32 + 96 + 96 + 16];
+    const float* __restrict__ PE = a.enc_params + (int64_t)blockIdx.y * a.enc_s_net;
+    stage_matrix(s_wih, ELDB, 3 * EHd, PE + a.enc_off[IPLAN_ENC_WIH], 3 * EHd, EHd);
+    stage_matrix(s_whh, ELDB, 3 * EHd, PE + a.enc_off[IPLAN_ENC_WHH], 3 * EHd, EHd);
+    stage_matrix(s_lin, 24, EHd, PE + a.enc_off[IPLAN_ENC_LIN_W], EHd, a.d);
+    stage_matrix(s_out, ELDB, 16, PE + a.enc_off[IPLAN_ENC_OUT_W], a.Z, EHd);
+    stage_vector(s_b, 32, PE + a.enc_off[IPLAN_ENC_LIN_B], 32);
+    stage_vector(s_b + 32, 96, PE + a.enc_off[IPLAN_ENC_BIH], 96);
+    stage_vector(s_b + 128, 96, PE + a.enc_off[IPLAN_ENC_BHH], 96);
+    stage_vector(s_b + 224, 16, PE + a.enc_off[IPLAN_ENC_OUT_B], a.Z);
     __syncthreads();
-
-    const int l = lane_id(), n = l & 15, g = l >> 4;
-    const int rows = a.E * a.N;
-    const int tiles = (rows + 15) / 16;
-    const int tile = (int)blockIdx.x * 4 + wave_id();
-    if (tile >= tiles) return;
-    const int row = tile * 16 + n;
-    const bool valid = row < rows;
-    const int e = valid ? row / a.N : 0, ent = valid ? row % a.N : 0;
-    const int J = beh_windows(a);
-    const float* __restrict__ hrow = a.hist ? a.hist + (int64_t)net * a.h_s_net + (int64_t)e * a.h_s_e + (int64_t)ent * a.d : nullptr;
-    const float* __restrict__ mrow = a.mask ? a.mask + ((int64_t)net * a.E + e) * a.T : nullptr;
-    const int64_t grow = (int64_t)net * rows + (valid ? row : 0);
-    const float inv_keep = 1.0f / (1.0f - a.drop_p);
-
-    f32x4 hd[DT], he[ET], lat;
-    for (int t = 0; t < DT; ++t) hd[t] = splat4(0.f);
+    BehChain c;
+    if (!beh_chain(a, c)) return;
+    const bool valid = c.valid;
+    const int g = c.g, J = c.J;
+    f32x4 he[ET], lat = splat4(0.f);
     for (int t = 0; t < ET; ++t) he[t] = splat4(0.f);
-    lat = splat4(0.f);
-    const bool dec_only = a.win != nullptr;                  // Behavior_Latent_Decoder.forward on an explicit window
-    if (dec_only) {
-        lat = vload(a.lat_in + grow * a.Z, valid, a.Z, 0);
-        for (int t = 0; t < DT; ++t) hd[t] = vload(a.hd_in + grow * DHd, valid, DHd, t);
-    }
-    float beh = 0.f, stab = 0.f;
     for (int j = 0; j < J; ++j) {
-        const float scale = dec_only ? 0.f : (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS);
-        float err = 0.f;
-        f32x4 zproj[DT], lat1[1];
-        lat1[0] = lat;
-        for (int T = 0; T < DT; ++T) zproj[T] = dense_tile<1>(s_dlinz, 20, 16 * T, lat1, bfrag_lds(s_db, T));
+        float* sl = a.saved_lat + (c.grow * J + j) * SVL;
+        vstore(sl + 16, valid, 16, 0, lat);                      // the latent the decoder uses in window j
         for (int t = 0; t < a.L; ++t) {
-            const f32x4 xt = dec_only ? vload(a.win + (grow * a.L + t) * a.d, valid, a.d, 0) : window_x(a, hrow, j, t, valid);
-            // ---- decoder step (behavior_net.py:39-45, 55-69)
-            float* sd = a.saved_dec + ((grow * J + j) * a.L + t) * SVD;
             f32x4 x1[1];
-            x1[0] = xt;
-            vstore(sd + SD_X, valid, 16, 0, xt);
-            vstore(sd + SD_LAT, valid, 16, 0, lat);
-            f32x4 u[DT];
-            for (int T = 0; T < DT; ++T) {
-                // Linear([x_t || latent]) = W[:, :d] x_t + (W[:, d:] latent + b)  -- the latent part is per window
-                u[T] = relu4(dense_tile<1>(s_dlin, 20, 16 * T, x1, zproj[T]));
-                vstore(sd + SD_U, valid, DHd, T, u[T]);
-            }
-            GruGates kg[DT];
-            gru_step_lds<DT, DT>(s_dwih, DLD, s_dwhh, DLD, s_db + 64, s_db + 256, u, hd, kg);
-            f32x4 act[DT];
-            for (int T = 0; T < DT; ++T) {
-                vstore(sd + SD_R, valid, DHd, T, kg[T].r);
-                vstore(sd + SD_Z, valid, DHd, T, kg[T].z);
-                vstore(sd + SD_N, valid, DHd, T, kg[T].n);
-                vstore(sd + SD_HN, valid, DHd, T, kg[T].hn);
-                vstore(sd + SD_H, valid, DHd, T, hd[T]);
-                const f32x4 km = keep_tile(a, net, j, row, t, T, valid, rows);
-                for (int q = 0; q < 4; ++q) act[T][q] = tanh_f(hd[T][q]) * (km[q] * inv_keep);
-                vstore(sd + SD_A, valid, DHd, T, act[T]);
-            }
-            const f32x4 y = dense_tile<DT>(s_dout, DLD, 0, act, bfrag_lds(s_db + 448, 0));
-            vstore(sd + SD_Y, valid, 16, 0, y);
-            if (dec_only) {
-                vstore(a.pred_out + (grow * a.L + t) * a.d, valid, a.d, 0, y);
-                continue;
-            }
-            // masked L1 against the next window, stability vs the current one (:226, 233-240)
-            const f32x4 nx = vload(hrow + (int64_t)beh_y_step(a, j, t) * a.h_s_t, valid, a.d, 0);
-            const float m = valid ? mrow[beh_m_step(a, j, t)] : 0.f;
-            float d2 = 0.f;
-            for (int q = 0; q < 4; ++q) {
-                if (4 * g + q < a.d) {
-                    err += fabsf(nx[q] - y[q]) * m;
-                    const float df = xt[q] - y[q];
-                    d2 = fmaf(df, df, d2);
-                }
-            }
-            d2 = group_sum(d2);
-            if (valid && g == 0) stab += fmaxf(sqrtf(d2) - a.thres, 0.f);
-            // ---- encoder step (behavior_net.py:17-22)
-            float* se = a.saved_enc + ((grow * J + j) * a.L + t) * SVE;
+            x1[0] = window_x(a, c.hrow, j, t, valid);
+            float* se = a.saved_enc + ((c.grow * J + j) * a.L + t) * SVE;
             f32x4 ue[ET];
             for (int T = 0; T < ET; ++T) {
-                ue[T] = relu4(dense_tile<1>(s_elin, 20, 16 * T, x1, bfrag_lds(s_eb, T)));
+                ue[T] = relu4(dense_tile<1>(s_lin, 24, 16 * T, x1, bfrag_lds(s_b, T)));
                 vstore(se + SE_U, valid, EHd, T, ue[T]);
             }
             GruGates ke[ET];
-            gru_step_lds<ET, ET>(s_ewih, ELDB, s_ewhh, ELDB, s_eb + 32, s_eb + 128, ue, he, ke);
+            gru_step_lds<ET, ET>(s_wih, ELDB, s_whh, ELDB, s_b + 32, s_b + 128, ue, he, ke);
             for (int T = 0; T < ET; ++T) {
                 vstore(se + SE_R, valid, EHd, T, ke[T].r);
                 vstore(se + SE_Z, valid, EHd, T, ke[T].z);
@@ -225,13 +168,8 @@ __global__ __launch_bounds__(256) void beh_fwd_kernel(IplanBehArgs a) {
                 vstore(se + SE_H, valid, EHd, T, he[T]);
             }
         }
-        if (dec_only) {
-            for (int t = 0; t < DT; ++t) vstore(a.hd_out + grow * DHd, valid, DHd, t, hd[t]);
-            return;
-        }
-        beh = fmaf(err, scale, beh);
-        // latent head + soft update (:223-230)
-        const f32x4 lg = dense_tile<ET>(s_eout, ELDB, 0, he, bfrag_lds(s_eb + 224, 0));
+        // latent head + soft / hard update (stable_behavior_policy.py:223-230, behavior_policy.py:174-176)
+        const f32x4 lg = dense_tile<ET>(s_out, ELDB, 0, he, bfrag_lds(s_b + 224, 0));
         float mx = -INFINITY;
         for (int q = 0; q < 4; ++q)
             if (4 * g + q < a.Z) mx = fmaxf(mx, lg[q]);
@@ -243,14 +181,112 @@ __global__ __launch_bounds__(256) void beh_fwd_kernel(IplanBehArgs a) {
         ss = group_sum(ss);
         f32x4 nl;
         for (int q = 0; q < 4; ++q) nl[q] = ex[q] / ss;
-        vstore(a.saved_lat + (grow * J + j) * SVL, valid, 16, 0, nl);
+        vstore(sl, valid, 16, 0, nl);
         for (int q = 0; q < 4; ++q) lat[q] = a.hard ? nl[q] : (1.0f - a.coef) * lat[q] + nl[q] * a.coef;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// decoder forward over the whole episode (+ masked-L1 loss and the stability statistic); also serves
+// Behavior_Latent_Decoder.forward on one explicit window (a.win != NULL)
+__global__ __launch_bounds__(256) void beh_dec_fwd_kernel(IplanBehArgs a) {
+    IPLAN_DYN_LDS(smem);
+    float* s_wih = smem;                                    // [192][DLD]
+    float* s_whh = s_wih + 3 * DHd * DLD;                   // [192][DLD]
+    float* s_linx = s_whh + 3 * DHd * DLD;                  // [64][24]   W_lin[:, :d]
+    float* s_linz = s_linx + DHd * 24;                      // [64][24]   W_lin[:, d:d+Z]
+    float* s_out = s_linz + DHd * 24;                       // [16][DLD]
+    float* s_b = s_out + 16 * DLD;                          // lin 64 | ih 192 | hh 192 | out 16
+    const float* __restrict__ PD = a.dec_params + (int64_t)blockIdx.y * a.dec_s_net;
+    const int din = a.d + a.Z;
+    stage_matrix(s_wih, DLD, 3 * DHd, PD + a.dec_off[IPLAN_DEC_WIH], 3 * DHd, DHd);
+    stage_matrix(s_whh, DLD, 3 * DHd, PD + a.dec_off[IPLAN_DEC_WHH], 3 * DHd, DHd);
+    {   // split the input Linear by source: columns [0, d) act on x_t, [d, d+Z) on the latent
+        const float* Wl = PD + a.dec_off[IPLAN_DEC_LIN_W];
+        for (int idx = (int)threadIdx.x; idx < DHd * 24; idx += (int)blockDim.x) {
+            const int m = idx / 24, cc = idx - m * 24;
+            s_linx[idx] = cc < a.d ? Wl[(int64_t)m * din + cc] : 0.f;
+            s_linz[idx] = cc < a.Z ? Wl[(int64_t)m * din + a.d + cc] : 0.f;
+        }
+    }
+    stage_matrix(s_out, DLD, 16, PD + a.dec_off[IPLAN_DEC_OUT_W], a.d, DHd);
+    stage_vector(s_b, 64, PD + a.dec_off[IPLAN_DEC_LIN_B], 64);
+    stage_vector(s_b + 64, 192, PD + a.dec_off[IPLAN_DEC_BIH], 192);
+    stage_vector(s_b + 256, 192, PD + a.dec_off[IPLAN_DEC_BHH], 192);
+    stage_vector(s_b + 448, 16, PD + a.dec_off[IPLAN_DEC_OUT_B], a.d);
+    __syncthreads();
+    BehChain c;
+    if (!beh_chain(a, c)) return;
+    const bool valid = c.valid;
+    const int g = c.g, J = c.J, net = c.net, row = c.row, rows = c.rows;
+    const float inv_keep = 1.0f / (1.0f - a.drop_p);
+    const bool dec_only = a.win != nullptr;
+    f32x4 hd[DT];
+    for (int t = 0; t < DT; ++t) hd[t] = dec_only ? vload(a.hd_in + c.grow * DHd, valid, DHd, t) : splat4(0.f);
+    float beh = 0.f, stab = 0.f;
+    for (int j = 0; j < J; ++j) {
+        const float scale = dec_only ? 0.f : (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS);
+        float err = 0.f;
+        f32x4 lat1[1], zproj[DT];
+        lat1[0] = dec_only ? vload(a.lat_in + c.grow * a.Z, valid, a.Z, 0) : vload(a.saved_lat + (c.grow * J + j) * SVL + 16, valid, 16, 0);
+        for (int T = 0; T < DT; ++T) zproj[T] = dense_tile<1>(s_linz, 24, 16 * T, lat1, bfrag_lds(s_b, T));
+        for (int t = 0; t < a.L; ++t) {
+            const f32x4 xt = dec_only ? vload(a.win + (c.grow * a.L + t) * a.d, valid, a.d, 0) : window_x(a, c.hrow, j, t, valid);
+            float* sd = a.saved_dec + ((c.grow * J + j) * a.L + t) * SVD;
+            f32x4 x1[1];
+            x1[0] = xt;
+            vstore(sd + SD_X, valid, 16, 0, xt);
+            vstore(sd + SD_LAT, valid, 16, 0, lat1[0]);
+            f32x4 u[DT];
+            for (int T = 0; T < DT; ++T) {
+                // Linear([x_t || latent]) = W[:, :d] x_t + (W[:, d:] latent + b): the latent part is per window
+                u[T] = relu4(dense_tile<1>(s_linx, 24, 16 * T, x1, zproj[T]));
+                vstore(sd + SD_U, valid, DHd, T, u[T]);
+            }
+            GruGates kg[DT];
+            gru_step_lds<DT, DT>(s_wih, DLD, s_whh, DLD, s_b + 64, s_b + 256, u, hd, kg);
+            f32x4 act[DT];
+            for (int T = 0; T < DT; ++T) {
+                vstore(sd + SD_R, valid, DHd, T, kg[T].r);
+                vstore(sd + SD_Z, valid, DHd, T, kg[T].z);
+                vstore(sd + SD_N, valid, DHd, T, kg[T].n);
+                vstore(sd + SD_HN, valid, DHd, T, kg[T].hn);
+                vstore(sd + SD_H, valid, DHd, T, hd[T]);
+                const f32x4 km = keep_tile(a, net, j, row, t, T, valid, rows);
+                for (int q = 0; q < 4; ++q) act[T][q] = tanh_f(hd[T][q]) * (km[q] * inv_keep);
+                vstore(sd + SD_A, valid, DHd, T, act[T]);
+            }
+            const f32x4 y = dense_tile<DT>(s_out, DLD, 0, act, bfrag_lds(s_b + 448, 0));
+            vstore(sd + SD_Y, valid, 16, 0, y);
+            if (dec_only) {
+                vstore(a.pred_out + (c.grow * a.L + t) * a.d, valid, a.d, 0, y);
+                continue;
+            }
+            // masked L1 against the target window, stability vs the current one (stable_behavior_policy.py:226, 233-240)
+            const f32x4 nx = vload(c.hrow + (int64_t)beh_y_step(a, j, t) * a.h_s_t, valid, a.d, 0);
+            const float m = valid ? c.mrow[beh_m_step(a, j, t)] : 0.f;
+            float d2 = 0.f;
+            for (int q = 0; q < 4; ++q) {
+                if (4 * g + q < a.d) {
+                    err += fabsf(nx[q] - y[q]) * m;
+                    const float df = xt[q] - y[q];
+                    d2 = fmaf(df, df, d2);
+                }
+            }
+            d2 = group_sum(d2);
+            if (valid && g == 0) stab += fmaxf(sqrtf(d2) - a.thres, 0.f);
+        }
+        if (dec_only) {
+            for (int t = 0; t < DT; ++t) vstore(a.hd_out + c.grow * DHd, valid, DHd, t, hd[t]);
+            return;
+        }
+        beh = fmaf(err, scale, beh);
     }
     beh = chain_sum_b(group_sum(beh)) / (a.hard ? 1.0f : (float)J);
     stab = chain_sum_b(group_sum(stab)) / (float)a.E / (float)a.L / (float)J;
-    if (l == 0) {
-        a.loss_part[((int64_t)net * tiles + tile) * 2] = beh;
-        a.loss_part[((int64_t)net * tiles + tile) * 2 + 1] = stab;
+    if (lane_id() == 0) {
+        a.loss_part[((int64_t)net * c.tiles + c.tile) * 2] = beh;
+        a.loss_part[((int64_t)net * c.tiles + c.tile) * 2 + 1] = stab;
     }
 }
 
@@ -270,204 +306,310 @@ __global__ __launch_bounds__(64) void beh_loss_kernel(IplanBehArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void beh_bwd_kernel(IplanBehArgs a) {
+// ------------------------------------------------------------------------------------------------------------
+// decoder BPTT: row gradients for wgrad.hip (dsave_dec) and d(loss)/d(latent_j) per window (dsave_lat)
+__global__ __launch_bounds__(256) void beh_dec_bwd_kernel(IplanBehArgs a) {
     IPLAN_DYN_LDS(smem);
     constexpr int TLD = 3 * DHd + 8;                        // 200: ld % 16 == 8 -> conflict-free ds_read_b128 fragments
-    constexpr int TLE = 3 * EHd + 8;                        // 104
-    float* s_dwihT = smem;                                  // [64][196]   W_ih^T
-    float* s_dwhhT = s_dwihT + DHd * TLD;                   // [64][196]
-    float* s_doutT = s_dwhhT + DHd * TLD;                   // [64][20]    W_out^T (cols = d)
-    float* s_dlatT = s_doutT + DHd * 20;                    // [16][DLD]   W_lin[:, d:d+Z]^T
-    float* s_ewihT = s_dlatT + 16 * DLD;                    // [32][100]
-    float* s_ewhhT = s_ewihT + EHd * TLE;                   // [32][100]
-    float* s_eoutT = s_ewhhT + EHd * TLE;                   // [32][20]    W_out_enc^T (cols = Z)
-
-    const int net = (int)blockIdx.y;
-    const float* __restrict__ PD = a.dec_params + (int64_t)net * a.dec_s_net;
-    const float* __restrict__ PE = a.enc_params + (int64_t)net * a.enc_s_net;
+    float* s_wihT = smem;                                   // [64][200]   W_ih^T
+    float* s_whhT = s_wihT + DHd * TLD;                     // [64][200]
+    float* s_outT = s_whhT + DHd * TLD;                     // [64][24]    W_out^T (cols = d)
+    float* s_latT = s_outT + DHd * 24;                      // [16][DLD]   W_lin[:, d:d+Z]^T
+    const float* __restrict__ PD = a.dec_params + (int64_t)blockIdx.y * a.dec_s_net;
     const int din = a.d + a.Z;
-    stage_matrix_t(s_dwihT, TLD, DHd, PD + a.dec_off[IPLAN_DEC_WIH], 3 * DHd, DHd);
-    stage_matrix_t(s_dwhhT, TLD, DHd, PD + a.dec_off[IPLAN_DEC_WHH], 3 * DHd, DHd);
-    stage_matrix_t(s_doutT, 20, DHd, PD + a.dec_off[IPLAN_DEC_OUT_W], a.d, DHd);
-    {   // s_dlatT[z][m] = W_lin[m][d + z]
+    stage_matrix_t(s_wihT, TLD, DHd, PD + a.dec_off[IPLAN_DEC_WIH], 3 * DHd, DHd);
+    stage_matrix_t(s_whhT, TLD, DHd, PD + a.dec_off[IPLAN_DEC_WHH], 3 * DHd, DHd);
+    stage_matrix_t(s_outT, 24, DHd, PD + a.dec_off[IPLAN_DEC_OUT_W], a.d, DHd);
+    {   // s_latT[z][m] = W_lin[m][d + z]
         const float* Wl = PD + a.dec_off[IPLAN_DEC_LIN_W];
         for (int idx = (int)threadIdx.x; idx < 16 * DLD; idx += (int)blockDim.x) {
             const int z = idx / DLD, m = idx - z * DLD;
-            s_dlatT[idx] = (z < a.Z && m < DHd) ? Wl[(int64_t)m * din + a.d + z] : 0.f;
+            s_latT[idx] = (z < a.Z && m < DHd) ? Wl[(int64_t)m * din + a.d + z] : 0.f;
         }
     }
-    stage_matrix_t(s_ewihT, TLE, EHd, PE + a.enc_off[IPLAN_ENC_WIH], 3 * EHd, EHd);
-    stage_matrix_t(s_ewhhT, TLE, EHd, PE + a.enc_off[IPLAN_ENC_WHH], 3 * EHd, EHd);
-    stage_matrix_t(s_eoutT, 20, EHd, PE + a.enc_off[IPLAN_ENC_OUT_W], a.Z, EHd);
     __syncthreads();
-
-    const int l = lane_id(), n = l & 15, g = l >> 4;
-    const int rows = a.E * a.N;
-    const int tiles = (rows + 15) / 16;
-    const int tile = (int)blockIdx.x * 4 + wave_id();
-    if (tile >= tiles) return;
-    const int row = tile * 16 + n;
-    const bool valid = row < rows;
-    const int e = valid ? row / a.N : 0, ent = valid ? row % a.N : 0;
-    const int J = beh_windows(a);
-    const float* __restrict__ hrow = a.hist + (int64_t)net * a.h_s_net + (int64_t)e * a.h_s_e + (int64_t)ent * a.d;
-    const float* __restrict__ mrow = a.mask + ((int64_t)net * a.E + e) * a.T;
-    const int64_t grow = (int64_t)net * rows + (valid ? row : 0);
+    BehChain c;
+    if (!beh_chain(a, c)) return;
+    const bool valid = c.valid;
+    const int g = c.g, J = c.J, net = c.net, row = c.row, rows = c.rows;
     const float inv_keep = 1.0f / (1.0f - a.drop_p);
 
-    // Everything one backward step reads from HBM (the forward's record of that step, the loss target, the mask
-    // and the dropout flags).  The NEXT step's record is fetched while the current step computes: with one wave
-    // per SIMD nothing else hides the ~2 us HBM latency, and the un-prefetched kernel spent half its cycles in
-    // s_waitcnt (profiles/).
+    // The forward's record of a step (gates + previous hidden state), the loss target and the mask.  The NEXT
+    // step's record is fetched between the lane-local part and the MFMA part of the current step: with one wave
+    // per SIMD nothing else hides the HBM latency.
     struct StepIn {
-        f32x4 e_r[ET], e_z[ET], e_n[ET], e_hn[ET], e_hp[ET];
-        f32x4 d_r[DT], d_z[DT], d_n[DT], d_hn[DT], d_hp[DT];
-        f32x4 d_y, d_nx;
+        f32x4 r[DT], z[DT], n[DT], hn[DT], hp[DT];
+        f32x4 y, nx;
         float m;
     };
     auto load_step = [&](int j, int t, StepIn& o) {
-        const int64_t step = (grow * J + j) * a.L + t;
+        const int64_t step = (c.grow * J + j) * a.L + t;
         const bool first = (j == 0 && t == 0);
-        const float* se = a.saved_enc + step * SVE;
         const float* sd = a.saved_dec + step * SVD;
-        for (int T = 0; T < ET; ++T) {
-            o.e_r[T] = vload(se + SE_R, valid, EHd, T);
-            o.e_z[T] = vload(se + SE_Z, valid, EHd, T);
-            o.e_n[T] = vload(se + SE_N, valid, EHd, T);
-            o.e_hn[T] = vload(se + SE_HN, valid, EHd, T);
-            o.e_hp[T] = vload(se - SVE + SE_H, valid && !first, EHd, T);
-        }
         for (int T = 0; T < DT; ++T) {
-            o.d_r[T] = vload(sd + SD_R, valid, DHd, T);
-            o.d_z[T] = vload(sd + SD_Z, valid, DHd, T);
-            o.d_n[T] = vload(sd + SD_N, valid, DHd, T);
-            o.d_hn[T] = vload(sd + SD_HN, valid, DHd, T);
-            o.d_hp[T] = vload(sd - SVD + SD_H, valid && !first, DHd, T);
+            o.r[T] = vload(sd + SD_R, valid, DHd, T);
+            o.z[T] = vload(sd + SD_Z, valid, DHd, T);
+            o.n[T] = vload(sd + SD_N, valid, DHd, T);
+            o.hn[T] = vload(sd + SD_HN, valid, DHd, T);
+            o.hp[T] = vload(sd - SVD + SD_H, valid && !first, DHd, T);
         }
-        o.d_y = vload(sd + SD_Y, valid, 16, 0);
-        o.d_nx = vload(hrow + (int64_t)beh_y_step(a, j, t) * a.h_s_t, valid, a.d, 0);
-        o.m = valid ? mrow[beh_m_step(a, j, t)] : 0.f;
+        o.y = vload(sd + SD_Y, valid, 16, 0);
+        o.nx = vload(c.hrow + (int64_t)beh_y_step(a, j, t) * a.h_s_t, valid, a.d, 0);
+        o.m = valid ? c.mrow[beh_m_step(a, j, t)] : 0.f;
     };
-
-    f32x4 dhd[DT], dhe[ET], dlat;
+    f32x4 dhd[DT], hcur[DT];
     for (int t = 0; t < DT; ++t) dhd[t] = splat4(0.f);
-    for (int t = 0; t < ET; ++t) dhe[t] = splat4(0.f);
-    dlat = splat4(0.f);
     StepIn cur;
     load_step(J - 1, a.L - 1, cur);
-    f32x4 hcur[DT];                                     // decoder h of the current step (= h_prev of the step just done)
-    for (int T = 0; T < DT; ++T) hcur[T] = vload(a.saved_dec + ((grow * J + (J - 1)) * a.L + (a.L - 1)) * SVD + SD_H, valid, DHd, T);
+    for (int T = 0; T < DT; ++T) hcur[T] = vload(a.saved_dec + ((c.grow * J + (J - 1)) * a.L + (a.L - 1)) * SVD + SD_H, valid, DHd, T);
     for (int j = J - 1; j >= 0; --j) {
         const float scale = (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS) / (a.hard ? 1.0f : (float)J);
-        // ---- soft update + latent head backward
-        f32x4 dlog[1];
-        {
-            const f32x4 nl = vload(a.saved_lat + (grow * J + j) * SVL, valid, 16, 0);
-            float s = 0.f;
-            f32x4 dnew;
-            const float cn = a.hard ? 1.0f : a.coef, ck = a.hard ? 0.0f : 1.0f - a.coef;
-            for (int q = 0; q < 4; ++q) { dnew[q] = cn * dlat[q]; s = fmaf(nl[q], dnew[q], s); }
-            s = group_sum(s);
-            for (int q = 0; q < 4; ++q) {
-                dlog[0][q] = nl[q] * (dnew[q] - s);
-                dlat[q] *= ck;
-            }
-            vstore(a.dsave_lat + (grow * J + j) * DSL, valid, 16, 0, dlog[0]);
-            for (int T = 0; T < ET; ++T) dhe[T] = dense_tile<1>(s_eoutT, 20, 16 * T, dlog, dhe[T]);
-        }
+        f32x4 dlat = splat4(0.f);                           // d(loss)/d(latent_j) through this window's decoder inputs
         for (int t = a.L - 1; t >= 0; --t) {
-            const int64_t step = (grow * J + j) * a.L + t;
-            float* de = a.dsave_enc + step * DSE;
+            const int64_t step = (c.grow * J + j) * a.L + t;
             float* dd_ = a.dsave_dec + step * DSD;
-            // ReLU inputs of the two input Linears: needed only after the first MFMA products, loaded here so their
-            // latency hides behind part A
-            f32x4 eu[ET], du_[DT];
-            for (int T = 0; T < ET; ++T) eu[T] = vload(a.saved_enc + step * SVE + SE_U, valid, EHd, T);
+            f32x4 du_[DT];
             for (int T = 0; T < DT; ++T) du_[T] = vload(a.saved_dec + step * SVD + SD_U, valid, DHd, T);
-            // ---- part A: everything lane-local that consumes the step's record
-            f32x4 eg[4 * ET], edd[ET];                     // encoder [dr | dz | dn_i | dn_h], direct path
-            for (int T = 0; T < ET; ++T) {
-                const GruGrads o = gru_gates_bwd(dhe[T], cur.e_r[T], cur.e_z[T], cur.e_n[T], cur.e_hn[T], cur.e_hp[T]);
-                vstore(de + DE_DR, valid, EHd, T, o.dr);
-                vstore(de + DE_DZ, valid, EHd, T, o.dz);
-                vstore(de + DE_DNI, valid, EHd, T, o.dni);
-                vstore(de + DE_DNH, valid, EHd, T, o.dnh);
-                eg[T] = o.dr; eg[ET + T] = o.dz; eg[2 * ET + T] = o.dni; eg[3 * ET + T] = o.dnh;
-                edd[T] = o.dh_direct;
-            }
+            // ---- part A: lane-local, consumes the step's record
             f32x4 dy[1];
             for (int q = 0; q < 4; ++q) {
                 float v = 0.f;
                 if (valid && 4 * g + q < a.d) {
-                    const float er = cur.d_nx[q] - cur.d_y[q];
+                    const float er = cur.nx[q] - cur.y[q];
                     v = -((er > 0.f) ? 1.0f : (er < 0.f ? -1.0f : 0.0f)) * cur.m * scale;
                 }
                 dy[0][q] = v;
             }
             vstore(dd_ + DD_DY, valid, 16, 0, dy[0]);
-            f32x4 dg[4 * DT], ddir[DT];                    // decoder [dr | dz | dn_i | dn_h]
+            f32x4 dg[4 * DT], ddir[DT];                    // [dr | dz | dn_i | dn_h]
             for (int T = 0; T < DT; ++T) {
-                const f32x4 da = dense_tile<1>(s_doutT, 20, 16 * T, dy, splat4(0.f));
+                const f32x4 da = dense_tile<1>(s_outT, 24, 16 * T, dy, splat4(0.f));
                 const f32x4 km = keep_tile(a, net, j, row, t, T, valid, rows);
                 f32x4 dht;
                 for (int q = 0; q < 4; ++q) {
                     const float th = tanh_f(hcur[T][q]);
                     dht[q] = fmaf(da[q] * km[q] * inv_keep, 1.0f - th * th, dhd[T][q]);
                 }
-                const GruGrads o = gru_gates_bwd(dht, cur.d_r[T], cur.d_z[T], cur.d_n[T], cur.d_hn[T], cur.d_hp[T]);
+                const GruGrads o = gru_gates_bwd(dht, cur.r[T], cur.z[T], cur.n[T], cur.hn[T], cur.hp[T]);
                 vstore(dd_ + DD_DR, valid, DHd, T, o.dr);
                 vstore(dd_ + DD_DZ, valid, DHd, T, o.dz);
                 vstore(dd_ + DD_DNI, valid, DHd, T, o.dni);
                 vstore(dd_ + DD_DNH, valid, DHd, T, o.dnh);
                 dg[T] = o.dr; dg[DT + T] = o.dz; dg[2 * DT + T] = o.dni; dg[3 * DT + T] = o.dnh;
                 ddir[T] = o.dh_direct;
-                hcur[T] = cur.d_hp[T];                     // h_{t-1}: the next step's "current" hidden state
+                hcur[T] = cur.hp[T];                       // h_{t-1}: the next step's "current" hidden state
             }
-            // ---- the record is consumed: fetch the next step's while the transposed-weight products below run
             IPLAN_SCHED_FENCE();
             if (t > 0) load_step(j, t - 1, cur);
             else if (j > 0) load_step(j - 1, a.L - 1, cur);
             IPLAN_SCHED_FENCE();
-            // ---- part B: backward-data products on MFMA (all output tiles of a product share the B operand)
-            {
-                const int oe[ET] = {0, 16};
-                f32x4 du[ET];
-                for (int T = 0; T < ET; ++T) du[T] = splat4(0.f);
-                dense_multi<ET, 3 * ET>(s_ewihT, TLE, oe, 0, eg, du);                       // W_ih^T [dr dz dn_i]
-                for (int T = 0; T < ET; ++T) {
-                    f32x4 dup;
-                    for (int q = 0; q < 4; ++q) dup[q] = eu[T][q] > 0.f ? du[T][q] : 0.f;
-                    vstore(de + DE_DU, valid, EHd, T, dup);
-                    dhe[T] = edd[T];
-                }
-                dense_multi<ET, 2 * ET>(s_ewhhT, TLE, oe, 0, eg, dhe);                      // W_hh^T [dr dz | dn_h]
-                dense_multi<ET, ET>(s_ewhhT, TLE, oe, 2 * EHd, eg + 3 * ET, dhe);
+            // ---- part B: backward-data products on MFMA (the 4 output tiles of a product share the B operand)
+            const int od[DT] = {0, 16, 32, 48};
+            f32x4 du[DT], dup[DT];
+            for (int T = 0; T < DT; ++T) du[T] = splat4(0.f);
+            dense_multi<DT, 3 * DT>(s_wihT, TLD, od, 0, dg, du);                            // W_ih^T [dr dz dn_i]
+            for (int T = 0; T < DT; ++T) {
+                for (int q = 0; q < 4; ++q) dup[T][q] = du_[T][q] > 0.f ? du[T][q] : 0.f;
+                vstore(dd_ + DD_DU, valid, DHd, T, dup[T]);
+                dhd[T] = ddir[T];
             }
-            f32x4 dup[DT];
-            {
-                const int od[DT] = {0, 16, 32, 48};
-                f32x4 du[DT];
-                for (int T = 0; T < DT; ++T) du[T] = splat4(0.f);
-                dense_multi<DT, 3 * DT>(s_dwihT, TLD, od, 0, dg, du);
-                for (int T = 0; T < DT; ++T) {
-                    for (int q = 0; q < 4; ++q) dup[T][q] = du_[T][q] > 0.f ? du[T][q] : 0.f;
-                    vstore(dd_ + DD_DU, valid, DHd, T, dup[T]);
-                    dhd[T] = ddir[T];
-                }
-                IPLAN_SCHED_FENCE();
-                dense_multi<DT, 2 * DT>(s_dwhhT, TLD, od, 0, dg, dhd);
-                dense_multi<DT, DT>(s_dwhhT, TLD, od, 2 * DHd, dg + 3 * DT, dhd);
-                IPLAN_SCHED_FENCE();
+            IPLAN_SCHED_FENCE();
+            dense_multi<DT, 2 * DT>(s_whhT, TLD, od, 0, dg, dhd);                           // W_hh^T [dr dz | dn_h]
+            dense_multi<DT, DT>(s_whhT, TLD, od, 2 * DHd, dg + 3 * DT, dhd);
+            IPLAN_SCHED_FENCE();
+            dlat = dense_tile<DT>(s_latT, DLD, 0, dup, dlat);                               // through the tiled latent input
+        }
+        vstore(a.dsave_lat + (c.grow * J + j) * DSL, valid, 16, 0, dlat);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// encoder BPTT with in-kernel weight gradients.  Per step the wave turns its 16-chain tiles of
+// [dr dz dn_i dn_h | du | u | h_prev | x] through LDS into MFMA operand order and accumulates
+//   dW_ih += [dr dz dn_i]^T u,  dW_hh += [dr dz dn_h]^T h_prev,  dW_lin += du^T x   (per window: dW_out += dlogit^T h_L)
+// in 28 register tiles; bias gradients are lane-local sums.  One partial per wave goes to enc_part, reduced by
+// beh_enc_grad_kernel in tile order (fixed summation order, no atomics).
+constexpr int EP_WIH = 0, EP_WHH = 3072, EP_BIH = 6144, EP_BHH = 6240, EP_LINW = 6336, EP_LINB = 6848, EP_OUTW = 6880, EP_OUTB = 7392;
+static_assert(IPLAN_BEH_ENC_PART == 7408, "enc_part layout");
+
+__global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
+    constexpr int TLE = 3 * EHd + 8;                        // 104
+    __shared__ __attribute__((aligned(16))) float s_wihT[EHd * TLE];
+    __shared__ __attribute__((aligned(16))) float s_whhT[EHd * TLE];
+    __shared__ __attribute__((aligned(16))) float s_outT[EHd * 24];
+    __shared__ __attribute__((aligned(16))) float s_turn[4][15][256];      // per wave: 8 dg + 2 du + 2 u + 2 hp + 1 x tiles
+    const float* __restrict__ PE = a.enc_params + (int64_t)blockIdx.y * a.enc_s_net;
+    stage_matrix_t(s_wihT, TLE, EHd, PE + a.enc_off[IPLAN_ENC_WIH], 3 * EHd, EHd);
+    stage_matrix_t(s_whhT, TLE, EHd, PE + a.enc_off[IPLAN_ENC_WHH], 3 * EHd, EHd);
+    stage_matrix_t(s_outT, 24, EHd, PE + a.enc_off[IPLAN_ENC_OUT_W], a.Z, EHd);
+    __syncthreads();
+    BehChain c;
+    const bool live = beh_chain(a, c);                      // dead waves still take part in the block barriers below
+    const bool valid = c.valid;
+    const int l = lane_id(), n = c.n, g = c.g, J = c.J;
+    float (*turn)[256] = s_turn[wave_id()];
+    const float cn = a.hard ? 1.0f : a.coef, ck = a.hard ? 0.0f : 1.0f - a.coef;
+
+    f32x4 aWih[6][2], aWhh[6][2], aLin[2], aOut[2];
+    f32x4 bG[8], bU[2], bO;
+    for (int t = 0; t < 6; ++t)
+        for (int u = 0; u < 2; ++u) { aWih[t][u] = splat4(0.f); aWhh[t][u] = splat4(0.f); }
+    for (int u = 0; u < 2; ++u) { aLin[u] = splat4(0.f); aOut[u] = splat4(0.f); bU[u] = splat4(0.f); }
+    for (int t = 0; t < 8; ++t) bG[t] = splat4(0.f);
+    bO = splat4(0.f);
+    auto park = [&](int slot, f32x4 v) { *reinterpret_cast<f32x4*>(&turn[slot][n * 16 + 4 * g]) = v; };
+    // operand element [chain 4s + g][column i] of a parked tile (i = lane & 15): conflict-free ds_read_b32
+    auto pick = [&](int slot, int s) { return turn[slot][(4 * s + g) * 16 + n]; };
+
+    f32x4 dhe[ET], dlat = splat4(0.f);
+    for (int t = 0; t < ET; ++t) dhe[t] = splat4(0.f);
+    for (int j = J - 1; j >= 0; --j) {
+        // ---- latent update + head backward (dlat = d(loss)/d(latent_{j+1}) on entry)
+        f32x4 dlog[1], hL[ET];
+        {
+            const f32x4 nl = vload(a.saved_lat + (c.grow * J + j) * SVL, valid && live, 16, 0);
+            float s = 0.f;
+            f32x4 dnew;
+            for (int q = 0; q < 4; ++q) { dnew[q] = cn * dlat[q]; s = fmaf(nl[q], dnew[q], s); }
+            s = group_sum(s);
+            const f32x4 dl_dec = vload(a.dsave_lat + (c.grow * J + j) * DSL, valid && live, 16, 0);
+            for (int q = 0; q < 4; ++q) {
+                dlog[0][q] = nl[q] * (dnew[q] - s);
+                dlat[q] = ck * dlat[q] + dl_dec[q];          // now d(loss)/d(latent_j)
+                bO[q] += dlog[0][q];
             }
-            dlat = dense_tile<DT>(s_dlatT, DLD, 0, dup, dlat);       // through the tiled latent input
+            const float* seL = a.saved_enc + ((c.grow * J + j) * a.L + (a.L - 1)) * SVE;
+            for (int T = 0; T < ET; ++T) {
+                hL[T] = vload(seL + SE_H, valid && live, EHd, T);
+                dhe[T] = dense_tile<1>(s_outT, 24, 16 * T, dlog, dhe[T]);
+            }
+            // dW_out += dlogit^T h_L
+            park(0, dlog[0]); park(1, hL[0]); park(2, hL[1]);
+            __syncthreads();
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float av = pick(0, s4);
+                aOut[0] = mfma4(av, pick(1, s4), aOut[0]);
+                aOut[1] = mfma4(av, pick(2, s4), aOut[1]);
+            }
+            __syncthreads();
+        }
+        for (int t = a.L - 1; t >= 0; --t) {
+            const int64_t step = (c.grow * J + j) * a.L + t;
+            const bool first = (j == 0 && t == 0);
+            const float* se = a.saved_enc + step * SVE;
+            const bool ok = valid && live;
+            f32x4 dg[4 * ET], dd[ET], u[ET], hp[ET];
+            for (int T = 0; T < ET; ++T) {
+                hp[T] = vload(se - SVE + SE_H, ok && !first, EHd, T);
+                u[T] = vload(se + SE_U, ok, EHd, T);
+                const GruGrads o = gru_gates_bwd(dhe[T], vload(se + SE_R, ok, EHd, T), vload(se + SE_Z, ok, EHd, T),
+                                                 vload(se + SE_N, ok, EHd, T), vload(se + SE_HN, ok, EHd, T), hp[T]);
+                dg[T] = o.dr; dg[ET + T] = o.dz; dg[2 * ET + T] = o.dni; dg[3 * ET + T] = o.dnh;
+                dd[T] = o.dh_direct;
+            }
+            for (int k = 0; k < 8; ++k) bG[k] += dg[k];
+            const int oe[ET] = {0, 16};
+            f32x4 du[ET], dup[ET];
+            for (int T = 0; T < ET; ++T) { du[T] = splat4(0.f); dhe[T] = dd[T]; }
+            dense_multi<ET, 3 * ET>(s_wihT, TLE, oe, 0, dg, du);                          // W_ih^T [dr dz dn_i]
+            dense_multi<ET, 2 * ET>(s_whhT, TLE, oe, 0, dg, dhe);                         // W_hh^T [dr dz | dn_h]
+            dense_multi<ET, ET>(s_whhT, TLE, oe, 2 * EHd, dg + 3 * ET, dhe);
+            for (int T = 0; T < ET; ++T) {
+                for (int q = 0; q < 4; ++q) dup[T][q] = u[T][q] > 0.f ? du[T][q] : 0.f;
+                bU[T] += dup[T];
+            }
+            // ---- weight gradients of this step
+            const f32x4 xt = window_x(a, c.hrow, j, t, ok);
+            for (int k = 0; k < 8; ++k) park(k, dg[k]);
+            park(8, dup[0]); park(9, dup[1]); park(10, u[0]); park(11, u[1]); park(12, hp[0]); park(13, hp[1]); park(14, xt);
+            __syncthreads();
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float u0 = pick(10, s4), u1 = pick(11, s4), h0 = pick(12, s4), h1 = pick(13, s4), xv = pick(14, s4);
+                for (int o = 0; o < 6; ++o) {
+                    const float ai = pick(o, s4);                                          // [dr dz dn_i] tiles 0..5
+                    const float ah = o < 4 ? ai : pick(o + 2, s4);                         // [dr dz dn_h]: tiles 0..3, 6, 7
+                    aWih[o][0] = mfma4(ai, u0, aWih[o][0]);
+                    aWih[o][1] = mfma4(ai, u1, aWih[o][1]);
+                    aWhh[o][0] = mfma4(ah, h0, aWhh[o][0]);
+                    aWhh[o][1] = mfma4(ah, h1, aWhh[o][1]);
+                }
+                aLin[0] = mfma4(pick(8, s4), xv, aLin[0]);
+                aLin[1] = mfma4(pick(9, s4), xv, aLin[1]);
+            }
+            __syncthreads();
         }
     }
+    if (!live) return;
+    // ---- one partial per wave: accumulator tiles are in D layout (lane (col j = n, rows 4g + q))
+    float* part = a.enc_part + ((int64_t)c.net * c.tiles + c.tile) * IPLAN_BEH_ENC_PART;
+    for (int o = 0; o < 6; ++o)
+        for (int u = 0; u < 2; ++u)
+            for (int q = 0; q < 4; ++q) {
+                const int orow = 16 * o + 4 * g + q, col = 16 * u + n;
+                part[EP_WIH + orow * EHd + col] = aWih[o][u][q];
+                part[EP_WHH + orow * EHd + col] = aWhh[o][u][q];
+            }
+    for (int u = 0; u < 2; ++u)
+        for (int q = 0; q < 4; ++q) {
+            part[EP_LINW + (16 * u + 4 * g + q) * 16 + n] = aLin[u][q];                    // [32][16]: row = du index, col = x index
+            part[EP_OUTW + (4 * g + q) * EHd + 16 * u + n] = aOut[u][q];                   // [16][32]: row = logit index, col = h index
+        }
+    // bias gradients: sums over the 16 chains of lane-local sums
+    for (int k = 0; k < 8; ++k)
+        for (int q = 0; q < 4; ++q) {
+            const float sum = chain_sum_b(bG[k][q]);
+            if (n == 0) {
+                const int gate = k >> 1, T = k & 1, idx = 16 * T + 4 * g + q;              // k = 2 * gate + T
+                if (gate < 3) part[EP_BIH + gate * EHd + idx] = sum;                       // b_ih: dr dz dn_i
+                if (gate < 2) part[EP_BHH + gate * EHd + idx] = sum;                       // b_hh: dr dz ...
+                if (gate == 3) part[EP_BHH + 2 * EHd + idx] = sum;                         //       ... dn_h
+            }
+        }
+    for (int T = 0; T < 2; ++T)
+        for (int q = 0; q < 4; ++q) {
+            const float sum = chain_sum_b(bU[T][q]);
+            if (n == 0) part[EP_LINB + 16 * T + 4 * g + q] = sum;
+        }
+    for (int q = 0; q < 4; ++q) {
+        const float sum = chain_sum_b(bO[q]);
+        if (n == 0) part[EP_OUTB + 4 * g + q] = sum;
+    }
+}
+
+// encoder gradient arena <- sum over the wave partials, in tile order.  grid: (ceil(P_enc / 256), n_nets)
+__global__ __launch_bounds__(256) void beh_enc_grad_kernel(IplanBehArgs a) {
+    const int net = (int)blockIdx.y;
+    const int tiles = (a.E * a.N + 15) / 16;
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    // destination tensors in state_dict order with their partial offsets / shapes
+    const int sizes[8] = {EHd * a.d, EHd, 3 * EHd * EHd, 3 * EHd * EHd, 3 * EHd, 3 * EHd, a.Z * EHd, a.Z};
+    int rem = idx, which = -1;
+    for (int k = 0; k < 8; ++k) {
+        if (rem < sizes[k]) { which = k; break; }
+        rem -= sizes[k];
+    }
+    if (which < 0) return;
+    int src;
+    switch (which) {
+        case IPLAN_ENC_LIN_W: src = EP_LINW + (rem / a.d) * 16 + rem % a.d; break;
+        case IPLAN_ENC_LIN_B: src = EP_LINB + rem; break;
+        case IPLAN_ENC_WIH: src = EP_WIH + rem; break;
+        case IPLAN_ENC_WHH: src = EP_WHH + rem; break;
+        case IPLAN_ENC_BIH: src = EP_BIH + rem; break;
+        case IPLAN_ENC_BHH: src = EP_BHH + rem; break;
+        case IPLAN_ENC_OUT_W: src = EP_OUTW + rem; break;
+        default: src = EP_OUTB + rem; break;
+    }
+    const float* part = a.enc_part + (int64_t)net * tiles * IPLAN_BEH_ENC_PART + src;
+    float s = 0.f;
+    for (int t = 0; t < tiles; ++t) s += part[(int64_t)t * IPLAN_BEH_ENC_PART];
+    a.enc_grad[(int64_t)net * a.enc_grad_s_net + a.enc_off[which] + rem] = s;
 }
 
 static int check_beh(const IplanBehArgs* a, const char* what) {
     if (!a) return fail(IPLAN_EINVAL, "%s: null args", what);
     if (a->n_nets < 1 || a->E < 1 || a->N < 1 || a->L < 1 || (a->hard ? a->T / a->L - 1 : a->T - 1 - a->L) < 1 || a->d < 1 || a->Z < 1 ||
-        a->d + a->Z > 16 || a->Z > 16)
+        a->d > 16 || a->Z > 16)
         return fail(IPLAN_EINVAL, "%s: unsupported dims E=%d N=%d T=%d L=%d d=%d Z=%d", what, a->E, a->N, a->T, a->L, a->d, a->Z);
     if (a->win) {
         if (!a->lat_in || !a->hd_in || !a->pred_out || !a->hd_out || a->T != a->L + 2 || !a->saved_dec)
@@ -488,13 +630,13 @@ extern "C" int iplan_beh_fwd(const IplanBehArgs* a, iplan_stream_t stream) {
     if (int rc = check_beh(a, "iplan_beh_fwd")) return rc;
     if (!a->win && (!a->loss_part || !a->loss)) return fail(IPLAN_EINVAL, "iplan_beh_fwd: loss buffers missing");
     const int tiles = (a->E * a->N + 15) / 16;
-    const size_t lds = sizeof(float) * (2 * 3 * DHd * DLD + 2 * DHd * 20 + 16 * DLD + 2 * 3 * EHd * ELDB + EHd * 20 + 16 * ELDB +
-                                        (64 + 192 + 192 + 16) + (32 + 96 + 96 + 16));
+    const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets);
+    if (!a->win) hipLaunchKernelGGL(beh_enc_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    const size_t lds = sizeof(float) * (2 * 3 * DHd * DLD + 2 * DHd * 24 + 16 * DLD + (64 + 192 + 192 + 16));
 #ifndef IPLAN_HOST_EMULATION
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_dec_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
-    hipLaunchKernelGGL(beh_fwd_kernel, dim3((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets), dim3(256), lds,
-                       (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(beh_dec_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, *a);
     if (!a->win) hipLaunchKernelGGL(beh_loss_kernel, dim3((unsigned)a->n_nets), dim3(64), 0, (hipStream_t)stream, *a);
     return check_launch("iplan_beh_fwd");
 }
@@ -502,13 +644,21 @@ extern "C" int iplan_beh_fwd(const IplanBehArgs* a, iplan_stream_t stream) {
 extern "C" int iplan_beh_bwd(const IplanBehArgs* a, iplan_stream_t stream) {
     using namespace iplan;
     if (int rc = check_beh(a, "iplan_beh_bwd")) return rc;
-    if (!a->dsave_dec || !a->dsave_enc || !a->dsave_lat) return fail(IPLAN_EINVAL, "iplan_beh_bwd: dsave buffers missing");
+    if (a->win) return fail(IPLAN_EINVAL, "iplan_beh_bwd: not available in single-window decoder mode");
+    if (!a->dsave_dec || !a->dsave_lat || !a->enc_part || !a->enc_grad)
+        return fail(IPLAN_EINVAL, "iplan_beh_bwd: dsave_dec / dsave_lat / enc_part / enc_grad missing");
     const int tiles = (a->E * a->N + 15) / 16;
-    const size_t lds = sizeof(float) * (2 * DHd * (3 * DHd + 8) + DHd * 20 + 16 * DLD + 2 * EHd * (3 * EHd + 8) + EHd * 20);
+    const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets);
+    const size_t lds = sizeof(float) * (2 * DHd * (3 * DHd + 8) + DHd * 24 + 16 * DLD);
 #ifndef IPLAN_HOST_EMULATION
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_dec_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
-    hipLaunchKernelGGL(beh_bwd_kernel, dim3((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets), dim3(256), lds,
-                       (hipStream_t)stream, *a);
+    if (a->bwd_phase != 2) hipLaunchKernelGGL(beh_dec_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, *a);
+    if (a->bwd_phase != 1) {
+        hipLaunchKernelGGL(beh_enc_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+        const int p_enc = 32 * a->d + 32 + 2 * 96 * 32 + 2 * 96 + a->Z * 32 + a->Z;
+        hipLaunchKernelGGL(beh_enc_grad_kernel, dim3((unsigned)((p_enc + 255) / 256), (unsigned)a->n_nets), dim3(256), 0,
+                           (hipStream_t)stream, *a);
+    }
     return check_launch("iplan_beh_bwd");
 }

@@ -156,6 +156,7 @@ __device__ __forceinline__ void gru_step_lds(const float* __restrict__ sWih, int
         const GruGates o = gru_gates(ah[0], ah[1], ai[2], ah[2], h[t]);
         hnew[t] = o.h;
         if (keep) keep[t] = o;
+        if (HT > 2) IPLAN_SCHED_FENCE();                  // 64-wide GRU: keep the next tile's fragment reads below this tile
     }
     for (int t = 0; t < HT; ++t) h[t] = hnew[t];
 }

@@ -246,6 +246,7 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
 
 # ---- weight gradients ----------------------------------------------------------------------------------
 _WORKSPACES = {}
+_SIDE_STREAMS = {}
 
 
 def workspace(device, floats, tag="wgrad"):
@@ -578,16 +579,35 @@ def beh_backward(enc_arena, dec_arena, fwd, lib=None):
     dev = fwd["loss"].device
     f32 = dict(dtype=torch.float32, device=dev)
     dd = torch.empty(n_nets, rows, J, Lw, L.BEH_DSAVE_DEC, **f32)
-    de = torch.empty(n_nets, rows, J, Lw, L.BEH_DSAVE_ENC, **f32)
     dl = torch.empty(n_nets, rows, J, L.BEH_DSAVE_LAT, **f32)
-    a.dsave_dec, a.dsave_enc, a.dsave_lat = dd.data_ptr(), de.data_ptr(), dl.data_ptr()
-    lib.call("iplan_beh_bwd", a, L.current_stream(dev))
-    SD, SE, DD, DE = L.BEH_SAVE_DEC, L.BEH_SAVE_ENC, L.BEH_DSAVE_DEC, L.BEH_DSAVE_ENC
+    tiles = (rows + 15) // 16
+    ep = torch.empty(n_nets, tiles, L.BEH_ENC_PART, **f32)
+    a.dsave_dec, a.dsave_lat, a.enc_part = dd.data_ptr(), dl.data_ptr(), ep.data_ptr()
+    a.enc_grad, a.enc_grad_s_net = enc_arena.grad.data_ptr(), enc_arena.grad.stride(0)
+    # decoder BPTT first; the encoder's BPTT (which only needs the decoder's per-window d(loss)/d(latent)) then runs on
+    # a side stream beside the decoder's weight-gradient contractions
+    side = None
+    if dev.type == "cuda":
+        main = torch.cuda.current_stream(dev)
+        side = _SIDE_STREAMS.setdefault((str(dev), main.cuda_stream), torch.cuda.Stream(dev))
+    if side is None:
+        a.bwd_phase = 0
+        lib.call("iplan_beh_bwd", a, L.current_stream(dev))
+    else:
+        a.bwd_phase = 1
+        lib.call("iplan_beh_bwd", a, main.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        a.bwd_phase = 2
+        lib.call("iplan_beh_bwd", a, side.cuda_stream)
+        ev_done = torch.cuda.Event()
+        ev_done.record(side)
+    SD, DD = L.BEH_SAVE_DEC, L.BEH_DSAVE_DEC
     n_in = J * Lw
-    sd, se = fwd["saved_dec"].data_ptr(), fwd["saved_enc"].data_ptr()
-    sd_st, se_st = (rows * n_in * SD, n_in * SD, SD), (rows * n_in * SE, n_in * SE, SE)
-    dd_st, de_st = (rows * n_in * DD, n_in * DD, DD), (rows * n_in * DE, n_in * DE, DE)
-    H, R = 64, 32
+    sd = fwd["saved_dec"].data_ptr()
+    sd_st, dd_st = (rows * n_in * SD, n_in * SD, SD), (rows * n_in * DD, n_in * DD, DD)
+    H = 64
     off = dec_arena.off
     w = Wgrad(dec_arena.grad, n_nets)
     w.add(dd.data_ptr(), dd_st, d, rows, n_in, x=sd + 4 * 416, x_strides=sd_st, K=H,
@@ -603,20 +623,11 @@ def beh_backward(enc_arena, dec_arena, fwd, lib=None):
           dw_off=off("decoder.linear.weight"))
     w._keep += [dd, fwd]
     w.run(lib)
-    off = enc_arena.off
-    w = Wgrad(enc_arena.grad, n_nets)
-    w.add(de.data_ptr() + 4 * 32, de_st, 3 * R, rows, n_in, x=se, x_strides=se_st, K=R,
-          dw_off=off("rnn.weight_ih_l0"), db_off=off("rnn.bias_ih_l0"))
-    w.add(de.data_ptr() + 4 * 32, de_st, 3 * R, rows, n_in, x=se + 4 * 160, x_strides=se_st, K=R, x_shift=-1,
-          dw_off=off("rnn.weight_hh_l0"), db_off=off("rnn.bias_hh_l0"), seg=(2 * R, 0, 3 * R))
-    w.add(de.data_ptr(), de_st, R, rows, n_in, x=sd, x_strides=sd_st, K=d, dw_off=off("linear.weight"), db_off=off("linear.bias"))
-    # latent head: one row per (chain, window); X = encoder hidden after the window's last step
-    w.add(dl.data_ptr(), (rows * J * L.BEH_DSAVE_LAT, J * L.BEH_DSAVE_LAT, L.BEH_DSAVE_LAT), Z, rows, J,
-          x=se + 4 * ((Lw - 1) * SE + 160), x_strides=(rows * n_in * SE, n_in * SE, Lw * SE), K=R,
-          dw_off=off("out.weight"), db_off=off("out.bias"))
-    w._keep += [de, dl, fwd]
-    w.run(lib)
-    return dict(dsave_dec=dd, dsave_enc=de, dsave_lat=dl)
+    if side is not None:
+        main.wait_event(ev_done)
+        for t in (dl, ep, fwd["saved_enc"], fwd["saved_lat"]):      # touched by the side stream: keep the allocator honest
+            t.record_stream(side)
+    return dict(dsave_dec=dd, dsave_lat=dl, enc_part=ep)
 
 
 def bdec_forward(enc_arena, dec_arena, window, latent, hidden, drop_p=0.0, keep=None, seed=0, lib=None):
