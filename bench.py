@@ -36,7 +36,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md (v
 # HBM bytes per launch from the committed PMC passes (profiles/r01*_pmc_*.txt), keyed by (kernel, envs per GPU):
 # (2 * FETCH_SIZE + WRITE_SIZE) KiB -> bytes.  Counters cannot be collected from inside bench.py; None = not profiled.
 PMC_TRAFFIC_BYTES = {
-    ("beh_bwd_kernel", 32): int((2 * 9357943.3 + 14332591.4) * 1024),    # profiles/r01c_pmc_gat_fwd_behaviour_learn.txt
+    ("beh_dec_bwd_kernel", 32): None,                                      # filled from the final PMC pass
     ("gat_fwd_kernel", 32): int((2 * 5037.5 + 1100.0) * 1024),
 }
 
@@ -235,7 +235,7 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters / 1e3
 
-    # (1) beh_bwd_kernel -- BPTT of Behavior_policy.learn, the largest single share of a training cycle (profiles/)
+    # (1) beh_dec_bwd_kernel -- decoder BPTT of Behavior_policy.learn, the largest single share of a training cycle
     with contextlib.redirect_stdout(io.StringIO()):
         batch = loop.rollout()
     hist_b = batch["history"][:, :-1].permute(2, 0, 1, 3, 4)
@@ -246,16 +246,19 @@ def main():
     T_b, Lw = args.episode_limit, args.max_history_len
     J = T_b - 1 - Lw
     rows_b = E * N
-    dsv = [torch.empty(nA, rows_b, J, Lw, w_, device=dev) for w_ in (L.BEH_DSAVE_DEC, L.BEH_DSAVE_ENC)]
+    dsd = torch.empty(nA, rows_b, J, Lw, L.BEH_DSAVE_DEC, device=dev)
     dsl = torch.empty(nA, rows_b, J, L.BEH_DSAVE_LAT, device=dev)
-    ba.dsave_dec, ba.dsave_enc, ba.dsave_lat = dsv[0].data_ptr(), dsv[1].data_ptr(), dsl.data_ptr()
+    epart = torch.empty(nA, (rows_b + 15) // 16, L.BEH_ENC_PART, device=dev)
+    ba.dsave_dec, ba.dsave_lat, ba.enc_part = dsd.data_ptr(), dsl.data_ptr(), epart.data_ptr()
+    ba.enc_grad, ba.enc_grad_s_net = loop.behavior.enc_arena.grad.data_ptr(), loop.behavior.enc_arena.grad.stride(0)
+    ba.bwd_phase = 1                                              # decoder BPTT only
     stream = L.current_stream(dev)
     bwd_s = event_time(lambda: lib.call("iplan_beh_bwd", ba, stream), iters=3, warm=1)
-    R_, Hd = args.encoder_rnn_dim, args.decoder_rnn_dim
-    # decoder V*L*(2(d+Z)*64 + 12*64^2 + 2*64*d) per window + encoder V*(L*(2dR + 12R^2) + 2RZ);
-    # the backward-data pass (this kernel) is 1x the forward FLOPs, the weight-gradient pass (wgrad) the other 1x
-    flops_b = nA * rows_b * J * (Lw * (2 * (d + Z) * Hd + 12 * Hd * Hd + 2 * Hd * d) + Lw * (2 * d * R_ + 12 * R_ * R_) + 2 * R_ * Z)
-    del fwd, dsv, dsl
+    Hd = args.decoder_rnn_dim
+    # decoder V*L*(2(d+Z)*64 + 12*64^2 + 2*64*d) FLOPs per window forward; the backward-data pass
+    # (this kernel) is 1x that, the weight-gradient pass (wgrad) the other 1x
+    flops_b = nA * rows_b * J * Lw * (2 * (d + Z) * Hd + 12 * Hd * Hd + 2 * Hd * d)
+    del fwd, dsd, dsl, epart
     torch.cuda.empty_cache()
 
     # (2) gat_fwd_kernel -- dominant kernel of the rollout
@@ -278,13 +281,13 @@ def main():
                                    "insert + Behavior_policy.learn + Prediction_policy.learn, then IPPOLearner.train "
                                    "(15 epochs x 255 x 90 rows x 5 agents)" + (" [ROLLOUT ONLY diagnostic]" if opt.rollout_only else ""),
                        "envs_per_gpu": E, "rollouts_per_step": rollouts_per_step, "env_steps_per_step": rollouts_per_step * E * args.episode_limit},
-            "roofline": {"kernel": "beh_bwd_kernel", "bound": "mfma", "achieved": flops_b / bwd_s / 1e12,
+            "roofline": {"kernel": "beh_dec_bwd_kernel", "bound": "mfma", "achieved": flops_b / bwd_s / 1e12,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops_b / bwd_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                          # HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB) of the rocprofv3 --pmc passes committed in
                          # profiles/ (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); measured at this exact shape
-                         "traffic": PMC_TRAFFIC_BYTES.get(("beh_bwd_kernel", E)), "us_per_launch": bwd_s * 1e6,
+                         "traffic": PMC_TRAFFIC_BYTES.get(("beh_dec_bwd_kernel", E)), "us_per_launch": bwd_s * 1e6,
                          "algorithmic_gflop_per_launch": flops_b / 1e9,
-                         "note": "BPTT of Behavior_policy.learn (5 nets x E*55 chains x 79 windows x 10 steps); launched "
+                         "note": "decoder BPTT of Behavior_policy.learn (5 nets x E*55 chains x 79 windows x 10 steps); launched "
                                  f"{rollouts_per_step}x per step"},
             "roofline_others": [
                 {"kernel": "gat_fwd_kernel", "bound": "mfma", "achieved": flops / gat_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
