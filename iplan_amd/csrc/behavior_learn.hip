@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
     for (int t = 0; t < ET; ++t) he[t] = splat4(0.f);
     for (int j = 0; j < J; ++j) {
         float* sl = a.saved_lat + (c.grow * J + j) * SVL;
-        vstore(sl + 16, valid, 16, 0, lat);                      // the latent the decoder uses in window j
+        vstore_a(sl + 16, valid, 0, lat);                      // the latent the decoder uses in window j
         for (int t = 0; t < a.L; ++t) {
             f32x4 x1[1];
             x1[0] = window_x(a, c.hrow, j, t, valid);
@@ -156,16 +156,16 @@ __global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
             f32x4 ue[ET];
             for (int T = 0; T < ET; ++T) {
                 ue[T] = relu4(dense_tile<1>(s_lin, 24, 16 * T, x1, bfrag_lds(s_b, T)));
-                vstore(se + SE_U, valid, EHd, T, ue[T]);
+                vstore_a(se + SE_U, valid, T, ue[T]);
             }
             GruGates ke[ET];
             gru_step_lds<ET, ET>(s_wih, ELDB, s_whh, ELDB, s_b + 32, s_b + 128, ue, he, ke);
             for (int T = 0; T < ET; ++T) {
-                vstore(se + SE_R, valid, EHd, T, ke[T].r);
-                vstore(se + SE_Z, valid, EHd, T, ke[T].z);
-                vstore(se + SE_N, valid, EHd, T, ke[T].n);
-                vstore(se + SE_HN, valid, EHd, T, ke[T].hn);
-                vstore(se + SE_H, valid, EHd, T, he[T]);
+                vstore_a(se + SE_R, valid, T, ke[T].r);
+                vstore_a(se + SE_Z, valid, T, ke[T].z);
+                vstore_a(se + SE_N, valid, T, ke[T].n);
+                vstore_a(se + SE_HN, valid, T, ke[T].hn);
+                vstore_a(se + SE_H, valid, T, he[T]);
             }
         }
         // latent head + soft / hard update (stable_behavior_policy.py:223-230, behavior_policy.py:174-176)
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
         ss = group_sum(ss);
         f32x4 nl;
         for (int q = 0; q < 4; ++q) nl[q] = ex[q] / ss;
-        vstore(sl, valid, 16, 0, nl);
+        vstore_a(sl, valid, 0, nl);
         for (int q = 0; q < 4; ++q) lat[q] = a.hard ? nl[q] : (1.0f - a.coef) * lat[q] + nl[q] * a.coef;
     }
 }
@@ -222,42 +222,42 @@ __global__ __launch_bounds__(256) void beh_dec_fwd_kernel(IplanBehArgs a) {
     const float inv_keep = 1.0f / (1.0f - a.drop_p);
     const bool dec_only = a.win != nullptr;
     f32x4 hd[DT];
-    for (int t = 0; t < DT; ++t) hd[t] = dec_only ? vload(a.hd_in + c.grow * DHd, valid, DHd, t) : splat4(0.f);
+    for (int t = 0; t < DT; ++t) hd[t] = dec_only ? vload_a(a.hd_in + c.grow * DHd, valid, t) : splat4(0.f);
     float beh = 0.f, stab = 0.f;
     for (int j = 0; j < J; ++j) {
         const float scale = dec_only ? 0.f : (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS);
         float err = 0.f;
         f32x4 lat1[1], zproj[DT];
-        lat1[0] = dec_only ? vload(a.lat_in + c.grow * a.Z, valid, a.Z, 0) : vload(a.saved_lat + (c.grow * J + j) * SVL + 16, valid, 16, 0);
+        lat1[0] = dec_only ? vload(a.lat_in + c.grow * a.Z, valid, a.Z, 0) : vload_a(a.saved_lat + (c.grow * J + j) * SVL + 16, valid, 0);
         for (int T = 0; T < DT; ++T) zproj[T] = dense_tile<1>(s_linz, 24, 16 * T, lat1, bfrag_lds(s_b, T));
         for (int t = 0; t < a.L; ++t) {
             const f32x4 xt = dec_only ? vload(a.win + (c.grow * a.L + t) * a.d, valid, a.d, 0) : window_x(a, c.hrow, j, t, valid);
             float* sd = a.saved_dec + ((c.grow * J + j) * a.L + t) * SVD;
             f32x4 x1[1];
             x1[0] = xt;
-            vstore(sd + SD_X, valid, 16, 0, xt);
-            vstore(sd + SD_LAT, valid, 16, 0, lat1[0]);
+            vstore_a(sd + SD_X, valid, 0, xt);
+            vstore_a(sd + SD_LAT, valid, 0, lat1[0]);
             f32x4 u[DT];
             for (int T = 0; T < DT; ++T) {
                 // Linear([x_t || latent]) = W[:, :d] x_t + (W[:, d:] latent + b): the latent part is per window
                 u[T] = relu4(dense_tile<1>(s_linx, 24, 16 * T, x1, zproj[T]));
-                vstore(sd + SD_U, valid, DHd, T, u[T]);
+                vstore_a(sd + SD_U, valid, T, u[T]);
             }
             GruGates kg[DT];
             gru_step_lds<DT, DT>(s_wih, DLD, s_whh, DLD, s_b + 64, s_b + 256, u, hd, kg);
             f32x4 act[DT];
             for (int T = 0; T < DT; ++T) {
-                vstore(sd + SD_R, valid, DHd, T, kg[T].r);
-                vstore(sd + SD_Z, valid, DHd, T, kg[T].z);
-                vstore(sd + SD_N, valid, DHd, T, kg[T].n);
-                vstore(sd + SD_HN, valid, DHd, T, kg[T].hn);
-                vstore(sd + SD_H, valid, DHd, T, hd[T]);
+                vstore_a(sd + SD_R, valid, T, kg[T].r);
+                vstore_a(sd + SD_Z, valid, T, kg[T].z);
+                vstore_a(sd + SD_N, valid, T, kg[T].n);
+                vstore_a(sd + SD_HN, valid, T, kg[T].hn);
+                vstore_a(sd + SD_H, valid, T, hd[T]);
                 const f32x4 km = keep_tile(a, net, j, row, t, T, valid, rows);
                 for (int q = 0; q < 4; ++q) act[T][q] = tanh_f(hd[T][q]) * (km[q] * inv_keep);
-                vstore(sd + SD_A, valid, DHd, T, act[T]);
+                vstore_a(sd + SD_A, valid, T, act[T]);
             }
             const f32x4 y = dense_tile<DT>(s_out, DLD, 0, act, bfrag_lds(s_b + 448, 0));
-            vstore(sd + SD_Y, valid, 16, 0, y);
+            vstore_a(sd + SD_Y, valid, 0, y);
             if (dec_only) {
                 vstore(a.pred_out + (c.grow * a.L + t) * a.d, valid, a.d, 0, y);
                 continue;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void beh_dec_fwd_kernel(IplanBehArgs a) {
             if (valid && g == 0) stab += fmaxf(sqrtf(d2) - a.thres, 0.f);
         }
         if (dec_only) {
-            for (int t = 0; t < DT; ++t) vstore(a.hd_out + c.grow * DHd, valid, DHd, t, hd[t]);
+            for (int t = 0; t < DT; ++t) vstore_a(a.hd_out + c.grow * DHd, valid, t, hd[t]);
             return;
         }
         beh = fmaf(err, scale, beh);
@@ -347,13 +347,13 @@ __global__ __launch_bounds__(256) void beh_dec_bwd_kernel(IplanBehArgs a) {
         const bool first = (j == 0 && t == 0);
         const float* sd = a.saved_dec + step * SVD;
         for (int T = 0; T < DT; ++T) {
-            o.r[T] = vload(sd + SD_R, valid, DHd, T);
-            o.z[T] = vload(sd + SD_Z, valid, DHd, T);
-            o.n[T] = vload(sd + SD_N, valid, DHd, T);
-            o.hn[T] = vload(sd + SD_HN, valid, DHd, T);
-            o.hp[T] = vload(sd - SVD + SD_H, valid && !first, DHd, T);
+            o.r[T] = vload_a(sd + SD_R, valid, T);
+            o.z[T] = vload_a(sd + SD_Z, valid, T);
+            o.n[T] = vload_a(sd + SD_N, valid, T);
+            o.hn[T] = vload_a(sd + SD_HN, valid, T);
+            o.hp[T] = vload_a(sd - SVD + SD_H, valid && !first, T);
         }
-        o.y = vload(sd + SD_Y, valid, 16, 0);
+        o.y = vload_a(sd + SD_Y, valid, 0);
         o.nx = vload(c.hrow + (int64_t)beh_y_step(a, j, t) * a.h_s_t, valid, a.d, 0);
         o.m = valid ? c.mrow[beh_m_step(a, j, t)] : 0.f;
     };
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void beh_dec_bwd_kernel(IplanBehArgs a) {
     for (int t = 0; t < DT; ++t) dhd[t] = splat4(0.f);
     StepIn cur;
     load_step(J - 1, a.L - 1, cur);
-    for (int T = 0; T < DT; ++T) hcur[T] = vload(a.saved_dec + ((c.grow * J + (J - 1)) * a.L + (a.L - 1)) * SVD + SD_H, valid, DHd, T);
+    for (int T = 0; T < DT; ++T) hcur[T] = vload_a(a.saved_dec + ((c.grow * J + (J - 1)) * a.L + (a.L - 1)) * SVD + SD_H, valid, T);
     for (int j = J - 1; j >= 0; --j) {
         const float scale = (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS) / (a.hard ? 1.0f : (float)J);
         f32x4 dlat = splat4(0.f);                           // d(loss)/d(latent_j) through this window's decoder inputs
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void beh_dec_bwd_kernel(IplanBehArgs a) {
             const int64_t step = (c.grow * J + j) * a.L + t;
             float* dd_ = a.dsave_dec + step * DSD;
             f32x4 du_[DT];
-            for (int T = 0; T < DT; ++T) du_[T] = vload(a.saved_dec + step * SVD + SD_U, valid, DHd, T);
+            for (int T = 0; T < DT; ++T) du_[T] = vload_a(a.saved_dec + step * SVD + SD_U, valid, T);
             // ---- part A: lane-local, consumes the step's record
             f32x4 dy[1];
             for (int q = 0; q < 4; ++q) {
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void beh_dec_bwd_kernel(IplanBehArgs a) {
                 }
                 dy[0][q] = v;
             }
-            vstore(dd_ + DD_DY, valid, 16, 0, dy[0]);
+            vstore_a(dd_ + DD_DY, valid, 0, dy[0]);
             f32x4 dg[4 * DT], ddir[DT];                    // [dr | dz | dn_i | dn_h]
             for (int T = 0; T < DT; ++T) {
                 const f32x4 da = dense_tile<1>(s_outT, 24, 16 * T, dy, splat4(0.f));
@@ -391,10 +391,10 @@ __global__ __launch_bounds__(256) void beh_dec_bwd_kernel(IplanBehArgs a) {
                     dht[q] = fmaf(da[q] * km[q] * inv_keep, 1.0f - th * th, dhd[T][q]);
                 }
                 const GruGrads o = gru_gates_bwd(dht, cur.r[T], cur.z[T], cur.n[T], cur.hn[T], cur.hp[T]);
-                vstore(dd_ + DD_DR, valid, DHd, T, o.dr);
-                vstore(dd_ + DD_DZ, valid, DHd, T, o.dz);
-                vstore(dd_ + DD_DNI, valid, DHd, T, o.dni);
-                vstore(dd_ + DD_DNH, valid, DHd, T, o.dnh);
+                vstore_a(dd_ + DD_DR, valid, T, o.dr);
+                vstore_a(dd_ + DD_DZ, valid, T, o.dz);
+                vstore_a(dd_ + DD_DNI, valid, T, o.dni);
+                vstore_a(dd_ + DD_DNH, valid, T, o.dnh);
                 dg[T] = o.dr; dg[DT + T] = o.dz; dg[2 * DT + T] = o.dni; dg[3 * DT + T] = o.dnh;
                 ddir[T] = o.dh_direct;
                 hcur[T] = cur.hp[T];                       // h_{t-1}: the next step's "current" hidden state
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void beh_dec_bwd_kernel(IplanBehArgs a) {
             dense_multi<DT, 3 * DT>(s_wihT, TLD, od, 0, dg, du);                            // W_ih^T [dr dz dn_i]
             for (int T = 0; T < DT; ++T) {
                 for (int q = 0; q < 4; ++q) dup[T][q] = du_[T][q] > 0.f ? du[T][q] : 0.f;
-                vstore(dd_ + DD_DU, valid, DHd, T, dup[T]);
+                vstore_a(dd_ + DD_DU, valid, T, dup[T]);
                 dhd[T] = ddir[T];
             }
             IPLAN_SCHED_FENCE();
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void beh_dec_bwd_kernel(IplanBehArgs a) {
             IPLAN_SCHED_FENCE();
             dlat = dense_tile<DT>(s_latT, DLD, 0, dup, dlat);                               // through the tiled latent input
         }
-        vstore(a.dsave_lat + (c.grow * J + j) * DSL, valid, 16, 0, dlat);
+        vstore_a(a.dsave_lat + (c.grow * J + j) * DSL, valid, 0, dlat);
     }
 }
 
@@ -467,12 +467,12 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
         // ---- latent update + head backward (dlat = d(loss)/d(latent_{j+1}) on entry)
         f32x4 dlog[1], hL[ET];
         {
-            const f32x4 nl = vload(a.saved_lat + (c.grow * J + j) * SVL, valid && live, 16, 0);
+            const f32x4 nl = vload_a(a.saved_lat + (c.grow * J + j) * SVL, valid && live, 0);
             float s = 0.f;
             f32x4 dnew;
             for (int q = 0; q < 4; ++q) { dnew[q] = cn * dlat[q]; s = fmaf(nl[q], dnew[q], s); }
             s = group_sum(s);
-            const f32x4 dl_dec = vload(a.dsave_lat + (c.grow * J + j) * DSL, valid && live, 16, 0);
+            const f32x4 dl_dec = vload_a(a.dsave_lat + (c.grow * J + j) * DSL, valid && live, 0);
             for (int q = 0; q < 4; ++q) {
                 dlog[0][q] = nl[q] * (dnew[q] - s);
                 dlat[q] = ck * dlat[q] + dl_dec[q];          // now d(loss)/d(latent_j)
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
             }
             const float* seL = a.saved_enc + ((c.grow * J + j) * a.L + (a.L - 1)) * SVE;
             for (int T = 0; T < ET; ++T) {
-                hL[T] = vload(seL + SE_H, valid && live, EHd, T);
+                hL[T] = vload_a(seL + SE_H, valid && live, T);
                 dhe[T] = dense_tile<1>(s_outT, 24, 16 * T, dlog, dhe[T]);
             }
             // dW_out += dlogit^T h_L
@@ -500,10 +500,10 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
             const bool ok = valid && live;
             f32x4 dg[4 * ET], dd[ET], u[ET], hp[ET];
             for (int T = 0; T < ET; ++T) {
-                hp[T] = vload(se - SVE + SE_H, ok && !first, EHd, T);
-                u[T] = vload(se + SE_U, ok, EHd, T);
-                const GruGrads o = gru_gates_bwd(dhe[T], vload(se + SE_R, ok, EHd, T), vload(se + SE_Z, ok, EHd, T),
-                                                 vload(se + SE_N, ok, EHd, T), vload(se + SE_HN, ok, EHd, T), hp[T]);
+                hp[T] = vload_a(se - SVE + SE_H, ok && !first, T);
+                u[T] = vload_a(se + SE_U, ok, T);
+                const GruGrads o = gru_gates_bwd(dhe[T], vload_a(se + SE_R, ok, T), vload_a(se + SE_Z, ok, T),
+                                                 vload_a(se + SE_N, ok, T), vload_a(se + SE_HN, ok, T), hp[T]);
                 dg[T] = o.dr; dg[ET + T] = o.dz; dg[2 * ET + T] = o.dni; dg[3 * ET + T] = o.dnh;
                 dd[T] = o.dh_direct;
             }

@@ -179,6 +179,17 @@ __device__ __forceinline__ void vstore(float* __restrict__ row, bool valid, int 
     }
 }
 
+// Aligned whole-tile variants (row 16-byte aligned, tile t entirely inside the vector): one predicated 16-byte
+// access, none of the per-lane alignment / tail branching of vload / vstore.
+__device__ __forceinline__ f32x4 vload_a(const float* __restrict__ row, bool valid, int t) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (valid) v = *reinterpret_cast<const f32x4*>(row + 16 * t + 4 * (lane_id() >> 4));
+    return v;
+}
+__device__ __forceinline__ void vstore_a(float* __restrict__ row, bool valid, int t, f32x4 v) {
+    if (valid) *reinterpret_cast<f32x4*>(row + 16 * t + 4 * (lane_id() >> 4)) = v;
+}
+
 // acc += W[o0.., k0..k0+15] . x   (one 16x16 weight block against tile T of the input vector)
 __device__ __forceinline__ f32x4 mma_block(f32x4 w, f32x4 x, f32x4 acc) {
     acc = mfma4(w[0], x[0], acc);

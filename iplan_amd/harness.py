@@ -127,7 +127,9 @@ class SyntheticLoop:
         self.t_env += self.E * self.args.episode_limit
         self.learner.insert_episode_batch(batch)
         dev = torch.device(self.device)
-        if dev.type != "cuda":
+        # data-parallel runs keep the learners (and therefore their gradient all-reduces) strictly ordered on one
+        # stream: every rank must issue its collectives in the same order
+        if dev.type != "cuda" or self.learner.dp is not None:
             if self.behavior is not None:
                 self.behavior.learn(batch, self.t_env)
             if self.prediction is not None:
