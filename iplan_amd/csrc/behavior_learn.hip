@@ -10,8 +10,11 @@
 // encoder's backward only consumes the decoder's per-window d(loss)/d(latent).  So the two chains are four
 // kernels, each with only its own weights in LDS:
 //   beh_enc_fwd  (all windows; light, several waves per SIMD)  -> latents per window, encoder records
-//   beh_dec_fwd  (416 MFMAs per step, one wave per SIMD, 129 KB of LDS weights) -> loss, decoder records
+//   beh_dec_fwd  (416 MFMAs per step, 126 KB of LDS weights) -> loss, decoder records
 //   beh_dec_bwd  BPTT of the decoder; streams row gradients for wgrad.hip and d(loss)/d(latent_j)
+//                In both decoder kernels a 16-chain tile is shared by TWO waves of the same SIMD (waves w, w + 4
+//                of a 512-thread block): each computes the gates of two of the four hidden tiles and the halves
+//                meet through LDS once per step (forward: the new h halves; backward: partial W^T products).
 //   beh_enc_bwd  BPTT of the encoder with its weight gradients accumulated IN the kernel (H = 32: the
 //                24 accumulator tiles fit in registers; operands are turned through LDS each step)
 // hidden states and the latent are carried from window to window in registers (D layout of wave_tile.h).
@@ -27,6 +30,7 @@ constexpr int ELDB = EHd + 8;
 constexpr int SVD = IPLAN_BEH_SAVE_DEC, SVE = IPLAN_BEH_SAVE_ENC, SVL = IPLAN_BEH_SAVE_LAT;
 constexpr int DSD = IPLAN_BEH_DSAVE_DEC, DSE = IPLAN_BEH_DSAVE_ENC, DSL = IPLAN_BEH_DSAVE_LAT;
 constexpr float BEPS = 1e-10f;
+constexpr int DEC_FWD_BIAS = 64 + 192 + 192 + 16;
 // saved_dec / dsave_dec / saved_enc / dsave_enc column offsets (include/iplan_hip.h)
 constexpr int SD_X = 0, SD_LAT = 16, SD_U = 32, SD_R = 96, SD_Z = 160, SD_N = 224, SD_HN = 288, SD_H = 352, SD_A = 416, SD_Y = 480;
 constexpr int DD_DY = 0, DD_DU = 16, DD_DR = 80, DD_DZ = 144, DD_DNI = 208, DD_DNH = 272;
@@ -47,16 +51,26 @@ __device__ __forceinline__ int beh_x_step(const IplanBehArgs& a, int j, int t) {
 __device__ __forceinline__ int beh_y_step(const IplanBehArgs& a, int j, int t) { return a.hard ? (j + 1) * a.L + t : j + 1 + t; }
 __device__ __forceinline__ int beh_m_step(const IplanBehArgs& a, int j, int t) { return a.hard ? j * a.L + t : j + 1 + t; }
 
-// counter-based Bernoulli(1-p) keep flag (used when no mask tensor is injected): same value in the
-// forward and the backward launch for the same (seed, element index)
-__device__ __forceinline__ float keep_flag(uint64_t seed, uint64_t idx, float p) {
-    // murmur3-style 32-bit finaliser over (element index, seed): two 32-bit multiplies per flag
+// counter-based Bernoulli(1-p) keep flags (used when no mask tensor is injected): same values in the forward
+// and the backward launch for the same (seed, element index).  One 32-bit murmur3-style finaliser yields two
+// 16-bit uniforms, so a lane's 4 flags of a tile cost two hashes (integer multiplies are quarter rate and do
+// not overlap with the MFMA pipe).
+__device__ __forceinline__ uint32_t keep_hash(uint64_t seed, uint64_t idx) {
     uint32_t x = (uint32_t)idx ^ ((uint32_t)(idx >> 32) * 0x9E3779B9u) ^ (uint32_t)seed;
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     x ^= (uint32_t)(seed >> 32);
     x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
-    const float u = (float)(x >> 8) * (1.0f / 16777216.0f);
-    return u >= p ? 1.0f : 0.0f;
+    return x;
+}
+__device__ __forceinline__ f32x4 keep_flags4(uint64_t seed, uint64_t base, float p) {
+    const uint32_t thr = (uint32_t)(p * 65536.0f);          // keep iff u16 >= p * 2^16
+    const uint32_t h0 = keep_hash(seed, base), h1 = keep_hash(seed, base + 2);
+    f32x4 k;
+    k[0] = (h0 & 0xFFFFu) >= thr ? 1.0f : 0.0f;
+    k[1] = (h0 >> 16) >= thr ? 1.0f : 0.0f;
+    k[2] = (h1 & 0xFFFFu) >= thr ? 1.0f : 0.0f;
+    k[3] = (h1 >> 16) >= thr ? 1.0f : 0.0f;
+    return k;
 }
 
 __device__ __forceinline__ f32x4 keep_tile(const IplanBehArgs& a, int net, int j, int row, int t, int T, bool valid, int rows) {
@@ -67,7 +81,7 @@ __device__ __forceinline__ f32x4 keep_tile(const IplanBehArgs& a, int net, int j
     if (a.keep) {
         for (int q = 0; q < 4; ++q) k[q] = (float)a.keep[base + q];
     } else if (a.drop_p > 0.f) {
-        for (int q = 0; q < 4; ++q) k[q] = keep_flag(a.seed, (uint64_t)(base + q), a.drop_p);
+        k = keep_flags4(a.seed, (uint64_t)base, a.drop_p);
     } else {
         k = splat4(1.0f);
     }
@@ -110,7 +124,7 @@ __device__ __forceinline__ bool beh_chain(const IplanBehArgs& a, BehChain& c) {
     c.net = (int)blockIdx.y;
     c.rows = a.E * a.N;
     c.tiles = (c.rows + 15) / 16;
-    c.tile = (int)blockIdx.x * 4 + wave_id();
+    c.tile = (int)blockIdx.x * 4 + (wave_id() & 3);      // the decoder kernels run two waves per tile (waves w, w + 4)
     c.row = c.tile * 16 + c.n;
     c.valid = c.tile < c.tiles && c.row < c.rows;
     c.e = c.valid ? c.row / a.N : 0;
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 // decoder forward over the whole episode (+ masked-L1 loss and the stability statistic); also serves
 // Behavior_Latent_Decoder.forward on one explicit window (a.win != NULL)
-__global__ __launch_bounds__(256) void beh_dec_fwd_kernel(IplanBehArgs a) {
+__global__ __launch_bounds__(512) void beh_dec_fwd_kernel(IplanBehArgs a) {
     IPLAN_DYN_LDS(smem);
     float* s_wih = smem;                                    // [192][DLD]
     float* s_whh = s_wih + 3 * DHd * DLD;                   // [192][DLD]
@@ -197,6 +211,7 @@ __global__ __launch_bounds__(256) void beh_dec_fwd_kernel(IplanBehArgs a) {
     float* s_linz = s_linx + DHd * 24;                      // [64][24]   W_lin[:, d:d+Z]
     float* s_out = s_linz + DHd * 24;                       // [16][DLD]
     float* s_b = s_out + 16 * DLD;                          // lin 64 | ih 192 | hh 192 | out 16
+    float* s_xch = s_b + DEC_FWD_BIAS;                      // [8 waves][3 tiles][256]: new h (own tiles) | partial y
     const float* __restrict__ PD = a.dec_params + (int64_t)blockIdx.y * a.dec_s_net;
     const int din = a.d + a.Z;
     stage_matrix(s_wih, DLD, 3 * DHd, PD + a.dec_off[IPLAN_DEC_WIH], 3 * DHd, DHd);
@@ -216,47 +231,79 @@ __global__ __launch_bounds__(256) void beh_dec_fwd_kernel(IplanBehArgs a) {
     stage_vector(s_b + 448, 16, PD + a.dec_off[IPLAN_DEC_OUT_B], a.d);
     __syncthreads();
     BehChain c;
-    if (!beh_chain(a, c)) return;
+    beh_chain(a, c);                                        // waves without a tile still take part in the block barriers
     const bool valid = c.valid;
-    const int g = c.g, J = c.J, net = c.net, row = c.row, rows = c.rows;
+    const int l = lane_id(), g = c.g, J = c.J, net = c.net, row = c.row, rows = c.rows;
     const float inv_keep = 1.0f / (1.0f - a.drop_p);
     const bool dec_only = a.win != nullptr;
+    // Gate split: waves w and w + 4 (same SIMD) share a 16-chain tile; half hf computes hidden tiles 2hf, 2hf+1.
+    // Per-tile register arrays are in ROTATED order: index i <-> hidden tile (2hf + i) & 3, so 0, 1 are the wave's own.
+    const int hf = wave_id() >> 2, own = 2 * hf, kown = 32 * hf, koth = 32 - kown;
+    float* xm = s_xch + wave_id() * 768;
+    const float* xp = s_xch + (wave_id() ^ 4) * 768;
+    auto put = [&](int slot, f32x4 v) { *reinterpret_cast<f32x4*>(xm + slot * 256 + 4 * l) = v; };
+    auto get = [&](int slot) { return *reinterpret_cast<const f32x4*>(xp + slot * 256 + 4 * l); };
     f32x4 hd[DT];
-    for (int t = 0; t < DT; ++t) hd[t] = dec_only ? vload_a(a.hd_in + c.grow * DHd, valid, t) : splat4(0.f);
+    for (int i = 0; i < DT; ++i) hd[i] = dec_only ? vload_a(a.hd_in + c.grow * DHd, valid, (own + i) & 3) : splat4(0.f);
     float beh = 0.f, stab = 0.f;
     for (int j = 0; j < J; ++j) {
-        const float scale = dec_only ? 0.f : (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS);
+        const float scale = (dec_only || hf) ? 0.f : (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS);
         float err = 0.f;
         f32x4 lat1[1], zproj[DT];
         lat1[0] = dec_only ? vload(a.lat_in + c.grow * a.Z, valid, a.Z, 0) : vload_a(a.saved_lat + (c.grow * J + j) * SVL + 16, valid, 0);
-        for (int T = 0; T < DT; ++T) zproj[T] = dense_tile<1>(s_linz, 24, 16 * T, lat1, bfrag_lds(s_b, T));
+        for (int i = 0; i < DT; ++i) zproj[i] = dense_tile<1>(s_linz, 24, 16 * ((own + i) & 3), lat1, bfrag_lds(s_b, (own + i) & 3));
         for (int t = 0; t < a.L; ++t) {
             const f32x4 xt = dec_only ? vload(a.win + (c.grow * a.L + t) * a.d, valid, a.d, 0) : window_x(a, c.hrow, j, t, valid);
             float* sd = a.saved_dec + ((c.grow * J + j) * a.L + t) * SVD;
             f32x4 x1[1];
             x1[0] = xt;
-            vstore_a(sd + SD_X, valid, 0, xt);
-            vstore_a(sd + SD_LAT, valid, 0, lat1[0]);
+            if (hf == 0) {
+                vstore_a(sd + SD_X, valid, 0, xt);
+                vstore_a(sd + SD_LAT, valid, 0, lat1[0]);
+            }
             f32x4 u[DT];
-            for (int T = 0; T < DT; ++T) {
-                // Linear([x_t || latent]) = W[:, :d] x_t + (W[:, d:] latent + b): the latent part is per window
-                u[T] = relu4(dense_tile<1>(s_linx, 24, 16 * T, x1, zproj[T]));
-                vstore_a(sd + SD_U, valid, T, u[T]);
-            }
-            GruGates kg[DT];
-            gru_step_lds<DT, DT>(s_wih, DLD, s_whh, DLD, s_b + 64, s_b + 256, u, hd, kg);
-            f32x4 act[DT];
-            for (int T = 0; T < DT; ++T) {
-                vstore_a(sd + SD_R, valid, T, kg[T].r);
-                vstore_a(sd + SD_Z, valid, T, kg[T].z);
-                vstore_a(sd + SD_N, valid, T, kg[T].n);
-                vstore_a(sd + SD_HN, valid, T, kg[T].hn);
-                vstore_a(sd + SD_H, valid, T, hd[T]);
+            // Linear([x_t || latent]) = W[:, :d] x_t + (W[:, d:] latent + b): the latent part is per window
+            for (int i = 0; i < DT; ++i) u[i] = relu4(dense_tile<1>(s_linx, 24, 16 * ((own + i) & 3), x1, zproj[i]));
+            vstore_a(sd + SD_U, valid, own, u[0]);
+            vstore_a(sd + SD_U, valid, own + 1, u[1]);
+            f32x4 hnew[2], act[2];
+            for (int tt = 0; tt < 2; ++tt) {
+                const int T = own + tt;
+                const int grow3[3] = {16 * T, DHd + 16 * T, 2 * DHd + 16 * T};        // r, z, n gate rows of this hidden tile
+                f32x4 ai[3], ah[3];
+                ai[0] = bfrag_lds(s_b + 64, T) + bfrag_lds(s_b + 256, T);
+                ai[1] = bfrag_lds(s_b + 64, DT + T) + bfrag_lds(s_b + 256, DT + T);
+                ai[2] = bfrag_lds(s_b + 64, 2 * DT + T);
+                dense_multi<3, 2>(s_wih, DLD, grow3, kown, u, ai);                     // W_ih u: pre_r, pre_z, gi_n
+                dense_multi<3, 2>(s_wih, DLD, grow3, koth, u + 2, ai);
+                ah[0] = ai[0];
+                ah[1] = ai[1];
+                ah[2] = bfrag_lds(s_b + 256, 2 * DT + T);
+                dense_multi<3, 2>(s_whh, DLD, grow3, kown, hd, ah);                    // + W_hh h: pre_r, pre_z, gh_n
+                dense_multi<3, 2>(s_whh, DLD, grow3, koth, hd + 2, ah);
+                const GruGates o = gru_gates(ah[0], ah[1], ai[2], ah[2], hd[tt]);
+                hnew[tt] = o.h;
+                vstore_a(sd + SD_R, valid, T, o.r);
+                vstore_a(sd + SD_Z, valid, T, o.z);
+                vstore_a(sd + SD_N, valid, T, o.n);
+                vstore_a(sd + SD_HN, valid, T, o.hn);
+                vstore_a(sd + SD_H, valid, T, o.h);
                 const f32x4 km = keep_tile(a, net, j, row, t, T, valid, rows);
-                for (int q = 0; q < 4; ++q) act[T][q] = tanh_f(hd[T][q]) * (km[q] * inv_keep);
-                vstore_a(sd + SD_A, valid, T, act[T]);
+                for (int q = 0; q < 4; ++q) act[tt][q] = tanh_f(o.h[q]) * (km[q] * inv_keep);
+                vstore_a(sd + SD_A, valid, T, act[tt]);
+                put(tt, o.h);
+                IPLAN_SCHED_FENCE();
             }
-            const f32x4 y = dense_tile<DT>(s_out, DLD, 0, act, bfrag_lds(s_b + 448, 0));
+            // y = W_out act + b: each half contracts its own two tiles, the second half hands its partial over
+            const f32x4 yp = dense_tile_k<2>(s_out, DLD, 0, kown, act, hf ? splat4(0.f) : bfrag_lds(s_b + 448, 0));
+            if (hf) put(2, yp);
+            __syncthreads();
+            hd[0] = hnew[0]; hd[1] = hnew[1];
+            hd[2] = get(0); hd[3] = get(1);
+            f32x4 y = yp;
+            if (hf == 0) y = yp + get(2);
+            __syncthreads();
+            if (hf) continue;                               // the rest of the step (output, loss terms) is the first half's
             vstore_a(sd + SD_Y, valid, 0, y);
             if (dec_only) {
                 vstore(a.pred_out + (c.grow * a.L + t) * a.d, valid, a.d, 0, y);
@@ -277,14 +324,15 @@ __global__ __launch_bounds__(256) void beh_dec_fwd_kernel(IplanBehArgs a) {
             if (valid && g == 0) stab += fmaxf(sqrtf(d2) - a.thres, 0.f);
         }
         if (dec_only) {
-            for (int t = 0; t < DT; ++t) vstore_a(a.hd_out + c.grow * DHd, valid, t, hd[t]);
+            vstore_a(a.hd_out + c.grow * DHd, valid, own, hd[0]);
+            vstore_a(a.hd_out + c.grow * DHd, valid, own + 1, hd[1]);
             return;
         }
         beh = fmaf(err, scale, beh);
     }
     beh = chain_sum_b(group_sum(beh)) / (a.hard ? 1.0f : (float)J);
     stab = chain_sum_b(group_sum(stab)) / (float)a.E / (float)a.L / (float)J;
-    if (lane_id() == 0) {
+    if (lane_id() == 0 && hf == 0 && c.tile < c.tiles) {
         a.loss_part[((int64_t)net * c.tiles + c.tile) * 2] = beh;
         a.loss_part[((int64_t)net * c.tiles + c.tile) * 2 + 1] = stab;
     }
@@ -308,13 +356,14 @@ __global__ __launch_bounds__(64) void beh_loss_kernel(IplanBehArgs a) {
 
 // ------------------------------------------------------------------------------------------------------------
 // decoder BPTT: row gradients for wgrad.hip (dsave_dec) and d(loss)/d(latent_j) per window (dsave_lat)
-__global__ __launch_bounds__(256) void beh_dec_bwd_kernel(IplanBehArgs a) {
+__global__ __launch_bounds__(512) void beh_dec_bwd_kernel(IplanBehArgs a) {
     IPLAN_DYN_LDS(smem);
     constexpr int TLD = 3 * DHd + 8;                        // 200: ld % 16 == 8 -> conflict-free ds_read_b128 fragments
     float* s_wihT = smem;                                   // [64][200]   W_ih^T
     float* s_whhT = s_wihT + DHd * TLD;                     // [64][200]
     float* s_outT = s_whhT + DHd * TLD;                     // [64][24]    W_out^T (cols = d)
     float* s_latT = s_outT + DHd * 24;                      // [16][DLD]   W_lin[:, d:d+Z]^T
+    float* s_xch = s_latT + 16 * DLD;                       // [8 waves][4 tiles][256]: partial du | partial dh for the partner's tiles
     const float* __restrict__ PD = a.dec_params + (int64_t)blockIdx.y * a.dec_s_net;
     const int din = a.d + a.Z;
     stage_matrix_t(s_wihT, TLD, DHd, PD + a.dec_off[IPLAN_DEC_WIH], 3 * DHd, DHd);
@@ -329,16 +378,22 @@ __global__ __launch_bounds__(256) void beh_dec_bwd_kernel(IplanBehArgs a) {
     }
     __syncthreads();
     BehChain c;
-    if (!beh_chain(a, c)) return;
+    beh_chain(a, c);                                        // waves without a tile still take part in the block barriers
     const bool valid = c.valid;
-    const int g = c.g, J = c.J, net = c.net, row = c.row, rows = c.rows;
+    const int l = lane_id(), g = c.g, J = c.J, net = c.net, row = c.row, rows = c.rows;
     const float inv_keep = 1.0f / (1.0f - a.drop_p);
+    // Gate split (see beh_dec_fwd_kernel): this wave owns hidden tiles own, own + 1 -- their gate gradients, their
+    // share (6 of the 12 k-tiles) of the two transposed products, and after the exchange their rows of du and dh.
+    const int hf = wave_id() >> 2, own = 2 * hf, kown = 32 * hf;
+    float* xm = s_xch + wave_id() * 1024;
+    const float* xp = s_xch + (wave_id() ^ 4) * 1024;
+    auto put = [&](int slot, f32x4 v) { *reinterpret_cast<f32x4*>(xm + slot * 256 + 4 * l) = v; };
+    auto get = [&](int slot) { return *reinterpret_cast<const f32x4*>(xp + slot * 256 + 4 * l); };
 
-    // The forward's record of a step (gates + previous hidden state), the loss target and the mask.  The NEXT
-    // step's record is fetched between the lane-local part and the MFMA part of the current step: with one wave
-    // per SIMD nothing else hides the HBM latency.
+    // The forward's record of a step (gates + previous hidden state of the own tiles), the loss target and the mask.
+    // The NEXT step's record is fetched between the lane-local part and the MFMA part of the current step.
     struct StepIn {
-        f32x4 r[DT], z[DT], n[DT], hn[DT], hp[DT];
+        f32x4 r[2], z[2], n[2], hn[2], hp[2];
         f32x4 y, nx;
         float m;
     };
@@ -346,30 +401,32 @@ __global__ __launch_bounds__(256) void beh_dec_bwd_kernel(IplanBehArgs a) {
         const int64_t step = (c.grow * J + j) * a.L + t;
         const bool first = (j == 0 && t == 0);
         const float* sd = a.saved_dec + step * SVD;
-        for (int T = 0; T < DT; ++T) {
-            o.r[T] = vload_a(sd + SD_R, valid, T);
-            o.z[T] = vload_a(sd + SD_Z, valid, T);
-            o.n[T] = vload_a(sd + SD_N, valid, T);
-            o.hn[T] = vload_a(sd + SD_HN, valid, T);
-            o.hp[T] = vload_a(sd - SVD + SD_H, valid && !first, T);
+        for (int tt = 0; tt < 2; ++tt) {
+            o.r[tt] = vload_a(sd + SD_R, valid, own + tt);
+            o.z[tt] = vload_a(sd + SD_Z, valid, own + tt);
+            o.n[tt] = vload_a(sd + SD_N, valid, own + tt);
+            o.hn[tt] = vload_a(sd + SD_HN, valid, own + tt);
+            o.hp[tt] = vload_a(sd - SVD + SD_H, valid && !first, own + tt);
         }
         o.y = vload_a(sd + SD_Y, valid, 0);
         o.nx = vload(c.hrow + (int64_t)beh_y_step(a, j, t) * a.h_s_t, valid, a.d, 0);
         o.m = valid ? c.mrow[beh_m_step(a, j, t)] : 0.f;
     };
-    f32x4 dhd[DT], hcur[DT];
-    for (int t = 0; t < DT; ++t) dhd[t] = splat4(0.f);
+    f32x4 dhd[2], hcur[2];
+    for (int tt = 0; tt < 2; ++tt) dhd[tt] = splat4(0.f);
     StepIn cur;
     load_step(J - 1, a.L - 1, cur);
-    for (int T = 0; T < DT; ++T) hcur[T] = vload_a(a.saved_dec + ((c.grow * J + (J - 1)) * a.L + (a.L - 1)) * SVD + SD_H, valid, T);
+    for (int tt = 0; tt < 2; ++tt) hcur[tt] = vload_a(a.saved_dec + ((c.grow * J + (J - 1)) * a.L + (a.L - 1)) * SVD + SD_H, valid, own + tt);
+    int od[DT];
+    for (int i = 0; i < DT; ++i) od[i] = 16 * ((own + i) & 3);                             // output tiles in rotated order
     for (int j = J - 1; j >= 0; --j) {
         const float scale = (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS) / (a.hard ? 1.0f : (float)J);
-        f32x4 dlat = splat4(0.f);                           // d(loss)/d(latent_j) through this window's decoder inputs
+        f32x4 dlat = splat4(0.f);                           // d(loss)/d(latent_j) through this window's decoder inputs (own share)
         for (int t = a.L - 1; t >= 0; --t) {
             const int64_t step = (c.grow * J + j) * a.L + t;
             float* dd_ = a.dsave_dec + step * DSD;
-            f32x4 du_[DT];
-            for (int T = 0; T < DT; ++T) du_[T] = vload_a(a.saved_dec + step * SVD + SD_U, valid, T);
+            f32x4 du_[2];
+            for (int tt = 0; tt < 2; ++tt) du_[tt] = vload_a(a.saved_dec + step * SVD + SD_U, valid, own + tt);
             // ---- part A: lane-local, consumes the step's record
             f32x4 dy[1];
             for (int q = 0; q < 4; ++q) {
@@ -380,46 +437,57 @@ __global__ __launch_bounds__(256) void beh_dec_bwd_kernel(IplanBehArgs a) {
                 }
                 dy[0][q] = v;
             }
-            vstore_a(dd_ + DD_DY, valid, 0, dy[0]);
-            f32x4 dg[4 * DT], ddir[DT];                    // [dr | dz | dn_i | dn_h]
-            for (int T = 0; T < DT; ++T) {
+            if (hf == 0) vstore_a(dd_ + DD_DY, valid, 0, dy[0]);
+            f32x4 dg[8], ddir[2];                          // [dr | dz | dn_i | dn_h] of the own tiles
+            for (int tt = 0; tt < 2; ++tt) {
+                const int T = own + tt;
                 const f32x4 da = dense_tile<1>(s_outT, 24, 16 * T, dy, splat4(0.f));
                 const f32x4 km = keep_tile(a, net, j, row, t, T, valid, rows);
                 f32x4 dht;
                 for (int q = 0; q < 4; ++q) {
-                    const float th = tanh_f(hcur[T][q]);
-                    dht[q] = fmaf(da[q] * km[q] * inv_keep, 1.0f - th * th, dhd[T][q]);
+                    const float th = tanh_f(hcur[tt][q]);
+                    dht[q] = fmaf(da[q] * km[q] * inv_keep, 1.0f - th * th, dhd[tt][q]);
                 }
-                const GruGrads o = gru_gates_bwd(dht, cur.r[T], cur.z[T], cur.n[T], cur.hn[T], cur.hp[T]);
+                const GruGrads o = gru_gates_bwd(dht, cur.r[tt], cur.z[tt], cur.n[tt], cur.hn[tt], cur.hp[tt]);
                 vstore_a(dd_ + DD_DR, valid, T, o.dr);
                 vstore_a(dd_ + DD_DZ, valid, T, o.dz);
                 vstore_a(dd_ + DD_DNI, valid, T, o.dni);
                 vstore_a(dd_ + DD_DNH, valid, T, o.dnh);
-                dg[T] = o.dr; dg[DT + T] = o.dz; dg[2 * DT + T] = o.dni; dg[3 * DT + T] = o.dnh;
-                ddir[T] = o.dh_direct;
-                hcur[T] = cur.hp[T];                       // h_{t-1}: the next step's "current" hidden state
+                dg[tt] = o.dr; dg[2 + tt] = o.dz; dg[4 + tt] = o.dni; dg[6 + tt] = o.dnh;
+                ddir[tt] = o.dh_direct;
+                hcur[tt] = cur.hp[tt];                     // h_{t-1}: the next step's "current" hidden state
             }
             IPLAN_SCHED_FENCE();
             if (t > 0) load_step(j, t - 1, cur);
             else if (j > 0) load_step(j - 1, a.L - 1, cur);
             IPLAN_SCHED_FENCE();
-            // ---- part B: backward-data products on MFMA (the 4 output tiles of a product share the B operand)
-            const int od[DT] = {0, 16, 32, 48};
-            f32x4 du[DT], dup[DT];
-            for (int T = 0; T < DT; ++T) du[T] = splat4(0.f);
-            dense_multi<DT, 3 * DT>(s_wihT, TLD, od, 0, dg, du);                            // W_ih^T [dr dz dn_i]
-            for (int T = 0; T < DT; ++T) {
-                for (int q = 0; q < 4; ++q) dup[T][q] = du_[T][q] > 0.f ? du[T][q] : 0.f;
-                vstore_a(dd_ + DD_DU, valid, T, dup[T]);
-                dhd[T] = ddir[T];
+            // ---- part B: this half's k-tiles of the backward-data products, all four output tiles
+            f32x4 du[DT], pd[DT];
+            for (int i = 0; i < DT; ++i) { du[i] = splat4(0.f); pd[i] = splat4(0.f); }
+            dense_multi<DT, 2>(s_wihT, TLD, od, kown, dg, du);                              // W_ih^T [dr dz dn_i]
+            dense_multi<DT, 2>(s_wihT, TLD, od, DHd + kown, dg + 2, du);
+            dense_multi<DT, 2>(s_wihT, TLD, od, 2 * DHd + kown, dg + 4, du);
+            put(0, du[2]); put(1, du[3]);
+            IPLAN_SCHED_FENCE();
+            dense_multi<DT, 2>(s_whhT, TLD, od, kown, dg, pd);                              // W_hh^T [dr dz | dn_h]
+            dense_multi<DT, 2>(s_whhT, TLD, od, DHd + kown, dg + 2, pd);
+            dense_multi<DT, 2>(s_whhT, TLD, od, 2 * DHd + kown, dg + 6, pd);
+            put(2, pd[2]); put(3, pd[3]);
+            __syncthreads();
+            f32x4 dup[2];
+            for (int tt = 0; tt < 2; ++tt) {
+                const f32x4 dut = du[tt] + get(tt);
+                for (int q = 0; q < 4; ++q) dup[tt][q] = du_[tt][q] > 0.f ? dut[q] : 0.f;
+                vstore_a(dd_ + DD_DU, valid, own + tt, dup[tt]);
+                dhd[tt] = ddir[tt] + (pd[tt] + get(2 + tt));
             }
-            IPLAN_SCHED_FENCE();
-            dense_multi<DT, 2 * DT>(s_whhT, TLD, od, 0, dg, dhd);                           // W_hh^T [dr dz | dn_h]
-            dense_multi<DT, DT>(s_whhT, TLD, od, 2 * DHd, dg + 3 * DT, dhd);
-            IPLAN_SCHED_FENCE();
-            dlat = dense_tile<DT>(s_latT, DLD, 0, dup, dlat);                               // through the tiled latent input
+            __syncthreads();
+            dlat = dense_tile_k<2>(s_latT, DLD, 0, kown, dup, dlat);                        // through the tiled latent input
         }
-        vstore_a(a.dsave_lat + (c.grow * J + j) * DSL, valid, 0, dlat);
+        if (hf) put(0, dlat);
+        __syncthreads();
+        if (hf == 0) vstore_a(a.dsave_lat + (c.grow * J + j) * DSL, valid, 0, dlat + get(0));
+        __syncthreads();
     }
 }
 
@@ -632,11 +700,11 @@ extern "C" int iplan_beh_fwd(const IplanBehArgs* a, iplan_stream_t stream) {
     const int tiles = (a->E * a->N + 15) / 16;
     const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets);
     if (!a->win) hipLaunchKernelGGL(beh_enc_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
-    const size_t lds = sizeof(float) * (2 * 3 * DHd * DLD + 2 * DHd * 24 + 16 * DLD + (64 + 192 + 192 + 16));
+    const size_t lds = sizeof(float) * (2 * 3 * DHd * DLD + 2 * DHd * 24 + 16 * DLD + DEC_FWD_BIAS + 8 * 3 * 256);
 #ifndef IPLAN_HOST_EMULATION
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_dec_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
-    hipLaunchKernelGGL(beh_dec_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(beh_dec_fwd_kernel, grid, dim3(512), lds, (hipStream_t)stream, *a);
     if (!a->win) hipLaunchKernelGGL(beh_loss_kernel, dim3((unsigned)a->n_nets), dim3(64), 0, (hipStream_t)stream, *a);
     return check_launch("iplan_beh_fwd");
 }
@@ -649,11 +717,11 @@ extern "C" int iplan_beh_bwd(const IplanBehArgs* a, iplan_stream_t stream) {
         return fail(IPLAN_EINVAL, "iplan_beh_bwd: dsave_dec / dsave_lat / enc_part / enc_grad missing");
     const int tiles = (a->E * a->N + 15) / 16;
     const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets);
-    const size_t lds = sizeof(float) * (2 * DHd * (3 * DHd + 8) + DHd * 24 + 16 * DLD);
+    const size_t lds = sizeof(float) * (2 * DHd * (3 * DHd + 8) + DHd * 24 + 16 * DLD + 8 * 4 * 256);
 #ifndef IPLAN_HOST_EMULATION
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_dec_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
-    if (a->bwd_phase != 2) hipLaunchKernelGGL(beh_dec_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, *a);
+    if (a->bwd_phase != 2) hipLaunchKernelGGL(beh_dec_bwd_kernel, grid, dim3(512), lds, (hipStream_t)stream, *a);
     if (a->bwd_phase != 1) {
         hipLaunchKernelGGL(beh_enc_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
         const int p_enc = 32 * a->d + 32 + 2 * 96 * 32 + 2 * 96 + a->Z * 32 + a->Z;

@@ -12,36 +12,50 @@
 // Reduction order is fixed: a wave owns a contiguous row range ("virtual chunk"), partial tiles go
 // to the workspace and a second kernel adds the chunks in index order -> bitwise reproducible, no
 // atomics.
+//
+// The contraction streams every row once per wave job, so it is HBM-bound by the bytes its jobs REQUEST: waves
+// that read the same rows drift apart by far more than the L2 a streaming wave can count on, i.e. sharing
+// through the cache does not happen.  Hence two job shapes:
+//   wide   12 x 4 tiles (192 accumulator registers, one wave per SIMD): a GRU weight [192 x 64] is ONE job --
+//          its dY rows and its X rows are read exactly once; the 192 MFMAs of a 16-row block (2.6 us) cover
+//          the latency of the next block's loads, so one wave per SIMD is enough
+//   narrow  4 x 4 tiles, three waves per SIMD: the small heads (a few MFMAs per block) are latency
+//          bound and get their parallelism from loads in flight and several waves per SIMD instead
+#include <cstdlib>
+
 #include "api_util.h"
 #include "wave_tile.h"
 
 namespace iplan {
 
-constexpr int WG_TO = 4;   // o-tiles per wave job
-constexpr int WG_TK = 4;   // k-tiles per wave job
+constexpr int WG_TK = 4;            // k-tiles per wave job (both shapes)
+constexpr int WG_TO_WIDE = 12;      // o-tiles per wave job: wide shape (problems with more than 8 o-tiles) ...
+constexpr int WG_TO_NARROW = 4;     // ... and narrow shape
 
 struct WgradGeom {
-    int OT, KT, n_og, n_kg, jobs, sub;      // sub = row sub-chunks per workgroup (4 waves / jobs)
+    int OT, KT, to, n_og, n_kg, jobs;
     int64_t rows;
     int vchunks, vrows;                      // virtual chunks and rows per virtual chunk (multiple of 16)
     int64_t part_floats;                     // floats per virtual chunk: OT*16 * (KT*16 + 1)
 };
 
-__host__ __device__ inline WgradGeom wgrad_geom(const IplanWgradProblem& p) {
+// chunks_wide: row chunks per net of the wide problems of this launch (the narrow ones use IPLAN_WGRAD_MAX_CHUNKS)
+__host__ __device__ inline WgradGeom wgrad_geom(const IplanWgradProblem& p, int chunks_wide) {
     WgradGeom g;
     g.OT = (p.O + 15) / 16;
     g.KT = (p.K + 15) / 16;
-    g.n_og = (g.OT + WG_TO - 1) / WG_TO;
+    g.to = g.OT > 2 * WG_TO_NARROW ? WG_TO_WIDE : WG_TO_NARROW;        // wide from 9 o-tiles on (at most 25 % idle accumulators)
+    g.n_og = (g.OT + g.to - 1) / g.to;
     g.n_kg = g.KT > 0 ? (g.KT + WG_TK - 1) / WG_TK : 1;
     g.jobs = g.n_og * g.n_kg;
     g.rows = (int64_t)p.n_outer * p.n_inner;
-    int64_t vr = (g.rows + IPLAN_WGRAD_MAX_CHUNKS - 1) / IPLAN_WGRAD_MAX_CHUNKS;
+    const int target = g.to == WG_TO_WIDE ? chunks_wide : IPLAN_WGRAD_MAX_CHUNKS;
+    int64_t vr = (g.rows + target - 1) / target;
     if (vr < 256) vr = 256;
     vr = (vr + 15) / 16 * 16;
     g.vrows = (int)vr;
     g.vchunks = (int)((g.rows + vr - 1) / vr);
     if (g.vchunks < 1) g.vchunks = 1;
-    g.sub = 1;
     g.part_floats = (int64_t)g.OT * 16 * (g.KT * 16 + 1);
     return g;
 }
@@ -50,153 +64,164 @@ __device__ __forceinline__ int ocol(const IplanWgradProblem& p, int o) {
     return o < p.seg_split ? p.seg_c0 + o : p.seg_c1 + (o - p.seg_split);
 }
 
-// grid: (problem * max_jobs + job, virtual chunk, net); block: 64 (one wave).  The (problem, job) index varies
-// fastest so that the waves that read the same rows (other tile jobs of a problem, and the other problems of a
-// launch -- a GRU's W_ih / W_hh share their dY rows) are dispatched together and meet in L2 / the Infinity Cache.
+// jobs of one shape in a launch
+constexpr int WG_MAX_JOBS = 64;
+struct WgradJobs {
+    int n;
+    int pj[WG_MAX_JOBS];                     // problem << 8 | job  (dwords: scalar loads straight from the kernel arguments)
+};
+
+// grid: (job of this shape, virtual chunk, net); block: 64 (one wave).
 //
-// Data path per 16-row block: every lane fetches ONE 16-byte piece of each operand tile (row = lane/4, 4
-// consecutive columns: 64 contiguous bytes per row, whole cache lines across neighbouring tiles), the 16x16 tiles
-// are parked in LDS and read back in MFMA operand order (lane (i, g), sub-step s: element [4s+g][i]; with a
-// 16-float row pitch the two 32-lane halves of a ds_read_b32 hit disjoint banks).  The next block's global loads
-// are in flight while the current block's 64 MFMAs run.
-__global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a, int max_jobs) {
-    __shared__ __attribute__((aligned(16))) float s_t[2][WG_TO + WG_TK][256];
-    const int pi = (int)blockIdx.x / max_jobs, job = (int)blockIdx.x % max_jobs, net = (int)blockIdx.z;
+// Data path: the operands are loaded from global memory DIRECTLY in MFMA operand order -- for sub-step s of a
+// 16-row block lane (i, g) fetches dY[row 4s+g][o0+i] and X[row 4s+g][k0+i], i.e. the 16 lanes of a group read
+// the 64 contiguous bytes of a row tile and a load instruction covers 4 rows.  No LDS, no transposes, no barriers.
+// Prefetch is rolling: as soon as the MFMAs of a sub-step are issued its operand registers are reloaded with the
+// same sub-step RB blocks ahead.  Bias gradients are lane-local column sums (VALU), reduced across the four
+// lane groups at the end.
+template <int TO, int RB>
+__global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a, WgradJobs jl, int chunks_wide) {
+    const int pj = jl.pj[blockIdx.x], pi = pj >> 8, job = pj & 255, net = (int)blockIdx.z;
     const IplanWgradProblem& p = a.p[pi];
-    const WgradGeom gm = wgrad_geom(p);
+    const WgradGeom gm = wgrad_geom(p, chunks_wide);
     const int vc = (int)blockIdx.y;
-    if (vc >= gm.vchunks || job >= gm.jobs) return;
+    if (vc >= gm.vchunks) return;
     const int og = job / gm.n_kg, kg = job % gm.n_kg;
-    const int l = lane_id(), i = l & 15, g = l >> 4;       // MFMA role
-    const int lr = l >> 2, lc = 4 * (l & 3);               // loader role: row of the block, first of 4 columns
-    const int ot0 = og * WG_TO, kt0 = kg * WG_TK;
-    const int not_ = imin(WG_TO, gm.OT - ot0), nkt = gm.KT > 0 ? imin(WG_TK, gm.KT - kt0) : 0;
+    const int l = lane_id(), i = l & 15, g = l >> 4;
+    const int ot0 = og * TO, kt0 = kg * WG_TK;
+    const int not_ = imin(TO, gm.OT - ot0), nkt = gm.KT > 0 ? imin(WG_TK, gm.KT - kt0) : 0;
     const bool want_bias = (kg == 0);
 
-    const float* __restrict__ dy = p.dy + (int64_t)net * p.dy_s_net;
-    const float* __restrict__ x = p.x ? p.x + (int64_t)net * p.x_s_net : nullptr;
-    const float* __restrict__ x0 = p.x0 ? p.x0 + (int64_t)net * p.x0_s_net : nullptr;
-
-    f32x4 acc[WG_TO][WG_TK];
-    f32x4 bacc[WG_TO];
-    for (int t = 0; t < WG_TO; ++t) {
-        bacc[t] = splat4(0.f);
+    f32x4 acc[TO][WG_TK];
+    float bsum[TO];
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+        bsum[t] = 0.f;
+#pragma unroll
         for (int u = 0; u < WG_TK; ++u) acc[t][u] = splat4(0.f);
-    }
-    // loader-side column bookkeeping: this lane's 4 columns of every tile
-    int acol[WG_TO], anv[WG_TO], bcol[WG_TK], bnv[WG_TK];
-    bool avec[WG_TO], bvec[WG_TK];
-    const bool dy_al = ((p.dy_s_outer | p.dy_s_inner | p.dy_s_net) & 3) == 0 && ((((size_t)p.dy) & 15) == 0);
-    const bool x_al = ((p.x_s_outer | p.x_s_inner | p.x_s_net | p.x0_s_outer | p.x0_s_net) & 3) == 0 &&
-                      ((((size_t)p.x) & 15) == 0) && ((((size_t)p.x0) & 15) == 0);
-    for (int t = 0; t < WG_TO; ++t) {
-        const int o = (ot0 + t) * 16 + lc;
-        const int rem = p.O - o;
-        anv[t] = t < not_ ? (rem >= 4 ? 4 : (rem > 0 ? rem : 0)) : 0;
-        acol[t] = anv[t] > 0 ? ocol(p, o) : 0;
-        avec[t] = anv[t] == 4 && ocol(p, o + 3) == acol[t] + 3 && dy_al && (acol[t] & 3) == 0;
-    }
-    for (int u = 0; u < WG_TK; ++u) {
-        const int k = (kt0 + u) * 16 + lc;
-        const int rem = p.K - k;
-        bnv[u] = u < nkt ? (rem >= 4 ? 4 : (rem > 0 ? rem : 0)) : 0;
-        bcol[u] = p.x_col0 + k;
-        bvec[u] = bnv[u] == 4 && x_al && (bcol[u] & 3) == 0;
     }
     const int64_t r_lo = (int64_t)vc * gm.vrows;
     const int64_t r_hi = gm.rows < r_lo + gm.vrows ? gm.rows : r_lo + gm.vrows;
-    // (outer, inner) of the row this lane loads, advanced by 16 rows per block (no division in the loop)
-    int o_s, i_s;
-    {
-        const int64_t r = r_lo + lr;
-        o_s = (int)(r / p.n_inner);
-        i_s = (int)(r - (int64_t)o_s * p.n_inner);
-    }
-    const int adv_o = 16 / p.n_inner, adv_i = 16 % p.n_inner;
-
-    struct Regs { f32x4 av[WG_TO]; f32x4 bv[WG_TK]; };
-    auto fetch = [&](int64_t rb, Regs& o) {
-        const int64_t r = rb + lr;
-        const bool rv = r < r_hi;
-        const int64_t outer = o_s;
-        const int inner = i_s;
-        o_s += adv_o;
-        i_s += adv_i;
-        if (i_s >= p.n_inner) { i_s -= p.n_inner; o_s += 1; }
-        const float* dyr = dy + outer * p.dy_s_outer + (int64_t)inner * p.dy_s_inner;
-        for (int t = 0; t < WG_TO; ++t) {
-            f32x4 v = splat4(0.f);
-            if (rv && anv[t] > 0) {
-                if (avec[t]) v = *reinterpret_cast<const f32x4*>(dyr + acol[t]);
-                else for (int q = 0; q < 4; ++q) if (q < anv[t]) v[q] = dyr[ocol(p, (ot0 + t) * 16 + lc + q)];
-            }
-            o.av[t] = v;
-        }
-        const float* xr = nullptr;
-        if (rv && nkt > 0) {
-            const int xi = inner + p.x_shift;
-            if (xi >= 0 && xi < p.n_inner) xr = x + outer * p.x_s_outer + (int64_t)xi * p.x_s_inner;
-            else if (x0) xr = x0 + outer * p.x0_s_outer - p.x_col0;
-        }
-        for (int u = 0; u < WG_TK; ++u) {
-            f32x4 v = splat4(0.f);
-            if (xr && bnv[u] > 0) {
-                if (bvec[u]) v = *reinterpret_cast<const f32x4*>(xr + bcol[u]);
-                else for (int q = 0; q < 4; ++q) if (q < bnv[u]) v[q] = xr[bcol[u] + q];
-            }
-            o.bv[u] = v;
-        }
-    };
-    auto park = [&](const Regs& o, int buf) {
-        for (int t = 0; t < WG_TO; ++t)
-            if (t < not_) *reinterpret_cast<f32x4*>(&s_t[buf][t][lr * 16 + lc]) = o.av[t];
-        for (int u = 0; u < WG_TK; ++u)
-            if (u < nkt) *reinterpret_cast<f32x4*>(&s_t[buf][WG_TO + u][lr * 16 + lc]) = o.bv[u];
-    };
-    auto contract = [&](int buf) {
+    // Addressing: one uniform base per operand (the chunk's first outer index) + 32-bit per-lane BYTE offsets, so a
+    // load costs one v_add_u32 and a global_load with scalar base.  The lane's column of every operand tile is
+    // clamped into the matrix: an out-of-range column only feeds accumulator rows / columns that the reduction never
+    // reads (element (o, k) of the product depends on column o of dY and column k of X alone).
+    const int o_lo = (int)(r_lo / p.n_inner);
+    const char* __restrict__ abase = reinterpret_cast<const char*>(p.dy + (int64_t)net * p.dy_s_net + (int64_t)o_lo * p.dy_s_outer);
+    const char* __restrict__ xbase = p.x ? reinterpret_cast<const char*>(p.x + (int64_t)net * p.x_s_net + (int64_t)o_lo * p.x_s_outer) : nullptr;
+    const float* __restrict__ x0 = p.x0 ? p.x0 + (int64_t)net * p.x0_s_net + (int64_t)o_lo * p.x0_s_outer : nullptr;
+    uint32_t acolb[TO], bcolb[WG_TK];
+#pragma unroll
+    for (int t = 0; t < TO; ++t) acolb[t] = 4u * (uint32_t)ocol(p, imin((ot0 + imin(t, not_ - 1)) * 16 + i, p.O - 1));
+#pragma unroll
+    for (int u = 0; u < WG_TK; ++u) bcolb[u] = nkt > 0 ? 4u * (uint32_t)(p.x_col0 + imin((kt0 + imin(u, nkt - 1)) * 16 + i, p.K - 1)) : 0u;
+    // cursors of the rows this lane loads next, one per (block slot j, sub-step s): rows 16j + 4s + g of the block,
+    // advanced by 16 * RB rows per reload without divisions
+    int ri[RB][4], orel[RB][4];
+    uint32_t aoff[RB][4], xoff[RB][4];
+#pragma unroll
+    for (int j = 0; j < RB; ++j)
+#pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int e = (4 * s + g) * 16 + i;
-            float av[WG_TO], bv[WG_TK];
-            for (int t = 0; t < WG_TO; ++t) av[t] = t < not_ ? s_t[buf][t][e] : 0.f;
-            for (int u = 0; u < WG_TK; ++u) bv[u] = u < nkt ? s_t[buf][WG_TO + u][e] : 0.f;
-            for (int t = 0; t < WG_TO; ++t) {
-                if (t < not_) {
-                    for (int u = 0; u < WG_TK; ++u)
-                        if (u < nkt) acc[t][u] = mfma4(av[t], bv[u], acc[t][u]);
-                    if (want_bias) bacc[t] = mfma4(av[t], 1.0f, bacc[t]);
-                }
-            }
+            const int64_t r = r_lo + 16 * j + 4 * s + g;
+            const int ro = (int)(r / p.n_inner);
+            ri[j][s] = (int)(r - (int64_t)ro * p.n_inner);
+            orel[j][s] = ro - o_lo;
+            aoff[j][s] = (uint32_t)(4 * ((int64_t)orel[j][s] * p.dy_s_outer + (int64_t)ri[j][s] * p.dy_s_inner));
+            xoff[j][s] = (uint32_t)(4 * ((int64_t)orel[j][s] * p.x_s_outer + (int64_t)(ri[j][s] + p.x_shift) * p.x_s_inner));
+        }
+    const int adv_o = (16 * RB) / p.n_inner, adv_i = (16 * RB) % p.n_inner;
+    const uint32_t a_adv = (uint32_t)(4 * ((int64_t)adv_o * p.dy_s_outer + (int64_t)adv_i * p.dy_s_inner));
+    const uint32_t x_adv = (uint32_t)(4 * ((int64_t)adv_o * p.x_s_outer + (int64_t)adv_i * p.x_s_inner));
+    const uint32_t a_wrap = (uint32_t)(4 * (p.dy_s_outer - (int64_t)p.n_inner * p.dy_s_inner));
+    const uint32_t x_wrap = (uint32_t)(4 * (p.x_s_outer - (int64_t)p.n_inner * p.x_s_inner));
+    const bool shifted = p.x_shift != 0;
+
+    float av[RB][4][TO], bv[RB][4][WG_TK];
+    // rb = first row of the block that goes to slot j; tail = the block may reach past r_hi (uniform)
+    auto fetch = [&](int64_t rb, int j, int s, bool tail) {
+        const int inner = ri[j][s], outer_rel = orel[j][s];
+        uint32_t ao = aoff[j][s], xo = xoff[j][s];
+        ri[j][s] += adv_i;
+        orel[j][s] += adv_o;
+        aoff[j][s] += a_adv;
+        xoff[j][s] += x_adv;
+        if (ri[j][s] >= p.n_inner) { ri[j][s] -= p.n_inner; orel[j][s] += 1; aoff[j][s] += a_wrap; xoff[j][s] += x_wrap; }
+        const bool rv = !tail || rb + 4 * s + g < r_hi;
+        const bool inr = !shifted || (unsigned)(inner + p.x_shift) < (unsigned)p.n_inner;
+        if (tail) { ao = rv ? ao : 0u; }
+        if (tail || shifted) { xo = (rv && inr) ? xo : 0u; }
+#pragma unroll
+        for (int t = 0; t < TO; ++t) av[j][s][t] = *reinterpret_cast<const float*>(abase + (ao + acolb[t]));
+        if (nkt > 0) {
+#pragma unroll
+            for (int u = 0; u < WG_TK; ++u) bv[j][s][u] = *reinterpret_cast<const float*>(xbase + (xo + bcolb[u]));
+        } else {
+#pragma unroll
+            for (int u = 0; u < WG_TK; ++u) bv[j][s][u] = 0.f;
+        }
+        if (tail && !rv) {
+#pragma unroll
+            for (int t = 0; t < TO; ++t) av[j][s][t] = 0.f;
+#pragma unroll
+            for (int u = 0; u < WG_TK; ++u) bv[j][s][u] = 0.f;
+        }
+        if (shifted && rv && !inr) {                         // the recurrent operand's step before the first one
+#pragma unroll
+            for (int u = 0; u < WG_TK; ++u) bv[j][s][u] = x0 ? x0[(int64_t)outer_rel * p.x0_s_outer + (bcolb[u] >> 2) - p.x_col0] : 0.f;
         }
     };
-    Regs rg;
-    fetch(r_lo, rg);
-    int buf = 0;
-    for (int64_t rb = r_lo; rb < r_hi; rb += 16) {
-        park(rg, buf);
-        if (rb + 16 < r_hi) fetch(rb + 16, rg);            // next block's global loads fly during the MFMAs below
-        __syncthreads();                                    // one wave per workgroup: orders the LDS hand-off
-        contract(buf);
-        buf ^= 1;
+#pragma unroll
+    for (int j = 0; j < RB; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fetch(r_lo + 16 * j, j, s, r_lo + 16 * (j + 1) > r_hi);
+    for (int64_t rb = r_lo; rb < r_hi; rb += 16 * RB) {
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int64_t nb = rb + 16 * (RB + j);           // the block that takes over slot j
+            const bool tail = nb + 16 > r_hi;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                // all TO x TK products, unguarded: tiles past the job's edge repeat the last valid tile (clamped
+                // columns) and their accumulators are simply never written out -- no branches between the MFMAs
+#pragma unroll
+                for (int t = 0; t < TO; ++t) {
+#pragma unroll
+                    for (int u = 0; u < WG_TK; ++u) acc[t][u] = mfma4(av[j][s][t], bv[j][s][u], acc[t][u]);
+                    bsum[t] += av[j][s][t];
+                }
+                // rolling prefetch: the registers of this sub-step are free again
+                fetch(nb, j, s, tail);
+            }
+        }
     }
     // partial tile layout: part[vc][o (OT*16)][KT*16 + 1]; D layout: lane (col j = i, row = 4g + q)
     float* __restrict__ part = a.workspace + p.ws_off + ((int64_t)net * gm.vchunks + vc) * gm.part_floats;
     const int ldp = gm.KT * 16 + 1;
-    for (int t = 0; t < WG_TO; ++t) {
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
         if (t >= not_) continue;
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int o = (ot0 + t) * 16 + 4 * g + q;
+#pragma unroll
             for (int u = 0; u < WG_TK; ++u)
                 if (u < nkt) part[(int64_t)o * ldp + (kt0 + u) * 16 + i] = acc[t][u][q];
-            if (want_bias && i == 0) part[(int64_t)o * ldp + gm.KT * 16] = bacc[t][q];
+        }
+        if (want_bias) {
+            float b = bsum[t];
+            b += __shfl_xor(b, 16);
+            b += __shfl_xor(b, 32);
+            if (g == 0) part[(int64_t)((ot0 + t) * 16 + i) * ldp + gm.KT * 16] = b;
         }
     }
 }
 
 // grid: (ceil(O*(K+1)/256), problem * n_nets + net)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(IplanWgradArgs a) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(IplanWgradArgs a, int chunks_wide) {
     const int pi = (int)blockIdx.y / a.n_nets, net = (int)blockIdx.y % a.n_nets;
     const IplanWgradProblem& p = a.p[pi];
-    const WgradGeom gm = wgrad_geom(p);
+    const WgradGeom gm = wgrad_geom(p, chunks_wide);
     const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int K1 = p.K + 1;
     if (idx >= p.O * K1) return;
@@ -221,7 +246,7 @@ extern "C" size_t iplan_wgrad_workspace_floats(const IplanWgradArgs* a) {
     if (!a) return 0;
     size_t total = 0;
     for (int i = 0; i < a->n_problems; ++i) {
-        const WgradGeom g = wgrad_geom(a->p[i]);
+        const WgradGeom g = wgrad_geom(a->p[i], IPLAN_WGRAD_MAX_CHUNKS);     // upper bound over the chunk targets
         total += (size_t)g.part_floats * g.vchunks * a->n_nets;
     }
     return total;
@@ -231,26 +256,58 @@ extern "C" int iplan_wgrad(IplanWgradArgs* a, iplan_stream_t stream) {
     using namespace iplan;
     if (!a || a->n_problems < 1 || a->n_problems > IPLAN_WGRAD_MAX || a->n_nets < 1 || !a->grad || !a->workspace)
         return fail(IPLAN_EINVAL, "iplan_wgrad: bad arguments");
-    int64_t off = 0;
-    int max_vc = 1, max_jobs = 1, max_elems = 1;
+    int wide_jobs = 0;
     for (int i = 0; i < a->n_problems; ++i) {
         IplanWgradProblem& p = a->p[i];
         if (!p.dy || p.O < 1 || p.O > 1024 || p.K < 0 || p.K > 1024 || (p.K > 0 && !p.x) || p.n_outer < 1 || p.n_inner < 1)
             return fail(IPLAN_EINVAL, "iplan_wgrad: problem %d has unsupported dims O=%d K=%d", i, p.O, p.K);
-        const WgradGeom g = wgrad_geom(p);
+        const WgradGeom g = wgrad_geom(p, IPLAN_WGRAD_MAX_CHUNKS);
+        if (g.to == WG_TO_WIDE) wide_jobs += g.jobs;
+    }
+    // Wide jobs run one wave per SIMD: trim their row chunks so that the waves fill whole rounds of the 1024 SIMDs.
+    int chunks_wide = IPLAN_WGRAD_MAX_CHUNKS;
+    if (wide_jobs > 0) {
+        const int per_chunk = wide_jobs * a->n_nets;
+        const int rounds = imax(1, per_chunk * IPLAN_WGRAD_MAX_CHUNKS / 1024);
+        chunks_wide = imax(1, imin(IPLAN_WGRAD_MAX_CHUNKS, rounds * 1024 / per_chunk));
+    }
+    int64_t off = 0;
+    int max_elems = 1;
+    WgradJobs wide, narrow;
+    wide.n = narrow.n = 0;
+    int vc_wide = 1, vc_narrow = 1;
+    for (int i = 0; i < a->n_problems; ++i) {
+        IplanWgradProblem& p = a->p[i];
+        const WgradGeom g = wgrad_geom(p, chunks_wide);
         p.ws_off = off;
         off += g.part_floats * g.vchunks * a->n_nets;
-        if (g.vchunks > max_vc) max_vc = g.vchunks;
-        if (g.jobs > max_jobs) max_jobs = g.jobs;
         if (p.O * (p.K + 1) > max_elems) max_elems = p.O * (p.K + 1);
+        // the kernel addresses a row chunk with 32-bit byte offsets from the chunk's first outer index
+        const int64_t outers = g.vrows / p.n_inner + 2;
+        const int64_t span_dy = 4 * (outers * llabs(p.dy_s_outer) + (int64_t)(p.n_inner + 1) * llabs(p.dy_s_inner) + 2048);
+        const int64_t span_x = 4 * (outers * llabs(p.x_s_outer) + (int64_t)(p.n_inner + 1) * llabs(p.x_s_inner) + 2048);
+        if (p.dy_s_outer < 0 || p.dy_s_inner < 0 || p.x_s_outer < 0 || p.x_s_inner < 0 || span_dy >= (1ll << 32) || span_x >= (1ll << 32))
+            return fail(IPLAN_EINVAL, "iplan_wgrad: problem %d: a row chunk spans more than 4 GiB (or negative strides)", i);
+        WgradJobs& jl = g.to == WG_TO_WIDE ? wide : narrow;
+        int& vc = g.to == WG_TO_WIDE ? vc_wide : vc_narrow;
+        if (g.vchunks > vc) vc = g.vchunks;
+        for (int j = 0; j < g.jobs; ++j) {
+            if (jl.n >= WG_MAX_JOBS) return fail(IPLAN_EINVAL, "iplan_wgrad: more than %d tile jobs of one shape", WG_MAX_JOBS);
+            jl.pj[jl.n++] = (i << 8) | j;
+        }
     }
     if (off > a->workspace_floats)
         return fail(IPLAN_EINVAL, "iplan_wgrad: workspace too small (%lld floats needed, %lld given)", (long long)off,
                     (long long)a->workspace_floats);
+    // narrow (latency-bound) jobs first: they finish in the shadow of the wide ones' start
+    if (narrow.n)
+        hipLaunchKernelGGL((wgrad_partial_kernel<WG_TO_NARROW, 1>), dim3((unsigned)narrow.n, (unsigned)vc_narrow, (unsigned)a->n_nets),
+                           dim3(64), 0, (hipStream_t)stream, *a, narrow, chunks_wide);
+    if (wide.n)
+        hipLaunchKernelGGL((wgrad_partial_kernel<WG_TO_WIDE, 1>), dim3((unsigned)wide.n, (unsigned)vc_wide, (unsigned)a->n_nets),
+                           dim3(64), 0, (hipStream_t)stream, *a, wide, chunks_wide);
     const unsigned z = (unsigned)(a->n_problems * a->n_nets);
-    hipLaunchKernelGGL(wgrad_partial_kernel, dim3((unsigned)(a->n_problems * max_jobs), (unsigned)max_vc, (unsigned)a->n_nets),
-                       dim3(64), 0, (hipStream_t)stream, *a, max_jobs);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((max_elems + 255) / 256), z), dim3(256), 0,
-                       (hipStream_t)stream, *a);
+                       (hipStream_t)stream, *a, chunks_wide);
     return check_launch("iplan_wgrad");
 }

@@ -7,6 +7,8 @@ the same kernel sources instead.
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -587,7 +589,7 @@ def beh_backward(enc_arena, dec_arena, fwd, lib=None):
     # decoder BPTT first; the encoder's BPTT (which only needs the decoder's per-window d(loss)/d(latent)) then runs on
     # a side stream beside the decoder's weight-gradient contractions
     side = None
-    if dev.type == "cuda":
+    if dev.type == "cuda" and not os.environ.get("IPLAN_BEH_SERIAL"):       # (the knob is for kernel timing experiments)
         main = torch.cuda.current_stream(dev)
         side = _SIDE_STREAMS.setdefault((str(dev), main.cuda_stream), torch.cuda.Stream(dev))
     if side is None:
