@@ -467,7 +467,7 @@ int iplan_pdec_bwd(const IplanPdecArgs* args, iplan_stream_t stream);
  * Encoder parameters: IPLAN_ENC_* (EncoderRNN); decoder parameters: IPLAN_DEC_* of
  * behavior_decoder[i].decoder (DecoderRNN, input d + Z, hidden 64).  rows = E * N, J = T - 1 - L.
  * Per-step records (floats):
- *   saved_dec  x 0 (16) | latent 16 (16) | u 32 | r 96 | z 160 | n 224 | hn 288 | h 352 | a 416 (64 each) | y 480 (16)
+ *   saved_dec  [x_t || latent] 0 (d+Z <= 16 cols) | 16 (16, unused) | u 32 | r 96 | z 160 | n 224 | hn 288 | h 352 | a 416 (64 each) | y 480 (16)
  *   saved_enc  u 0 | r 32 | z 64 | n 96 | hn 128 | h 160 (32 each)
  *   dsave_dec  dy 0 (16) | du 16 | dr 80 | dz 144 | dn_i 208 | dn_h 272 (64 each)
  *   dsave_enc  du 0 | dr 32 | dz 64 | dn_i 96 | dn_h 128 (32 each)

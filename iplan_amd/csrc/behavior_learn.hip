@@ -32,7 +32,7 @@ constexpr int DSD = IPLAN_BEH_DSAVE_DEC, DSE = IPLAN_BEH_DSAVE_ENC, DSL = IPLAN_
 constexpr float BEPS = 1e-10f;
 constexpr int DEC_FWD_BIAS = 64 + 192 + 192 + 16;
 // saved_dec / dsave_dec / saved_enc / dsave_enc column offsets (include/iplan_hip.h)
-constexpr int SD_X = 0, SD_LAT = 16, SD_U = 32, SD_R = 96, SD_Z = 160, SD_N = 224, SD_HN = 288, SD_H = 352, SD_A = 416, SD_Y = 480;
+constexpr int SD_X = 0, SD_U = 32, SD_R = 96, SD_Z = 160, SD_N = 224, SD_HN = 288, SD_H = 352, SD_A = 416, SD_Y = 480;
 constexpr int DD_DY = 0, DD_DU = 16, DD_DR = 80, DD_DZ = 144, DD_DNI = 208, DD_DNH = 272;
 constexpr int SE_U = 0, SE_R = 32, SE_Z = 64, SE_N = 96, SE_HN = 128, SE_H = 160;
 constexpr int DE_DU = 0, DE_DR = 32, DE_DZ = 64, DE_DNI = 96, DE_DNH = 128;
@@ -252,15 +252,22 @@ __global__ __launch_bounds__(512) void beh_dec_fwd_kernel(IplanBehArgs a) {
         f32x4 lat1[1], zproj[DT];
         lat1[0] = dec_only ? vload(a.lat_in + c.grow * a.Z, valid, a.Z, 0) : vload_a(a.saved_lat + (c.grow * J + j) * SVL + 16, valid, 0);
         for (int i = 0; i < DT; ++i) zproj[i] = dense_tile<1>(s_linz, 24, 16 * ((own + i) & 3), lat1, bfrag_lds(s_b, (own + i) & 3));
+        // The record keeps the Linear's input row [x_t || latent] as ONE tile (the weight-gradient contraction then
+        // reads a single operand tile): the latent moved up by d columns, through the wave's exchange area.
+        f32x4 latsh;
+        put(0, lat1[0]);
+        __syncthreads();
+        for (int q = 0; q < 4; ++q) {
+            const int z = 4 * g + q - a.d;
+            latsh[q] = (z >= 0 && z < a.Z) ? xm[64 * (z >> 2) + 4 * c.n + (z & 3)] : 0.f;
+        }
+        __syncthreads();
         for (int t = 0; t < a.L; ++t) {
             const f32x4 xt = dec_only ? vload(a.win + (c.grow * a.L + t) * a.d, valid, a.d, 0) : window_x(a, c.hrow, j, t, valid);
             float* sd = a.saved_dec + ((c.grow * J + j) * a.L + t) * SVD;
             f32x4 x1[1];
             x1[0] = xt;
-            if (hf == 0) {
-                vstore_a(sd + SD_X, valid, 0, xt);
-                vstore_a(sd + SD_LAT, valid, 0, lat1[0]);
-            }
+            if (hf == 0) vstore_a(sd + SD_X, valid, 0, xt + latsh);
             f32x4 u[DT];
             // Linear([x_t || latent]) = W[:, :d] x_t + (W[:, d:] latent + b): the latent part is per window
             for (int i = 0; i < DT; ++i) u[i] = relu4(dense_tile<1>(s_linx, 24, 16 * ((own + i) & 3), x1, zproj[i]));
@@ -677,7 +684,7 @@ __global__ __launch_bounds__(256) void beh_enc_grad_kernel(IplanBehArgs a) {
 static int check_beh(const IplanBehArgs* a, const char* what) {
     if (!a) return fail(IPLAN_EINVAL, "%s: null args", what);
     if (a->n_nets < 1 || a->E < 1 || a->N < 1 || a->L < 1 || (a->hard ? a->T / a->L - 1 : a->T - 1 - a->L) < 1 || a->d < 1 || a->Z < 1 ||
-        a->d > 16 || a->Z > 16)
+        a->d > 16 || a->Z > 16 || a->d + a->Z > 16)
         return fail(IPLAN_EINVAL, "%s: unsupported dims E=%d N=%d T=%d L=%d d=%d Z=%d", what, a->E, a->N, a->T, a->L, a->d, a->Z);
     if (a->win) {
         if (!a->lat_in || !a->hd_in || !a->pred_out || !a->hd_out || a->T != a->L + 2 || !a->saved_dec)

@@ -618,11 +618,9 @@ def beh_backward(enc_arena, dec_arena, fwd, lib=None):
           dw_off=off("decoder.rnn.weight_ih_l0"), db_off=off("decoder.rnn.bias_ih_l0"))
     w.add(dd.data_ptr() + 4 * 80, dd_st, 3 * H, rows, n_in, x=sd + 4 * 352, x_strides=sd_st, K=H, x_shift=-1,
           dw_off=off("decoder.rnn.weight_hh_l0"), db_off=off("decoder.rnn.bias_hh_l0"), seg=(2 * H, 0, 3 * H))
-    # input Linear, split by source column block: [x_t | latent]
-    w.add(dd.data_ptr() + 4 * 16, dd_st, H, rows, n_in, x=sd, x_strides=sd_st, K=d, dw_ld=d + Z,
+    # input Linear: the record keeps its input row [x_t || latent] as one tile
+    w.add(dd.data_ptr() + 4 * 16, dd_st, H, rows, n_in, x=sd, x_strides=sd_st, K=d + Z,
           dw_off=off("decoder.linear.weight"), db_off=off("decoder.linear.bias"))
-    w.add(dd.data_ptr() + 4 * 16, dd_st, H, rows, n_in, x=sd + 4 * 16, x_strides=sd_st, K=Z, dw_ld=d + Z, dw_col0=d,
-          dw_off=off("decoder.linear.weight"))
     w._keep += [dd, fwd]
     w.run(lib)
     if side is not None:
