@@ -346,6 +346,8 @@ typedef struct {
 } IplanAcBwdArgs;
 
 int iplan_ac_kpad(const IplanAcFeatures* feat);   /* padded length of the kernels' source-major feature order */
+int iplan_ac_fc1_groups(const IplanAcFeatures* feat); /* wave jobs along the feature axis of iplan_ac_bwd_fc1 (the caller
+                                                          sizes fc1_chunks so that groups x chunks x nets fill the chip) */
 int iplan_ac_bwd_tail(const IplanAcBwdArgs* args, iplan_stream_t stream);
 int iplan_ac_bwd_fc1(const IplanAcBwdArgs* args, iplan_stream_t stream);
 int iplan_ac_bwd_fc1_finalize(const IplanAcBwdArgs* args, iplan_stream_t stream);
@@ -521,6 +523,12 @@ typedef struct {
     int32_t bwd_phase;          /* iplan_beh_bwd: 0 = decoder then encoder, 1 = decoder BPTT only, 2 = encoder BPTT only
                                    (lets the host run the encoder's BPTT on a second stream beside the decoder's
                                    weight-gradient contractions; phase 2 needs phase 1's dsave_lat)               */
+    /* Decoder BPTT in pieces (bwd_phase == 1): windows [bwd_j_lo, bwd_j_hi) only, processed from the top down;
+     * bwd_j_hi == 0 means all windows.  A piece that does not end at window 0 leaves d(loss)/d(h) of its last
+     * step in dec_carry, the next piece (bwd_j_hi = the previous bwd_j_lo) picks it up -- so the weight-gradient
+     * contraction of the rows a piece produced can run beside the next piece.                                */
+    int32_t bwd_j_lo, bwd_j_hi;
+    float* dec_carry;           /* [n_nets, ceil(rows/16), 2, 512]; needed when the BPTT runs in pieces    */
 } IplanBehArgs;
 
 int iplan_beh_fwd(const IplanBehArgs* args, iplan_stream_t stream);

@@ -51,7 +51,7 @@ class IplanError(RuntimeError):
 ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step", "iplan_wgrad",
                 "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_loss", "iplan_gat_bwd",
                 "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd"]
-RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad"]      # non (args*, stream) signatures
+RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups"]      # non (args*, stream) signatures
 
 
 class Lib:
@@ -295,4 +295,5 @@ class BehArgs(C.Structure):
         ("dsave_dec", fp), ("dsave_enc", fp), ("dsave_lat", fp),
         ("win", fp), ("lat_in", fp), ("hd_in", fp), ("pred_out", fp), ("hd_out", fp), ("hard", i32),
         ("enc_part", fp), ("enc_grad", fp), ("enc_grad_s_net", i64), ("bwd_phase", i32),
+        ("bwd_j_lo", i32), ("bwd_j_hi", i32), ("dec_carry", fp),
     ]

@@ -212,101 +212,149 @@ __global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // G[m][kb] = sum_r dz1[r][m] * xhat[r][kb]   (xhat = (x - mu_r) * rstd_r, LN(F) without its affine part), with the
-// feature axis in the SOURCE-MAJOR K order of ac_kmap.h, so the feature operand is read with plain 16-byte loads
-// from the episode-buffer fields.  Same data path as wgrad.hip: per 16-row block every lane fetches one 16-byte
-// piece of each 16x16 operand tile (row = lane / 4), the tiles are parked in LDS and read back in MFMA operand
-// order, and the next block's loads fly during the current block's 64 MFMAs.
-// grid: (group of 4 k-tiles, row chunk, which * n_agents + net); one wave per workgroup.
+// feature axis in the SOURCE-MAJOR K order of ac_kmap.h.  Same data path as wgrad.hip's wide jobs: a wave owns all
+// 4 o-tiles x up to FC1_KG k-tiles (192 accumulator registers, one wave per SIMD), both operands are loaded from
+// global memory directly in MFMA operand order (sub-step s: lane (i, g) reads dz1[row 4s+g][16t+i] and feature
+// 16u+i of row 4s+g from its source field), addressing is one uniform base per field + 32-bit byte offsets advanced
+// incrementally, and the registers of a sub-step are reloaded for the next block as soon as its MFMAs are issued.
+// dz1 is re-read once per k-group (14 groups at F = 2485), the feature fields exactly once.
+// A wave job never straddles two source blocks of the K order (each block's k-tiles are cut into groups of at most
+// FC1_KG), so a job reads ONE field: one base, one row offset per sub-step, no per-tile selection.
+// grid: (k-group, row chunk, which * n_agents + net); one wave per workgroup.
+constexpr int FC1_KG = 12;
+
+struct Fc1Group { int blk, T0, nkt; };
+// k-group `gid` of the launch -> (source block, first k-tile, tiles); returns the number of groups when gid < 0
+__host__ __device__ inline int fc1_group(const int (&kt0)[5], int gid, Fc1Group* out) {
+    int n = 0;
+    for (int b = 0; b < 4; ++b) {
+        const int tiles = kt0[b + 1] - kt0[b];
+        const int ng = (tiles + FC1_KG - 1) / FC1_KG;
+        if (gid >= n && gid < n + ng && out) {
+            const int j = gid - n;
+            out->blk = b;
+            out->T0 = kt0[b] + (int)(((int64_t)j * tiles) / ng);
+            out->nkt = kt0[b] + (int)(((int64_t)(j + 1) * tiles) / ng) - out->T0;
+        }
+        n += ng;
+    }
+    return n;
+}
+
 __global__ __launch_bounds__(64) void ac_fc1_wgrad_kernel(IplanAcBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_t[2][8][256];
     const IplanAcFwdArgs& fa = a.fwd;
     const IplanAcFeatures& ft = fa.feat;
     const int nz = (int)blockIdx.z;
     const int which_i = nz / fa.n_agents, net = nz % fa.n_agents;
     const int which = fa.which == 2 ? which_i : fa.which;
-    const int l = lane_id(), i = l & 15, g = l >> 4;           // MFMA role
-    const int lr = l >> 2, lc = 4 * (l & 3);                   // loader role
+    const int l = lane_id(), i = l & 15, g = l >> 4;
     const KMap km = make_kmap(ft);
     const int KT = km.kt0[4], Kpad = KT * 16;
-    const int T0 = (int)blockIdx.x * 4;
-    const int nkt = imin(4, KT - T0);
+    Fc1Group grp;
+    grp.blk = 0; grp.T0 = 0; grp.nkt = 0;
+    fc1_group(km.kt0, (int)blockIdx.x, &grp);
+    const int T0 = grp.T0, nkt = grp.nkt, blk = grp.blk;
     const int chunk = (int)blockIdx.y;
     const int64_t r_lo = (int64_t)chunk * a.fc1_chunk_rows;
     const int64_t r_hi = r_lo + a.fc1_chunk_rows < fa.rows ? r_lo + a.fc1_chunk_rows : fa.rows;
+    if (r_lo >= r_hi || nkt <= 0) return;
+    const int n_rows = (int)(r_hi - r_lo);
     const int64_t sbase = ((int64_t)which * fa.n_agents + net) * fa.rows;
+    const bool onehot = blk == 3;
+    const int sk = onehot ? 0 : blk;                           // source field of this job
 
-    // per-tile loader bookkeeping (wave-uniform class: fast = whole tile inside a source block of width % 4 == 0)
-    KTile kt[4];
-    bool fast[4];
-    for (int u = 0; u < 4; ++u) {
-        kt[u] = ktile_at(km, imin(T0 + u, KT - 1), lc);
-        const int s = kt[u].s;
-        fast[u] = u < nkt && s < 3 && (km.w[s] & 3) == 0 && 16 * (T0 + u - km.kt0[s]) + 16 <= km.len[s];
+    // uniform bases; everything per lane is a 32-bit byte offset from them
+    const char* __restrict__ dzb = reinterpret_cast<const char*>(a.dsave + (sbase + r_lo) * IPLAN_AC_DSAVE_FLOATS);
+    const char* __restrict__ stb = reinterpret_cast<const char*>(fa.saved + (sbase + r_lo) * IPLAN_AC_SAVE_FLOATS + 10 * BM);
+    const bool la32 = ft.n_actions > 0 && ft.last_action != nullptr, la64 = ft.n_actions > 0 && !la32 && ft.last_action64 != nullptr;
+    const char* __restrict__ fb =                              // the field the job's feature operand comes from
+        onehot ? (la32 ? reinterpret_cast<const char*>(ft.last_action + (int64_t)net * ft.la_s_net)
+                       : (la64 ? reinterpret_cast<const char*>(ft.last_action64 + (int64_t)net * ft.la64_s_net) : nullptr))
+               : reinterpret_cast<const char*>(ft.src[sk] + (int64_t)net * ft.s_net[sk]);
+    const int64_t f_row = onehot ? (la32 ? 4 * ft.la_s_row : 8 * ft.la64_s_row) : 4 * ft.s_row[sk];   // bytes per physical row
+
+    // this lane's entry of every k-tile: byte offset inside a source row (one-hot block: the index itself).  Entries
+    // past the block's end are clamped: they only feed partial columns that the finalize kernel never reads.
+    uint32_t foff[FC1_KG];
+#pragma unroll
+    for (int u = 0; u < FC1_KG; ++u) {
+        const int f = imin(16 * (T0 + imin(u, nkt - 1) - km.kt0[blk]) + i, km.len[blk] - 1);
+        foff[u] = onehot ? (uint32_t)f : 4u * (uint32_t)f;
     }
-    f32x4 acc[BT][4];
+    // row cursors, one per sub-step s (rows 4s + g of the block): row inside the chunk, step inside the episode and the
+    // offset of the physical row in the field; a block = 16 rows = adv_ep whole episodes + adv_t steps
+    const int adv_ep = 16 / ft.T, adv_t = 16 % ft.T;
+    const uint32_t f_adv = (uint32_t)(((int64_t)adv_ep * ft.T_phys + adv_t) * f_row);
+    const uint32_t f_wrap = (uint32_t)((int64_t)(ft.T_phys - ft.T) * f_row);
+    int rrel[4], tt[4];
+    uint32_t fo[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int64_t r = r_lo + 4 * s + g;
+        const int64_t ep = r / ft.T;
+        rrel[s] = 4 * s + g;
+        tt[s] = (int)(r - ep * ft.T);
+        fo[s] = (uint32_t)((ep * ft.T_phys + tt[s]) * f_row);
+    }
+    f32x4 acc[BT][FC1_KG];
+#pragma unroll
     for (int t = 0; t < BT; ++t)
-        for (int u = 0; u < 4; ++u) acc[t][u] = splat4(0.f);
-
-    struct Regs { f32x4 av[BT]; f32x4 bv[4]; };
-    auto fetch = [&](int64_t rb, Regs& o) {
-        const int64_t r = rb + lr;
-        const bool rv = r < r_hi;
-        const int64_t rc = rv ? r : r_lo;
-        const int64_t pr = (rc / ft.T) * ft.T_phys + (rc % ft.T);
-        const float* dz = a.dsave + (sbase + rc) * IPLAN_AC_DSAVE_FLOATS;
+#pragma unroll
+        for (int u = 0; u < FC1_KG; ++u) acc[t][u] = splat4(0.f);
+    float av[4][BT], bv[4][FC1_KG];
+    // load sub-step s of the next block (tail: its rows may lie past the chunk's end)
+    auto fetch = [&](int s, bool tail) {
+        const bool rv = !tail || rrel[s] < n_rows;
+        uint32_t of = fo[s];
+        uint32_t od = (uint32_t)rrel[s] * (uint32_t)(4 * IPLAN_AC_DSAVE_FLOATS), os = (uint32_t)rrel[s] * (uint32_t)(4 * IPLAN_AC_SAVE_FLOATS);
+        if (tail) { of = rv ? of : 0u; od = rv ? od : 0u; os = rv ? os : 0u; }
+        rrel[s] += 16;
+        tt[s] += adv_t;
+        fo[s] += f_adv;
+        if (tt[s] >= ft.T) { tt[s] -= ft.T; fo[s] += f_wrap; }
+        const float mu = *reinterpret_cast<const float*>(stb + os), rstd = *reinterpret_cast<const float*>(stb + (os + 4u));
+        const float nm = -mu * rstd;
+#pragma unroll
         for (int t = 0; t < BT; ++t) {
-            o.av[t] = *reinterpret_cast<const f32x4*>(dz + 16 * t + lc);
-            if (!rv) o.av[t] = splat4(0.f);
+            const float v = *reinterpret_cast<const float*>(dzb + (od + (uint32_t)(64 * t + 4 * i)));
+            av[s][t] = rv ? v : 0.f;
         }
-        const float* st = fa.saved + (sbase + rc) * IPLAN_AC_SAVE_FLOATS + 10 * BM;
-        const float mu = st[0], rstd = st[1];
-        const float* src[3];
-        for (int s = 0; s < 3; ++s) src[s] = ft.w[s] > 0 ? ft.src[s] + (int64_t)net * ft.s_net[s] + pr * ft.s_row[s] : nullptr;
-        int last = -1;
-        if (ft.n_actions > 0) {
-            if (ft.last_action) last = ft.last_action[(int64_t)net * ft.la_s_net + pr * ft.la_s_row];
-            else if (ft.last_action64) last = (int)ft.last_action64[(int64_t)net * ft.la64_s_net + pr * ft.la64_s_row];
-        }
-        for (int u = 0; u < 4; ++u) {
-            f32x4 x = splat4(0.f);
-            int nv = 0;
-            if (u < nkt) {
-                if (fast[u]) { x = ldu4(src[kt[u].s] + kt[u].f0); nv = 4; }
-                else { x = kfeat(km, kt[u], src, true, last, net); nv = kt[u].nv; }
+        if (!onehot) {
+#pragma unroll
+            for (int u = 0; u < FC1_KG; ++u) bv[s][u] = fmaf(*reinterpret_cast<const float*>(fb + (of + foff[u])), rstd, nm);
+        } else {
+            int last = -1;
+            if (la32) last = *reinterpret_cast<const int32_t*>(fb + of);
+            else if (la64) last = (int)*reinterpret_cast<const int64_t*>(fb + of);
+#pragma unroll
+            for (int u = 0; u < FC1_KG; ++u) {
+                const int idx = (int)foff[u];
+                const float x = idx < km.n_actions ? (idx == last ? 1.0f : 0.0f) : (idx - km.n_actions == net ? 1.0f : 0.0f);
+                bv[s][u] = fmaf(x, rstd, nm);
             }
-            for (int q = 0; q < 4; ++q) x[q] = (rv && q < nv) ? (x[q] - mu) * rstd : 0.f;
-            o.bv[u] = x;
         }
     };
-    auto park = [&](const Regs& o, int buf) {
-        for (int t = 0; t < BT; ++t) *reinterpret_cast<f32x4*>(&s_t[buf][t][lr * 16 + lc]) = o.av[t];
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(&s_t[buf][4 + u][lr * 16 + lc]) = o.bv[u];
-    };
-    auto contract = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fetch(s, 16 > n_rows);
+    for (int rb = 0; rb < n_rows; rb += 16) {
+        const bool tail = rb + 32 > n_rows;
+#pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int e = (4 * s + g) * 16 + i;
-            float av[BT], bv[4];
-            for (int t = 0; t < BT; ++t) av[t] = s_t[buf][t][e];
-            for (int u = 0; u < 4; ++u) bv[u] = s_t[buf][4 + u][e];
+#pragma unroll
             for (int t = 0; t < BT; ++t)
-                for (int u = 0; u < 4; ++u) acc[t][u] = mfma4(av[t], bv[u], acc[t][u]);
+#pragma unroll
+                for (int u = 0; u < FC1_KG; ++u) acc[t][u] = mfma4(av[s][t], bv[s][u], acc[t][u]);
+            fetch(s, tail);                                  // rolling prefetch of the next block's sub-step s
         }
-    };
-    Regs rg;
-    fetch(r_lo, rg);
-    int buf = 0;
-    for (int64_t rb = r_lo; rb < r_hi; rb += 16) {
-        park(rg, buf);
-        if (rb + 16 < r_hi) fetch(rb + 16, rg);
-        __syncthreads();
-        contract(buf);
-        buf ^= 1;
     }
     float* part = a.g_part + (((int64_t)which_i * fa.n_agents + net) * a.fc1_chunks + chunk) * (int64_t)BM * Kpad;
+#pragma unroll
     for (int t = 0; t < BT; ++t)
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int m = 16 * t + 4 * g + q;
-            for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int u = 0; u < FC1_KG; ++u)
                 if (u < nkt) part[(int64_t)m * Kpad + (T0 + u) * 16 + i] = acc[t][u][q];
         }
 }
@@ -374,6 +422,17 @@ extern "C" int iplan_ac_bwd_tail(const IplanAcBwdArgs* a, iplan_stream_t stream)
     return check_launch("iplan_ac_bwd_tail");
 }
 
+extern "C" int iplan_ac_fc1_groups(const IplanAcFeatures* ft) {
+    using namespace iplan;
+    if (!ft) return 0;
+    int kt0[5], t = 0;
+    for (int s = 0; s < 3; ++s) { kt0[s] = t; t += (ft->N * ft->w[s] + 15) / 16; }
+    kt0[3] = t;
+    t += (ft->n_actions + ft->n_id + 15) / 16;
+    kt0[4] = t;
+    return fc1_group(kt0, -1, nullptr);
+}
+
 extern "C" int iplan_ac_bwd_fc1(const IplanAcBwdArgs* a, iplan_stream_t stream) {
     using namespace iplan;
     if (int rc = check_bwd_args(a, "iplan_ac_bwd_fc1")) return rc;
@@ -382,7 +441,7 @@ extern "C" int iplan_ac_bwd_fc1(const IplanAcBwdArgs* a, iplan_stream_t stream) 
         return fail(IPLAN_EINVAL, "iplan_ac_bwd_fc1: bad chunking (%d chunks x %d rows for %d rows)", a->fc1_chunks,
                     a->fc1_chunk_rows, a->fwd.rows);
     const unsigned nw = a->fwd.which == 2 ? 2u : 1u;
-    dim3 grid((unsigned)((iplan_ac_kpad(&a->fwd.feat) / 16 + 3) / 4), (unsigned)a->fc1_chunks, nw * (unsigned)a->fwd.n_agents);
+    dim3 grid((unsigned)iplan_ac_fc1_groups(&a->fwd.feat), (unsigned)a->fc1_chunks, nw * (unsigned)a->fwd.n_agents);
     hipLaunchKernelGGL(ac_fc1_wgrad_kernel, grid, dim3(64), 0, (hipStream_t)stream, *a);
     return check_launch("iplan_ac_bwd_fc1");
 }

@@ -419,14 +419,18 @@ __global__ __launch_bounds__(512) void beh_dec_bwd_kernel(IplanBehArgs a) {
         o.nx = vload(c.hrow + (int64_t)beh_y_step(a, j, t) * a.h_s_t, valid, a.d, 0);
         o.m = valid ? c.mrow[beh_m_step(a, j, t)] : 0.f;
     };
+    // window range of this launch (the BPTT may run in pieces, see bwd_j_lo / bwd_j_hi in the header)
+    const int j_hi = a.bwd_j_hi > 0 ? imin(a.bwd_j_hi, J) : J, j_lo = imax(a.bwd_j_lo, 0);
+    float* carry = a.dec_carry ? a.dec_carry + ((((int64_t)net * c.tiles + imin(c.tile, c.tiles - 1)) * 2 + hf) * 512) : nullptr;
     f32x4 dhd[2], hcur[2];
-    for (int tt = 0; tt < 2; ++tt) dhd[tt] = splat4(0.f);
+    for (int tt = 0; tt < 2; ++tt)
+        dhd[tt] = (j_hi < J && carry) ? *reinterpret_cast<const f32x4*>(carry + 256 * tt + 4 * l) : splat4(0.f);
     StepIn cur;
-    load_step(J - 1, a.L - 1, cur);
-    for (int tt = 0; tt < 2; ++tt) hcur[tt] = vload_a(a.saved_dec + ((c.grow * J + (J - 1)) * a.L + (a.L - 1)) * SVD + SD_H, valid, own + tt);
+    load_step(j_hi - 1, a.L - 1, cur);
+    for (int tt = 0; tt < 2; ++tt) hcur[tt] = vload_a(a.saved_dec + ((c.grow * J + (j_hi - 1)) * a.L + (a.L - 1)) * SVD + SD_H, valid, own + tt);
     int od[DT];
     for (int i = 0; i < DT; ++i) od[i] = 16 * ((own + i) & 3);                             // output tiles in rotated order
-    for (int j = J - 1; j >= 0; --j) {
+    for (int j = j_hi - 1; j >= j_lo; --j) {
         const float scale = (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS) / (a.hard ? 1.0f : (float)J);
         f32x4 dlat = splat4(0.f);                           // d(loss)/d(latent_j) through this window's decoder inputs (own share)
         for (int t = a.L - 1; t >= 0; --t) {
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(512) void beh_dec_bwd_kernel(IplanBehArgs a) {
             }
             IPLAN_SCHED_FENCE();
             if (t > 0) load_step(j, t - 1, cur);
-            else if (j > 0) load_step(j - 1, a.L - 1, cur);
+            else if (j > j_lo) load_step(j - 1, a.L - 1, cur);
             IPLAN_SCHED_FENCE();
             // ---- part B: this half's k-tiles of the backward-data products, all four output tiles
             f32x4 du[DT], pd[DT];
@@ -496,6 +500,8 @@ __global__ __launch_bounds__(512) void beh_dec_bwd_kernel(IplanBehArgs a) {
         if (hf == 0) vstore_a(a.dsave_lat + (c.grow * J + j) * DSL, valid, 0, dlat + get(0));
         __syncthreads();
     }
+    if (j_lo > 0 && carry && c.tile < c.tiles)
+        for (int tt = 0; tt < 2; ++tt) *reinterpret_cast<f32x4*>(carry + 256 * tt + 4 * l) = dhd[tt];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -722,6 +728,9 @@ extern "C" int iplan_beh_bwd(const IplanBehArgs* a, iplan_stream_t stream) {
     if (a->win) return fail(IPLAN_EINVAL, "iplan_beh_bwd: not available in single-window decoder mode");
     if (!a->dsave_dec || !a->dsave_lat || !a->enc_part || !a->enc_grad)
         return fail(IPLAN_EINVAL, "iplan_beh_bwd: dsave_dec / dsave_lat / enc_part / enc_grad missing");
+    if ((a->bwd_j_lo > 0 || a->bwd_j_hi > 0) && (a->bwd_phase != 1 || !a->dec_carry || a->bwd_j_lo < 0 ||
+                                                 (a->bwd_j_hi > 0 && a->bwd_j_hi <= a->bwd_j_lo)))
+        return fail(IPLAN_EINVAL, "iplan_beh_bwd: a window range needs bwd_phase == 1, dec_carry and 0 <= bwd_j_lo < bwd_j_hi");
     const int tiles = (a->E * a->N + 15) / 16;
     const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets);
     const size_t lds = sizeof(float) * (2 * DHd * (3 * DHd + 8) + DHd * 24 + 16 * DLD + 8 * 4 * 256);

@@ -377,9 +377,12 @@ def ac_backward(fwd, actor_arena, critic_arena, g_logp=None, g_entropy=0.0, g_va
     ln_part = torch.empty(2, n_agents, tiles, L.AC_LNPART_FLOATS, **f32)
     a.dsave, a.ln_part = dsave.data_ptr(), ln_part.data_ptr()
     Fpad = int(lib.c.iplan_ac_kpad(C.byref(fa.feat)))
-    chunk_rows = max(256, ((rows + 31) // 32 + 15) // 16 * 16)
-    chunks = (rows + chunk_rows - 1) // chunk_rows
     n_which = 2 if which == 2 else 1
+    # the fc1 contraction runs one wave per SIMD (12 k-tiles x 4 o-tiles per wave): as many row chunks as fill the chip once
+    k_groups = int(lib.c.iplan_ac_fc1_groups(C.byref(fa.feat)))
+    want = max(1, 1024 // (k_groups * n_which * n_agents))
+    chunk_rows = max(256, ((rows + want - 1) // want + 15) // 16 * 16)
+    chunks = (rows + chunk_rows - 1) // chunk_rows
     g_part = workspace(dev, n_which * n_agents * chunks * L.AC_HIDDEN * Fpad, "fc1")
     a.g_part, a.fc1_chunk_rows, a.fc1_chunks = g_part.data_ptr(), chunk_rows, chunks
     stream = L.current_stream(dev)
@@ -586,46 +589,62 @@ def beh_backward(enc_arena, dec_arena, fwd, lib=None):
     ep = torch.empty(n_nets, tiles, L.BEH_ENC_PART, **f32)
     a.dsave_dec, a.dsave_lat, a.enc_part = dd.data_ptr(), dl.data_ptr(), ep.data_ptr()
     a.enc_grad, a.enc_grad_s_net = enc_arena.grad.data_ptr(), enc_arena.grad.stride(0)
-    # decoder BPTT first; the encoder's BPTT (which only needs the decoder's per-window d(loss)/d(latent)) then runs on
-    # a side stream beside the decoder's weight-gradient contractions
-    side = None
-    if dev.type == "cuda" and not os.environ.get("IPLAN_BEH_SERIAL"):       # (the knob is for kernel timing experiments)
-        main = torch.cuda.current_stream(dev)
-        side = _SIDE_STREAMS.setdefault((str(dev), main.cuda_stream), torch.cuda.Stream(dev))
-    if side is None:
-        a.bwd_phase = 0
-        lib.call("iplan_beh_bwd", a, L.current_stream(dev))
-    else:
-        a.bwd_phase = 1
-        lib.call("iplan_beh_bwd", a, main.cuda_stream)
-        ev = torch.cuda.Event()
-        ev.record(main)
-        side.wait_event(ev)
-        a.bwd_phase = 2
-        lib.call("iplan_beh_bwd", a, side.cuda_stream)
-        ev_done = torch.cuda.Event()
-        ev_done.record(side)
     SD, DD = L.BEH_SAVE_DEC, L.BEH_DSAVE_DEC
     n_in = J * Lw
     sd = fwd["saved_dec"].data_ptr()
     sd_st, dd_st = (rows * n_in * SD, n_in * SD, SD), (rows * n_in * DD, n_in * DD, DD)
     H = 64
     off = dec_arena.off
-    w = Wgrad(dec_arena.grad, n_nets)
-    w.add(dd.data_ptr(), dd_st, d, rows, n_in, x=sd + 4 * 416, x_strides=sd_st, K=H,
-          dw_off=off("decoder.out.weight"), db_off=off("decoder.out.bias"))
-    w.add(dd.data_ptr() + 4 * 80, dd_st, 3 * H, rows, n_in, x=sd + 4 * 32, x_strides=sd_st, K=H,
-          dw_off=off("decoder.rnn.weight_ih_l0"), db_off=off("decoder.rnn.bias_ih_l0"))
-    w.add(dd.data_ptr() + 4 * 80, dd_st, 3 * H, rows, n_in, x=sd + 4 * 352, x_strides=sd_st, K=H, x_shift=-1,
-          dw_off=off("decoder.rnn.weight_hh_l0"), db_off=off("decoder.rnn.bias_hh_l0"), seg=(2 * H, 0, 3 * H))
-    # input Linear: the record keeps its input row [x_t || latent] as one tile
-    w.add(dd.data_ptr() + 4 * 16, dd_st, H, rows, n_in, x=sd, x_strides=sd_st, K=d + Z,
-          dw_off=off("decoder.linear.weight"), db_off=off("decoder.linear.bias"))
-    w._keep += [dd, fwd]
-    w.run(lib)
+
+    def dec_wgrad(s0, s1, beta):
+        """decoder weight gradients over the rows of steps [s0, s1) of every chain (accumulating when beta = 1)"""
+        w = Wgrad(dec_arena.grad, n_nets)
+        ddp, sdp, n = dd.data_ptr() + 4 * s0 * DD, sd + 4 * s0 * SD, s1 - s0
+        w.add(ddp, dd_st, d, rows, n, x=sdp + 4 * 416, x_strides=sd_st, K=H, beta=beta,
+              dw_off=off("decoder.out.weight"), db_off=off("decoder.out.bias"))
+        w.add(ddp + 4 * 80, dd_st, 3 * H, rows, n, x=sdp + 4 * 32, x_strides=sd_st, K=H, beta=beta,
+              dw_off=off("decoder.rnn.weight_ih_l0"), db_off=off("decoder.rnn.bias_ih_l0"))
+        # recurrent operand = the previous step's hidden state; the step before a piece's first one is still in the record
+        w.add(ddp + 4 * 80, dd_st, 3 * H, rows, n, x=sdp + 4 * 352, x_strides=sd_st, K=H, x_shift=-1, beta=beta,
+              x0=(sdp + 4 * 352 - 4 * SD) if s0 > 0 else None, x0_strides=(sd_st[0], sd_st[1]),
+              dw_off=off("decoder.rnn.weight_hh_l0"), db_off=off("decoder.rnn.bias_hh_l0"), seg=(2 * H, 0, 3 * H))
+        # input Linear: the record keeps its input row [x_t || latent] as one tile
+        w.add(ddp + 4 * 16, dd_st, H, rows, n, x=sdp, x_strides=sd_st, K=d + Z, beta=beta,
+              dw_off=off("decoder.linear.weight"), db_off=off("decoder.linear.bias"))
+        w._keep += [dd, fwd]
+        w.run(lib)
+
+    # Pipeline: the decoder BPTT runs in pieces (top windows first) on the main stream; the weight-gradient contraction
+    # of the rows a piece produced runs on a side stream beside the next piece (the BPTT kernel holds 138 of the 256
+    # CUs), and the encoder's BPTT -- which needs every window's d(loss)/d(latent) -- follows the last piece.
+    side = None
+    if dev.type == "cuda" and not os.environ.get("IPLAN_BEH_SERIAL"):       # (the knob is for kernel timing experiments)
+        main = torch.cuda.current_stream(dev)
+        side = _SIDE_STREAMS.setdefault((str(dev), main.cuda_stream), torch.cuda.Stream(dev))
+    pieces = max(1, min(int(os.environ.get("IPLAN_BEH_PIECES", "4" if side is not None else "1")), J))
+    bounds = [round(J * k / pieces) for k in range(pieces + 1)]
+    carry = torch.empty(n_nets, tiles, 2, 512, **f32)
+    a.dec_carry = carry.data_ptr()
+    stream = L.current_stream(dev)
+    for k in range(pieces, 0, -1):
+        a.bwd_phase, a.bwd_j_lo, a.bwd_j_hi = 1, bounds[k - 1], bounds[k]
+        lib.call("iplan_beh_bwd", a, stream)
+        beta = 0.0 if k == pieces else 1.0
+        if side is None:
+            dec_wgrad(bounds[k - 1] * Lw, bounds[k] * Lw, beta)
+        else:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                dec_wgrad(bounds[k - 1] * Lw, bounds[k] * Lw, beta)
+    a.bwd_phase, a.bwd_j_lo, a.bwd_j_hi = 2, 0, 0
+    lib.call("iplan_beh_bwd", a, stream)
     if side is not None:
+        ev_done = torch.cuda.Event()
+        ev_done.record(side)
         main.wait_event(ev_done)
-        for t in (dl, ep, fwd["saved_enc"], fwd["saved_lat"]):      # touched by the side stream: keep the allocator honest
+        for t in (dd, carry, fwd["saved_dec"]):                         # touched by the side stream: keep the allocator honest
             t.record_stream(side)
     return dict(dsave_dec=dd, dsave_lat=dl, enc_part=ep)
 

@@ -124,6 +124,13 @@ def test_behavior_learn_emulated(golden):
     check_behavior_learn(golden("behavior_learn"), "cpu")
 
 
+def test_behavior_learn_bptt_in_pieces_emulated(golden, monkeypatch):
+    """The decoder BPTT cut into window ranges (carry of d(loss)/d(h) between the launches, weight gradients
+    accumulated piece by piece -- the GPU path's pipelining) lands on the same reference parameters."""
+    monkeypatch.setenv("IPLAN_BEH_PIECES", "3")
+    check_behavior_learn(golden("behavior_learn"), "cpu")
+
+
 def test_ippo_reference_shaped_methods_emulated(golden):
     """compute_returns / generate_data / ppo_update (the reference's per-agent surface) reproduce the fused train():
     replaying the golden run agent by agent, epoch by epoch, lands on the reference's post-train parameters."""
