@@ -206,69 +206,35 @@ def main():
     for _ in range(opt.warmup):
         one_step()
     barrier()
+    # roofline timing of the two dominant kernels, live in the timed region: HIP events on the launch stream right
+    # around every beh_dec_bwd launch and every 8th gat_fwd launch (ops.KernelTimers)
+    from iplan_amd import ops
+    ops.TIMERS = ops.KernelTimers(every={"gat_fwd_kernel": 8})
     t0 = time.perf_counter()
     for _ in range(opt.steps):
         one_step()
     barrier()
     dt = time.perf_counter() - t0
+    timed = ops.TIMERS.summary()
+    ops.TIMERS = None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     env_steps = opt.steps * rollouts_per_step * E * args.episode_limit * world
 
-    # ---- roofline of the dominant kernels, timed live with HIP events on the launch stream (torch's current stream)
-    from iplan_amd import _lib as L
-    from iplan_amd import ops
-    from iplan_amd.nova.GAT_Net import gumbel_noise
-    nA, N, d, Z, A = args.n_agents, args.max_vehicle_num, args.obs_shape_single, args.latent_dim, args.attention_dim
-    lib = L.get_lib()
-
-    def event_time(fn, iters, warm=2):
-        for _ in range(warm):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters / 1e3
-
-    # (1) beh_dec_bwd_kernel -- decoder BPTT of Behavior_policy.learn, the largest single share of a training cycle
-    with contextlib.redirect_stdout(io.StringIO()):
-        batch = loop.rollout()
-    hist_b = batch["history"][:, :-1].permute(2, 0, 1, 3, 4)
-    mask_b = batch["terminated"][:, :-1, :, 0].permute(2, 0, 1).to(torch.float32).contiguous()
-    fwd = ops.beh_forward(loop.behavior.enc_arena, loop.behavior.dec_arena, hist_b, mask_b, args.max_history_len, Z,
-                          args.soft_update_coef, args.thres_small_variation, args.decoder_dropout, seed=1)
-    ba = fwd["_args"]
-    T_b, Lw = args.episode_limit, args.max_history_len
-    J = T_b - 1 - Lw
-    rows_b = E * N
-    dsd = torch.empty(nA, rows_b, J, Lw, L.BEH_DSAVE_DEC, device=dev)
-    dsl = torch.empty(nA, rows_b, J, L.BEH_DSAVE_LAT, device=dev)
-    epart = torch.empty(nA, (rows_b + 15) // 16, L.BEH_ENC_PART, device=dev)
-    ba.dsave_dec, ba.dsave_lat, ba.enc_part = dsd.data_ptr(), dsl.data_ptr(), epart.data_ptr()
-    ba.enc_grad, ba.enc_grad_s_net = loop.behavior.enc_arena.grad.data_ptr(), loop.behavior.enc_arena.grad.stride(0)
-    ba.bwd_phase = 1                                              # decoder BPTT only
-    stream = L.current_stream(dev)
-    bwd_s = event_time(lambda: lib.call("iplan_beh_bwd", ba, stream), iters=3, warm=1)
-    Hd = args.decoder_rnn_dim
-    # decoder V*L*(2(d+Z)*64 + 12*64^2 + 2*64*d) FLOPs per window forward; the backward-data pass
-    # (this kernel) is 1x that, the weight-gradient pass (wgrad) the other 1x
-    flops_b = nA * rows_b * J * Lw * (2 * (d + Z) * Hd + 12 * Hd * Hd + 2 * Hd * d)
-    del fwd, dsd, dsl, epart
-    torch.cuda.empty_cache()
-
-    # (2) gat_fwd_kernel -- dominant kernel of the rollout
-    hist = loop.obs_sets[0]["hist"][0].permute(1, 0, 2, 3)
-    lat = torch.softmax(torch.randn(nA, E, N, Z, device=dev), -1)
-    hid = torch.randn(nA, E, N, A, device=dev) * 0.1
-    noise = gumbel_noise((nA, E, N, N - 1, 2), dev)
-    out = torch.empty(nA, E, N, A, device=dev)
-    gat_s = event_time(lambda: ops.gat_forward(loop.prediction.gat_arena, hist, lat, hid, noise, out=out), iters=20, warm=3)
+    nA, N, d, Z = args.n_agents, args.max_vehicle_num, args.obs_shape_single, args.latent_dim
+    # (1) gat_fwd_kernel -- rollout GAT_latent_update, the largest share of a training cycle and on its critical path
+    gat_n, gat_s = timed.get("gat_fwd_kernel", (0, float("nan")))
     flops = gat_algorithmic_flops(nA, E, N, d + Z)
+    # (2) beh_dec_bwd_kernel -- decoder BPTT of Behavior_policy.learn; one learn() launches it BEH_PIECES times (window
+    # ranges, pipelined with the weight-gradient contraction).  SURVEY.md §8(d): decoder V*L*(2(d+Z)*64 + 12*64^2 + 2*64*d)
+    # FLOPs per window forward; the backward-data pass (this kernel) is 1x that, the weight-gradient pass the other 1x.
+    bwd_n, bwd_s = timed.get("beh_dec_bwd_kernel", (0, float("nan")))
+    Hd, Lw = args.decoder_rnn_dim, args.max_history_len
+    J = args.episode_limit - 1 - Lw
+    pieces = max(1, bwd_n // max(1, opt.steps * rollouts_per_step))
+    flops_b = nA * E * N * J * Lw * (2 * (d + Z) * Hd + 12 * Hd * Hd + 2 * Hd * d) / pieces
 
     if rank == 0:
         line = {
@@ -281,20 +247,22 @@ def main():
                                    "insert + Behavior_policy.learn + Prediction_policy.learn, then IPPOLearner.train "
                                    "(15 epochs x 255 x 90 rows x 5 agents)" + (" [ROLLOUT ONLY diagnostic]" if opt.rollout_only else ""),
                        "envs_per_gpu": E, "rollouts_per_step": rollouts_per_step, "env_steps_per_step": rollouts_per_step * E * args.episode_limit},
-            "roofline": {"kernel": "beh_dec_bwd_kernel", "bound": "mfma", "achieved": flops_b / bwd_s / 1e12,
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops_b / bwd_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                         # HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB) of the rocprofv3 --pmc passes committed in
-                         # profiles/ (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); measured at this exact shape
-                         "traffic": PMC_TRAFFIC_BYTES.get(("beh_dec_bwd_kernel", E)), "us_per_launch": bwd_s * 1e6,
-                         "algorithmic_gflop_per_launch": flops_b / 1e9,
-                         "note": "decoder BPTT of Behavior_policy.learn (5 nets x E*55 chains x 79 windows x 10 steps); launched "
-                                 f"{rollouts_per_step}x per step"},
+            # HBM bytes per launch ("traffic") = 2 x FETCH_SIZE + WRITE_SIZE (KiB) of the rocprofv3 --pmc passes committed in
+            # profiles/ (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); measured at this exact shape
+            "roofline": {"kernel": "gat_fwd_kernel", "bound": "mfma", "achieved": flops / gat_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flops / gat_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": PMC_TRAFFIC_BYTES.get(("gat_fwd_kernel", E)), "us_per_launch": gat_s * 1e6,
+                         "launches_timed": gat_n, "algorithmic_gflop_per_launch": flops / 1e9,
+                         "note": f"rollout GAT_latent_update (5 nets x {E} envs x 55 entities), launched "
+                                 f"{rollouts_per_step * (args.episode_limit + 1)}x per step; timed in the timed region"},
             "roofline_others": [
-                {"kernel": "gat_fwd_kernel", "bound": "mfma", "achieved": flops / gat_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
-                 "unit": "TFLOP/s", "frac": flops / gat_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                 "traffic": PMC_TRAFFIC_BYTES.get(("gat_fwd_kernel", E)), "us_per_launch": gat_s * 1e6,
-                 "algorithmic_gflop_per_launch": flops / 1e9,
-                 "note": f"rollout GAT_latent_update, launched {rollouts_per_step * (args.episode_limit + 1)}x per step"}],
+                {"kernel": "beh_dec_bwd_kernel", "bound": "mfma", "achieved": flops_b / bwd_s / 1e12,
+                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops_b / bwd_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                 "traffic": PMC_TRAFFIC_BYTES.get(("beh_dec_bwd_kernel", E)), "us_per_launch": bwd_s * 1e6,
+                 "launches_timed": bwd_n, "algorithmic_gflop_per_launch": flops_b / 1e9,
+                 "note": f"decoder BPTT of Behavior_policy.learn (5 nets x E*55 chains x 79 windows x 10 steps) in {pieces} "
+                         f"window-range launches per learn(), {pieces * rollouts_per_step} per step; runs beside the weight-gradient "
+                         "contraction of the previous piece, timed in the timed region"}],
         }
         if not opt.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, E)

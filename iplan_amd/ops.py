@@ -75,7 +75,7 @@ def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None
         )
         for k, v in saved.items():
             setattr(a.saved, k, v.data_ptr())
-    lib.call("iplan_gat_fwd", a, L.current_stream(dev))
+    _launch("gat_fwd_kernel", lambda: lib.call("iplan_gat_fwd", a, L.current_stream(dev)))
     if saved is not None:
         saved["_args"] = a
         saved["_keep"] = (src0, src1, h_prev, noise, out)
@@ -249,6 +249,40 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
 # ---- weight gradients ----------------------------------------------------------------------------------
 _WORKSPACES = {}
 _SIDE_STREAMS = {}
+
+
+class KernelTimers:
+    """In-situ kernel timing for bench.py's roofline: HIP events recorded on the launch stream right around selected
+    launches (every ``every[name]``-th one) while the real workload runs.  ``ops.TIMERS = KernelTimers(...)`` turns
+    it on; ``summary()`` (after a device synchronise) gives {name: (launches timed, mean seconds)}."""
+
+    def __init__(self, every=None):
+        self.every = dict(every or {})
+        self.count = {}
+        self.spans = {}
+
+    def launch(self, name, fn):
+        n = self.count.get(name, 0)
+        self.count[name] = n + 1
+        if n % self.every.get(name, 1):
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.spans.setdefault(name, []).append((e0, e1))
+
+    def summary(self):
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v) / 1e3) for k, v in self.spans.items()}
+
+
+TIMERS = None
+
+
+def _launch(name, fn):
+    if TIMERS is None:
+        return fn()
+    return TIMERS.launch(name, fn)
 
 
 def workspace(device, floats, tag="wgrad"):
@@ -628,7 +662,7 @@ def beh_backward(enc_arena, dec_arena, fwd, lib=None):
     stream = L.current_stream(dev)
     for k in range(pieces, 0, -1):
         a.bwd_phase, a.bwd_j_lo, a.bwd_j_hi = 1, bounds[k - 1], bounds[k]
-        lib.call("iplan_beh_bwd", a, stream)
+        _launch("beh_dec_bwd_kernel", lambda: lib.call("iplan_beh_bwd", a, stream))
         beta = 0.0 if k == pieces else 1.0
         if side is None:
             dec_wgrad(bounds[k - 1] * Lw, bounds[k] * Lw, beta)
