@@ -528,7 +528,13 @@ typedef struct {
      * step in dec_carry, the next piece (bwd_j_hi = the previous bwd_j_lo) picks it up -- so the weight-gradient
      * contraction of the rows a piece produced can run beside the next piece.                                */
     int32_t bwd_j_lo, bwd_j_hi;
-    float* dec_carry;           /* [n_nets, ceil(rows/16), 2, 512]; needed when the BPTT runs in pieces    */
+    float* dec_carry;           /* [n_nets, ceil(rows/16), 2, 512]; needed when the decoder runs in pieces */
+    /* The forward in pieces, same idea (the encoder of the next windows runs beside the decoder of the current
+     * ones): fwd_phase 0 = encoder, decoder and loss reduction; 1 = encoder only; 2 = decoder only; 3 = loss
+     * reduction only.  Windows [fwd_j_lo, fwd_j_hi), bottom up; fwd_j_hi == 0 means all.  Hidden states / latent
+     * cross the pieces in enc_carry [n_nets, ceil(rows/16), 768] and dec_carry; loss partials accumulate.      */
+    int32_t fwd_phase, fwd_j_lo, fwd_j_hi;
+    float* enc_carry;
 } IplanBehArgs;
 
 int iplan_beh_fwd(const IplanBehArgs* args, iplan_stream_t stream);

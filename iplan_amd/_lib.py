@@ -296,4 +296,5 @@ class BehArgs(C.Structure):
         ("win", fp), ("lat_in", fp), ("hd_in", fp), ("pred_out", fp), ("hd_out", fp), ("hard", i32),
         ("enc_part", fp), ("enc_grad", fp), ("enc_grad_s_net", i64), ("bwd_phase", i32),
         ("bwd_j_lo", i32), ("bwd_j_hi", i32), ("dec_carry", fp),
+        ("fwd_phase", i32), ("fwd_j_lo", i32), ("fwd_j_hi", i32), ("enc_carry", fp),
     ]

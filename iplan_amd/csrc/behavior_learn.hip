@@ -157,10 +157,16 @@ __global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
     BehChain c;
     if (!beh_chain(a, c)) return;
     const bool valid = c.valid;
-    const int g = c.g, J = c.J;
+    const int g = c.g, J = c.J, l = lane_id();
+    const int j_lo = imax(a.fwd_j_lo, 0), j_hi = a.fwd_j_hi > 0 ? imin(a.fwd_j_hi, J) : J;
+    float* carry = a.enc_carry ? a.enc_carry + ((int64_t)c.net * c.tiles + c.tile) * 768 : nullptr;
     f32x4 he[ET], lat = splat4(0.f);
     for (int t = 0; t < ET; ++t) he[t] = splat4(0.f);
-    for (int j = 0; j < J; ++j) {
+    if (j_lo > 0 && carry) {                                // hidden state and latent handed over by the previous piece
+        for (int t = 0; t < ET; ++t) he[t] = *reinterpret_cast<const f32x4*>(carry + 256 * t + 4 * l);
+        lat = *reinterpret_cast<const f32x4*>(carry + 512 + 4 * l);
+    }
+    for (int j = j_lo; j < j_hi; ++j) {
         float* sl = a.saved_lat + (c.grow * J + j) * SVL;
         vstore_a(sl + 16, valid, 0, lat);                      // the latent the decoder uses in window j
         for (int t = 0; t < a.L; ++t) {
@@ -197,6 +203,10 @@ __global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
         for (int q = 0; q < 4; ++q) nl[q] = ex[q] / ss;
         vstore_a(sl, valid, 0, nl);
         for (int q = 0; q < 4; ++q) lat[q] = a.hard ? nl[q] : (1.0f - a.coef) * lat[q] + nl[q] * a.coef;
+    }
+    if (j_hi < J && carry) {
+        for (int t = 0; t < ET; ++t) *reinterpret_cast<f32x4*>(carry + 256 * t + 4 * l) = he[t];
+        *reinterpret_cast<f32x4*>(carry + 512 + 4 * l) = lat;
     }
 }
 
@@ -243,10 +253,15 @@ __global__ __launch_bounds__(512) void beh_dec_fwd_kernel(IplanBehArgs a) {
     const float* xp = s_xch + (wave_id() ^ 4) * 768;
     auto put = [&](int slot, f32x4 v) { *reinterpret_cast<f32x4*>(xm + slot * 256 + 4 * l) = v; };
     auto get = [&](int slot) { return *reinterpret_cast<const f32x4*>(xp + slot * 256 + 4 * l); };
+    const int j_lo = dec_only ? 0 : imax(a.fwd_j_lo, 0), j_hi = (!dec_only && a.fwd_j_hi > 0) ? imin(a.fwd_j_hi, J) : J;
+    // carry of the hidden state between pieces: every wave keeps its own two tiles in its half of the tile's slot
+    float* carry = a.dec_carry ? a.dec_carry + (((int64_t)net * c.tiles + imin(c.tile, c.tiles - 1)) * 2) * 512 : nullptr;
     f32x4 hd[DT];
     for (int i = 0; i < DT; ++i) hd[i] = dec_only ? vload_a(a.hd_in + c.grow * DHd, valid, (own + i) & 3) : splat4(0.f);
+    if (j_lo > 0 && carry)
+        for (int i = 0; i < DT; ++i) hd[i] = *reinterpret_cast<const f32x4*>(carry + 512 * (hf ^ (i >> 1)) + 256 * (i & 1) + 4 * l);
     float beh = 0.f, stab = 0.f;
-    for (int j = 0; j < J; ++j) {
+    for (int j = j_lo; j < j_hi; ++j) {
         const float scale = (dec_only || hf) ? 0.f : (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS);
         float err = 0.f;
         f32x4 lat1[1], zproj[DT];
@@ -337,11 +352,16 @@ __global__ __launch_bounds__(512) void beh_dec_fwd_kernel(IplanBehArgs a) {
         }
         beh = fmaf(err, scale, beh);
     }
+    if (j_hi < J && carry && c.tile < c.tiles) {
+        *reinterpret_cast<f32x4*>(carry + 512 * hf + 4 * l) = hd[0];
+        *reinterpret_cast<f32x4*>(carry + 512 * hf + 256 + 4 * l) = hd[1];
+    }
     beh = chain_sum_b(group_sum(beh)) / (a.hard ? 1.0f : (float)J);
     stab = chain_sum_b(group_sum(stab)) / (float)a.E / (float)a.L / (float)J;
     if (lane_id() == 0 && hf == 0 && c.tile < c.tiles) {
-        a.loss_part[((int64_t)net * c.tiles + c.tile) * 2] = beh;
-        a.loss_part[((int64_t)net * c.tiles + c.tile) * 2 + 1] = stab;
+        float* lp = a.loss_part + ((int64_t)net * c.tiles + c.tile) * 2;
+        lp[0] = j_lo > 0 ? lp[0] + beh : beh;             // pieces accumulate
+        lp[1] = j_lo > 0 ? lp[1] + stab : stab;
     }
 }
 
@@ -710,15 +730,21 @@ extern "C" int iplan_beh_fwd(const IplanBehArgs* a, iplan_stream_t stream) {
     using namespace iplan;
     if (int rc = check_beh(a, "iplan_beh_fwd")) return rc;
     if (!a->win && (!a->loss_part || !a->loss)) return fail(IPLAN_EINVAL, "iplan_beh_fwd: loss buffers missing");
+    if ((a->fwd_j_lo > 0 || a->fwd_j_hi > 0) && (a->win || !a->enc_carry || !a->dec_carry || a->fwd_j_lo < 0 ||
+                                                 (a->fwd_j_hi > 0 && a->fwd_j_hi <= a->fwd_j_lo)))
+        return fail(IPLAN_EINVAL, "iplan_beh_fwd: a window range needs enc_carry, dec_carry and 0 <= fwd_j_lo < fwd_j_hi");
     const int tiles = (a->E * a->N + 15) / 16;
     const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets);
-    if (!a->win) hipLaunchKernelGGL(beh_enc_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
-    const size_t lds = sizeof(float) * (2 * 3 * DHd * DLD + 2 * DHd * 24 + 16 * DLD + DEC_FWD_BIAS + 8 * 3 * 256);
+    const int ph = a->win ? 2 : a->fwd_phase;
+    if (ph == 0 || ph == 1) hipLaunchKernelGGL(beh_enc_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    if (ph == 0 || ph == 2) {
+        const size_t lds = sizeof(float) * (2 * 3 * DHd * DLD + 2 * DHd * 24 + 16 * DLD + DEC_FWD_BIAS + 8 * 3 * 256);
 #ifndef IPLAN_HOST_EMULATION
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_dec_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_dec_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
-    hipLaunchKernelGGL(beh_dec_fwd_kernel, grid, dim3(512), lds, (hipStream_t)stream, *a);
-    if (!a->win) hipLaunchKernelGGL(beh_loss_kernel, dim3((unsigned)a->n_nets), dim3(64), 0, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL(beh_dec_fwd_kernel, grid, dim3(512), lds, (hipStream_t)stream, *a);
+    }
+    if (!a->win && (ph == 0 || ph == 3)) hipLaunchKernelGGL(beh_loss_kernel, dim3((unsigned)a->n_nets), dim3(64), 0, (hipStream_t)stream, *a);
     return check_launch("iplan_beh_fwd");
 }
 

@@ -603,7 +603,46 @@ def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p,
                loss_part=torch.empty(n_nets, tiles, 2, **f32), loss=torch.empty(n_nets, 2, **f32))
     for k in ("saved_dec", "saved_enc", "saved_lat", "loss_part", "loss"):
         setattr(a, k, out[k].data_ptr())
-    lib.call("iplan_beh_fwd", a, L.current_stream(dev))
+    # Pipeline (GPU): the decoder holds 138 of the 256 CUs for the whole episode, so the forward runs in window pieces --
+    # the encoder of piece k+1 on a side stream beside the decoder of piece k on the main stream.
+    side = None
+    if dev.type == "cuda" and not os.environ.get("IPLAN_BEH_SERIAL"):
+        main = torch.cuda.current_stream(dev)
+        side = _SIDE_STREAMS.setdefault((str(dev), main.cuda_stream), torch.cuda.Stream(dev))
+    pieces = max(1, min(int(os.environ.get("IPLAN_BEH_PIECES", "4" if side is not None else "1")), J))
+    stream = L.current_stream(dev)
+    if pieces == 1:
+        lib.call("iplan_beh_fwd", a, stream)
+    else:
+        bounds = [round(J * k / pieces) for k in range(pieces + 1)]
+        out["enc_carry"] = torch.empty(n_nets, tiles, 768, **f32)
+        out["dec_carry"] = torch.empty(n_nets, tiles, 2, 512, **f32)
+        a.enc_carry, a.dec_carry = out["enc_carry"].data_ptr(), out["dec_carry"].data_ptr()
+        if side is not None:
+            side.wait_stream(main)                           # the inputs were produced on the main stream
+        enc_done = []
+        for k in range(pieces):                              # encoder pieces, back to back (side stream on the GPU)
+            a.fwd_phase, a.fwd_j_lo, a.fwd_j_hi = 1, bounds[k], bounds[k + 1]
+            if side is None:
+                lib.call("iplan_beh_fwd", a, stream)
+            else:
+                lib.call("iplan_beh_fwd", a, side.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                enc_done.append(ev)
+        for k in range(pieces):                              # decoder pieces, each behind its encoder piece
+            if side is not None:
+                main.wait_event(enc_done[k])
+            a.fwd_phase, a.fwd_j_lo, a.fwd_j_hi = 2, bounds[k], bounds[k + 1]
+            lib.call("iplan_beh_fwd", a, stream)
+        a.fwd_phase, a.fwd_j_lo, a.fwd_j_hi = 3, 0, 0
+        lib.call("iplan_beh_fwd", a, stream)
+        a.fwd_phase = 0
+        if side is not None:
+            for k in ("saved_enc", "saved_lat", "enc_carry"):
+                out[k].record_stream(side)
+            for t in (hist, mask):
+                t.record_stream(side)
     out["_args"] = a
     out["_keep"] = (hist, mask, keep)
     return out
