@@ -12,8 +12,9 @@
 //            lane-local.  At step s every chain needs W_b h_j for j = s + [s >= i], i.e. one of two
 //            LDS rows -> near-broadcast reads.  Each step's contribution to the 2 hard logits is
 //            reduced over the 4 lane groups and parked in LDS.
-//   phase 3  per ego (one wave each): scaled dot-product scores, wave-shuffle softmax over the
-//            N-1 neighbours, gumbel-softmax gate (tau = 0.01), gated aggregation of v.
+//   phase 3  per 16-ego tile (one wave each): scaled dot-product scores and the gated aggregation of v as two
+//            small MFMA products with the ego as the column of the D layout (the softmax over the N-1
+//            neighbours and the gumbel-softmax gate, tau = 0.01, are then lane-local).
 //   phase 4  output GRUCell (MFMA) -> new attention latent.
 // HBM traffic per scene is the compulsory obs + h_prev + noise + out (~1.4 MB per net at cfg3);
 // everything else lives in the 150 KB of LDS / registers.  Training launches additionally stream
@@ -205,43 +206,88 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
     if (clk && threadIdx.x == 0) clk[2] = IPLAN_CLOCK();
 
     // ---------------------------------------------------------------- phase 3: gated soft attention
-    {
+    // Wave `tile` (dir 0) owns 16 egos; everything is a tiny GEMM in the D layout with the ego as the COLUMN, so
+    // the softmax over an ego's neighbours is lane-local plus a reduction over the 4 lane groups:
+    //   S^T[j][i] = k_j . q_i            A = k rows (LDS), B = q rows of the ego tile (LDS)        32 MFMAs
+    //   w[i][j]   = softmax_j(S) * gumbel-gate(i, j)      lane (ego n, g) holds j = 16T + 4g + q
+    //   x[i][c]   = sum_j w[i][j] v[j][c]  A = w straight from these registers, B = v rows (LDS)    32 MFMAs
+    if (dir == 0 && tile_live) {
         const float hb0 = P[a.off[IPLAN_GAT_HARD_B]], hb1 = P[a.off[IPLAN_GAT_HARD_B] + 1];
         const float* noise = a.noise + sb * N * (N - 1) * 2;
-        for (int i = w; i < N; i += 8) {
-            const int s = l;
-            const bool live = s < N - 1;
-            const int j = live ? s + (s >= i ? 1 : 0) : 0;
-            float sc = 0.f;
-            for (int c = 0; c < GH; ++c) sc = fmaf(s_q[i][c], s_k[j][c], sc);
-            sc = sc / 5.656854249492381f;                       // / sqrt(attention_dim)  (GAT_Net.py:126)
-            const float m = wave_max(live ? sc : -INFINITY);
-            const float e = live ? expf(sc - m) : 0.f;
-            const float soft = e / wave_sum(e);
-            float hard = 0.f;
-            if (live) {
-                const float l0 = hb0 + s_pl[0][i][s][0] + s_pl[1][i][s][0];
-                const float l1 = hb1 + s_pl[0][i][s][1] + s_pl[1][i][s][1];
-                const float* gz = noise + ((int64_t)i * (N - 1) + s) * 2;
-                const float y0 = (l0 + gz[0]) / a.tau, y1 = (l1 + gz[1]) / a.tau;   // gumbel_softmax, GAT_Net.py:93
-                const float mm = fmaxf(y0, y1);
-                const float e0 = expf(y0 - mm), e1 = expf(y1 - mm);
-                hard = e1 / (e0 + e1);
-                if (sv.soft) sv.soft[(sb * N + i) * (N - 1) + s] = soft;
-                if (sv.hard) sv.hard[(sb * N + i) * (N - 1) + s] = hard;
+        const int i = node;                                  // this lane's ego (column)
+        const int NT = (N + 15) / 16;
+        // gumbel noise of the lane's 16 (ego, neighbour) pairs: issued first, consumed after the score GEMM
+        float gz0[4][4], gz1[4][4];
+        for (int T = 0; T < 4; ++T)
+            for (int q = 0; q < 4; ++q) {
+                const int j = 16 * T + 4 * g + q;
+                const bool ok = valid && j < N && j != i;
+                const int sidx = j - (j > i ? 1 : 0);
+                const float* gz = noise + ((int64_t)i * (N - 1) + (ok ? sidx : 0)) * 2;
+                gz0[T][q] = ok ? gz[0] : 0.f;
+                gz1[T][q] = ok ? gz[1] : 0.f;
             }
-            const int c = l & 31, hf = l >> 5;
-            float acc = 0.f;
-            for (int it = 0; 2 * it < N - 1; ++it) {
-                const int s2 = 2 * it + hf;
-                const float so = __shfl(soft, s2), ha = __shfl(hard, s2);
-                const int j2 = s2 < N - 1 ? s2 + (s2 >= i ? 1 : 0) : 0;
-                acc += (s_v[j2][c] * so) * ha;                 // no renormalisation (GAT_Net.py:132)
+        f32x4 sc[4];
+        for (int T = 0; T < 4; ++T) sc[T] = splat4(0.f);
+        for (int ks = 0; ks < GH / 4; ++ks) {
+            const float qv = s_q[node][4 * ks + g];
+            for (int T = 0; T < 4; ++T)
+                if (T < NT) sc[T] = mfma4(s_k[16 * T + n][4 * ks + g], qv, sc[T]);
+        }
+        float m = -INFINITY;
+        for (int T = 0; T < 4; ++T)
+            for (int q = 0; q < 4; ++q) {
+                const int j = 16 * T + 4 * g + q;
+                const bool ok = j < N && j != i;
+                sc[T][q] = ok ? sc[T][q] / 5.656854249492381f : -INFINITY;     // / sqrt(attention_dim)  (GAT_Net.py:126)
+                m = fmaxf(m, sc[T][q]);
             }
-            acc += __shfl_xor(acc, 32);
-            if (l < 32) {
-                s_x[i][c] = acc;
-                if (sv.x) sv.x[(sb * N + i) * GH + c] = acc;
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float den = 0.f;
+        f32x4 w[4];
+        for (int T = 0; T < 4; ++T)
+            for (int q = 0; q < 4; ++q) {
+                const int j = 16 * T + 4 * g + q;
+                const float e = (j < N && j != i) ? expf(sc[T][q] - m) : 0.f;
+                w[T][q] = e;
+                den += e;
+            }
+        den = group_sum(den);
+        for (int T = 0; T < 4; ++T)
+            for (int q = 0; q < 4; ++q) {
+                const int j = 16 * T + 4 * g + q;
+                const bool ok = valid && j < N && j != i;
+                const int sidx = j - (j > i ? 1 : 0);
+                const float soft = w[T][q] / den;
+                float hard = 0.f;
+                if (ok) {
+                    const float l0 = hb0 + s_pl[0][i][sidx][0] + s_pl[1][i][sidx][0];
+                    const float l1 = hb1 + s_pl[0][i][sidx][1] + s_pl[1][i][sidx][1];
+                    const float y0 = (l0 + gz0[T][q]) / a.tau, y1 = (l1 + gz1[T][q]) / a.tau;   // gumbel_softmax, GAT_Net.py:93
+                    const float mm = fmaxf(y0, y1);
+                    const float e0 = expf(y0 - mm), e1 = expf(y1 - mm);
+                    hard = e1 / (e0 + e1);
+                    if (sv.soft) sv.soft[(sb * N + i) * (N - 1) + sidx] = soft;
+                    if (sv.hard) sv.hard[(sb * N + i) * (N - 1) + sidx] = hard;
+                }
+                w[T][q] = ok ? soft * hard : 0.f;            // no renormalisation (GAT_Net.py:132)
+            }
+        for (int ct = 0; ct < 2; ++ct) {
+            f32x4 xa = splat4(0.f);
+            for (int T = 0; T < 4; ++T)
+                if (T < NT)
+                    for (int q = 0; q < 4; ++q) {
+                        const int j = 16 * T + 4 * g + q;
+                        xa = mfma4(w[T][q], s_v[j < N ? j : 0][16 * ct + n], xa);
+                    }
+            // D layout: lane (c = n, g) holds x[ego 16 tile + 4g + q][16 ct + n]
+            for (int q = 0; q < 4; ++q) {
+                const int e = 16 * tile + 4 * g + q;
+                if (e < N) {
+                    s_x[e][16 * ct + n] = xa[q];
+                    if (sv.x) sv.x[(sb * N + e) * GH + 16 * ct + n] = xa[q];
+                }
             }
         }
     }
