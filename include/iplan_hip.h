@@ -523,10 +523,12 @@ typedef struct {
     int32_t bwd_phase;          /* iplan_beh_bwd: 0 = decoder then encoder, 1 = decoder BPTT only, 2 = encoder BPTT only
                                    (lets the host run the encoder's BPTT on a second stream beside the decoder's
                                    weight-gradient contractions; phase 2 needs phase 1's dsave_lat)               */
-    /* Decoder BPTT in pieces (bwd_phase == 1): windows [bwd_j_lo, bwd_j_hi) only, processed from the top down;
+    /* BPTT in pieces (bwd_phase 1 or 2): windows [bwd_j_lo, bwd_j_hi) only, processed from the top down;
      * bwd_j_hi == 0 means all windows.  A piece that does not end at window 0 leaves d(loss)/d(h) of its last
-     * step in dec_carry, the next piece (bwd_j_hi = the previous bwd_j_lo) picks it up -- so the weight-gradient
-     * contraction of the rows a piece produced can run beside the next piece.                                */
+     * step in dec_carry (decoder) / enc_carry (encoder, plus d(loss)/d(latent)), the next piece (bwd_j_hi = the
+     * previous bwd_j_lo) picks it up -- so the weight-gradient contraction of the rows a decoder piece produced and
+     * the encoder piece of the same windows can run beside the next decoder piece.  Encoder pieces accumulate
+     * their weight-gradient partials in enc_part; the piece with bwd_j_lo == 0 reduces them into enc_grad.      */
     int32_t bwd_j_lo, bwd_j_hi;
     float* dec_carry;           /* [n_nets, ceil(rows/16), 2, 512]; needed when the decoder runs in pieces */
     /* The forward in pieces, same idea (the encoder of the next windows runs beside the decoder of the current

@@ -562,9 +562,17 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
     // operand element [chain 4s + g][column i] of a parked tile (i = lane & 15): conflict-free ds_read_b32
     auto pick = [&](int slot, int s) { return turn[slot][(4 * s + g) * 16 + n]; };
 
+    // window range of this launch (pieces, top down: see bwd_j_lo / bwd_j_hi in the header); d(loss)/d(h), d(loss)/d(latent)
+    // cross the pieces in enc_carry, the weight-gradient partials accumulate in enc_part
+    const int j_hi = a.bwd_j_hi > 0 ? imin(a.bwd_j_hi, J) : J, j_lo = imax(a.bwd_j_lo, 0);
+    float* carry = (a.enc_carry && live) ? a.enc_carry + ((int64_t)c.net * c.tiles + c.tile) * 768 : nullptr;
     f32x4 dhe[ET], dlat = splat4(0.f);
     for (int t = 0; t < ET; ++t) dhe[t] = splat4(0.f);
-    for (int j = J - 1; j >= 0; --j) {
+    if (j_hi < J && carry) {
+        for (int t = 0; t < ET; ++t) dhe[t] = *reinterpret_cast<const f32x4*>(carry + 256 * t + 4 * l);
+        dlat = *reinterpret_cast<const f32x4*>(carry + 512 + 4 * l);
+    }
+    for (int j = j_hi - 1; j >= j_lo; --j) {
         // ---- latent update + head backward (dlat = d(loss)/d(latent_{j+1}) on entry)
         f32x4 dlog[1], hL[ET];
         {
@@ -641,19 +649,25 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
         }
     }
     if (!live) return;
+    if (j_lo > 0 && carry) {
+        for (int t = 0; t < ET; ++t) *reinterpret_cast<f32x4*>(carry + 256 * t + 4 * l) = dhe[t];
+        *reinterpret_cast<f32x4*>(carry + 512 + 4 * l) = dlat;
+    }
+    const bool add = j_hi < J;                              // later pieces add to the first piece's partials
     // ---- one partial per wave: accumulator tiles are in D layout (lane (col j = n, rows 4g + q))
     float* part = a.enc_part + ((int64_t)c.net * c.tiles + c.tile) * IPLAN_BEH_ENC_PART;
+    auto put_part = [&](int idx, float v) { part[idx] = add ? part[idx] + v : v; };
     for (int o = 0; o < 6; ++o)
         for (int u = 0; u < 2; ++u)
             for (int q = 0; q < 4; ++q) {
                 const int orow = 16 * o + 4 * g + q, col = 16 * u + n;
-                part[EP_WIH + orow * EHd + col] = aWih[o][u][q];
-                part[EP_WHH + orow * EHd + col] = aWhh[o][u][q];
+                put_part(EP_WIH + orow * EHd + col, aWih[o][u][q]);
+                put_part(EP_WHH + orow * EHd + col, aWhh[o][u][q]);
             }
     for (int u = 0; u < 2; ++u)
         for (int q = 0; q < 4; ++q) {
-            part[EP_LINW + (16 * u + 4 * g + q) * 16 + n] = aLin[u][q];                    // [32][16]: row = du index, col = x index
-            part[EP_OUTW + (4 * g + q) * EHd + 16 * u + n] = aOut[u][q];                   // [16][32]: row = logit index, col = h index
+            put_part(EP_LINW + (16 * u + 4 * g + q) * 16 + n, aLin[u][q]);                    // [32][16]: row = du index, col = x index
+            put_part(EP_OUTW + (4 * g + q) * EHd + 16 * u + n, aOut[u][q]);                   // [16][32]: row = logit index, col = h index
         }
     // bias gradients: sums over the 16 chains of lane-local sums
     for (int k = 0; k < 8; ++k)
@@ -661,19 +675,19 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
             const float sum = chain_sum_b(bG[k][q]);
             if (n == 0) {
                 const int gate = k >> 1, T = k & 1, idx = 16 * T + 4 * g + q;              // k = 2 * gate + T
-                if (gate < 3) part[EP_BIH + gate * EHd + idx] = sum;                       // b_ih: dr dz dn_i
-                if (gate < 2) part[EP_BHH + gate * EHd + idx] = sum;                       // b_hh: dr dz ...
-                if (gate == 3) part[EP_BHH + 2 * EHd + idx] = sum;                         //       ... dn_h
+                if (gate < 3) put_part(EP_BIH + gate * EHd + idx, sum);                       // b_ih: dr dz dn_i
+                if (gate < 2) put_part(EP_BHH + gate * EHd + idx, sum);                       // b_hh: dr dz ...
+                if (gate == 3) put_part(EP_BHH + 2 * EHd + idx, sum);                         //       ... dn_h
             }
         }
     for (int T = 0; T < 2; ++T)
         for (int q = 0; q < 4; ++q) {
             const float sum = chain_sum_b(bU[T][q]);
-            if (n == 0) part[EP_LINB + 16 * T + 4 * g + q] = sum;
+            if (n == 0) put_part(EP_LINB + 16 * T + 4 * g + q, sum);
         }
     for (int q = 0; q < 4; ++q) {
         const float sum = chain_sum_b(bO[q]);
-        if (n == 0) part[EP_OUTB + 4 * g + q] = sum;
+        if (n == 0) put_part(EP_OUTB + 4 * g + q, sum);
     }
 }
 
@@ -754,9 +768,10 @@ extern "C" int iplan_beh_bwd(const IplanBehArgs* a, iplan_stream_t stream) {
     if (a->win) return fail(IPLAN_EINVAL, "iplan_beh_bwd: not available in single-window decoder mode");
     if (!a->dsave_dec || !a->dsave_lat || !a->enc_part || !a->enc_grad)
         return fail(IPLAN_EINVAL, "iplan_beh_bwd: dsave_dec / dsave_lat / enc_part / enc_grad missing");
-    if ((a->bwd_j_lo > 0 || a->bwd_j_hi > 0) && (a->bwd_phase != 1 || !a->dec_carry || a->bwd_j_lo < 0 ||
-                                                 (a->bwd_j_hi > 0 && a->bwd_j_hi <= a->bwd_j_lo)))
-        return fail(IPLAN_EINVAL, "iplan_beh_bwd: a window range needs bwd_phase == 1, dec_carry and 0 <= bwd_j_lo < bwd_j_hi");
+    if ((a->bwd_j_lo > 0 || a->bwd_j_hi > 0) &&
+        (a->bwd_phase == 0 || (a->bwd_phase == 1 && !a->dec_carry) || (a->bwd_phase == 2 && !a->enc_carry) || a->bwd_j_lo < 0 ||
+         (a->bwd_j_hi > 0 && a->bwd_j_hi <= a->bwd_j_lo)))
+        return fail(IPLAN_EINVAL, "iplan_beh_bwd: a window range needs bwd_phase 1 (+ dec_carry) or 2 (+ enc_carry) and 0 <= bwd_j_lo < bwd_j_hi");
     const int tiles = (a->E * a->N + 15) / 16;
     const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets);
     const size_t lds = sizeof(float) * (2 * DHd * (3 * DHd + 8) + DHd * 24 + 16 * DLD + 8 * 4 * 256);
@@ -766,9 +781,11 @@ extern "C" int iplan_beh_bwd(const IplanBehArgs* a, iplan_stream_t stream) {
     if (a->bwd_phase != 2) hipLaunchKernelGGL(beh_dec_bwd_kernel, grid, dim3(512), lds, (hipStream_t)stream, *a);
     if (a->bwd_phase != 1) {
         hipLaunchKernelGGL(beh_enc_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
-        const int p_enc = 32 * a->d + 32 + 2 * 96 * 32 + 2 * 96 + a->Z * 32 + a->Z;
-        hipLaunchKernelGGL(beh_enc_grad_kernel, dim3((unsigned)((p_enc + 255) / 256), (unsigned)a->n_nets), dim3(256), 0,
-                           (hipStream_t)stream, *a);
+        if (a->bwd_j_lo <= 0) {                             // the last (or only) piece: reduce the wave partials
+            const int p_enc = 32 * a->d + 32 + 2 * 96 * 32 + 2 * 96 + a->Z * 32 + a->Z;
+            hipLaunchKernelGGL(beh_enc_grad_kernel, dim3((unsigned)((p_enc + 255) / 256), (unsigned)a->n_nets), dim3(256), 0,
+                               (hipStream_t)stream, *a);
+        }
     }
     return check_launch("iplan_beh_bwd");
 }

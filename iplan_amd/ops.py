@@ -569,6 +569,11 @@ def pdec_backward(arena, fwd, lib=None):
 
 
 # ---- behaviour learning ---------------------------------------------------------------------------------
+def _beh_pieces(which, default):
+    """Window pieces of the behaviour forward / backward pipelines (IPLAN_BEH_PIECES[_FWD|_BWD]: tuning / test knobs)."""
+    return int(os.environ.get("IPLAN_BEH_PIECES_" + which, os.environ.get("IPLAN_BEH_PIECES", str(default))))
+
+
 def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p, keep=None, seed=0, hard=False, lib=None):
     """Forward of Behavior_policy.learn for all nets.  hist [n_nets, E, T, N, d] (first three dims may be
     strided), mask [n_nets, E, T] contiguous, keep uint8 [n_nets, J, E*N, L, 64] or None (in-kernel draw from
@@ -609,7 +614,7 @@ def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p,
     if dev.type == "cuda" and not os.environ.get("IPLAN_BEH_SERIAL"):
         main = torch.cuda.current_stream(dev)
         side = _SIDE_STREAMS.setdefault((str(dev), main.cuda_stream), torch.cuda.Stream(dev))
-    pieces = max(1, min(int(os.environ.get("IPLAN_BEH_PIECES", "4" if side is not None else "1")), J))
+    pieces = max(1, min(_beh_pieces("FWD", 4 if side is not None else 1), J))
     stream = L.current_stream(dev)
     if pieces == 1:
         lib.call("iplan_beh_fwd", a, stream)
@@ -688,16 +693,18 @@ def beh_backward(enc_arena, dec_arena, fwd, lib=None):
         w.run(lib)
 
     # Pipeline: the decoder BPTT runs in pieces (top windows first) on the main stream; the weight-gradient contraction
-    # of the rows a piece produced runs on a side stream beside the next piece (the BPTT kernel holds 138 of the 256
-    # CUs), and the encoder's BPTT -- which needs every window's d(loss)/d(latent) -- follows the last piece.
-    side = None
+    # of the rows a piece produced and the encoder's BPTT over the same windows (it needs their d(loss)/d(latent)) run
+    # on two side streams beside the next decoder piece (the decoder kernel holds 138 of the 256 CUs).
+    side = side2 = None
     if dev.type == "cuda" and not os.environ.get("IPLAN_BEH_SERIAL"):       # (the knob is for kernel timing experiments)
         main = torch.cuda.current_stream(dev)
         side = _SIDE_STREAMS.setdefault((str(dev), main.cuda_stream), torch.cuda.Stream(dev))
-    pieces = max(1, min(int(os.environ.get("IPLAN_BEH_PIECES", "4" if side is not None else "1")), J))
+        side2 = _SIDE_STREAMS.setdefault((str(dev), main.cuda_stream, 2), torch.cuda.Stream(dev))
+    pieces = max(1, min(_beh_pieces("BWD", 6 if side is not None else 1), J))
     bounds = [round(J * k / pieces) for k in range(pieces + 1)]
     carry = torch.empty(n_nets, tiles, 2, 512, **f32)
-    a.dec_carry = carry.data_ptr()
+    ecarry = torch.empty(n_nets, tiles, 768, **f32)
+    a.dec_carry, a.enc_carry = carry.data_ptr(), ecarry.data_ptr()
     stream = L.current_stream(dev)
     for k in range(pieces, 0, -1):
         a.bwd_phase, a.bwd_j_lo, a.bwd_j_hi = 1, bounds[k - 1], bounds[k]
@@ -705,20 +712,27 @@ def beh_backward(enc_arena, dec_arena, fwd, lib=None):
         beta = 0.0 if k == pieces else 1.0
         if side is None:
             dec_wgrad(bounds[k - 1] * Lw, bounds[k] * Lw, beta)
+            a.bwd_phase = 2
+            lib.call("iplan_beh_bwd", a, stream)
         else:
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
+            side2.wait_event(ev)
             with torch.cuda.stream(side):
                 dec_wgrad(bounds[k - 1] * Lw, bounds[k] * Lw, beta)
-    a.bwd_phase, a.bwd_j_lo, a.bwd_j_hi = 2, 0, 0
-    lib.call("iplan_beh_bwd", a, stream)
+            a.bwd_phase = 2
+            lib.call("iplan_beh_bwd", a, side2.cuda_stream)
+    a.bwd_phase, a.bwd_j_lo, a.bwd_j_hi = 0, 0, 0
     if side is not None:
-        ev_done = torch.cuda.Event()
-        ev_done.record(side)
-        main.wait_event(ev_done)
-        for t in (dd, carry, fwd["saved_dec"]):                         # touched by the side stream: keep the allocator honest
+        for st in (side, side2):
+            ev_done = torch.cuda.Event()
+            ev_done.record(st)
+            main.wait_event(ev_done)
+        for t in (dd, carry, fwd["saved_dec"]):                         # touched by the side streams: keep the allocator honest
             t.record_stream(side)
+        for t in (dl, ep, ecarry, fwd["saved_enc"], fwd["saved_lat"]):
+            t.record_stream(side2)
     return dict(dsave_dec=dd, dsave_lat=dl, enc_part=ep)
 
 
