@@ -127,9 +127,10 @@ class SyntheticLoop:
         self.t_env += self.E * self.args.episode_limit
         self.learner.insert_episode_batch(batch)
         dev = torch.device(self.device)
-        # data-parallel runs keep the learners (and therefore their gradient all-reduces) strictly ordered on one
-        # stream: every rank must issue its collectives in the same order
-        if dev.type != "cuda" or self.learner.dp is not None:
+        # (Data-parallel runs overlap the learners too: the host issues the gradient all-reduces in the same order on
+        # every rank -- prediction, PPO epochs, behaviour -- and RCCL runs them in that order on its own stream,
+        # each behind the event of the stream that produced its gradients.)
+        if dev.type != "cuda":
             if self.behavior is not None:
                 self.behavior.learn(batch, self.t_env)
             if self.prediction is not None:
