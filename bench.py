@@ -36,8 +36,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md (v
 # HBM bytes per launch from the committed PMC passes (profiles/r01*_pmc_*.txt), keyed by (kernel, envs per GPU):
 # (2 * FETCH_SIZE + WRITE_SIZE) KiB -> bytes.  Counters cannot be collected from inside bench.py; None = not profiled.
 PMC_TRAFFIC_BYTES = {
-    ("beh_dec_bwd_kernel", 32): None,                                      # filled from the final PMC pass
-    ("gat_fwd_kernel", 32): int((2 * 5037.5 + 1100.0) * 1024),
+    ("gat_fwd_kernel", 32): int((2 * 5173.6 + 1759.0) * 1024),             # profiles/r01g_pmc_*.txt
+    ("beh_dec_bwd_kernel", 32): int((2 * 1045886.8 + 1676182.8) * 1024),   # per window-range launch (6 per BPTT)
 }
 
 

@@ -18,6 +18,9 @@ namespace iplan {
 
 constexpr int AM = IPLAN_AC_HIDDEN;    // 64
 constexpr int AT = AM / 16;            // 4 tiles
+#ifndef AC_RT
+#define AC_RT 2                       // row tiles per wave in the streaming (PPO) variant
+#endif
 
 template <int RT>
 __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
@@ -386,8 +389,8 @@ extern "C" int iplan_ac_fwd(const IplanAcFwdArgs* a, iplan_stream_t stream) {
         dim3 grid((unsigned)tiles, (unsigned)a->n_agents, a->which == 2 ? 2u : 1u);
         hipLaunchKernelGGL(ac_fwd_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, *a);
     } else {
-        dim3 grid((unsigned)((tiles + 15) / 16), (unsigned)a->n_agents, a->which == 2 ? 2u : 1u);   // 8 waves x 2 row tiles
-        hipLaunchKernelGGL(ac_fwd_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, *a);
+        dim3 grid((unsigned)((tiles + 8 * AC_RT - 1) / (8 * AC_RT)), (unsigned)a->n_agents, a->which == 2 ? 2u : 1u);   // 8 waves x AC_RT row tiles
+        hipLaunchKernelGGL(ac_fwd_kernel<AC_RT>, grid, dim3(512), 0, (hipStream_t)stream, *a);
     }
     return check_launch("iplan_ac_fwd");
 }
