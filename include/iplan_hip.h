@@ -371,6 +371,8 @@ typedef struct {
     float* adv;                  /* [n_agents, bs, T] normalised advantages                          */
     float* mask;                 /* [n_agents, bs, T] 1 - terminated                                 */
     float* value_preds;          /* [n_agents, bs, T] = values[:, :, :T]                             */
+    int32_t skip_norm;           /* 1 = leave adv un-normalised (data-parallel callers normalise with the
+                                    mean / std over ALL ranks' rows between this call and iplan_ppo_loss)      */
 } IplanPpoPrepareArgs;
 
 int iplan_ppo_prepare(const IplanPpoPrepareArgs* args, iplan_stream_t stream);
@@ -393,6 +395,8 @@ typedef struct {
     float* g_logp;               /* [n_agents, rows]                                                 */
     float* g_values;             /* [n_agents, rows]                                                 */
     float* stats;                /* [n_agents, 8]                                                    */
+    const float* mask_sum;       /* optional [n_agents]: sum(mask) over the rows of ALL data-parallel ranks -- the
+                                    losses' denominator (NULL = this launch's own rows)                        */
 } IplanPpoLossArgs;
 
 int iplan_ppo_loss(const IplanPpoLossArgs* args, iplan_stream_t stream);
@@ -458,6 +462,8 @@ typedef struct {
     float* loss;                /* [n_nets]  sum|target-pred|*m / (sum m + 1e-10) * d * P               */
     float* dsave;               /* backward: [n_nets, rows, P, IPLAN_PDEC_DSAVE]                        */
     float* g_h0;                /* backward: [n_nets, rows, 32] dLoss/d h0                              */
+    const float* mask_sum;      /* optional [n_nets]: sum(mask) over the samples of ALL data-parallel ranks (the
+                                   loss normaliser); NULL = this launch's own samples                       */
 } IplanPdecArgs;
 
 int iplan_pdec_fwd(const IplanPdecArgs* args, iplan_stream_t stream);
@@ -537,6 +543,9 @@ typedef struct {
      * cross the pieces in enc_carry [n_nets, ceil(rows/16), 768] and dec_carry; loss partials accumulate.      */
     int32_t fwd_phase, fwd_j_lo, fwd_j_hi;
     float* enc_carry;
+    const float* win_norm;      /* optional [n_nets, J]: per window, sum of the mask over the window's target steps and
+                                   the envs of ALL data-parallel ranks (hard update: the one global sum, repeated);
+                                   NULL = summed in-kernel over this launch's envs                              */
 } IplanBehArgs;
 
 int iplan_beh_fwd(const IplanBehArgs* args, iplan_stream_t stream);

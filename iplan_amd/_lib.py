@@ -238,7 +238,7 @@ class PpoPrepareArgs(C.Structure):
         ("reward", fp), ("rw_s_net", i64), ("rw_s_ep", i64), ("rw_s_t", i64),
         ("terminated", fp), ("tm_s_net", i64), ("tm_s_ep", i64), ("tm_s_t", i64),
         ("values", fp), ("gamma", C.c_float), ("lam", C.c_float),
-        ("returns", fp), ("adv", fp), ("mask", fp), ("value_preds", fp),
+        ("returns", fp), ("adv", fp), ("mask", fp), ("value_preds", fp), ("skip_norm", i32),
     ]
 
 
@@ -248,7 +248,7 @@ class PpoLossArgs(C.Structure):
         ("logp", fp), ("entropy", fp), ("values", fp), ("old_logp", fp), ("adv", fp),
         ("value_preds", fp), ("returns", fp), ("mask", fp),
         ("clip", C.c_float), ("huber_delta", C.c_float), ("value_loss_coef", C.c_float),
-        ("g_logp", fp), ("g_values", fp), ("stats", fp),
+        ("g_logp", fp), ("g_values", fp), ("stats", fp), ("mask_sum", fp),
     ]
 
 
@@ -273,7 +273,7 @@ class PdecArgs(C.Structure):
         ("n_nets", i32), ("rows", i32), ("N", i32), ("P", i32), ("d", i32),
         ("x0", fp), ("h0", fp), ("target", fp), ("mask", fp), ("keep", fp), ("drop_p", C.c_float),
         ("teacher", fp), ("params", fp), ("params_s_net", i64), ("off", i64 * len(DEC_PARAM_ORDER)),
-        ("pred", fp), ("saved", fp), ("loss_part", fp), ("loss", fp), ("dsave", fp), ("g_h0", fp),
+        ("pred", fp), ("saved", fp), ("loss_part", fp), ("loss", fp), ("dsave", fp), ("g_h0", fp), ("mask_sum", fp),
     ]
 
 
@@ -296,5 +296,5 @@ class BehArgs(C.Structure):
         ("win", fp), ("lat_in", fp), ("hd_in", fp), ("pred_out", fp), ("hd_out", fp), ("hard", i32),
         ("enc_part", fp), ("enc_grad", fp), ("enc_grad_s_net", i64), ("bwd_phase", i32),
         ("bwd_j_lo", i32), ("bwd_j_hi", i32), ("dec_carry", fp),
-        ("fwd_phase", i32), ("fwd_j_lo", i32), ("fwd_j_hi", i32), ("enc_carry", fp),
+        ("fwd_phase", i32), ("fwd_j_lo", i32), ("fwd_j_hi", i32), ("enc_carry", fp), ("win_norm", fp),
     ]

@@ -90,6 +90,7 @@ __device__ __forceinline__ f32x4 keep_tile(const IplanBehArgs& a, int net, int j
 
 // sum of the mask over the window's target steps (all envs), times N * d  (mask_over_next_traj.sum())
 __device__ __forceinline__ float window_mask_sum(const IplanBehArgs& a, int net, int j) {
+    if (a.win_norm) return a.win_norm[(int64_t)net * beh_windows(a) + j] * (float)(a.N * a.d);   // all data-parallel ranks' envs
     float s = 0.f;
     // hard update: ONE normaliser over all windows (nova/behavior_policy.py:185-187)
     const int span = a.hard ? beh_windows(a) * a.L : a.L;

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(1024) void ppo_prepare_kernel(IplanPpoPrepareArgs a
             adv[(int64_t)b * T + t] = m0 == 0.0f ? 0.0f : r - v0;
         }
     }
+    if (a.skip_norm) return;                                // the caller normalises over all data-parallel ranks
     __syncthreads();
     const int n = bs * T;
     float s = 0.f;
@@ -77,7 +78,8 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(IplanPpoLossArgs a) {
     const int n = a.rows;
     float sm = 0.f;
     for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) sm += a.mask[o + i];
-    const float msum = block_sum_1024(sm, s_part);
+    const float msum_own = block_sum_1024(sm, s_part);
+    const float msum = a.mask_sum ? a.mask_sum[net] : msum_own;
     float pol = 0.f, vls = 0.f, rat = 0.f, en = 0.f;
     for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
         const float m = a.mask[o + i], ad = a.adv[o + i];

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64) void pdec_loss_kernel(IplanPdecArgs a) {
     float ms = 0.f, es = 0.f;
     for (int i = lane_id(); i < S; i += 64) ms += a.mask[(int64_t)net * S + i];
     for (int i = lane_id(); i < tiles; i += 64) es += a.loss_part[(int64_t)net * tiles + i];
-    ms = wave_sum(ms);
+    ms = a.mask_sum ? a.mask_sum[net] : wave_sum(ms);
     es = wave_sum(es);
     if (lane_id() == 0) a.loss[net] = es / (ms * (float)(a.N * a.P * a.d) + PEPS) * (float)(a.d * a.P);
 }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void pdec_bwd_kernel(IplanPdecArgs a) {
     const int S = a.rows / a.N;
     float ms = 0.f;
     for (int i = l; i < S; i += 64) ms += a.mask[(int64_t)net * S + i];
-    ms = wave_sum(ms);
+    ms = a.mask_sum ? a.mask_sum[net] : wave_sum(ms);
     const float scale = (float)(a.d * a.P) / (ms * (float)(a.N * a.P * a.d) + PEPS);
     const float m = valid ? a.mask[(int64_t)net * S + row / a.N] : 0.f;
     const float inv_keep = 1.0f / (1.0f - a.drop_p);

@@ -208,7 +208,15 @@ class IPPOLearner:
         pp.returns, pp.adv, pp.mask, pp.value_preds = returns.data_ptr(), adv.data_ptr(), mask.data_ptr(), vpred.data_ptr()
         lib = L.get_lib()
         stream = L.current_stream(dev)
+        pp.skip_norm = 0 if self.dp is None else 1
         lib.call("iplan_ppo_prepare", pp, stream)
+        if self.dp is not None:
+            # data-parallel: advantage mean / unbiased std over ALL ranks' rows (two tiny all-reduces), same formula
+            # as the kernel: (adv - mean) / (std + 1e-5)
+            cnt = float(bs * T * self.dp.world)              # every rank stores the same number of episodes
+            mean = self.dp.all_reduce_sum(adv.sum(dim=1)) / cnt
+            var = self.dp.all_reduce_sum(((adv - mean[:, None]) ** 2).sum(dim=1)) / (cnt - 1.0)
+            adv.sub_(mean[:, None]).mul_((1.0 / (var.sqrt() + 1e-5))[:, None])
         # generate_data (:368-424): the first batch_size * T rows
         rows = self.batch_size * T
         spec = self._feature_spec(T, T1, last)
@@ -231,13 +239,19 @@ class IPPOLearner:
         norms = th.zeros(self.ppo_epoch, 2, nA, **f32)
         pl.g_logp, pl.g_values = g_logp.data_ptr(), g_v.data_ptr()
         max_norm = self.max_grad_norm if self._use_max_grad_norm else None
+        n_rows = float(rows)
+        if self.dp is not None:
+            # the losses' denominators over all ranks: sum(mask) of the PPO rows and the row count (entropy mean)
+            msum = self.dp.all_reduce_sum(mask[:, :rows].sum(dim=1).contiguous())
+            pl.mask_sum = msum.data_ptr()
+            n_rows = float(rows * self.dp.world)
         for ep in range(self.ppo_epoch):
             out = ops.ac_forward(mac.actor_arena, mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True, **fwd_kw)
             pl.logp, pl.entropy, pl.values = out["logp"].data_ptr(), out["entropy"].data_ptr(), out["values"].data_ptr()
             pl.stats = stats[ep].data_ptr()
             lib.call("iplan_ppo_loss", pl, stream)
             ops.ac_backward(out, mac.actor_arena, mac.critic_arena, g_logp=g_logp,
-                            g_entropy=-self.entropy_coef / rows, g_values=g_v)
+                            g_entropy=-self.entropy_coef / n_rows, g_values=g_v)
             if self.dp is not None:
                 self.dp.all_reduce_grads(mac.actor_arena, mac.critic_arena)
             sq_a = step_all(self.actor_optimizers, max_norm)

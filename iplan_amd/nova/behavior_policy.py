@@ -45,7 +45,8 @@ class Behavior_policy(_SoftBehaviorPolicy):
         hist = history.permute(2, 0, 1, 3, 4)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if keep is None else 0
         fwd = ops.beh_forward(self.enc_arena, self.dec_arena, hist, mask, self.max_history_len, self.latent_dim, 1.0, 0.0,
-                              a.decoder_dropout, keep=keep, seed=seed, hard=True)
+                              a.decoder_dropout, keep=keep, seed=seed, hard=True,
+                              win_norm=self._global_window_sums(mask, hard=True))
         ops.beh_backward(self.enc_arena, self.dec_arena, fwd)
         if getattr(self, "dp", None) is not None:
             self.dp.all_reduce_grads(self.enc_arena, self.dec_arena)

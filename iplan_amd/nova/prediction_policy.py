@@ -98,7 +98,7 @@ class Prediction_policy:
         coins = [np.random.random() < self.args.teacher_forcing_ratio for _ in range(self.pred_length)]
         return sel, coins
 
-    def learn(self, batch, t_env, noise=None, keep=None, defer=False):
+    def learn(self, batch, t_env, noise=None, keep=None, defer=False, sel=None):
         """nova/prediction_policy.py:168-253 for all agents at once: sample -> fused GAT forward ->
         decoder forward + masked L1 -> decoder backward -> GAT backward -> weight gradients ->
         separate clip of the GAT and decoder groups -> Adam.  ``noise`` (gumbel, [nA, S, N, N-1, 2]) and
@@ -117,7 +117,11 @@ class Prediction_policy:
         d = history.shape[-1]
         avail_len = T - P - 1
         sels, coins = zip(*[self._sample(E, avail_len) for _ in range(nA)])
-        sel = torch.as_tensor(np.stack(sels), dtype=torch.long, device=dev)        # [nA, S]
+        if sel is None:
+            sel = torch.as_tensor(np.stack(sels), dtype=torch.long, device=dev)    # [nA, S]
+        else:                                                                       # injected (episode * avail_len + t) indices
+            sel = torch.as_tensor(np.asarray(sel), dtype=torch.long, device=dev)
+            S = sel.shape[1]
         bi, ti = sel // avail_len, sel % avail_len
         ag = torch.arange(nA, device=dev)[:, None].expand(nA, S)
         # gathers = data movement only (prediction_batch_wrapper, :123-164)
@@ -135,8 +139,12 @@ class Prediction_policy:
         if any(any(c) for c in coins):
             teacher = torch.as_tensor(np.array(coins, dtype=np.int32), device=dev).contiguous()
         hid, saved = ops.gat_forward(self.gat_arena, x0, lat, att, noise, save=True)
+        # data-parallel runs: the loss normaliser counts the samples of ALL ranks (parallel.py)
+        dp = getattr(self, "dp", None)
+        mask_sum = dp.all_reduce_sum(mask.sum(dim=1)) if dp is not None else None
         fwd = ops.pdec_forward(self.dec_arena, x0.reshape(nA, S * N, d), hid.reshape(nA, S * N, -1),
-                               actual.reshape(nA, S * N, P, d), mask, N, keep=keep, drop_p=a.decoder_dropout, teacher=teacher)
+                               actual.reshape(nA, S * N, P, d), mask, N, keep=keep, drop_p=a.decoder_dropout, teacher=teacher,
+                               mask_sum=mask_sum)
         g_h0 = ops.pdec_backward(self.dec_arena, fwd)
         ops.gat_backward(self.gat_arena, saved, g_h0.reshape(nA, S, N, -1))
         if getattr(self, "dp", None) is not None:

@@ -80,6 +80,13 @@ class Behavior_policy:
 
 
     # ---------------------------------------------------------------------------- learning
+    def _global_window_sums(self, mask, hard=False):
+        """Data-parallel runs: the loss normalisers (mask sums per window) over ALL ranks' envs; None otherwise."""
+        dp = getattr(self, "dp", None)
+        if dp is None:
+            return None
+        return dp.all_reduce_sum(ops.beh_window_mask_sums(mask, self.max_history_len, hard=hard))
+
     def learn(self, batch, t_env, keep=None):
         """nova/stable_behavior_policy.py:161-279 for all agents at once: ONE persistent forward launch
         walks every (env, entity) chain through the T-1-L windows (decoder + encoder GRUs, soft latent
@@ -100,7 +107,8 @@ class Behavior_policy:
         hist = history.permute(2, 0, 1, 3, 4)                                       # [nA, E, T, N, d] view
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if keep is None else 0
         fwd = ops.beh_forward(self.enc_arena, self.dec_arena, hist, mask, self.max_history_len, self.latent_dim,
-                              self.soft_update_coef, self.thres_small_variation, a.decoder_dropout, keep=keep, seed=seed)
+                              self.soft_update_coef, self.thres_small_variation, a.decoder_dropout, keep=keep, seed=seed,
+                              win_norm=self._global_window_sums(mask))
         ops.beh_backward(self.enc_arena, self.dec_arena, fwd)
         if getattr(self, "dp", None) is not None:
             self.dp.all_reduce_grads(self.enc_arena, self.dec_arena)

@@ -506,7 +506,7 @@ def gat_backward(arena, saved, g_out, lib=None):
 
 
 # ---- prediction decoder --------------------------------------------------------------------------------
-def pdec_forward(arena, x0, h0, target, mask, N, keep=None, drop_p=0.0, teacher=None, lib=None):
+def pdec_forward(arena, x0, h0, target, mask, N, keep=None, drop_p=0.0, teacher=None, mask_sum=None, lib=None):
     """Prediction_Decoder.forward + masked-L1 loss for all nets.  x0 [n_nets, rows, d], h0 [n_nets, rows, 32],
     target [n_nets, rows, P, d], mask [n_nets, rows // N], keep [n_nets, P, rows, 32] or None, teacher int32
     [n_nets, P] or None.  Returns dict(pred, loss [n_nets], saved, ...)."""
@@ -531,6 +531,9 @@ def pdec_forward(arena, x0, h0, target, mask, N, keep=None, drop_p=0.0, teacher=
     a.params, a.params_s_net = arena.data.data_ptr(), arena.net_stride
     for i, k in enumerate(L.DEC_PARAM_ORDER):
         a.off[i] = arena.off(k)
+    if mask_sum is not None:                               # loss normaliser over all data-parallel ranks' samples
+        assert mask_sum.shape == (n_nets,) and mask_sum.dtype == torch.float32 and mask_sum.is_contiguous()
+        a.mask_sum = mask_sum.data_ptr()
     tiles = (rows + 15) // 16
     out = dict(pred=torch.empty(n_nets, rows, P, d, **f32), saved=torch.empty(n_nets, rows, P, L.PDEC_SAVE, **f32),
                loss_part=torch.empty(n_nets, tiles, **f32), loss=torch.empty(n_nets, **f32))
@@ -574,7 +577,8 @@ def _beh_pieces(which, default):
     return int(os.environ.get("IPLAN_BEH_PIECES_" + which, os.environ.get("IPLAN_BEH_PIECES", str(default))))
 
 
-def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p, keep=None, seed=0, hard=False, lib=None):
+def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p, keep=None, seed=0, hard=False, win_norm=None,
+                lib=None):
     """Forward of Behavior_policy.learn for all nets.  hist [n_nets, E, T, N, d] (first three dims may be
     strided), mask [n_nets, E, T] contiguous, keep uint8 [n_nets, J, E*N, L, 64] or None (in-kernel draw from
     ``seed``).  Returns dict(loss [n_nets, 2] = (behaviour, stability), saved...)."""
@@ -595,6 +599,9 @@ def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p,
         assert keep.dtype == torch.uint8 and keep.shape == (n_nets, J, rows, L_win, 64) and keep.is_contiguous()
         a.keep = keep.data_ptr()
     a.seed, a.drop_p, a.coef, a.thres = seed, drop_p, coef, thres
+    if win_norm is not None:                               # per-window mask sums over all data-parallel ranks' envs
+        assert win_norm.shape == (n_nets, J) and win_norm.dtype == torch.float32 and win_norm.is_contiguous()
+        a.win_norm = win_norm.data_ptr()
     a.enc_params, a.enc_s_net = enc_arena.data.data_ptr(), enc_arena.net_stride
     for i, k in enumerate(L.ENC_PARAM_ORDER):
         a.enc_off[i] = enc_arena.off(k)
@@ -649,8 +656,22 @@ def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p,
             for t in (hist, mask):
                 t.record_stream(side)
     out["_args"] = a
-    out["_keep"] = (hist, mask, keep)
+    out["_keep"] = (hist, mask, keep, win_norm)
     return out
+
+
+def beh_window_mask_sums(mask, L_win, hard=False):
+    """[n_nets, J] float32: for every window the sum of ``mask`` [n_nets, E, T] over the envs and the window's target
+    steps -- what the behaviour kernels sum in-kernel when no ``win_norm`` is given (sums of 0/1 flags: exact)."""
+    n_nets, E, T = mask.shape
+    col = mask.sum(dim=1)                                  # [n_nets, T]
+    if hard:
+        J = T // L_win - 1
+        return col[:, :J * L_win].sum(dim=1, keepdim=True).expand(n_nets, J).contiguous()
+    J = T - 1 - L_win
+    cs = torch.cat([torch.zeros(n_nets, 1, dtype=col.dtype, device=col.device), col.cumsum(dim=1)], dim=1)   # cs[k] = sum_{t<k}
+    j = torch.arange(J, device=col.device)
+    return (cs[:, j + 1 + L_win] - cs[:, j + 1]).contiguous()
 
 
 def beh_backward(enc_arena, dec_arena, fwd, lib=None):

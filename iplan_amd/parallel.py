@@ -8,9 +8,13 @@ no communication; the only exchange step is ONE sum all-reduce per gradient aren
 (PPO: actor + critic arenas, 15x per train(); prediction: GAT + decoder arenas once per rollout;
 behaviour: encoder + decoder arenas once per rollout) -- each arena is a single contiguous fp32
 buffer holding all agents' gradients, so there are no per-tensor collectives.  Messages are 0.3-4 MB:
-latency-bound on the xGMI mesh, hence as few and as large as the algorithm allows.  Gradients are
-averaged over ranks (each rank normalises its loss by its own mask counts), then clipped and applied
-identically on every rank, which keeps the replicas bit-identical without parameter broadcasts.
+latency-bound on the xGMI mesh, hence as few and as large as the algorithm allows.
+
+Semantics: an N-rank step computes exactly the gradient of ONE process that holds the union of the ranks' data.
+Every loss on the path is a masked sum divided by a normaliser (sum of the mask over a window / the sampled rows /
+the PPO rows; advantage mean and std), so before its backward pass each learner all-reduces those few scalars
+(``all_reduce_sum``) and scales its local loss by the GLOBAL denominators; the gradient arenas are then SUMMED, clipped
+and applied identically on every rank, which keeps the replicas bit-identical without parameter broadcasts.
 """
 import torch
 import torch.distributed as dist
@@ -41,16 +45,14 @@ class DataParallel:
             self.broadcast_arena(a)
         return self
 
+    def all_reduce_sum(self, tensor):
+        """Sum a (small) tensor of loss normalisers over the ranks, in place; returns it."""
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
+        return tensor
+
     def all_reduce_grads(self, *arenas):
-        """Average the gradient arenas over the ranks: one collective per arena, in place."""
-        works = []
-        for a in arenas:
-            if self.backend == "nccl":
-                works.append(dist.all_reduce(a.grad, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
-            else:
-                works.append(dist.all_reduce(a.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        """Sum the gradient arenas over the ranks (the local losses are already scaled by the global normalisers): one
+        collective per arena, in place."""
+        works = [dist.all_reduce(a.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for a in arenas]
         for w in works:
             w.wait()
-        if self.backend != "nccl":
-            for a in arenas:
-                a.grad.div_(self.world)

@@ -1,6 +1,10 @@
-"""CPU, world_size 2, gloo: the data-parallel exchange step.  Each rank runs the learners on its own
-shard (host-emulated kernels); after the gradient all-reduce the replicas must hold bit-identical
-parameters, and the averaged gradient must equal the mean of the two single-rank gradients."""
+"""CPU, world_size 2, gloo: the data-parallel exchange step (host-emulated kernels).
+
+Two things are checked on both ranks:
+* EXACTNESS -- a 2-rank step equals the step of ONE process that holds the union of the ranks' data: every learner
+  (behaviour, prediction, PPO) is run once on the full 4-env batch in a single-process replica and once data-parallel on
+  the rank's 2-env half; the post-step parameters must agree (global loss normalisers + summed gradients);
+* the replicas stay bit-identical through a full synthetic training cycle."""
 import os
 import subprocess
 import sys
@@ -12,43 +16,94 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = r'''
 import os, sys, io, contextlib
 sys.path.insert(0, os.environ["IPLAN_ROOT"])
+import numpy as np
 import torch
 import torch.distributed as dist
 from iplan_amd import _lib as L
 from tests.emu.emu_lib import get_emu_lib
 L.use_library_for_tests(get_emu_lib())
+from iplan_amd import synth
 from iplan_amd.config import default_args
 from iplan_amd.harness import SyntheticLoop
 from iplan_amd.parallel import DataParallel
 dist.init_process_group("gloo")
-rank = dist.get_rank()
-args = default_args("highway", use_cuda=False, max_vehicle_num=4, n_agents=2, episode_limit=12, batch_size_run=2,
-                    buffer_size=2, batch_size=1, ppo_epoch=2, pred_batch_size=4, max_history_len=3)
-loop = SyntheticLoop(args, 2, seed=100 + rank, device="cpu")       # different data AND different initial weights per rank
-dp = DataParallel().attach(loop)
-arenas = [loop.mac.actor_arena, loop.mac.critic_arena, loop.behavior.enc_arena, loop.behavior.dec_arena,
-          loop.prediction.gat_arena, loop.prediction.dec_arena]
+rank, world = dist.get_rank(), dist.get_world_size()
+EF, ER = 4, 2                                                       # envs of the union / of one rank
+kw = dict(use_cuda=False, max_vehicle_num=4, n_agents=2, episode_limit=12, ppo_epoch=2, pred_batch_size=4, max_history_len=3)
+args_f = default_args("highway", batch_size_run=EF, buffer_size=EF, batch_size=EF, **kw)
+args_r = default_args("highway", batch_size_run=ER, buffer_size=ER, batch_size=ER, **kw)
+nA, N, T, Lw, P = args_f.n_agents, args_f.max_vehicle_num, args_f.episode_limit, args_f.max_history_len, args_f.pred_length
+full = SyntheticLoop(args_f, EF, seed=100, device="cpu")            # the single-process replica (same on every rank)
+loop = SyntheticLoop(args_r, ER, seed=100 + rank, device="cpu")     # this rank: different data AND initial weights ...
+def arenas_of(l):
+    return [l.mac.actor_arena, l.mac.critic_arena, l.behavior.enc_arena, l.behavior.dec_arena,
+            l.prediction.gat_arena, l.prediction.dec_arena]
+if rank == 0:
+    for a, b in zip(arenas_of(loop), arenas_of(full)):
+        a.data.copy_(b.data)
+dp = DataParallel().attach(loop)                                    # ... until rank 0's weights are broadcast
 def gathered(t):
-    out = [torch.empty_like(t) for _ in range(2)]
+    out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t.contiguous())
     return out
-for a in arenas:                                                    # broadcast made the replicas identical
+for a, b in zip(arenas_of(loop), arenas_of(full)):
     g = gathered(a.data)
-    assert torch.equal(g[0], g[1])
-# averaged gradient == mean of the per-rank gradients (check on the behaviour nets)
+    assert torch.equal(g[0], g[1]) and torch.equal(a.data, b.data)
+
+# ---------------------------------------------------------------- exactness: union batch vs. 2 ranks x half
+fields = synth.make_episode_fields(args_f, EF, seed=5, terminated_p=0.5)
+T1 = T + 1
+b_full = synth.DictBatch(fields, EF, T1)
+b_rank = synth.DictBatch({k: v[rank * ER:(rank + 1) * ER].contiguous() for k, v in fields.items()}, ER, T1)
+gen = torch.Generator().manual_seed(11)
+def close(a, b, what):
+    err = (a - b).abs().max().item() / max(1e-12, b.abs().max().item())
+    assert err < 2e-6, (what, err)
+# behaviour: same dropout flags on the same (env, entity) chains
+J = T - 1 - Lw
+keep_f = (torch.rand(nA, J, EF * N, Lw, 64, generator=gen) < 0.9).to(torch.uint8)
+keep_r = keep_f[:, :, rank * ER * N:(rank + 1) * ER * N].contiguous()
+lf = full.behavior.learn(b_full, 0, keep=keep_f)
+lr_ = loop.behavior.learn(b_rank, 0, keep=keep_r)
+close(loop.behavior.enc_arena.data, full.behavior.enc_arena.data, "behaviour encoder")
+close(loop.behavior.dec_arena.data, full.behavior.dec_arena.data, "behaviour decoder")
+# prediction: S samples per rank; the single process sees rank 0's samples followed by rank 1's
+S, avail = args_f.pred_batch_size, T - P - 1
+ep = torch.stack([torch.randint(r * ER, (r + 1) * ER, (nA, S), generator=gen) for r in range(world)], 1)   # [nA, world, S]
+tt = torch.randint(0, avail, (nA, world, S), generator=gen)
+sel_f = (ep * avail + tt).reshape(nA, world * S)
+sel_r = ((ep[:, rank] - rank * ER) * avail + tt[:, rank])
+u = torch.rand(nA, world, S, N, N - 1, 2, generator=gen).clamp_(1e-10, 1.0)
+noise = -torch.log(-torch.log(u))
+keep_p = (torch.rand(nA, P, world, S * N, args_f.attention_dim, generator=gen) < 0.9).float()
+full.prediction.learn(b_full, 0, noise=noise.reshape(nA, world * S, N, N - 1, 2), keep=keep_p.reshape(nA, P, world * S * N, -1),
+                      sel=sel_f.numpy())
+loop.prediction.learn(b_rank, 0, noise=noise[:, rank].contiguous(), keep=keep_p[:, :, rank].contiguous(), sel=sel_r.numpy())
+close(loop.prediction.gat_arena.data, full.prediction.gat_arena.data, "prediction GAT")
+close(loop.prediction.dec_arena.data, full.prediction.dec_arena.data, "prediction decoder")
+# PPO: advantage statistics, mask sums and the entropy mean run over the union's rows
+with contextlib.redirect_stdout(io.StringIO()):
+    full.learner.insert_episode_batch(b_full)
+    full.learner.train(0)
+    loop.learner.insert_episode_batch(b_rank)
+    loop.learner.train(0)
+close(loop.mac.actor_arena.data, full.mac.actor_arena.data, "PPO actors")
+close(loop.mac.critic_arena.data, full.mac.critic_arena.data, "PPO critics")
+
+# ---------------------------------------------------------------- a full synthetic cycle keeps the replicas identical
 calls = []
 orig = dp.all_reduce_grads
 def spy(*ar):
     before = [gathered(a.grad) for a in ar]
     orig(*ar)
     for a, b in zip(ar, before):
-        assert torch.allclose(a.grad, (b[0] + b[1]) / 2, rtol=0, atol=1e-7)
+        assert torch.allclose(a.grad, b[0] + b[1], rtol=0, atol=1e-7)
     calls.append(len(ar))
 dp.all_reduce_grads = spy
 with contextlib.redirect_stdout(io.StringIO()):
     loop.cycle()
-assert len(calls) == 1 + 1 + args.ppo_epoch, calls               # behaviour, prediction, one per PPO epoch
-for a in arenas:                                                    # replicas still bit-identical after all updates
+assert len(calls) == 1 + 1 + args_r.ppo_epoch, calls                # behaviour, prediction, one per PPO epoch
+for a in arenas_of(loop):
     g = gathered(a.data)
     assert torch.equal(g[0], g[1]), "replicas diverged"
     assert torch.isfinite(a.data).all()
