@@ -41,6 +41,9 @@ enum {
 
 const char* iplan_last_error(void);
 int iplan_version(void);
+/* sizeof() of an argument struct by name ("IplanGatFwdArgs", ...), 0 if unknown: lets a foreign-language binding check
+ * its own struct mirror against the library it loaded. */
+size_t iplan_sizeof(const char* struct_name);
 
 /* Limits of this build (compile-time tile sizes). */
 #define IPLAN_MAX_ENTITIES 64      /* N  : entities per (env, agent) scene             */

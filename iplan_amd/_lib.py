@@ -51,7 +51,7 @@ class IplanError(RuntimeError):
 ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step", "iplan_wgrad",
                 "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_loss", "iplan_gat_bwd",
                 "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd"]
-RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups"]      # non (args*, stream) signatures
+RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups", "iplan_sizeof"]      # non (args*, stream) signatures
 
 
 class Lib:
@@ -71,6 +71,8 @@ class Lib:
             if not hasattr(cdll, name):
                 raise IplanError(f"{name} missing from the loaded library")
             getattr(cdll, name).restype = C.c_int
+        cdll.iplan_sizeof.restype = C.c_size_t
+        cdll.iplan_sizeof.argtypes = [C.c_char_p]
         cdll.iplan_wgrad_workspace_floats.restype = C.c_size_t
         cdll.iplan_wgrad_workspace_floats.argtypes = [C.c_void_p]
 
@@ -298,3 +300,11 @@ class BehArgs(C.Structure):
         ("bwd_j_lo", i32), ("bwd_j_hi", i32), ("dec_carry", fp),
         ("fwd_phase", i32), ("fwd_j_lo", i32), ("fwd_j_hi", i32), ("enc_carry", fp), ("win_norm", fp),
     ]
+
+
+# ctypes mirror -> C struct name (checked against iplan_sizeof() of the loaded library by tests/test_abi.py)
+STRUCT_MIRRORS = {"IplanGatSaved": GatSaved, "IplanGatFwdArgs": GatFwdArgs, "IplanGatBwdArgs": GatBwdArgs,
+                  "IplanEncFwdArgs": EncFwdArgs, "IplanAcNet": AcNet, "IplanAcFeatures": AcFeatures, "IplanAcFwdArgs": AcFwdArgs,
+                  "IplanAcBwdArgs": AcBwdArgs, "IplanAdamArgs": AdamArgs, "IplanWgradProblem": WgradProblem,
+                  "IplanWgradArgs": WgradArgs, "IplanPpoPrepareArgs": PpoPrepareArgs, "IplanPpoLossArgs": PpoLossArgs,
+                  "IplanPdecArgs": PdecArgs, "IplanBehArgs": BehArgs}

@@ -1,0 +1,55 @@
+"""The C ABI (include/iplan_hip.h): the gfx950 library loads without a GPU and exports every entry point the header
+declares; the ctypes mirrors of the argument structs have the sizes the loaded library was compiled with (for the HIP
+library and for the host-emulated build of the same sources).  No compute calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "iplan_hip.h")
+HIP_LIB = os.path.join(ROOT, "iplan_amd", "libiplan_hip.so")
+
+
+def declared_entry_points():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+char\s*\*|int|int64_t|size_t)\s+(iplan_\w+)\s*\(", text, flags=re.M)
+    assert len(names) >= 22, names
+    return sorted(set(names))
+
+
+@pytest.fixture(scope="module")
+def hip_lib():
+    if not os.path.exists(HIP_LIB):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "iplan_amd", "csrc"), "all"], check=True, timeout=1800)
+    return C.CDLL(HIP_LIB)
+
+
+def test_hip_library_exports_every_declared_entry_point(hip_lib):
+    missing = [n for n in declared_entry_points() if not hasattr(hip_lib, n)]
+    assert not missing, missing
+    hip_lib.iplan_version.restype = C.c_int
+    assert hip_lib.iplan_version() >= 100
+
+
+def _check_sizes(cdll):
+    from iplan_amd import _lib as L
+    cdll.iplan_sizeof.restype = C.c_size_t
+    cdll.iplan_sizeof.argtypes = [C.c_char_p]
+    structs = set(re.findall(r"^\}\s*(Iplan\w+)\s*;", open(HEADER).read(), flags=re.M))
+    assert structs == set(L.STRUCT_MIRRORS), structs ^ set(L.STRUCT_MIRRORS)
+    for name, mirror in L.STRUCT_MIRRORS.items():
+        assert cdll.iplan_sizeof(name.encode()) == C.sizeof(mirror), (name, cdll.iplan_sizeof(name.encode()), C.sizeof(mirror))
+    assert cdll.iplan_sizeof(b"NoSuchStruct") == 0
+
+
+def test_struct_mirrors_match_the_hip_library(hip_lib):
+    _check_sizes(hip_lib)
+
+
+def test_struct_mirrors_match_the_emulated_library():
+    from tests.emu.emu_lib import get_emu_lib
+    _check_sizes(get_emu_lib().c)
