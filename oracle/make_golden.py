@@ -528,6 +528,55 @@ def golden_ippo_train(seed=70, env="highway"):
                os.path.join(GOLD, f"{tag}.pt"))
 
 
+
+def obs_stream(K, nA, obs_num, d, T, seed, n_ids=14, p_seen=0.6):
+    """Synthetic Highway-style observation stream [T][K, nA, obs_num, 1 + d]: row 0 = the ego (id = agent index + 1),
+    other rows = vehicles drawn from a pool of ids that come and go; unobserved rows are all-zero."""
+    rng = np.random.default_rng(seed)
+    steps = []
+    for _ in range(T):
+        obs = np.zeros((K, nA, obs_num, d + 1))
+        for k in range(K):
+            for i in range(nA):
+                obs[k, i, 0, 0] = i + 1
+                obs[k, i, 0, 1:] = rng.uniform(-1, 1, d)
+                ids = rng.choice(np.arange(10, 10 + n_ids), size=obs_num - 1, replace=False)
+                for j in range(1, obs_num):
+                    if rng.random() < p_seen:
+                        obs[k, i, j, 0] = ids[j - 1]
+                        obs[k, i, j, 1:] = rng.uniform(-1, 1, d)
+        steps.append(obs)
+    return steps
+
+
+def golden_obs_wrapper(seed=80):
+    """observation_wrapper.py: the reference class on a synthetic stream; outputs after every step + the episode output."""
+    from types import SimpleNamespace
+    import observation_wrapper as ref_ow                       # the reference's (REF is on sys.path)
+    from oracle.obs_wrapper_oracle import HistoryWrapperOracle
+    K, nA, obs_num, d, T, L, N = 3, 2, 6, 4, 12, 3, 16
+    steps = obs_stream(K, nA, obs_num, d, T, seed)
+    ref = ref_ow.observersation_state_history_wrapper(SimpleNamespace(obs_shape_single=d, batch_size_run=K), nA, N, T, L)
+    orc = HistoryWrapperOracle(K, nA, N, T, L, d)
+    ref.agent_obs_profile_init(steps[0])
+    orc.init(steps[0])
+    hist, single = [], []
+    for o in steps:
+        ref.obs_history_create(o)
+        orc.create(o)
+        hist.append(ref.obs_history_output().copy())
+        single.append(ref.obs_single_history_output().copy())
+        assert np.array_equal(hist[-1], orc.window(L)) and np.array_equal(single[-1], orc.single())
+    mask = (np.random.default_rng(seed + 1).random((K, T, nA)) < 0.8).astype(np.float64)
+    raw, seg = ref.obs_history_episode_output(mask)
+    assert np.array_equal(raw, orc.window(T, mask))
+    state = np.random.default_rng(seed + 2).uniform(-1, 1, (K, 1, 7 * (d + 1)))
+    ns, no = ref.pure_obs_state_wrapper(state, steps[-1])
+    torch.save(dict(dims=dict(K=K, nA=nA, obs_num=obs_num, d=d, T=T, L=L, N=N), steps=np.stack(steps), hist=np.stack(hist),
+                    single=np.stack(single), mask=mask, raw=raw, seg=seg, vehicle_ids=ref.obs_vehicle_id, agent_ids=ref.agent_id,
+                    state=state, new_state=ns, new_obs=no), os.path.join(GOLD, "obs_wrapper.pt"))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(4)
@@ -544,11 +593,9 @@ def main():
     golden_ippo_train(80, "mpe_easy")
     golden_checkpoint()
     golden_behavior_hard_learn()
+    golden_obs_wrapper()
     print("all golden fixtures written to", GOLD)
 
-
-if __name__ == "__main__":
-    main()
 
 
 def golden_checkpoint():
@@ -618,3 +665,7 @@ def golden_behavior_hard_learn(seed=55):
     torch.save(dict(args=vars(args), fields=fields, pre=pre, post=post, clipped=clipped,
                     behavior_loss=[float(x) for x in bl], dropout=drops),
                os.path.join(GOLD, "behavior_hard_learn.pt"))
+
+
+if __name__ == "__main__":
+    main()
