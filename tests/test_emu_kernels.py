@@ -239,3 +239,21 @@ def check_reference_checkpoint(golden, device, tmp_path):
 
 def test_reference_checkpoint_emulated(golden, tmp_path):
     check_reference_checkpoint(golden, "cpu", tmp_path)
+
+
+def test_size_independent_properties_emulated():
+    """tests/properties.py at small sizes through the host emulator (the GPU suite runs them at config 3's sizes)."""
+    from iplan_amd.config import default_args
+    from tests import properties as P
+    args = default_args("highway", use_cuda=False, max_vehicle_num=4, n_agents=2, episode_limit=9, batch_size_run=2,
+                        buffer_size=2, batch_size=1, max_history_len=3)
+    loop = P.make_loop(args, 2, "cpu")
+    batch = P.check_env_independence(loop, sub=1)
+    P.check_behaviour_properties(loop, batch, fd_tol=5e-2)
+    P.check_wgrad_additivity("cpu", n_nets=2, rows=40, n_inner=5, O=192, K=64)
+
+
+@pytest.mark.parametrize("N", [2, 17])
+def test_gat_entity_count_edges_emulated(N):
+    from tests.test_gpu_gat import gat_vs_oracle
+    gat_vs_oracle(B=2, N=N, D=13, seed=N, device="cpu")

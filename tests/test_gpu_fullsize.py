@@ -1,0 +1,32 @@
+"""Properties of the hot path at BASELINE config 3's full sizes (32 envs x 5 agents x 55 entities x 90 steps) on the
+GPU -- where an oracle run is not affordable -- see tests/properties.py; plus the entity-count edge cases of the GAT."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def loop():
+    from iplan_amd.config import default_args
+    from tests.properties import make_loop
+    args = default_args("highway", use_cuda=True, batch_size_run=32)
+    return make_loop(args, 32, torch.device("cuda"))
+
+
+def test_env_independence_and_learner_properties_full_size(loop):
+    from tests import properties as P
+    batch = P.check_env_independence(loop, sub=7)
+    P.check_behaviour_properties(loop, batch)
+
+
+def test_wgrad_additivity_full_size():
+    from tests.properties import check_wgrad_additivity
+    check_wgrad_additivity("cuda", n_nets=5, rows=1760 * 8, n_inner=79, O=192, K=64)
+
+
+@pytest.mark.parametrize("N", [2, 17, 64])
+def test_gat_entity_count_edges_vs_oracle(N):
+    """minimum (2), ragged (17) and maximum (64) entity counts against the CPU oracle"""
+    from tests.test_gpu_gat import gat_vs_oracle
+    gat_vs_oracle(B=3, N=N, D=13, seed=N)

@@ -46,3 +46,21 @@ def test_gat_forward_stacked_nets_vs_oracle():
         ref = O.gat_forward(cpu_params[i], torch.cat([hist[:, i], lat[:, i]], -1), hid[:, i].reshape(E * N, A),
                             noise[i].reshape(-1, 2))
         assert rel_err(out[i].reshape(E * N, A), ref) < 1e-5, i
+
+
+def gat_vs_oracle(B, N, D, seed, device="cuda"):
+    """One GAT_Net forward of random weights / inputs against the CPU oracle (any entity count 2..64)."""
+    from iplan_amd.config import default_args
+    from iplan_amd.nova.GAT_Net import GAT_Net, gumbel_noise
+    from oracle import iplan_oracle as O
+    args = default_args("highway", use_cuda=(device != "cpu"))
+    torch.manual_seed(seed)
+    net = GAT_Net(D, args)
+    params = {k: v.detach().clone().cpu() for k, v in net.state_dict().items()}
+    obs = torch.rand(B, N, D) * 2 - 1
+    h_prev = torch.randn(B * N, args.attention_dim) * 0.1
+    noise = gumbel_noise((B * N * (N - 1), 2), "cpu")
+    with torch.no_grad():
+        out = net(obs.to(device), h_prev.to(device), noise=noise.to(device))
+    ref = O.gat_forward(params, obs, h_prev, noise)
+    assert rel_err(out, ref) < 1e-5, rel_err(out, ref)
