@@ -554,6 +554,35 @@ typedef struct {
 int iplan_beh_fwd(const IplanBehArgs* args, iplan_stream_t stream);
 int iplan_beh_bwd(const IplanBehArgs* args, iplan_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Three-layer perceptron of the FC behaviour ablation (nova/behavior_FC_net.py:6-37, Encoder_3FC / Decoder_3FC):
+ *   out = [softmax] (W3 tanh(W2 tanh(W1 x + b1) + b2) + b3)   for n_nets stacked nets, rows per net.
+ * off[0..5] = linear_1.weight [H,K0], linear_1.bias, linear_2.weight [H,H], linear_2.bias, out.weight [O,H], out.bias.
+ * Forward: writes out, saved = [tanh1 (H) | tanh2 (H)] per row and, when `target` is given, the per-wave sums of
+ * |target - out| (L1 loss numerator) in loss_part [n_nets, 4 * ceil(rows/64)].
+ * Backward: d(out) = g_out, or -sign(target - out) * g_scale when g_out is NULL; writes dsave = [d pre1 (H) | d pre2 (H) |
+ * d pre3 (16 * ceil(O/16))] per row (operands of iplan_wgrad) and dx [n_nets, rows, K0] if not NULL.
+ */
+typedef struct {
+    int32_t n_nets, K0, H, O, softmax;
+    int64_t rows;
+    const float* x;             /* [n_nets, rows, K0]                                                   */
+    const float* params;
+    int64_t params_s_net;
+    int64_t off[6];
+    float* out;                 /* [n_nets, rows, O]                                                    */
+    float* saved;               /* [n_nets, rows, 2H] (forward: optional)                               */
+    const float* target;        /* [n_nets, rows, O] or NULL                                            */
+    float* loss_part;
+    const float* g_out;         /* backward: [n_nets, rows, O] or NULL                                  */
+    float g_scale;
+    float* dsave;               /* backward: [n_nets, rows, 2H + 16*ceil(O/16)]                         */
+    float* dx;                  /* backward: [n_nets, rows, K0] or NULL                                 */
+} IplanMlp3Args;
+
+int iplan_mlp3_fwd(const IplanMlp3Args* args, iplan_stream_t stream);
+int iplan_mlp3_bwd(const IplanMlp3Args* args, iplan_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,7 +50,7 @@ class IplanError(RuntimeError):
 # every entry point include/iplan_hip.h declares
 ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step", "iplan_wgrad",
                 "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_loss", "iplan_gat_bwd",
-                "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd"]
+                "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd", "iplan_mlp3_fwd", "iplan_mlp3_bwd"]
 RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups", "iplan_sizeof"]      # non (args*, stream) signatures
 
 
@@ -302,9 +302,19 @@ class BehArgs(C.Structure):
     ]
 
 
+# ---- FC behaviour ablation -------------------------------------------------------------------------------
+class Mlp3Args(C.Structure):
+    _fields_ = [
+        ("n_nets", i32), ("K0", i32), ("H", i32), ("O", i32), ("softmax", i32), ("rows", i64),
+        ("x", fp), ("params", fp), ("params_s_net", i64), ("off", i64 * 6),
+        ("out", fp), ("saved", fp), ("target", fp), ("loss_part", fp), ("g_out", fp), ("g_scale", C.c_float),
+        ("dsave", fp), ("dx", fp),
+    ]
+
+
 # ctypes mirror -> C struct name (checked against iplan_sizeof() of the loaded library by tests/test_abi.py)
 STRUCT_MIRRORS = {"IplanGatSaved": GatSaved, "IplanGatFwdArgs": GatFwdArgs, "IplanGatBwdArgs": GatBwdArgs,
                   "IplanEncFwdArgs": EncFwdArgs, "IplanAcNet": AcNet, "IplanAcFeatures": AcFeatures, "IplanAcFwdArgs": AcFwdArgs,
                   "IplanAcBwdArgs": AcBwdArgs, "IplanAdamArgs": AdamArgs, "IplanWgradProblem": WgradProblem,
                   "IplanWgradArgs": WgradArgs, "IplanPpoPrepareArgs": PpoPrepareArgs, "IplanPpoLossArgs": PpoLossArgs,
-                  "IplanPdecArgs": PdecArgs, "IplanBehArgs": BehArgs}
+                  "IplanPdecArgs": PdecArgs, "IplanBehArgs": BehArgs, "IplanMlp3Args": Mlp3Args}

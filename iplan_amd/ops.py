@@ -786,3 +786,73 @@ def bdec_forward(enc_arena, dec_arena, window, latent, hidden, drop_p=0.0, keep=
         a.dec_off[i] = dec_arena.off(k)
     lib.call("iplan_beh_fwd", a, L.current_stream(dev))
     return pred, hout
+
+
+# ---- FC behaviour ablation: stacked three-layer perceptrons -------------------------------------------------
+MLP3_PARAM_ORDER = ("linear_1.weight", "linear_1.bias", "linear_2.weight", "linear_2.bias", "out.weight", "out.bias")
+
+
+def mlp3_forward(arena, prefix, x, H, O, softmax=False, target=None, save=True, lib=None):
+    """out = [softmax](W3 tanh(W2 tanh(W1 x + b1) + b2) + b3) for all nets: x [n_nets, rows, K0] -> out [n_nets, rows, O].
+    ``prefix``: parameter-name prefix inside the arena ("" or "decoder.").  With ``target`` also returns the per-net sum of
+    |target - out| (L1 numerator).  Returns dict(out, saved, l1, _args)."""
+    lib = _lib(lib)
+    n_nets, rows, K0 = x.shape
+    assert x.is_contiguous() and x.dtype == torch.float32
+    dev = x.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    a = L.Mlp3Args()
+    a.n_nets, a.K0, a.H, a.O, a.softmax, a.rows = n_nets, K0, H, O, 1 if softmax else 0, rows
+    a.x, a.params, a.params_s_net = x.data_ptr(), arena.data.data_ptr(), arena.net_stride
+    for i, k in enumerate(MLP3_PARAM_ORDER):
+        a.off[i] = arena.off(prefix + k)
+    out = dict(out=torch.empty(n_nets, rows, O, **f32))
+    a.out = out["out"].data_ptr()
+    if save:
+        out["saved"] = torch.empty(n_nets, rows, 2 * H, **f32)
+        a.saved = out["saved"].data_ptr()
+    if target is not None:
+        assert target.shape == (n_nets, rows, O) and target.is_contiguous()
+        part = torch.empty(n_nets, 4 * ((rows + 63) // 64), **f32)
+        a.target, a.loss_part = target.data_ptr(), part.data_ptr()
+    lib.call("iplan_mlp3_fwd", a, L.current_stream(dev))
+    if target is not None:
+        out["l1"] = part.sum(dim=1)
+    out["_args"] = a
+    out["_keep"] = (x, target)
+    return out
+
+
+def mlp3_backward(arena, prefix, fwd, g_out=None, g_scale=0.0, want_dx=False, beta=0.0, lib=None):
+    """Backward of mlp3_forward: fills the arena's gradient entries of the six tensors (accumulating when beta = 1) and
+    returns dx [n_nets, rows, K0] if asked.  d(out) = g_out, or the L1 loss's -sign(target - out) * g_scale."""
+    lib = _lib(lib)
+    a = fwd["_args"]
+    n_nets, rows, K0, H, O = a.n_nets, a.rows, a.K0, a.H, a.O
+    dev = fwd["out"].device
+    f32 = dict(dtype=torch.float32, device=dev)
+    O16 = 16 * ((O + 15) // 16)
+    DS = 2 * H + O16
+    ds = torch.empty(n_nets, rows, DS, **f32)
+    a.dsave = ds.data_ptr()
+    dx = torch.empty(n_nets, rows, K0, **f32) if want_dx else None
+    a.dx = dx.data_ptr() if want_dx else None
+    if g_out is not None:
+        assert g_out.shape == (n_nets, rows, O) and g_out.is_contiguous()
+        a.g_out = g_out.data_ptr()
+    else:
+        a.g_out, a.g_scale = None, g_scale
+    lib.call("iplan_mlp3_bwd", a, L.current_stream(dev))
+    off = arena.off
+    sv, x = fwd["saved"], fwd["_keep"][0]
+    w = Wgrad(arena.grad, n_nets)
+    dst = (rows * DS, DS, DS)
+    w.add(ds.data_ptr(), dst, H, rows, 1, x=x.data_ptr(), x_strides=(rows * K0, K0, K0), K=K0, beta=beta,
+          dw_off=off(prefix + "linear_1.weight"), db_off=off(prefix + "linear_1.bias"))
+    w.add(ds.data_ptr() + 4 * H, dst, H, rows, 1, x=sv.data_ptr(), x_strides=(rows * 2 * H, 2 * H, 2 * H), K=H, beta=beta,
+          dw_off=off(prefix + "linear_2.weight"), db_off=off(prefix + "linear_2.bias"))
+    w.add(ds.data_ptr() + 8 * H, dst, O, rows, 1, x=sv.data_ptr() + 4 * H, x_strides=(rows * 2 * H, 2 * H, 2 * H), K=H, beta=beta,
+          dw_off=off(prefix + "out.weight"), db_off=off(prefix + "out.bias"))
+    w._keep += [ds, sv, x]
+    w.run(lib)
+    return dx

@@ -444,3 +444,32 @@ def behavior_hard_learn_loss(enc_p, dec_p, history, mask, L, drop_masks, drop_p)
     pred = torch.stack(preds, 1).reshape(E, J * L, N, d)
     m = mask[:, :J * L].to(history.dtype)[:, :, None, None].expand(E, J * L, N, d)
     return (torch.abs(nxt - pred) * m).sum() / (m.sum() + EPS) * d * N
+
+
+def mlp3(p, x, softmax=False):
+    """nova/behavior_FC_net.py:15-19 / :32-36: out(tanh(linear_2(tanh(linear_1(x))))), optionally softmaxed."""
+    h = torch.tanh(x @ p["linear_1.weight"].t() + p["linear_1.bias"])
+    h = torch.tanh(h @ p["linear_2.weight"].t() + p["linear_2.bias"])
+    y = h @ p["out.weight"].t() + p["out.bias"]
+    return torch.softmax(y, dim=-1) if softmax else y
+
+
+def behavior_fc_learn_loss(enc_p, dec_p, history, L):
+    """nova/behavior_FC_policy.py:168-201 for one agent.  history [E,T,N,d] (already [:, :-1]).  Right-aligned zero-padded
+    windows (behavior_traj_wrapper :110-138); the decoder of window j is fed the encoder output of window j-1 (zeros at
+    j = 0); the "mask" over the next trajectory is all ones (the wrapper fills the CURRENT mask twice, :131-136), so every
+    window's error is the unmasked sum / (E N L d + EPS) * d * N, averaged over the J = T-1-L windows."""
+    E, T, N, d = history.shape
+    Z = enc_p["out.weight"].shape[0]
+    dp = strip_prefix(dec_p, "decoder.")
+    J = T - 1 - L
+    pad = torch.cat([torch.zeros(E, L - 1, N, d, dtype=history.dtype), history], dim=1)
+    latent = torch.zeros(E, N, Z, dtype=history.dtype)
+    total = 0.0
+    for j in range(J):
+        curr = pad[:, j:j + L].permute(0, 2, 1, 3).reshape(E, N, L * d)           # steps j-L+1 .. j
+        nxt = pad[:, j + 1:j + 1 + L].permute(0, 2, 1, 3).reshape(E, N, L * d)    # steps j-L+2 .. j+1
+        pred = mlp3(dp, torch.cat([curr, latent], dim=-1))
+        latent = mlp3(enc_p, curr, softmax=True)
+        total = total + torch.abs(nxt - pred).sum() / (float(E * N * L * d) + EPS) * d * N
+    return total / J

@@ -594,6 +594,7 @@ def main():
     golden_checkpoint()
     golden_behavior_hard_learn()
     golden_obs_wrapper()
+    golden_behavior_fc_learn()
     print("all golden fixtures written to", GOLD)
 
 
@@ -665,6 +666,40 @@ def golden_behavior_hard_learn(seed=55):
     torch.save(dict(args=vars(args), fields=fields, pre=pre, post=post, clipped=clipped,
                     behavior_loss=[float(x) for x in bl], dropout=drops),
                os.path.join(GOLD, "behavior_hard_learn.pt"))
+
+
+def golden_behavior_fc_learn(seed=58):
+    """iPLAN-FC ablation (nova/behavior_FC_policy.py): three-layer perceptrons, no recurrent state."""
+    from nova.behavior_FC_policy import Behavior_policy
+    print("behavior learn (FC ablation)")
+    args = small_args(max_vehicle_num=5, n_agents=2, episode_limit=14, batch_size_run=3, max_history_len=4)
+    E = 3
+    torch.manual_seed(seed)
+    pol = Behavior_policy(args, NullLogger())
+    batch, fields = ref_episode_batch(args, E, seed + 1, 0.8)
+    pre = dict(enc=[sd(m) for m in pol.behavior_encoder], dec=[sd(m) for m in pol.behavior_decoder])
+    win = torch.rand(E, args.n_agents, args.max_vehicle_num, args.max_history_len, args.obs_shape_single) * 2 - 1
+    lat_roll, _ = pol.latent_update(win.numpy(), None, None)
+    bl, _, _ = pol.learn(batch, 0)
+    post = dict(enc=[sd(m) for m in pol.behavior_encoder], dec=[sd(m) for m in pol.behavior_decoder])
+    clipped = dict(enc=[{k: v.grad.clone() for k, v in m.named_parameters()} for m in pol.behavior_encoder],
+                   dec=[{k: v.grad.clone() for k, v in m.named_parameters()} for m in pol.behavior_decoder])
+    hist = fields["history"][:, :-1]
+    for i in range(args.n_agents):
+        ep, dp = req(pre["enc"][i]), req(pre["dec"][i])
+        loss = O.behavior_fc_learn_loss(ep, dp, hist[:, :, i], args.max_history_len)
+        check(f"agent{i} FC behavior loss", loss, bl[i], 1e-5)
+        loss.backward()
+        O.clip_grad_norm([ep[k].grad for k in ep], args.max_grad_norm)
+        O.clip_grad_norm([dp[k].grad for k in dp], args.max_grad_norm)
+        for k in ep:
+            check(f"agent{i} clipped grad enc.{k}", ep[k].grad, clipped["enc"][i][k], 2e-4)
+        for k in dp:
+            check(f"agent{i} clipped grad dec.{k}", dp[k].grad, clipped["dec"][i][k], 2e-4)
+        check(f"agent{i} FC rollout latent", O.mlp3(pre["enc"][i], win[:, i].reshape(E, args.max_vehicle_num, -1), softmax=True),
+              torch.as_tensor(lat_roll[:, i]), 1e-5)
+    torch.save(dict(args=vars(args), fields=fields, pre=pre, post=post, clipped=clipped, behavior_loss=[float(x) for x in bl],
+                    window=win, latent=torch.as_tensor(lat_roll)), os.path.join(GOLD, "behavior_fc_learn.pt"))
 
 
 if __name__ == "__main__":

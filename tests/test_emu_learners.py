@@ -201,3 +201,42 @@ def check_behavior_hard_learn(g, device):
 
 def test_behavior_hard_learn_emulated(golden):
     check_behavior_hard_learn(golden("behavior_hard_learn"), "cpu")
+
+
+def check_behavior_fc_learn(g, device):
+    """iPLAN-FC ablation: rollout latent, loss, clipped gradients and post-Adam parameters vs the reference."""
+    from iplan_amd.nova.behavior_FC_policy import Behavior_policy
+    args = SimpleNamespace(**dict(g["args"], use_cuda=(device != "cpu")))
+    pol = Behavior_policy(args, RecLogger())
+    nA = args.n_agents
+    for i in range(nA):
+        pol.behavior_encoder[i].load_state_dict(g["pre"]["enc"][i])
+        pol.behavior_decoder[i].load_state_dict(g["pre"]["dec"][i])
+    lat, hid = pol.latent_update(g["window"].numpy(), None, None)
+    assert hid is None and max_rel(torch.as_tensor(lat), g["latent"]) < 1e-5
+    E = g["fields"]["history"].shape[0]
+    batch = synth.DictBatch(g["fields"], E, args.episode_limit + 1).to(device)
+    bl, stab, total = pol.learn(batch, 0)
+    assert stab == [] and len(total) == nA
+    changed = 0.0
+    for i in range(nA):
+        assert abs(float(bl[i]) - g["behavior_loss"][i]) <= 1e-5 * max(1.0, abs(g["behavior_loss"][i])), (i, bl[i])
+        for name, mods, arena in (("enc", pol.behavior_encoder, pol.enc_arena), ("dec", pol.behavior_decoder, pol.dec_arena)):
+            for k, ref in g["clipped"][name][i].items():
+                err = (arena.grad_of(i, k).cpu().double() - ref.double()).abs().max().item()
+                assert err <= 2e-5 * ref.abs().max().item() + 1e-9, ("clipped grad", name, i, k, err)
+            sd = mods[i].state_dict()
+            for k, ref in g["post"][name][i].items():
+                assert max_rel(sd[k], ref) < 1e-6, ("post", name, i, k)
+                changed = max(changed, (ref - g["pre"][name][i][k]).abs().max().item())
+    assert changed > 0                                           # the fixture really moved the parameters
+    # the module-level forwards (nova/behavior_FC_net.py) on the kernels
+    from iplan_amd.nova.behavior_FC_net import Encoder_3FC
+    enc = Encoder_3FC(args.obs_shape_single * args.max_history_len, args.encoder_rnn_dim, args.latent_dim)
+    enc.load_state_dict(g["pre"]["enc"][0])
+    x = g["window"][:, 0].reshape(E, args.max_vehicle_num, -1).to(device)
+    assert max_rel(enc(x).cpu(), g["latent"][:, 0]) < 1e-5
+
+
+def test_behavior_fc_learn_emulated(golden):
+    check_behavior_fc_learn(golden("behavior_fc_learn"), "cpu")

@@ -30,3 +30,8 @@ def test_gat_backward_matches_reference(golden, tag):
 def test_behavior_hard_learn_matches_reference(golden):
     from tests.test_emu_learners import check_behavior_hard_learn
     check_behavior_hard_learn(golden("behavior_hard_learn"), "cuda")
+
+
+def test_behavior_fc_learn_matches_reference(golden):
+    from tests.test_emu_learners import check_behavior_fc_learn
+    check_behavior_fc_learn(golden("behavior_fc_learn"), "cuda")
