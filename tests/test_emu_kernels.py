@@ -156,7 +156,7 @@ def test_harness_full_cycle_emulated(capsys):
     """rollout -> insert -> behaviour learn -> prediction learn -> PPO train, end to end (tiny dims)."""
     from iplan_amd.config import default_args
     from iplan_amd.harness import SyntheticLoop
-    args = default_args("highway", use_cuda=False, max_vehicle_num=4, n_agents=2, episode_limit=14, batch_size_run=2,
+    args = default_args("highway", use_cuda=False, max_vehicle_num=3, n_agents=2, episode_limit=10, batch_size_run=2,
                         buffer_size=2, batch_size=1, ppo_epoch=2, pred_batch_size=4, max_history_len=3)
     loop = SyntheticLoop(args, 2, seed=0, device="cpu")
     before = [p.detach().clone() for p in loop.mac.agents[0].parameters()]
@@ -166,7 +166,7 @@ def test_harness_full_cycle_emulated(capsys):
         # Highway polarity: the prediction / behaviour loss mask IS `terminated`, PPO's is 1 - terminated
         o["terminated"].copy_((torch.rand(o["terminated"].shape) < 0.5).to(torch.uint8))
     n = loop.cycle()
-    assert n == 2 * 14
+    assert n == 2 * 10
     assert loop.learner.last_train_info is not None and not loop.learner.buffers[0].can_sample()
     assert any((a - b).abs().max() > 0 for a, b in zip(before, loop.mac.agents[0].parameters()))
     assert (loop.behavior.enc_arena.data - enc_before).abs().max() > 0
@@ -245,7 +245,7 @@ def test_size_independent_properties_emulated():
     """tests/properties.py at small sizes through the host emulator (the GPU suite runs them at config 3's sizes)."""
     from iplan_amd.config import default_args
     from tests import properties as P
-    args = default_args("highway", use_cuda=False, max_vehicle_num=4, n_agents=2, episode_limit=9, batch_size_run=2,
+    args = default_args("highway", use_cuda=False, max_vehicle_num=3, n_agents=1, episode_limit=8, batch_size_run=2,
                         buffer_size=2, batch_size=1, max_history_len=3)
     loop = P.make_loop(args, 2, "cpu")
     batch = P.check_env_independence(loop, sub=1)

@@ -125,10 +125,10 @@ def test_behavior_learn_emulated(golden):
 
 
 def test_behavior_learn_bptt_in_pieces_emulated(golden, monkeypatch):
-    """The decoder BPTT cut into window ranges (carry of d(loss)/d(h) between the launches, weight gradients
-    accumulated piece by piece -- the GPU path's pipelining) lands on the same reference parameters."""
+    """The forward and the BPTT cut into window ranges (carries between the launches, weight gradients accumulated piece by
+    piece -- the GPU path's pipelining) land on the same reference parameters (hard-update fixture: 4 windows, 3 pieces)."""
     monkeypatch.setenv("IPLAN_BEH_PIECES", "3")
-    check_behavior_learn(golden("behavior_learn"), "cpu")
+    check_behavior_hard_learn(golden("behavior_hard_learn"), "cpu")
 
 
 def test_ippo_reference_shaped_methods_emulated(golden):
