@@ -45,6 +45,7 @@ class SyntheticLoop:
                 terminated=(torch.rand(T1, E, nA, 1, generator=gen) < 0.1).to(torch.uint8).to(device),
             ))
         self._rollouts = 0
+        self._graphs, self._g_batch, self._graph_failed = {}, None, False
 
     def new_batch(self):
         a, E = self.args, self.E
@@ -66,14 +67,66 @@ class SyntheticLoop:
         """One vectorised episode of E envs x T steps (ippo_parallel_runner.py:105-281 order of calls).
         Device resident: the three fused launches of a vector step read their inputs from, and write their
         outputs into, the episode-buffer tensors in place; the per-step random draws (gumbel noise of the hard
-        attention, the exponential race of the action sampling) are drawn for the whole rollout in two launches."""
+        attention, the exponential race of the action sampling) are drawn for the whole rollout in two launches.
+
+        IPLAN_ROLLOUT_GRAPH=1 (opt-in): the whole episode -- 3 x 90 launches on two streams plus the draws -- is captured
+        ONCE per observation set in a HIP graph and replayed into one static episode batch.  Measured on MI355X
+        (profiles/r01g_notes.md): an isolated rollout gains 2 % (22.5 vs 23.1 ms: the gaps between the three dependent
+        kernels of a vector step shrink), but inside the full training cycle graph replays cost 5-15 % (the learners'
+        multi-stream pipelines start later), so eager launches stay the default.  An active ops.KernelTimers sample or a
+        failed capture also falls back to eager launches."""
+        idx = self._rollouts % len(self.obs_sets)
+        self._rollouts += 1
+        obs = self.obs_sets[idx]
+        if self._graph_ok(idx):
+            g = self._graphs.get(idx)
+            if g is None:
+                g = self._capture(idx, obs)
+            if g is not None:
+                g.replay()
+                return self._g_batch
+        batch = self.new_batch()
+        self._rollout_body(obs, batch)
+        return batch
+
+    def _graph_ok(self, idx):
+        import os
+        from . import ops
+        if torch.device(self.device).type != "cuda" or os.environ.get("IPLAN_ROLLOUT_GRAPH", "0") != "1" or self._graph_failed:
+            return False
+        # bench.py's in-situ kernel timing brackets single launches with events, which a graph cannot hold: while it is
+        # active every 8th rollout runs eagerly (and is the one that gets timed)
+        return not (ops.TIMERS is not None and (self._rollouts - 1) % 8 == 0)
+
+    def _capture(self, idx, obs):
+        dev = torch.device(self.device)
+        try:
+            if self._g_batch is None:
+                self._g_batch = self.new_batch()
+            s = torch.cuda.Stream(dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):                       # warm-up outside the capture: allocations, lazy inits
+                self._rollout_body(obs, self._g_batch)
+            torch.cuda.current_stream(dev).wait_stream(s)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                self._rollout_body(obs, self._g_batch)
+            self._graphs[idx] = g
+            return g
+        except Exception as e:                               # noqa: BLE001 -- any capture problem: run eagerly from now on
+            print(f"[iplan_amd] rollout graph capture failed ({type(e).__name__}: {str(e)[:120]}); using eager launches")
+            self._graph_failed = True
+            torch.cuda.synchronize(dev)
+            return None
+
+    def _rollout_body(self, obs, batch):
         a, E = self.args, self.E
         T, nA, N, L = a.episode_limit, a.n_agents, a.max_vehicle_num, a.max_history_len
         dev = self.device
-        obs = self.obs_sets[self._rollouts % len(self.obs_sets)]
-        self._rollouts += 1
-        batch = self.new_batch()
         D = batch.data
+        for k in ("attention_latent", "behavior_latent", "rnn_states_actors", "rnn_states_critics"):
+            D[k].zero_()                                     # episode-initial state (the batch may be a re-used static one)
         hist_all = obs["hist"]                                         # [T1 + L - 1, E, nA, N, d] time-major "environment"
         # what env.step + EpisodeBatch.update would deliver step by step, copied once
         D["history"].copy_(hist_all[L - 1:L + T].permute(1, 0, 2, 3, 4))
@@ -94,25 +147,22 @@ class SyntheticLoop:
             main = torch.cuda.current_stream(dev)
             if getattr(self, "_side", None) is None:
                 self._side = torch.cuda.Stream(dev)
-                self._ev = (torch.cuda.Event(), torch.cuda.Event())
-            side, (ev_go, ev_done) = self._side, self._ev
+            side = self._side
         for t in range(T):
             self.mac.select_actions_ippo(batch, t, test_mode=False, q_noise=q_all[t], as_numpy=False, write_back=True)
             # env.step would run here; its outputs are the pre-generated tensors
             if two_streams:
-                ev_go.record(main)
+                side.wait_stream(main)
             if self.prediction is not None:
                 self.prediction.GAT_latent_update(D["history"][:, t + 1], D["attention_latent"][:, t], D["behavior_latent"][:, t],
                                                   noise=noise[t], out=D["attention_latent"][:, t + 1])
             if self.behavior is not None:
                 window = hist_all[t + 1:t + 1 + L].permute(1, 2, 3, 0, 4)           # [E, nA, N, L, d] sliding view, read in place
                 if two_streams:
-                    side.wait_event(ev_go)
                     with torch.cuda.stream(side):
                         self.behavior.latent_update(window, eh[t & 1], D["behavior_latent"][:, t],
                                                     out_latent=D["behavior_latent"][:, t + 1], out_hidden=eh[(t + 1) & 1][:, 0])
-                        ev_done.record(side)
-                    main.wait_event(ev_done)
+                    main.wait_stream(side)
                 else:
                     self.behavior.latent_update(window, eh[t & 1], D["behavior_latent"][:, t],
                                                 out_latent=D["behavior_latent"][:, t + 1], out_hidden=eh[(t + 1) & 1][:, 0])
