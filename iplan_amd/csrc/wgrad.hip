@@ -49,7 +49,10 @@ __host__ __device__ inline WgradGeom wgrad_geom(const IplanWgradProblem& p, int 
     g.n_kg = g.KT > 0 ? (g.KT + WG_TK - 1) / WG_TK : 1;
     g.jobs = g.n_og * g.n_kg;
     g.rows = (int64_t)p.n_outer * p.n_inner;
-    const int target = g.to == WG_TO_WIDE ? chunks_wide : IPLAN_WGRAD_MAX_CHUNKS;
+    // thin problems (one tile along O or K: a few MFMAs per 16 rows) are latency bound and their partial tiles are tiny:
+    // 8x more, shorter row chunks give them the waves in flight that hide the load latency
+    const bool thin = g.to != WG_TO_WIDE && (g.KT <= 1 || g.OT == 1);
+    const int target = g.to == WG_TO_WIDE ? chunks_wide : (thin ? 8 * IPLAN_WGRAD_MAX_CHUNKS : IPLAN_WGRAD_MAX_CHUNKS);
     int64_t vr = (g.rows + target - 1) / target;
     if (vr < 256) vr = 256;
     vr = (vr + 15) / 16 * 16;
@@ -79,7 +82,7 @@ struct WgradJobs {
 // Prefetch is rolling: as soon as the MFMAs of a sub-step are issued its operand registers are reloaded with the
 // same sub-step RB blocks ahead.  Bias gradients are lane-local column sums (VALU), reduced across the four
 // lane groups at the end.
-template <int TO, int RB>
+template <int TO, int TK, int RB>
 __global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a, WgradJobs jl, int chunks_wide) {
     const int pj = jl.pj[blockIdx.x], pi = pj >> 8, job = pj & 255, net = (int)blockIdx.z;
     const IplanWgradProblem& p = a.p[pi];
@@ -88,17 +91,17 @@ __global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a, Wgr
     if (vc >= gm.vchunks) return;
     const int og = job / gm.n_kg, kg = job % gm.n_kg;
     const int l = lane_id(), i = l & 15, g = l >> 4;
-    const int ot0 = og * TO, kt0 = kg * WG_TK;
-    const int not_ = imin(TO, gm.OT - ot0), nkt = gm.KT > 0 ? imin(WG_TK, gm.KT - kt0) : 0;
+    const int ot0 = og * (TO == 1 ? WG_TO_NARROW : TO), kt0 = kg * WG_TK;        // (job origin: the geometry's tile counts)
+    const int not_ = imin(TO, gm.OT - ot0), nkt = gm.KT > 0 ? imin(TK, gm.KT - kt0) : 0;
     const bool want_bias = (kg == 0);
 
-    f32x4 acc[TO][WG_TK];
+    f32x4 acc[TO][TK];
     float bsum[TO];
 #pragma unroll
     for (int t = 0; t < TO; ++t) {
         bsum[t] = 0.f;
 #pragma unroll
-        for (int u = 0; u < WG_TK; ++u) acc[t][u] = splat4(0.f);
+        for (int u = 0; u < TK; ++u) acc[t][u] = splat4(0.f);
     }
     const int64_t r_lo = (int64_t)vc * gm.vrows;
     const int64_t r_hi = gm.rows < r_lo + gm.vrows ? gm.rows : r_lo + gm.vrows;
@@ -110,11 +113,11 @@ __global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a, Wgr
     const char* __restrict__ abase = reinterpret_cast<const char*>(p.dy + (int64_t)net * p.dy_s_net + (int64_t)o_lo * p.dy_s_outer);
     const char* __restrict__ xbase = p.x ? reinterpret_cast<const char*>(p.x + (int64_t)net * p.x_s_net + (int64_t)o_lo * p.x_s_outer) : nullptr;
     const float* __restrict__ x0 = p.x0 ? p.x0 + (int64_t)net * p.x0_s_net + (int64_t)o_lo * p.x0_s_outer : nullptr;
-    uint32_t acolb[TO], bcolb[WG_TK];
+    uint32_t acolb[TO], bcolb[TK];
 #pragma unroll
     for (int t = 0; t < TO; ++t) acolb[t] = 4u * (uint32_t)ocol(p, imin((ot0 + imin(t, not_ - 1)) * 16 + i, p.O - 1));
 #pragma unroll
-    for (int u = 0; u < WG_TK; ++u) bcolb[u] = nkt > 0 ? 4u * (uint32_t)(p.x_col0 + imin((kt0 + imin(u, nkt - 1)) * 16 + i, p.K - 1)) : 0u;
+    for (int u = 0; u < TK; ++u) bcolb[u] = nkt > 0 ? 4u * (uint32_t)(p.x_col0 + imin((kt0 + imin(u, nkt - 1)) * 16 + i, p.K - 1)) : 0u;
     // cursors of the rows this lane loads next, one per (block slot j, sub-step s): rows 16j + 4s + g of the block,
     // advanced by 16 * RB rows per reload without divisions
     int ri[RB][4], orel[RB][4];
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a, Wgr
     const uint32_t x_wrap = (uint32_t)(4 * (p.x_s_outer - (int64_t)p.n_inner * p.x_s_inner));
     const bool shifted = p.x_shift != 0;
 
-    float av[RB][4][TO], bv[RB][4][WG_TK];
+    float av[RB][4][TO], bv[RB][4][TK];
     // rb = first row of the block that goes to slot j; tail = the block may reach past r_hi (uniform)
     auto fetch = [&](int64_t rb, int j, int s, bool tail) {
         const int inner = ri[j][s], outer_rel = orel[j][s];
@@ -155,20 +158,20 @@ __global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a, Wgr
         for (int t = 0; t < TO; ++t) av[j][s][t] = *reinterpret_cast<const float*>(abase + (ao + acolb[t]));
         if (nkt > 0) {
 #pragma unroll
-            for (int u = 0; u < WG_TK; ++u) bv[j][s][u] = *reinterpret_cast<const float*>(xbase + (xo + bcolb[u]));
+            for (int u = 0; u < TK; ++u) bv[j][s][u] = *reinterpret_cast<const float*>(xbase + (xo + bcolb[u]));
         } else {
 #pragma unroll
-            for (int u = 0; u < WG_TK; ++u) bv[j][s][u] = 0.f;
+            for (int u = 0; u < TK; ++u) bv[j][s][u] = 0.f;
         }
         if (tail && !rv) {
 #pragma unroll
             for (int t = 0; t < TO; ++t) av[j][s][t] = 0.f;
 #pragma unroll
-            for (int u = 0; u < WG_TK; ++u) bv[j][s][u] = 0.f;
+            for (int u = 0; u < TK; ++u) bv[j][s][u] = 0.f;
         }
         if (shifted && rv && !inr) {                         // the recurrent operand's step before the first one
 #pragma unroll
-            for (int u = 0; u < WG_TK; ++u) bv[j][s][u] = x0 ? x0[(int64_t)outer_rel * p.x0_s_outer + (bcolb[u] >> 2) - p.x_col0] : 0.f;
+            for (int u = 0; u < TK; ++u) bv[j][s][u] = x0 ? x0[(int64_t)outer_rel * p.x0_s_outer + (bcolb[u] >> 2) - p.x_col0] : 0.f;
         }
     };
 #pragma unroll
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a, Wgr
 #pragma unroll
                 for (int t = 0; t < TO; ++t) {
 #pragma unroll
-                    for (int u = 0; u < WG_TK; ++u) acc[t][u] = mfma4(av[j][s][t], bv[j][s][u], acc[t][u]);
+                    for (int u = 0; u < TK; ++u) acc[t][u] = mfma4(av[j][s][t], bv[j][s][u], acc[t][u]);
                     bsum[t] += av[j][s][t];
                 }
                 // rolling prefetch: the registers of this sub-step are free again
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a, Wgr
         for (int q = 0; q < 4; ++q) {
             const int o = (ot0 + t) * 16 + 4 * g + q;
 #pragma unroll
-            for (int u = 0; u < WG_TK; ++u)
+            for (int u = 0; u < TK; ++u)
                 if (u < nkt) part[(int64_t)o * ldp + (kt0 + u) * 16 + i] = acc[t][u][q];
         }
         if (want_bias) {
@@ -231,8 +234,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(IplanWgradArgs a, int
     const int ldp = gm.KT * 16 + 1;
     const float* __restrict__ part = a.workspace + p.ws_off + (int64_t)net * gm.vchunks * gm.part_floats +
                                      (int64_t)o * ldp + (is_bias ? gm.KT * 16 : k);
-    float s = 0.f;
-    for (int vc = 0; vc < gm.vchunks; ++vc) s += part[(int64_t)vc * gm.part_floats];
+    // fixed order: four interleaved running sums (independent loads in flight), combined at the end
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    int vc = 0;
+    for (; vc + 4 <= gm.vchunks; vc += 4) {
+        const float v0 = part[(int64_t)vc * gm.part_floats], v1 = part[(int64_t)(vc + 1) * gm.part_floats];
+        const float v2 = part[(int64_t)(vc + 2) * gm.part_floats], v3 = part[(int64_t)(vc + 3) * gm.part_floats];
+        s4[0] += v0; s4[1] += v1; s4[2] += v2; s4[3] += v3;
+    }
+    for (; vc < gm.vchunks; ++vc) s4[vc & 3] += part[(int64_t)vc * gm.part_floats];
+    float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     s *= p.scale;
     float* dst = a.grad + (int64_t)net * a.grad_s_net +
                  (is_bias ? p.db_off + o : p.dw_off + (int64_t)o * p.dw_ld + p.dw_col0 + k);
@@ -273,9 +284,12 @@ extern "C" int iplan_wgrad(IplanWgradArgs* a, iplan_stream_t stream) {
     }
     int64_t off = 0;
     int max_elems = 1;
-    WgradJobs wide, narrow;
-    wide.n = narrow.n = 0;
-    int vc_wide = 1, vc_narrow = 1;
+    // job shapes: wide (12 x 4 tiles) for the big weights; for the rest 4 x 4, or the exact thin shapes 4 x 1 (K <= 16) and
+    // 1 x 4 (O <= 16): the thin jobs are latency / issue bound, so they load and multiply only the tiles they own
+    enum { J_WIDE = 0, J_SQUARE, J_THIN_K, J_THIN_O, J_KINDS };
+    WgradJobs jl[J_KINDS];
+    int vcs[J_KINDS];
+    for (int k = 0; k < J_KINDS; ++k) { jl[k].n = 0; vcs[k] = 1; }
     for (int i = 0; i < a->n_problems; ++i) {
         IplanWgradProblem& p = a->p[i];
         const WgradGeom g = wgrad_geom(p, chunks_wide);
@@ -288,24 +302,26 @@ extern "C" int iplan_wgrad(IplanWgradArgs* a, iplan_stream_t stream) {
         const int64_t span_x = 4 * (outers * llabs(p.x_s_outer) + (int64_t)(p.n_inner + 1) * llabs(p.x_s_inner) + 2048);
         if (p.dy_s_outer < 0 || p.dy_s_inner < 0 || p.x_s_outer < 0 || p.x_s_inner < 0 || span_dy >= (1ll << 32) || span_x >= (1ll << 32))
             return fail(IPLAN_EINVAL, "iplan_wgrad: problem %d: a row chunk spans more than 4 GiB (or negative strides)", i);
-        WgradJobs& jl = g.to == WG_TO_WIDE ? wide : narrow;
-        int& vc = g.to == WG_TO_WIDE ? vc_wide : vc_narrow;
-        if (g.vchunks > vc) vc = g.vchunks;
+        const int kind = g.to == WG_TO_WIDE ? J_WIDE : (g.KT <= 1 ? J_THIN_K : (g.OT == 1 ? J_THIN_O : J_SQUARE));
+        if (g.vchunks > vcs[kind]) vcs[kind] = g.vchunks;
         for (int j = 0; j < g.jobs; ++j) {
-            if (jl.n >= WG_MAX_JOBS) return fail(IPLAN_EINVAL, "iplan_wgrad: more than %d tile jobs of one shape", WG_MAX_JOBS);
-            jl.pj[jl.n++] = (i << 8) | j;
+            if (jl[kind].n >= WG_MAX_JOBS) return fail(IPLAN_EINVAL, "iplan_wgrad: more than %d tile jobs of one shape", WG_MAX_JOBS);
+            jl[kind].pj[jl[kind].n++] = (i << 8) | j;
         }
     }
     if (off > a->workspace_floats)
         return fail(IPLAN_EINVAL, "iplan_wgrad: workspace too small (%lld floats needed, %lld given)", (long long)off,
                     (long long)a->workspace_floats);
-    // narrow (latency-bound) jobs first: they finish in the shadow of the wide ones' start
-    if (narrow.n)
-        hipLaunchKernelGGL((wgrad_partial_kernel<WG_TO_NARROW, 1>), dim3((unsigned)narrow.n, (unsigned)vc_narrow, (unsigned)a->n_nets),
-                           dim3(64), 0, (hipStream_t)stream, *a, narrow, chunks_wide);
-    if (wide.n)
-        hipLaunchKernelGGL((wgrad_partial_kernel<WG_TO_WIDE, 1>), dim3((unsigned)wide.n, (unsigned)vc_wide, (unsigned)a->n_nets),
-                           dim3(64), 0, (hipStream_t)stream, *a, wide, chunks_wide);
+    // thin / square (latency-bound) jobs first: they finish in the shadow of the wide ones' start
+#define IPLAN_WGRAD_LAUNCH(KIND, TO_, TK_, RB_)                                                                              \
+    if (jl[KIND].n)                                                                                                          \
+        hipLaunchKernelGGL((wgrad_partial_kernel<TO_, TK_, RB_>), dim3((unsigned)jl[KIND].n, (unsigned)vcs[KIND], (unsigned)a->n_nets), \
+                           dim3(64), 0, (hipStream_t)stream, *a, jl[KIND], chunks_wide);
+    IPLAN_WGRAD_LAUNCH(J_THIN_K, WG_TO_NARROW, 1, 2)
+    IPLAN_WGRAD_LAUNCH(J_THIN_O, 1, WG_TK, 2)
+    IPLAN_WGRAD_LAUNCH(J_SQUARE, WG_TO_NARROW, WG_TK, 1)
+    IPLAN_WGRAD_LAUNCH(J_WIDE, WG_TO_WIDE, WG_TK, 1)
+#undef IPLAN_WGRAD_LAUNCH
     const unsigned z = (unsigned)(a->n_problems * a->n_nets);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((max_elems + 255) / 256), z), dim3(256), 0,
                        (hipStream_t)stream, *a, chunks_wide);
