@@ -481,13 +481,11 @@ int iplan_pdec_bwd(const IplanPdecArgs* args, iplan_stream_t stream);
  *   saved_dec  [x_t || latent] 0 (d+Z <= 16 cols) | 16 (16, unused) | u 32 | r 96 | z 160 | n 224 | hn 288 | h 352 | a 416 (64 each) | y 480 (16)
  *   saved_enc  u 0 | r 32 | z 64 | n 96 | hn 128 | h 160 (32 each)
  *   dsave_dec  dy 0 (16) | du 16 | dr 80 | dz 144 | dn_i 208 | dn_h 272 (64 each)
- *   dsave_enc  du 0 | dr 32 | dz 64 | dn_i 96 | dn_h 128 (32 each)
  */
 #define IPLAN_BEH_SAVE_DEC 496
 #define IPLAN_BEH_SAVE_ENC 192
 #define IPLAN_BEH_SAVE_LAT 32        /* per (row, window): softmax output 0 (16) | latent used by the decoder 16 (16) */
 #define IPLAN_BEH_DSAVE_DEC 336
-#define IPLAN_BEH_DSAVE_ENC 160
 #define IPLAN_BEH_DSAVE_LAT 16
 #define IPLAN_BEH_ENC_PART 7408       /* per-wave encoder weight-gradient partial: W_ih 0 | W_hh 3072 | b_ih 6144 | b_hh 6240
                                          | lin.W [32][16] 6336 | lin.b 6848 | out.W [16][32] 6880 | out.b 7392          */
@@ -512,7 +510,6 @@ typedef struct {
     float* loss_part;           /* [n_nets, ceil(rows/16), 2]                                           */
     float* loss;                /* [n_nets, 2]  behaviour error, stability error                        */
     float* dsave_dec;           /* backward: [n_nets, rows, J, L, IPLAN_BEH_DSAVE_DEC]                  */
-    float* dsave_enc;           /* unused since the encoder accumulates its weight gradients in-kernel  */
     float* dsave_lat;           /* backward: [n_nets, rows, J, IPLAN_BEH_DSAVE_LAT] d(loss)/d(latent_j) through
                                    the decoder inputs of window j (decoder BPTT -> encoder BPTT hand-off) */
     /* single-window decoder mode = Behavior_Latent_Decoder.forward (nova/behavior_net.py:55-69): set T = L + 2 (one

@@ -282,7 +282,7 @@ class PdecArgs(C.Structure):
 # ---- behaviour learning ------------------------------------------------------------------------------
 BEH_SAVE_DEC, BEH_SAVE_ENC, BEH_SAVE_LAT = 496, 192, 32
 BEH_ENC_PART = 7408
-BEH_DSAVE_DEC, BEH_DSAVE_ENC, BEH_DSAVE_LAT = 336, 160, 16
+BEH_DSAVE_DEC, BEH_DSAVE_LAT = 336, 16
 
 
 class BehArgs(C.Structure):
@@ -294,7 +294,7 @@ class BehArgs(C.Structure):
         ("enc_params", fp), ("enc_s_net", i64), ("enc_off", i64 * len(ENC_PARAM_ORDER)),
         ("dec_params", fp), ("dec_s_net", i64), ("dec_off", i64 * len(DEC_PARAM_ORDER)),
         ("saved_dec", fp), ("saved_enc", fp), ("saved_lat", fp), ("loss_part", fp), ("loss", fp),
-        ("dsave_dec", fp), ("dsave_enc", fp), ("dsave_lat", fp),
+        ("dsave_dec", fp), ("dsave_lat", fp),
         ("win", fp), ("lat_in", fp), ("hd_in", fp), ("pred_out", fp), ("hd_out", fp), ("hard", i32),
         ("enc_part", fp), ("enc_grad", fp), ("enc_grad_s_net", i64), ("bwd_phase", i32),
         ("bwd_j_lo", i32), ("bwd_j_hi", i32), ("dec_carry", fp),

@@ -28,14 +28,13 @@ constexpr int EHd = 32, ET = 2;          // encoder_rnn_dim
 constexpr int DLD = DHd + 8;             // LDS leading dims: ld % 16 == 8 -> conflict-free ds_read_b128 fragment reads
 constexpr int ELDB = EHd + 8;
 constexpr int SVD = IPLAN_BEH_SAVE_DEC, SVE = IPLAN_BEH_SAVE_ENC, SVL = IPLAN_BEH_SAVE_LAT;
-constexpr int DSD = IPLAN_BEH_DSAVE_DEC, DSE = IPLAN_BEH_DSAVE_ENC, DSL = IPLAN_BEH_DSAVE_LAT;
+constexpr int DSD = IPLAN_BEH_DSAVE_DEC, DSL = IPLAN_BEH_DSAVE_LAT;
 constexpr float BEPS = 1e-10f;
 constexpr int DEC_FWD_BIAS = 64 + 192 + 192 + 16;
-// saved_dec / dsave_dec / saved_enc / dsave_enc column offsets (include/iplan_hip.h)
+// saved_dec / dsave_dec / saved_enc column offsets (include/iplan_hip.h)
 constexpr int SD_X = 0, SD_U = 32, SD_R = 96, SD_Z = 160, SD_N = 224, SD_HN = 288, SD_H = 352, SD_A = 416, SD_Y = 480;
 constexpr int DD_DY = 0, DD_DU = 16, DD_DR = 80, DD_DZ = 144, DD_DNI = 208, DD_DNH = 272;
 constexpr int SE_U = 0, SE_R = 32, SE_Z = 64, SE_N = 96, SE_HN = 128, SE_H = 160;
-constexpr int DE_DU = 0, DE_DR = 32, DE_DZ = 64, DE_DNI = 96, DE_DNH = 128;
 
 __device__ __forceinline__ float chain_sum_b(float v) {
     v += __shfl_xor(v, 1);

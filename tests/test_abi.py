@@ -53,3 +53,14 @@ def test_struct_mirrors_match_the_hip_library(hip_lib):
 def test_struct_mirrors_match_the_emulated_library():
     from tests.emu.emu_lib import get_emu_lib
     _check_sizes(get_emu_lib().c)
+
+
+def test_product_path_fails_loudly_without_the_library(tmp_path):
+    """No CPU fallback: with the shared library missing, the first op raises instead of computing something else."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['IPLAN_HIP_LIB'] = %r\n"
+            "from iplan_amd import _lib\n"
+            "try:\n    _lib.get_lib()\nexcept _lib.IplanError as e:\n    print('RAISED', 'no CPU fallback' in str(e))\n") % (ROOT, str(tmp_path / "missing.so"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "RAISED True" in r.stdout, r.stdout + r.stderr
