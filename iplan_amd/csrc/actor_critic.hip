@@ -24,7 +24,7 @@ constexpr int AT = AM / 16;            // 4 tiles
 
 template <int RT>
 __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
-    __shared__ float s_red[8][16];
+    __shared__ float s_red[8][16], s_red2[8][16], s_cc[8][2][AM];
     __shared__ __attribute__((aligned(16))) f32x4 s_acc[8][AT][64];
 
     const int net = (int)blockIdx.y;
@@ -64,8 +64,18 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     }
 
     // ---- LayerNorm(F) statistics, two passes (mean, then centred second moment) over L2-resident rows
+    // Rollout shape (a few row tiles per net, K split over the 8 waves): ONE pass instead -- the contraction accumulates
+    //   P1 = W (gamma o x) on MFMA,  W gamma and W beta (lane-local dot products with the same W fragments),  sum x,  sum x^2
+    // and  fc1(LN(x)) = rstd (P1 - mu W gamma) + W beta  is finished after the cross-wave reduction (no statistics pre-pass
+    // over the row: it cost a third of the launch, all of it load latency).
+    const bool fold = RT == 1 && ks > 1 && a.ln_stats_mode == 0;
     float mu[RT], rstd[RT];
-    if (a.ln_stats_mode == 2) {
+    float fsx = 0.f, fsxx = 0.f;
+    float c1a[AT], c2a[AT];                                   // lane-local partial (W gamma)[16 oo + n], (W beta)[16 oo + n]
+    for (int o = 0; o < AT; ++o) { c1a[o] = 0.f; c2a[o] = 0.f; }
+    if (fold) {
+        for (int t = 0; t < RT; ++t) { mu[t] = 0.f; rstd[t] = 1.f; }
+    } else if (a.ln_stats_mode == 2) {
         for (int t = 0; t < RT; ++t) {
             mu[t] = 0.f; rstd[t] = 0.f;
             if (vld[t]) {
@@ -142,7 +152,28 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         for (int t = 0; t < RT; ++t) o.x[t] = kfeat(km, o.kt, src[t], vld[t], last[t], net);
         for (int oo = 0; oo < AT; ++oo) o.wf[oo] = kcols(o.kt, W1 + (int64_t)(16 * oo + n) * F);
     };
+    // folded variant of the normalisation: B operand = gamma o x (plus the [gamma beta] columns), statistics on the side
+    auto fold_mma = [&](const f32x4& x, const f32x4& gm, const f32x4& bt, const f32x4 (&wf)[AT], int nv) {
+        f32x4 xg, gz, bz;
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = q < nv;
+            const float xv = (vld[0] && ok) ? x[q] : 0.f;
+            xg[q] = ok ? xv * gm[q] : 0.f;
+            fsx += xv;
+            fsxx = fmaf(xv, xv, fsxx);
+            gz[q] = ok ? gm[q] : 0.f;
+            bz[q] = ok ? bt[q] : 0.f;
+        }
+        for (int oo = 0; oo < AT; ++oo) {
+            accs[0][oo] = mma_block(wf[oo], xg, accs[0][oo]);
+            for (int q = 0; q < 4; ++q) {                      // wf[oo] = W[16 oo + n][4g .. 4g+3] of this k-tile
+                c1a[oo] = fmaf(wf[oo][q], gz[q], c1a[oo]);
+                c2a[oo] = fmaf(wf[oo][q], bz[q], c2a[oo]);
+            }
+        }
+    };
     auto kmma = [&](const KOps& o) {
+        if (fold) { fold_mma(o.x[0], o.gm, o.bt, o.wf, o.kt.nv); return; }
         f32x4 xn[RT];
         for (int t = 0; t < RT; ++t)
             for (int q = 0; q < 4; ++q)
@@ -168,6 +199,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         for (int oo = 0; oo < AT; ++oo) o.wf[oo] = ldu4(W1 + (int64_t)(16 * oo + n) * F + c0);
     };
     auto fmma = [&](const FOps& o) {
+        if (fold) { fold_mma(o.x[0], o.gm, o.bt, o.wf, 4); return; }
         f32x4 xn[RT];
         for (int t = 0; t < RT; ++t)
             for (int q = 0; q < 4; ++q) xn[t][q] = vld[t] ? (o.x[t][q] - mu[t]) * rstd[t] * o.gm[q] + o.bt[q] : 0.f;
@@ -215,6 +247,29 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
                 f32x4 sum = s_acc[w][t][l];
                 for (int p2 = 1; p2 < ks; ++p2) sum += s_acc[w + p2][t][l];
                 accs[0][t] = sum;
+            }
+        }
+        if (fold) {                                           // W gamma, W beta and the row statistics of the 8 waves
+            fsx = group_sum(fsx);
+            fsxx = group_sum(fsxx);
+            if (g == 0) { s_red[w][n] = fsx; s_red2[w][n] = fsxx; }
+            for (int t = 0; t < AT; ++t) {
+                const float c1 = group_sum(c1a[t]), c2 = group_sum(c2a[t]);
+                if (g == 0) { s_cc[w][0][16 * t + n] = c1; s_cc[w][1][16 * t + n] = c2; }
+            }
+            __syncthreads();
+            if (part == 0) {
+                float sx = 0.f, sxx = 0.f;
+                for (int p2 = 0; p2 < ks; ++p2) { sx += s_red[w + p2][n]; sxx += s_red2[w + p2][n]; }
+                mu[0] = sx / (float)F;
+                rstd[0] = 1.0f / sqrtf(fmaxf(sxx / (float)F - mu[0] * mu[0], 0.f) + 1e-5f);
+                for (int t = 0; t < AT; ++t)
+                    for (int q = 0; q < 4; ++q) {
+                        const int o = 16 * t + 4 * g + q;
+                        float c1 = 0.f, c2 = 0.f;
+                        for (int p2 = 0; p2 < ks; ++p2) { c1 += s_cc[w + p2][0][o]; c2 += s_cc[w + p2][1][o]; }
+                        accs[0][t][q] = rstd[0] * (accs[0][t][q] - mu[0] * c1) + c2;
+                    }
             }
         }
     }
