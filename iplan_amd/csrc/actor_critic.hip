@@ -206,7 +206,10 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         for (int oo = 0; oo < AT; ++oo)
             for (int t = 0; t < RT; ++t) accs[t][oo] = mma_block(o.wf[oo], xn[t], accs[t][oo]);
     };
-    constexpr int PF = 3;
+#ifndef AC_PF
+#define AC_PF 3
+#endif
+    constexpr int PF = AC_PF;
     for (int s = 0; s < 4; ++s) {
         // this wave's tiles of block s: T in [b_lo, b_hi) with T % T_st == part; the fast ones are below f_hi
         const int b_end = imin(T_hi, km.kt0[s + 1]);
