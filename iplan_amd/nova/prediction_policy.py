@@ -98,6 +98,26 @@ class Prediction_policy:
         coins = [np.random.random() < self.args.teacher_forcing_ratio for _ in range(self.pred_length)]
         return sel, coins
 
+    def prediction_batch_wrapper(self, history, attention_rnn, mask, behavior_latent=None):
+        """nova/prediction_policy.py:122-164, vectorised: sample ``pred_batch_size`` (episode, t) pairs of one agent's
+        episodes (same ``np.random.choice`` draw as the reference) and gather the input state, the stored attention /
+        behaviour latents, the next ``pred_length`` states and the mask.  history [E,T,N,d], attention_rnn [E,T,N,A],
+        mask [E,T], behavior_latent [E,T,N,Z] -> (input_traj [S,N,1,d], input_attention [S,N,1,A], input_latent [S,N,1,Z] or
+        None, actual_traj [S,N,P,d], mask_over_traj [S,N,P,d]).  ``learn`` gathers for all agents at once instead."""
+        history, attention_rnn, mask = torch.as_tensor(history), torch.as_tensor(attention_rnn), torch.as_tensor(mask)
+        E, T, N, d = history.shape
+        S, P = self.prediction_batch_size, self.pred_length
+        avail_len = T - P - 1
+        sel = torch.as_tensor(np.random.choice(E * avail_len, size=S, replace=False), dtype=torch.long, device=history.device)
+        bi, ti = sel // avail_len, sel % avail_len
+        input_traj = history[bi, ti].unsqueeze(2)
+        input_attention = attention_rnn[bi, ti].unsqueeze(2)
+        input_latent = torch.as_tensor(behavior_latent)[bi, ti].unsqueeze(2) if self.args.GAT_use_behavior else None
+        steps = ti[:, None] + 1 + torch.arange(P, device=history.device)[None, :]
+        actual_traj = history[bi[:, None], steps].permute(0, 2, 1, 3)
+        mask_over_traj = mask[bi, ti].to(history.dtype)[:, None, None, None].expand(S, N, P, d).contiguous()
+        return input_traj, input_attention, input_latent, actual_traj, mask_over_traj
+
     def learn(self, batch, t_env, noise=None, keep=None, defer=False, sel=None):
         """nova/prediction_policy.py:168-253 for all agents at once: sample -> fused GAT forward ->
         decoder forward + masked L1 -> decoder backward -> GAT backward -> weight gradients ->

@@ -80,6 +80,25 @@ class Behavior_policy:
 
 
     # ---------------------------------------------------------------------------- learning
+    def behavior_traj_wrapper(self, history, step, mask):
+        """nova/stable_behavior_policy.py:128-157, vectorised: window ``step`` of one agent's episode.
+        history [E, T, N, d], mask [E, T] -> (curr [E,N,L,d] = steps step-L+1..step right-aligned / zero-padded,
+        next [E,N,L,d] = steps step+1..step+L, and their per-step masks broadcast to the same shapes; padded positions of the
+        current mask stay 1 like the reference's).  ``learn`` does not call this -- the kernels walk the windows in place --
+        it is kept for callers that want the reference's per-window tensors."""
+        history, mask = torch.as_tensor(history), torch.as_tensor(mask)
+        E, T, N, d = history.shape
+        L = self.max_history_len
+        start, plug = max(0, step - L + 1), max(0, L - step - 1)
+        curr = torch.zeros(E, N, L, d, dtype=history.dtype, device=history.device)
+        curr[:, :, plug:] = history[:, start:step + 1].permute(0, 2, 1, 3)
+        nxt = history[:, step + 1:step + L + 1].permute(0, 2, 1, 3)
+        m = mask.to(history.dtype)
+        m_curr = torch.ones_like(curr)
+        m_curr[:, :, plug:] = m[:, start:step + 1, None, None].permute(0, 2, 1, 3).expand(E, N, step + 1 - start, d)
+        m_next = m[:, step + 1:step + L + 1, None, None].permute(0, 2, 1, 3).expand(E, N, L, d).contiguous()
+        return curr, nxt, m_curr, m_next
+
     def _global_window_sums(self, mask, hard=False):
         """Data-parallel runs: the loss normalisers (mask sums per window) over ALL ranks' envs; None otherwise."""
         dp = getattr(self, "dp", None)

@@ -595,6 +595,7 @@ def main():
     golden_behavior_hard_learn()
     golden_obs_wrapper()
     golden_behavior_fc_learn()
+    golden_wrappers()
     print("all golden fixtures written to", GOLD)
 
 
@@ -700,6 +701,26 @@ def golden_behavior_fc_learn(seed=58):
               torch.as_tensor(lat_roll[:, i]), 1e-5)
     torch.save(dict(args=vars(args), fields=fields, pre=pre, post=post, clipped=clipped, behavior_loss=[float(x) for x in bl],
                     window=win, latent=torch.as_tensor(lat_roll)), os.path.join(GOLD, "behavior_fc_learn.pt"))
+
+
+def golden_wrappers(seed=90):
+    """behavior_traj_wrapper (stable_behavior_policy.py:128-157) and prediction_batch_wrapper (prediction_policy.py:122-164)."""
+    from nova.stable_behavior_policy import Behavior_policy
+    from nova.prediction_policy import Prediction_policy
+    args = small_args(max_vehicle_num=4, n_agents=2, episode_limit=16, batch_size_run=3, max_history_len=4, pred_batch_size=6)
+    torch.manual_seed(seed)
+    E, T, N, d = 3, args.episode_limit, args.max_vehicle_num, args.obs_shape_single
+    history = torch.rand(E, T, N, d) * 2 - 1
+    attention = torch.randn(E, T, N, args.attention_dim) * 0.1
+    latent = torch.softmax(torch.randn(E, T, N, args.latent_dim), -1)
+    mask = (torch.rand(E, T) < 0.7).float()
+    beh = Behavior_policy(args, NullLogger())
+    traj = {step: tuple(t.clone() for t in beh.behavior_traj_wrapper(history, step, mask)) for step in (0, 2, 3, 7, T - 2 - args.max_history_len)}
+    pred = Prediction_policy(args, NullLogger())
+    np.random.seed(seed)
+    out = pred.prediction_batch_wrapper(history, attention, mask, latent)
+    torch.save(dict(args=vars(args), history=history, attention=attention, latent=latent, mask=mask, traj=traj, np_seed=seed,
+                    pred=tuple(t.clone() for t in out)), os.path.join(GOLD, "wrappers.pt"))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,44 @@
+"""The reference's per-window / per-sample gather helpers kept on the policy classes:
+``Behavior_policy.behavior_traj_wrapper`` and ``Prediction_policy.prediction_batch_wrapper`` against fixtures recorded from
+the reference methods (tests/golden/wrappers.pt, oracle/make_golden.py:golden_wrappers)."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wrappers.pt")
+
+
+class _Log:
+    def log_stat(self, *a):
+        pass
+
+
+@pytest.fixture(scope="module")
+def g():
+    from tests.emu.emu_lib import get_emu_lib
+    from iplan_amd import _lib as L
+    L.use_library_for_tests(get_emu_lib())
+    return torch.load(GOLD, weights_only=False)
+
+
+def test_behavior_traj_wrapper_matches_reference(g):
+    from iplan_amd.nova.stable_behavior_policy import Behavior_policy
+    args = SimpleNamespace(**dict(g["args"], use_cuda=False))
+    pol = Behavior_policy(args, _Log())
+    for step, ref in g["traj"].items():
+        out = pol.behavior_traj_wrapper(g["history"], step, g["mask"])
+        for a, b in zip(out, ref):
+            assert a.shape == b.shape and torch.equal(a.to(b.dtype), b), step
+
+
+def test_prediction_batch_wrapper_matches_reference(g):
+    from iplan_amd.nova.prediction_policy import Prediction_policy
+    args = SimpleNamespace(**dict(g["args"], use_cuda=False))
+    pol = Prediction_policy(args, _Log())
+    np.random.seed(g["np_seed"])
+    out = pol.prediction_batch_wrapper(g["history"], g["attention"], g["mask"], g["latent"])
+    for a, b in zip(out, g["pred"]):
+        assert a.shape == b.shape and torch.equal(a.to(b.dtype), b)
