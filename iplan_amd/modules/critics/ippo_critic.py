@@ -2,7 +2,6 @@
 import torch
 import torch.nn as nn
 
-from ... import ops
 from ...utils.mappo_utils.blocks import MLPBase, PopArt, RNNLayer
 from ...utils.mappo_utils.util import check, init
 from ..agents.ippo_actor import _FusedNet

@@ -9,7 +9,6 @@ the arithmetic is the fused HIP kernel ``iplan_gat_fwd`` / ``iplan_gat_bwd``.
 import torch
 import torch.nn as nn
 
-from .. import ops
 from ..arena import ParamArena
 
 

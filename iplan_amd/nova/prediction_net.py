@@ -1,6 +1,5 @@
 """Trajectory-prediction decoder (mirror of nova/prediction_net.py:6-63): parameter containers
 with the reference's ``state_dict`` keys; arithmetic in the fused prediction-learning kernels."""
-import torch.nn as nn
 
 from .behavior_net import DecoderRNN, _ArenaModule  # noqa: F401  (same layer stack, prediction_net.py:6-26)
 

@@ -16,7 +16,6 @@ the PPO rows; advantage mean and std), so before its backward pass each learner 
 (``all_reduce_sum``) and scales its local loss by the GLOBAL denominators; the gradient arenas are then SUMMED, clipped
 and applied identically on every rank, which keeps the replicas bit-identical without parameter broadcasts.
 """
-import torch
 import torch.distributed as dist
 
 

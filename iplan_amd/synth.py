@@ -7,7 +7,6 @@ container mirrors the subset of pymarl's ``EpisodeBatch`` interface the hot path
 components/episode_buffer.py:118-130,200-201) so the reference's own ``EpisodeBatch`` and this
 stand-in are interchangeable.
 """
-import numpy as np
 import torch
 
 
