@@ -266,7 +266,16 @@ def main():
         }
         if not opt.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, E)
-        print(json.dumps(line))
+
+        def clean(o):                                            # a kernel that was not launched (diagnostic modes): null, not NaN
+            if isinstance(o, float) and o != o:
+                return None
+            if isinstance(o, dict):
+                return {k: clean(v) for k, v in o.items()}
+            if isinstance(o, list):
+                return [clean(v) for v in o]
+            return o
+        print(json.dumps(clean(line)))
     if world > 1:
         dist.destroy_process_group()
 
