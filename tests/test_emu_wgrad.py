@@ -64,3 +64,37 @@ def test_wgrad_many_rows_chunked():
     ref = dy[0, :, 0].t() @ x[0, :, 0]
     assert torch.allclose(grad[0, :1400].view(20, 70), ref, rtol=1e-5, atol=1e-4)
     assert torch.allclose(grad[0, 3000:3020], dy[0, :, 0].sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("O,K,rows,n_inner,shift", [
+    (5, 64, 37, 3, 0),         # thin along O  (1 x 4 tiles), ragged rows
+    (64, 13, 1000, 1, 0),      # thin along K  (4 x 1), many 8x-short chunks
+    (192, 64, 300, 5, -1),     # wide (12 x 4), recurrent operand
+    (130, 40, 45, 9, 1),       # wide with ragged tiles on both axes, reverse shift
+    (100, 70, 333, 1, 0),      # square jobs (7 x 5 tiles -> 2 x 2 jobs)
+    (16, 16, 16, 1, 0),        # exactly one tile, one block
+    (7, 0, 50, 2, 0),          # bias only
+])
+def test_wgrad_job_shapes_vs_torch(O, K, rows, n_inner, shift):
+    """every job shape of wgrad.hip (wide / square / thin), ragged edges, row tails and the shifted recurrent operand"""
+    torch.manual_seed(O * 1000 + K)
+    n_nets = 2
+    dy = torch.randn(n_nets, rows, n_inner, O + 3)               # row pitch wider than O: extra columns must be ignored
+    x = torch.randn(n_nets, rows, n_inner, K + 5) if K else None
+    grad = torch.zeros(n_nets, O * (K + 1) + 8)
+    w = ops.Wgrad(grad, n_nets)
+    w.add(dy, (dy.stride(0), dy.stride(1), dy.stride(2)), O, rows, n_inner, x=x,
+          x_strides=(x.stride(0), x.stride(1), x.stride(2)) if K else (0, 0, 0), K=K, x_col0=2 if K else 0, x_shift=shift,
+          dw_off=0 if K else -1, db_off=O * K)
+    w.run()
+    for n in range(n_nets):
+        d = dy[n, :, :, :O].double()
+        assert torch.allclose(grad[n, O * K:O * K + O].double(), d.reshape(-1, O).sum(0), rtol=1e-5, atol=1e-4)
+        if K:
+            xs = x[n, :, :, 2:2 + K].double()
+            if shift == -1:
+                xs = torch.cat([torch.zeros(rows, 1, K, dtype=torch.double), xs[:, :-1]], 1)
+            elif shift == 1:
+                xs = torch.cat([xs[:, 1:], torch.zeros(rows, 1, K, dtype=torch.double)], 1)
+            ref = torch.einsum("rto,rtk->ok", d, xs)
+            assert torch.allclose(grad[n, :O * K].view(O, K).double(), ref, rtol=1e-5, atol=2e-4), (O, K)
