@@ -7,6 +7,7 @@ container mirrors the subset of pymarl's ``EpisodeBatch`` interface the hot path
 components/episode_buffer.py:118-130,200-201) so the reference's own ``EpisodeBatch`` and this
 stand-in are interchangeable.
 """
+import numpy as np
 import torch
 
 
@@ -104,3 +105,23 @@ def rollout_step_inputs(args, E, seed=0):
     hist_single = make_history(gen, (E, nA), N, d).double().numpy()
     window = make_history(gen, (E, nA, N), L, d)           # [E,nA,N,L,d]
     return hist_single, window.double().numpy()
+
+
+def obs_stream(K, nA, obs_num, d, T, seed, n_ids=14, p_seen=0.6):
+    """Synthetic Highway-style observation stream [T][K, nA, obs_num, 1 + d]: row 0 = the ego (id = agent index + 1),
+    other rows = vehicles drawn from a pool of ids that come and go; unobserved rows are all-zero."""
+    rng = np.random.default_rng(seed)
+    steps = []
+    for _ in range(T):
+        obs = np.zeros((K, nA, obs_num, d + 1))
+        for k in range(K):
+            for i in range(nA):
+                obs[k, i, 0, 0] = i + 1
+                obs[k, i, 0, 1:] = rng.uniform(-1, 1, d)
+                ids = rng.choice(np.arange(10, 10 + n_ids), size=obs_num - 1, replace=False)
+                for j in range(1, obs_num):
+                    if rng.random() < p_seen:
+                        obs[k, i, j, 0] = ids[j - 1]
+                        obs[k, i, j, 1:] = rng.uniform(-1, 1, d)
+        steps.append(obs)
+    return steps

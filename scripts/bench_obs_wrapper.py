@@ -1,4 +1,5 @@
-"""Host cost of the id -> slot history wrapper per vector step at BASELINE config 3 (32 threads, 5 agents, 15 observed
+"""CPU-baseline leg for SURVEY.md §8f.2 (like bench.py's cpu_baseline it may time the oracle; nothing here is product code).
+Host cost of the id -> slot history wrapper per vector step at BASELINE config 3 (32 threads, 5 agents, 15 observed
 rows, 55 slots, L = 10): the loop restatement of the reference (oracle, = the reference's own cost) vs the vectorised
 iplan_amd.observation_wrapper.  Pure CPU; python scripts/bench_obs_wrapper.py"""
 import os
@@ -10,7 +11,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from iplan_amd.observation_wrapper import observersation_state_history_wrapper as Wrapper  # noqa: E402
-from oracle.make_golden import obs_stream  # noqa: E402  (stream generator only; needs no reference import)
+from iplan_amd.synth import obs_stream  # noqa: E402
 from oracle.obs_wrapper_oracle import HistoryWrapperOracle  # noqa: E402
 
 K, nA, obs_num, d, T, L, N = 32, 5, 15, 5, 90, 10, 55
