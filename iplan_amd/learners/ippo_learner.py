@@ -38,8 +38,10 @@ class EpisodeStore:
         self.device = device
         self.count = 0
         self.data = {}
+        self.consumed = set()                       # agents whose per-agent view was cleared since the last insert / clear
 
     def insert(self, ep_batch, n_eps):
+        self.consumed.clear()
         for key in _STORE_KEYS:
             try:
                 src = ep_batch[key]
@@ -62,29 +64,38 @@ class EpisodeStore:
 
     def clear(self):
         self.count = 0
+        self.consumed.clear()
 
 
 class _AgentBuffer:
-    """Per-agent view with the SeparatedReplayBuffer surface callers touch."""
+    """Per-agent view with the SeparatedReplayBuffer surface callers touch.  The n_agents views share one EpisodeStore;
+    ``clear_buffer`` marks only THIS agent's view consumed (the reference clears one agent's deque,
+    separated_buffer.py:44-50) and the store is reset once every agent has cleared -- so the reference-shaped per-agent
+    loop (get_batch / ppo_update / clear_buffer, agent after agent) sees every agent's data."""
 
-    def __init__(self, store, agent):
-        self.store, self.agent = store, agent
+    def __init__(self, store, agent, n_agents):
+        self.store, self.agent, self.n_agents = store, agent, n_agents
 
     def can_sample(self):
-        return self.store.count == self.store.size
+        return self.store.count == self.store.size and self.agent not in self.store.consumed
 
     def clear_buffer(self):
-        self.store.clear()
+        self.store.consumed.add(self.agent)
+        if len(self.store.consumed) >= self.n_agents:
+            self.store.clear()
 
     def get_batch(self):
         if not self.can_sample():
             return None
         d, i = self.store.data, self.agent
-        out = {"obs": d["obs"][:, :, i], "state": d["state"], "actions": d["actions"][:, :, i],
-               "actions_onehot": d["actions_onehot"][:, :, i], "rnn_states_actor": d["rnn_states_actors"][:, :, i],
-               "rnn_states_critic": d["rnn_states_critics"][:, :, i], "reward": d["reward"][:, :, i],
-               "terminated_masks": 1 - d["terminated"][:, :, i], "history": d["history"][:, :, i],
-               "available_actions": d["avail_actions"][:, :, i]}
+        out = {"actions": d["actions"][:, :, i], "actions_onehot": d["actions_onehot"][:, :, i],
+               "rnn_states_actor": d["rnn_states_actors"][:, :, i], "rnn_states_critic": d["rnn_states_critics"][:, :, i],
+               "reward": d["reward"][:, :, i], "terminated_masks": 1 - d["terminated"][:, :, i],
+               "history": d["history"][:, :, i], "available_actions": d["avail_actions"][:, :, i]}
+        if "obs" in d:
+            out["obs"] = d["obs"][:, :, i]
+        if "state" in d:
+            out["state"] = d["state"]
         for k in ("behavior_latent", "attention_latent"):
             if k in d:
                 out[k] = d[k][:, :, i]
@@ -115,7 +126,7 @@ class IPPOLearner:
         self.log_stats_t = -self.args.learner_log_interval - 1
 
         self.store = EpisodeStore(args, self.device)
-        self.buffers = [_AgentBuffer(self.store, i) for i in range(self.n_agents)]
+        self.buffers = [_AgentBuffer(self.store, i, self.n_agents) for i in range(self.n_agents)]
 
         self.clip_param = args.clip_param
         self.ppo_epoch = args.ppo_epoch
@@ -163,6 +174,21 @@ class IPPOLearner:
                                  last_action=last, la_strides=(1, self.n_agents),
                                  n_id=self.n_agents if a.obs_agent_id else 0, T=T, T_phys=T_phys)
 
+    def _last_action_index(self):
+        """Hot index of the last-action block of every stored step ([bs, T1, nA] int32, -1 = an all-zero block): the
+        reference feeds ``actions_onehot`` shifted by one step, ``actions_onehot[0]`` at t = 0
+        (dcntrl_controller.py:105-108).  Steps a rollout never wrote (the runner breaks once every env has terminated,
+        ippo_parallel_runner.py:212-214) keep ``actions`` = 0 but an all-zero ``actions_onehot`` row -- the OneHot
+        preprocess only runs on updated slices -- so the index comes from the stored one-hot rows, not from ``actions``.
+        Index bookkeeping only (the rows are exact one-hots or zeros)."""
+        d = self.store.data
+        oh = d.get("actions_onehot")
+        if oh is None:
+            idx = d["actions"][..., 0]
+        else:
+            idx = th.where(oh.sum(dim=-1) > 0, oh.argmax(dim=-1), th.full_like(oh[..., 0], -1, dtype=th.long))
+        return th.cat([idx[:, :1], idx[:, :-1]], dim=1).to(th.int32).contiguous()
+
     def train(self, t_env, defer=False):
         """learners/ippo_learner.py:227-317.  ``defer=True``: enqueue everything on the current stream and return a
         ``finish()`` callable that does the single host read-back + logging (None when the buffer is not full)."""
@@ -177,9 +203,7 @@ class IPPOLearner:
         T1 = T + 1
         dev = self.device
         f32 = dict(dtype=th.float32, device=dev)
-        # last-action index per stored step: action[0] at t = 0, action[t-1] after (dcntrl_controller.py:107)
-        acts = d["actions"][..., 0]                                        # [bs, T1, nA]
-        last = th.cat([acts[:, :1], acts[:, :-1]], dim=1).to(th.int32).contiguous()
+        last = self._last_action_index()
         ha, hc = d["rnn_states_actors"], d["rnn_states_critics"]            # [bs, T1, nA, M]
         hs = (ha.stride(2), ha.stride(1))
         avail = d["avail_actions"]

@@ -85,7 +85,12 @@ class observersation_state_history_wrapper:                        # (sic) the r
         K, nA, obs_num, obs_dim = obs.shape
         N = self.max_vehicle_num
         ego = obs[:, :, 0, 0].astype(np.int64)
-        agent_idx = (self._agent_ids[:, None, :] == ego[:, :, None]).argmax(axis=2)       # self.agent_id[k].index(agent_id)
+        hit = self._agent_ids[:, None, :] == ego[:, :, None]
+        if not hit.any(axis=2).all():                                                      # list.index raises in the reference
+            k, a = np.argwhere(~hit.any(axis=2))[0]
+            raise ValueError(f"{int(ego[k, a])} is not in list (ego id of thread {k}, agent {a} was never registered by "
+                             "agent_obs_profile_init)")
+        agent_idx = hit.argmax(axis=2)                                                    # self.agent_id[k].index(agent_id)
         kk = np.repeat(np.arange(K), nA)
         aa = agent_idx.reshape(-1)
         seen = np.zeros((K * nA, N), dtype=bool)                     # slots this (thread, agent) pair observed in this step

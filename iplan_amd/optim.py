@@ -14,14 +14,13 @@ import torch
 
 from . import _lib as L
 
-_MOMENTS = {}   # id(arena) -> (exp_avg, exp_avg_sq) arenas, shared by the per-agent optimisers
-
-
 def _moments(arena):
-    key = id(arena)
-    if key not in _MOMENTS:
-        _MOMENTS[key] = (torch.zeros_like(arena.data), torch.zeros_like(arena.data), arena)
-    return _MOMENTS[key][0], _MOMENTS[key][1]
+    """(exp_avg, exp_avg_sq) twins of an arena, shared by the per-agent optimisers over it; they live ON the arena object,
+    so they are released with it."""
+    mv = getattr(arena, "_adam_moments", None)
+    if mv is None:
+        mv = arena._adam_moments = (torch.zeros_like(arena.data), torch.zeros_like(arena.data))
+    return mv
 
 
 def grad_sqnorm(arena, nets, out, slot, lib=None):
@@ -110,10 +109,16 @@ class FusedAdam(torch.optim.Optimizer):
     def state_dict(self):
         state = {}
         if self._steps > 0:
-            for idx, (trainable, m, v) in enumerate(self._param_moments()):
-                # torch.optim.Adam only creates state for parameters that ever received a gradient (the unused
-                # `fc_h` template layer of MLPLayer never does): here that is "second moment still all zero"
-                if trainable and bool((v != 0).any()):
+            pm = self._param_moments()
+            # torch.optim.Adam only creates state for parameters that ever received a gradient (the unused `fc_h`
+            # template layer of MLPLayer never does).  Every arena tensor has a gradient view here, so "received a
+            # gradient" is read off the second moment (non-zero somewhere); ONE host read-back for all tensors.  A
+            # parameter whose gradients were exactly zero at every step is written without state, which torch loads as
+            # "state not created yet" -- the same values it would have held (all-zero moments).
+            live = torch.stack([(v != 0).any() if trainable else torch.zeros((), dtype=torch.bool, device=v.device)
+                                for trainable, _, v in pm]).cpu().tolist()
+            for idx, (trainable, m, v) in enumerate(pm):
+                if live[idx]:
                     state[idx] = {"step": torch.tensor(float(self._steps)), "exp_avg": m.detach().clone(),
                                   "exp_avg_sq": v.detach().clone()}
         g = dict(self.param_groups[0])
@@ -122,6 +127,10 @@ class FusedAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, sd):
         pm = self._param_moments()
+        for _, m, v in pm:                          # parameters absent from the file have no state: zero moments
+            m.zero_()
+            v.zero_()
+        self._steps = 0
         for idx, st in sd["state"].items():
             _, m, v = pm[int(idx)]
             m.copy_(st["exp_avg"])

@@ -473,3 +473,69 @@ def behavior_fc_learn_loss(enc_p, dec_p, history, L):
         latent = mlp3(enc_p, curr, softmax=True)
         total = total + torch.abs(nxt - pred).sum() / (float(E * N * L * d) + EPS) * d * N
     return total / J
+
+
+# ----------------------------------------------------------------------------------------------
+# a17 IPPOLearner.train for ONE agent (learners/ippo_learner.py:227-317): compute_returns -> advantage
+#     normalisation -> ppo_epoch x (evaluate, losses, clip, Adam) on the first batch_size * T rows.
+#     num_mini_batch == 1: every epoch is a full-batch step, so the randperm order does not matter.
+# ----------------------------------------------------------------------------------------------
+def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_index_lists=None):
+    """fields: dict of [E, T+1, nA, ...] episode tensors (the buffer content).  actor_p / critic_p: dicts of leaf
+    tensors with requires_grad (updated IN PLACE by Adam).  ``row_index_lists``: optional list (per epoch) of lists of
+    row-index tensors (minibatches, generate_data :368-424); default = one minibatch with the first ``rows`` rows.
+    Returns dict(returns, adv, old_logp, values_all, stats per epoch)."""
+    f, i = fields, agent_id
+    gat, behv = args.GAT_enable, args.Behavior_enable
+    E, T1 = f["history"].shape[:2]
+    T = T1 - 1
+    dt = f["history"].dtype
+    M = f["rnn_states_actors"].shape[-1]
+    if rows is None:
+        rows = args.batch_size * T
+    x_all = build_inputs_train(i, f["history"][:, :, i], f["attention_latent"][:, :, i] if gat else None,
+                               f["behavior_latent"][:, :, i] if behv else None, f["actions_onehot"][:, :, i],
+                               args.n_agents, gat, behv)
+    masks_all = 1.0 - f["terminated"][:, :, i].to(dt)
+    F_ = x_all.shape[-1]
+    with torch.no_grad():
+        v_all, _ = critic_value(critic_p, x_all.reshape(-1, F_), f["rnn_states_critics"][:, :, i].reshape(-1, M))
+        v_all = v_all.reshape(E, T + 1, 1)
+        rets = gae_returns(f["reward"][:, :-1, i].to(dt), v_all, masks_all, args.gamma, args.gae_lambda)
+        adv = normalise_advantages(rets, v_all[:, :-1], masks_all[:, :-1])
+        x = x_all[:, :-1].reshape(-1, F_)
+        ha = f["rnn_states_actors"][:, :-1, i].reshape(-1, M)
+        hc = f["rnn_states_critics"][:, :-1, i].reshape(-1, M)
+        acts = f["actions"][:, :-1, i].reshape(-1, 1)
+        avail = f["avail_actions"][:, :-1, i].reshape(-1, args.n_actions)
+        old_logp, _ = actor_evaluate(actor_p, x, ha, acts, avail)
+    ms = [{k: torch.zeros_like(v) for k, v in prm.items()} for prm in (actor_p, critic_p)]
+    vs = [{k: torch.zeros_like(v) for k, v in prm.items()} for prm in (actor_p, critic_p)]
+    steps = [0, 0]
+    stats = []
+    for ep in range(args.ppo_epoch):
+        batches = [slice(0, rows)] if row_index_lists is None else row_index_lists[ep]
+        for sl in batches:
+            for prm in (actor_p, critic_p):
+                for v in prm.values():
+                    v.grad = None
+            logp, ent = actor_evaluate(actor_p, x[sl], ha[sl], acts[sl], avail[sl])
+            val, _ = critic_value(critic_p, x[sl], hc[sl])
+            a_obj, pol, c_obj, vl, ratio = ppo_losses(
+                logp, ent, val, old_logp[sl], adv.reshape(-1, 1)[sl], v_all[:, :-1].reshape(-1, 1)[sl],
+                rets.reshape(-1, 1)[sl], masks_all[:, :-1].reshape(-1, 1)[sl],
+                args.clip_param, args.huber_delta, args.entropy_coef, args.value_loss_coef)
+            a_obj.backward()
+            c_obj.backward()
+            norms = []
+            for gi, prm in enumerate((actor_p, critic_p)):
+                trainable = [k for k in prm if prm[k].grad is not None]
+                norms.append(float(clip_grad_norm([prm[k].grad for k in trainable], args.max_grad_norm)))
+                steps[gi] += 1
+                with torch.no_grad():
+                    for k in trainable:
+                        adam_step(prm[k], prm[k].grad, ms[gi][k], vs[gi][k], steps[gi],
+                                  args.lr if gi == 0 else args.critic_lr, args.optim_eps)
+            stats.append(dict(policy_loss=float(pol.detach()), value_loss=float(vl.detach()), entropy=float(ent.detach()), ratio=float(ratio.detach().mean()),
+                              actor_grad_norm=norms[0], critic_grad_norm=norms[1]))
+    return dict(returns=rets, adv=adv, old_logp=old_logp, values_all=v_all, stats=stats)

@@ -475,51 +475,10 @@ def golden_ippo_train(seed=70, env="highway"):
     post = dict(actors=[sd(m) for m in mac.agents], critics=[sd(m) for m in mac.critics])
 
     # oracle replay (order-independent: one minibatch with all rows)
-    gat, behv = args.GAT_enable, args.Behavior_enable
-    T = args.episode_limit
-    nrow = args.batch_size * T
     for i in range(args.n_agents):
         ap = req(pre["actors"][i])
         cp = req(pre["critics"][i])
-        f = fields
-        x_all = O.build_inputs_train(i, f["history"][:, :, i], f["attention_latent"][:, :, i],
-                                     f["behavior_latent"][:, :, i], f["actions_onehot"][:, :, i],
-                                     args.n_agents, gat, behv)
-        masks_all = 1.0 - f["terminated"][:, :, i].float()
-        F_ = x_all.shape[-1]
-        with torch.no_grad():
-            v_all, _ = O.critic_value(cp, x_all.reshape(-1, F_), f["rnn_states_critics"][:, :, i].reshape(-1, 64))
-            v_all = v_all.reshape(E, T + 1, 1)
-            rets = O.gae_returns(f["reward"][:, :-1, i], v_all, masks_all, args.gamma, args.gae_lambda)
-            adv = O.normalise_advantages(rets, v_all[:, :-1], masks_all[:, :-1])
-            x = x_all[:, :-1].reshape(-1, F_)
-            ha = f["rnn_states_actors"][:, :-1, i].reshape(-1, 64)
-            hc = f["rnn_states_critics"][:, :-1, i].reshape(-1, 64)
-            acts = f["actions"][:, :-1, i].reshape(-1, 1)
-            avail = f["avail_actions"][:, :-1, i].reshape(-1, args.n_actions)
-            old_logp, _ = O.actor_evaluate(ap, x, ha, acts, avail)
-        ms = [{k: torch.zeros_like(v) for k, v in prm.items()} for prm in (ap, cp)]
-        vs = [{k: torch.zeros_like(v) for k, v in prm.items()} for prm in (ap, cp)]
-        sl = slice(0, nrow)
-        for ep in range(args.ppo_epoch):
-            for prm in (ap, cp):
-                for v in prm.values():
-                    v.grad = None
-            logp, ent = O.actor_evaluate(ap, x[sl], ha[sl], acts[sl], avail[sl])
-            val, _ = O.critic_value(cp, x[sl], hc[sl])
-            a_obj, pol, c_obj, vl, ratio = O.ppo_losses(
-                logp, ent, val, old_logp[sl], adv.reshape(-1, 1)[sl], v_all[:, :-1].reshape(-1, 1)[sl],
-                rets.reshape(-1, 1)[sl], masks_all[:, :-1].reshape(-1, 1)[sl],
-                args.clip_param, args.huber_delta, args.entropy_coef, args.value_loss_coef)
-            a_obj.backward()
-            c_obj.backward()
-            for gi, prm in enumerate((ap, cp)):
-                trainable = [k for k in prm if prm[k].grad is not None]
-                O.clip_grad_norm([prm[k].grad for k in trainable], args.max_grad_norm)
-                with torch.no_grad():
-                    for k in trainable:
-                        O.adam_step(prm[k], prm[k].grad, ms[gi][k], vs[gi][k], ep + 1,
-                                    args.lr if gi == 0 else args.critic_lr, args.optim_eps)
+        O.ppo_train_agent(i, ap, cp, fields, args)
         for k in ap:
             check(f"agent{i} post actor.{k}", ap[k], post["actors"][i][k], 2e-5)
         for k in cp:

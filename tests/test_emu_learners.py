@@ -240,3 +240,95 @@ def check_behavior_fc_learn(g, device):
 
 def test_behavior_fc_learn_emulated(golden):
     check_behavior_fc_learn(golden("behavior_fc_learn"), "cpu")
+
+
+def check_ippo_train_vs_oracle(g, device, mutate=None, tol=2e-5, **arg_overrides):
+    """IPPOLearner.train against the oracle's per-agent PPO replay (oracle.ppo_train_agent) on the fixture's episode fields,
+    optionally mutated -- covers buffer contents the recorded reference run does not (unfilled trailing steps ...)."""
+    import copy
+    from iplan_amd.controllers.dcntrl_controller import DcntrlMAC
+    from iplan_amd.learners.ippo_learner import IPPOLearner
+    from oracle import iplan_oracle as O
+    args = SimpleNamespace(**dict(g["args"], use_cuda=(device != "cpu"), **arg_overrides))
+    fields = copy.deepcopy(g["fields"])
+    if mutate is not None:
+        mutate(fields, args)
+    scheme = synth.make_scheme(args)
+    mac = DcntrlMAC(scheme, {"agents": args.n_agents}, args)
+    for i in range(args.n_agents):
+        mac.agents[i].load_state_dict(g["pre"]["actors"][i])
+        mac.critics[i].load_state_dict(g["pre"]["critics"][i])
+    learner = IPPOLearner(mac, scheme, RecLogger(), args)
+    E = fields["history"].shape[0]
+    learner.insert_episode_batch(synth.DictBatch(fields, E, args.episode_limit + 1).to(device))
+    learner.train(0)
+    worst = 0.0
+    for i in range(args.n_agents):
+        ap = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in g["pre"]["actors"][i].items()}
+        cp = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in g["pre"]["critics"][i].items()}
+        O.ppo_train_agent(i, ap, cp, fields, args)
+        for name, ref_p, mods in (("actor", ap, mac.agents), ("critic", cp, mac.critics)):
+            sd = mods[i].state_dict()
+            for k, ref in ref_p.items():
+                e = max_rel(sd[k], ref.detach())
+                worst = max(worst, e)
+                assert e < tol, (name, i, k, e)
+    return worst
+
+
+def unfilled_tail(fields, args):
+    """What ippo_parallel_runner.py:212-214 leaves behind when every env terminates early: the trailing steps were never
+    written -- ``actions`` = 0, ``actions_onehot`` = all zeros (OneHot only runs on updated slices), terminated = 0."""
+    for k in ("actions", "actions_onehot", "terminated", "reward"):
+        fields[k][:, -3:] = 0
+    fields["actions"][:, 0] = 2               # make sure index 0 is not what a wrong reconstruction would need
+
+
+def test_ippo_train_unfilled_trailing_steps_emulated(golden):
+    check_ippo_train_vs_oracle(golden("ippo_train"), "cpu", mutate=unfilled_tail)
+
+
+def test_per_agent_buffer_surface_emulated(golden):
+    """The reference-shaped per-agent loop (buffers[i].get_batch() ... buffers[i].clear_buffer(), agent after agent,
+    separated_buffer.py:39-50) sees every agent's data; the shared store is released when the last agent has cleared."""
+    from iplan_amd.controllers.dcntrl_controller import DcntrlMAC
+    from iplan_amd.learners.ippo_learner import IPPOLearner
+    g = golden("ippo_train_mpe")
+    args = SimpleNamespace(**dict(g["args"], use_cuda=False))
+    scheme = synth.make_scheme(args)
+    learner = IPPOLearner(DcntrlMAC(scheme, {"agents": args.n_agents}, args), scheme, RecLogger(), args)
+    f = dict(g["fields"])
+    f.pop("state")                                                   # optional field: get_batch must not require it
+    learner.insert_episode_batch(synth.DictBatch(f, f["history"].shape[0], args.episode_limit + 1))
+    for i in range(args.n_agents):
+        b = learner.buffers[i].get_batch()
+        assert b is not None and "state" not in b and torch.equal(b["history"], f["history"][:, :, i])
+        learner.buffers[i].clear_buffer()
+        assert learner.buffers[i].get_batch() is None
+    assert learner.store.count == 0
+
+
+def test_optimizer_load_resets_state_emulated():
+    """load_state_dict into an already-trained optimiser: parameters absent from the file get zero moments, an empty state
+    resets the step count (torch.optim.Adam semantics); moment arenas live on the arena object."""
+    from iplan_amd.arena import ParamArena
+    from iplan_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    mods = [torch.nn.Linear(4, 3)]
+    arena = ParamArena(mods, "cpu")
+    opt = FusedAdam([(arena, 0)], lr=1e-2, eps=1e-5)
+    fresh = opt.state_dict()
+    assert fresh["state"] == {}
+    for p in mods[0].parameters():
+        p.grad.copy_(torch.randn_like(p))
+    opt.step(max_norm=1.0)
+    sd = opt.state_dict()
+    assert set(sd["state"].keys()) == {0, 1} and opt._steps == 1
+    partial = {"state": {0: sd["state"][0]}, "param_groups": sd["param_groups"]}
+    opt.load_state_dict(partial)
+    m, v = arena._adam_moments
+    bias = arena.ranges(["bias"])[0]
+    assert float(m[0, bias[0]:bias[0] + bias[1]].abs().max()) == 0.0 and float(v[0, bias[0]:bias[0] + bias[1]].abs().max()) == 0.0
+    assert set(opt.state_dict()["state"].keys()) == {0}
+    opt.load_state_dict(fresh)
+    assert opt._steps == 0 and float(m.abs().max()) == 0.0

@@ -67,3 +67,16 @@ def test_loop_oracle_matches_reference(g):
         o.create(obs)
         assert np.array_equal(o.window(D["L"]), g["hist"][t]) and np.array_equal(o.single(), g["single"][t])
     assert np.array_equal(o.window(D["T"], g["mask"]), g["raw"])
+
+
+def test_unregistered_ego_id_raises_like_the_reference(g):
+    """observation_wrapper.py:76 does ``self.agent_id[k].index(agent_id)``: an ego id agent_obs_profile_init never saw is a
+    ValueError, not a silent write into agent slot 0."""
+    from iplan_amd.observation_wrapper import observersation_state_history_wrapper as Wrapper
+    D = g["dims"]
+    w = Wrapper(SimpleNamespace(obs_shape_single=D["d"], batch_size_run=D["K"]), D["nA"], D["N"], D["T"], D["L"])
+    w.agent_obs_profile_init(g["steps"][0])
+    bad = np.array(g["steps"][1], copy=True)
+    bad[1, 0, 0, 0] = 9999
+    with pytest.raises(ValueError):
+        w.obs_history_create(bad)
