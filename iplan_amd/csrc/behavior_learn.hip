@@ -558,9 +558,13 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
     for (int u = 0; u < 2; ++u) { aLin[u] = splat4(0.f); aOut[u] = splat4(0.f); bU[u] = splat4(0.f); }
     for (int t = 0; t < 8; ++t) bG[t] = splat4(0.f);
     bO = splat4(0.f);
-    auto park = [&](int slot, f32x4 v) { *reinterpret_cast<f32x4*>(&turn[slot][n * 16 + 4 * g]) = v; };
-    // operand element [chain 4s + g][column i] of a parked tile (i = lane & 15): conflict-free ds_read_b32
-    auto pick = [&](int slot, int s) { return turn[slot][(4 * s + g) * 16 + n]; };
+    // A parked tile is [16 chains][16 columns] with the columns of chain r rotated by 4 * (r >> 1): the ds_write_b128 of a
+    // group of 8 lanes (chains 2k, 2k + 1 at one g) then covers all 32 banks once, and the ds_read_b32 of a group of 32
+    // lanes (rows 4s + {0, 1} or {2, 3}: one rotation, banks [0, 16) and [16, 32)) is conflict free as well.  (Unrotated,
+    // the stores were 4-way conflicted: SQ_LDS_BANK_CONFLICT 27 M cycles against 5 M LDS instructions, profiles/r01g_pmc_*.)
+    auto park = [&](int slot, f32x4 v) { *reinterpret_cast<f32x4*>(&turn[slot][n * 16 + ((4 * g + 4 * (n >> 1)) & 15)]) = v; };
+    // operand element [chain 4s + g][column i] of a parked tile (i = lane & 15)
+    auto pick = [&](int slot, int s) { const int r = 4 * s + g; return turn[slot][r * 16 + ((n + 4 * (r >> 1)) & 15)]; };
 
     // window range of this launch (pieces, top down: see bwd_j_lo / bwd_j_hi in the header); d(loss)/d(h), d(loss)/d(latent)
     // cross the pieces in enc_carry, the weight-gradient partials accumulate in enc_part

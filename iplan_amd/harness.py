@@ -120,7 +120,10 @@ class SyntheticLoop:
             torch.cuda.synchronize(dev)
             return None
 
-    def _rollout_body(self, obs, batch):
+    def _rollout_body(self, obs, batch, noise=None, q_all=None):
+        """``noise`` ([T + 1, nA, E, N, N - 1, 2] gumbel samples; entry T feeds the episode-initial GAT update) and ``q_all``
+        ([T, nA, E, n_actions] exponential draws of the action race) may be injected (parity tests); by default they are
+        drawn on the device."""
         a, E = self.args, self.E
         T, nA, N, L = a.episode_limit, a.n_agents, a.max_vehicle_num, a.max_history_len
         dev = self.device
@@ -134,11 +137,13 @@ class SyntheticLoop:
         D["terminated"][:, :T].copy_(obs["terminated"][:T].permute(1, 0, 2, 3))
         eh = torch.zeros(2, E, 1, nA, N, a.encoder_rnn_dim, device=dev)   # ping-pong encoder hidden state
         if self.prediction is not None:
-            from .nova.GAT_Net import gumbel_noise
-            noise = gumbel_noise((T + 1, nA, E, N, N - 1, 2), dev)
+            if noise is None:
+                from .nova.GAT_Net import gumbel_noise
+                noise = gumbel_noise((T + 1, nA, E, N, N - 1, 2), dev)
             self.prediction.GAT_latent_update(D["history"][:, 0], D["attention_latent"][:, 0], D["behavior_latent"][:, 0],
                                               noise=noise[T], out=D["attention_latent"][:, 0])
-        q_all = torch.empty(T, nA, E, a.n_actions, device=dev).exponential_()
+        if q_all is None:
+            q_all = torch.empty(T, nA, E, a.n_actions, device=dev).exponential_()
         # The instant-incentive (GAT) and behavioural-incentive (encoder) updates of a step are independent of each
         # other (both read the PREVIOUS latents), and the GAT launch leaves 96 of the 256 CUs idle (one scene per
         # workgroup): the encoder runs beside it on a second HIP stream, joined before the next action selection.

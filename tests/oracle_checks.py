@@ -1,0 +1,308 @@
+"""TEST INFRASTRUCTURE: oracle-driven parity checks of the three learners and the GAT at ARBITRARY sizes (no recorded
+fixture needed: the CPU oracle -- pinned against the real reference by oracle/make_golden.py -- is run on the same seeded
+inputs).  The CPU suite calls them at small sizes through the host emulator; the ``-m gpu`` suite at BASELINE config 3 /
+2 / 5 sizes for ONE agent (tests/test_gpu_parity_fullsize.py), which is what bench.py times.
+
+Tolerances (north_star: 1e-5 fp32): losses and outputs <= 1e-5 * max(1, |ref|); gradients <= 1e-5 of the tensor's own max;
+post-Adam parameters <= 1e-6 (one step) / 1e-5 (PPO epochs).  Ground truth for gradients is the oracle in FP64; the fp32
+oracle (= the reference's own arithmetic) is run beside it, and where the reference's own fp32 rounding error e32 on a
+parameter group exceeds 2.5e-6 the bound widens to 4 x e32 ("no worse than four times the reference's own distance from the
+exact result"): gradients through the tau = 0.01 gumbel-softmax gate and second-epoch PPO gradients are conditioned such
+that NO fp32 implementation, the reference included, reproduces them to 1e-5.  Every check returns the worst errors it saw
+(kernel vs fp64, fp32 oracle vs fp64) so the GPU run can log them (profiles/*_parity_errors.json)."""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from iplan_amd import synth
+from oracle import iplan_oracle as O
+
+
+class _Log:
+    def __init__(self):
+        self.stats = {}
+
+    def log_stat(self, k, v, t):
+        self.stats[k] = float(v)
+
+
+def _sd(m):
+    return {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+
+
+def _req(p, dtype=None):
+    return {k: (v.detach().clone() if dtype is None or not v.is_floating_point() else v.detach().to(dtype).clone())
+            .requires_grad_(v.is_floating_point()) for k, v in p.items()}
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return (a - b).abs().max().item() / max(1.0, b.abs().max().item())
+
+
+def _grad_err(got, ref):
+    """error relative to the tensor's own scale"""
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+
+
+def _fields(args, E, seed, terminated_p, device):
+    f = synth.make_episode_fields(args, E, seed, terminated_p)
+    # the action a rollout took is always an available one (it was sampled from the masked distribution); with an
+    # unavailable one logp = -1e10 - lse, which fp32 rounds to -1e10 (ratio == 1 exactly) but fp64 does not -- the fp64
+    # ground truth used below would then differ from ANY fp32 implementation by O(1)
+    f["avail_actions"].scatter_(-1, f["actions"], 1)
+    return f, synth.DictBatch(f, E, args.episode_limit + 1).to(device)
+
+
+# ------------------------------------------------------------------------------------------------ Behavior_policy.learn
+def check_behavior_learn_vs_oracle(args, E, device, seed=0, tol=1e-5, post_tol=1e-6, with_fp64=True, agents=None):
+    from iplan_amd.nova.stable_behavior_policy import Behavior_policy
+    args = SimpleNamespace(**dict(vars(args), use_cuda=(torch.device(device).type == "cuda")))
+    torch.manual_seed(seed)
+    pol = Behavior_policy(args, _Log())
+    nA, N, Lw, T = args.n_agents, args.max_vehicle_num, args.max_history_len, args.episode_limit
+    J = T - 1 - Lw
+    pre = dict(enc=[_sd(m) for m in pol.behavior_encoder], dec=[_sd(m) for m in pol.behavior_decoder])
+    fields, batch = _fields(args, E, seed + 1, 0.8, device)
+    gen = torch.Generator().manual_seed(seed + 2)
+    keep = (torch.rand(nA, J, E * N, Lw, args.decoder_rnn_dim, generator=gen) < 1.0 - args.decoder_dropout).to(torch.uint8)
+    bl, sl, tl = pol.learn(batch, 0, keep=keep.to(device))
+    hist, term = fields["history"][:, :-1], fields["terminated"][:, :-1]
+    worst = dict(loss=0.0, grad=0.0, post=0.0, fp32_oracle_grad_vs_fp64=0.0)
+    for i in (range(nA) if agents is None else agents):       # ``agents``: replay only these with the (slow) oracle
+        mask = term[:, :, i, 0] if args.env != "MPE" else 1 - term[:, :, i, 0]
+        res = {}
+        for dt in ((torch.float32, torch.float64) if with_fp64 else (torch.float32,)):
+            ep, dp = _req(pre["enc"][i], dt), _req(pre["dec"][i], dt)
+            beh, stab, loss = O.behavior_learn_loss(ep, dp, hist[:, :, i].to(dt), mask, Lw, args.soft_update_coef, keep[i].to(dt),
+                                                    args.decoder_dropout, args.behavior_variation_penalty, args.thres_small_variation)
+            loss.backward()
+            O.clip_grad_norm([ep[k].grad for k in ep], args.max_grad_norm)
+            O.clip_grad_norm([dp[k].grad for k in dp], args.max_grad_norm)
+            res[dt] = (float(beh.detach()), float(stab.detach()), ep, dp)
+        beh, stab, ep32, dp32 = res[torch.float32]
+        _, _, ep_t, dp_t = res[torch.float64 if with_fp64 else torch.float32]     # ground truth for the gradients
+        worst["loss"] = max(worst["loss"], abs(float(bl[i]) - beh) / max(1.0, abs(beh)), abs(float(sl[i]) - stab) / max(1.0, abs(stab)))
+        gtol = tol
+        if with_fp64:
+            e32 = max(_grad_err(p32[k].grad, pt[k].grad) for p32, pt in ((ep32, ep_t), (dp32, dp_t)) for k in pt)
+            worst["fp32_oracle_grad_vs_fp64"] = max(worst["fp32_oracle_grad_vs_fp64"], e32)
+            gtol = max(tol, 4.0 * e32)
+        for name, prm, prm32, arena, mods in (("enc", ep_t, ep32, pol.enc_arena, pol.behavior_encoder),
+                                              ("dec", dp_t, dp32, pol.dec_arena, pol.behavior_decoder)):
+            sd = mods[i].state_dict()
+            for k in prm:
+                e = _grad_err(arena.grad_of(i, k), prm[k].grad)
+                worst["grad"] = max(worst["grad"], e)
+                assert e <= gtol, ("clipped grad", name, i, k, e, gtol)
+                w = prm32[k].detach().clone()
+                O.adam_step(w, prm32[k].grad, torch.zeros_like(w), torch.zeros_like(w), 1, args.lr_behavior, args.optim_eps)
+                pe = _rel(sd[k], w)
+                worst["post"] = max(worst["post"], pe)
+                assert pe <= post_tol, ("post", name, i, k, pe)
+    assert worst["loss"] <= tol, worst
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------ Prediction_policy.learn
+def check_prediction_learn_vs_oracle(args, E, device, seed=0, tol=1e-5, post_tol=1e-6, agents=None):
+    from iplan_amd.nova.prediction_policy import Prediction_policy
+    args = SimpleNamespace(**dict(vars(args), use_cuda=(torch.device(device).type == "cuda")))
+    torch.manual_seed(seed)
+    pol = Prediction_policy(args, _Log())
+    nA, N, S, P, T = args.n_agents, args.max_vehicle_num, args.pred_batch_size, args.pred_length, args.episode_limit
+    pre = dict(gat=[_sd(m) for m in pol.pred_GAT], dec=[_sd(m) for m in pol.pred_decoder])
+    fields, batch = _fields(args, E, seed + 1, 0.9, device)
+    gen = torch.Generator().manual_seed(seed + 2)
+    u = torch.rand(nA, S, N, N - 1, 2, generator=gen).clamp_min(1e-20)
+    noise = -torch.log((-torch.log(u)).clamp_min(1e-20))
+    keep = (torch.rand(nA, P, S * N, args.attention_dim, generator=gen) < 1.0 - args.decoder_dropout).float()
+    np.random.seed(seed + 3)
+    losses = pol.learn(batch, 0, noise=noise.to(device), keep=keep.to(device))
+    np.random.seed(seed + 3)
+    hist, att = fields["history"][:, :-1], fields["attention_latent"][:, :-1]
+    lat, term = fields["behavior_latent"][:, :-1], fields["terminated"][:, :-1]
+    sels = []
+    for i in range(nA):                                                    # the host draws, in Prediction_policy._sample's order
+        sels.append(np.random.choice(E * (T - P - 1), size=S, replace=False))
+        for _ in range(P):
+            np.random.random()
+    worst = dict(loss=0.0, grad_dec=0.0, grad_gat=0.0, gat_fp32_oracle_vs_fp64=0.0, post=0.0)
+    for i in (range(nA) if agents is None else agents):
+        res = {}
+        for dt in (torch.float32, torch.float64):
+            it, ia, il, act, mo = O.prediction_gather(hist[:, :, i].to(dt), att[:, :, i].to(dt), lat[:, :, i].to(dt), term[:, :, i, 0],
+                                                      sels[i], P)
+            gp, dp = _req(pre["gat"][i], dt), _req(pre["dec"][i], dt)
+            masks = keep[i].reshape(P, S * N, 1, -1).to(dt)
+            loss, _ = O.prediction_loss(gp, dp, it, ia, il, act, mo, noise[i].reshape(-1, 2).to(dt), masks, args.decoder_dropout, P,
+                                        use_behavior=args.GAT_use_behavior)
+            loss.backward()
+            O.clip_grad_norm([gp[k].grad for k in gp], args.max_grad_norm)
+            O.clip_grad_norm([dp[k].grad for k in dp], args.max_grad_norm)
+            res[dt] = (float(loss.detach()), gp, dp)
+        l32, gp32, dp32 = res[torch.float32]
+        l64, gp64, dp64 = res[torch.float64]
+        worst["loss"] = max(worst["loss"], abs(float(losses[i]) - l32) / max(1.0, abs(l32)))
+        # The hard-attention gate is a gumbel-softmax at tau = 0.01: d(gate)/d(logit) = 100 gate (1 - gate), so a 1-ulp
+        # difference in a logit moves the few unsaturated gates' derivatives -- which dominate every gradient that flows
+        # through the gate -- by ~1e-5 relative.  The fp32 reference itself carries that error (measured here against the
+        # fp64 oracle), so the GAT group's bound is max(tol, 4 x the fp32 oracle's own worst error); the decoder group
+        # (no gate on its path) stays at tol.
+        e32 = max(_grad_err(gp32[k].grad, gp64[k].grad) for k in gp32)
+        worst["gat_fp32_oracle_vs_fp64"] = max(worst["gat_fp32_oracle_vs_fp64"], e32)
+        gat_tol = max(tol, 4.0 * e32)
+        for name, prm, prm32, arena, mods, gtol in (("gat", gp64, gp32, pol.gat_arena, pol.pred_GAT, gat_tol),
+                                                    ("dec", dp64, dp32, pol.dec_arena, pol.pred_decoder, tol)):
+            sd = mods[i].state_dict()
+            for k in prm:
+                e = _grad_err(arena.grad_of(i, k), prm[k].grad)
+                worst["grad_" + name] = max(worst["grad_" + name], e)
+                assert e <= gtol, ("clipped grad vs fp64 oracle", name, i, k, e, gtol)
+                w = prm32[k].detach().clone()
+                O.adam_step(w, prm32[k].grad, torch.zeros_like(w), torch.zeros_like(w), 1, args.lr_predict, args.optim_eps)
+                pe = _rel(sd[k], w)
+                worst["post"] = max(worst["post"], pe)
+                assert pe <= post_tol, ("post", name, i, k, pe)
+    assert worst["loss"] <= tol, worst
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------ IPPOLearner.train
+def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, terminated_p=0.15, also_fp32=True, agents=None):
+    """insert buffer_size episodes -> train() (ppo_epoch fused epochs) vs oracle.ppo_train_agent, every agent: clipped
+    gradients of the LAST epoch and the post-train parameters."""
+    from iplan_amd.controllers.dcntrl_controller import DcntrlMAC
+    from iplan_amd.learners.ippo_learner import IPPOLearner
+    args = SimpleNamespace(**dict(vars(args), use_cuda=(torch.device(device).type == "cuda")))
+    torch.manual_seed(seed)
+    scheme = synth.make_scheme(args)
+    mac = DcntrlMAC(scheme, {"agents": args.n_agents}, args)
+    pre = dict(actors=[_sd(m) for m in mac.agents], critics=[_sd(m) for m in mac.critics])
+    log = _Log()
+    learner = IPPOLearner(mac, scheme, log, args)
+    E = args.buffer_size
+    fields, batch = _fields(args, E, seed + 1, terminated_p, device)
+    learner.batch_size_run = E
+    learner.insert_episode_batch(batch)
+    assert learner.buffers[0].can_sample()
+    learner.train(0)
+    worst = dict(grad=0.0, post=0.0, fp32_oracle_grad_vs_fp64=0.0, fp32_oracle_post_vs_fp64=0.0)
+    f64 = {k: (v.double() if v.is_floating_point() else v) for k, v in fields.items()}
+    for i in (range(args.n_agents) if agents is None else agents):
+        # ground truth = the oracle in fp64; the fp32 oracle (= the reference's arithmetic) is run beside it (when
+        # ``also_fp32``) to record how far the reference's own fp32 rounding sits from it
+        ap, cp = _req(pre["actors"][i], torch.float64), _req(pre["critics"][i], torch.float64)
+        O.ppo_train_agent(i, ap, cp, f64, args)
+        if also_fp32:
+            a32, c32 = _req(pre["actors"][i]), _req(pre["critics"][i])
+            O.ppo_train_agent(i, a32, c32, fields, args)
+            for p32, p64 in ((a32, ap), (c32, cp)):
+                for k in p64:
+                    if p64[k].grad is not None:
+                        worst["fp32_oracle_grad_vs_fp64"] = max(worst["fp32_oracle_grad_vs_fp64"], _grad_err(p32[k].grad, p64[k].grad))
+                    worst["fp32_oracle_post_vs_fp64"] = max(worst["fp32_oracle_post_vs_fp64"], _rel(p32[k].detach(), p64[k].detach()))
+        gtol = max(tol, 4.0 * worst["fp32_oracle_grad_vs_fp64"])       # see the module docstring
+        ptol = max(post_tol, 4.0 * worst["fp32_oracle_post_vs_fp64"])
+        for name, prm, arena, mods in (("actor", ap, mac.actor_arena, mac.agents), ("critic", cp, mac.critic_arena, mac.critics)):
+            sd = mods[i].state_dict()
+            for k in prm:
+                if prm[k].grad is not None:
+                    e = _grad_err(arena.grad_of(i, k), prm[k].grad)
+                    worst["grad"] = max(worst["grad"], e)
+                    assert e <= gtol, ("clipped grad (last epoch) vs fp64 oracle", name, i, k, e, gtol)
+                pe = _rel(sd[k], prm[k].detach())
+                worst["post"] = max(worst["post"], pe)
+                assert pe <= ptol, ("post", name, i, k, pe, ptol)
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------ GAT forward + backward
+def check_gat_fwd_bwd_vs_oracle(B, N, D, device, seed=0, tol=1e-5):
+    """One GAT_Net (random weights) forward + backward through the module's autograd path vs the oracle in fp64 (the
+    kernel must be as close to the exact result as the fp32 reference is)."""
+    from iplan_amd.config import default_args
+    from iplan_amd.nova.GAT_Net import GAT_Net
+    args = default_args("highway", use_cuda=(torch.device(device).type == "cuda"), max_vehicle_num=N)
+    torch.manual_seed(seed)
+    net = GAT_Net(D, args)
+    params = _sd(net)
+    gen = torch.Generator().manual_seed(seed + 1)
+    obs = torch.rand(B, N, D, generator=gen) * 2 - 1
+    h_prev = torch.randn(B * N, args.attention_dim, generator=gen) * 0.1
+    u = torch.rand(B * N * (N - 1), 2, generator=gen).clamp_min(1e-20)
+    noise = -torch.log((-torch.log(u)).clamp_min(1e-20))
+    gout = torch.randn(B * N, args.attention_dim, generator=gen)
+    out = net(obs.to(device), h_prev.to(device), noise=noise.to(device))
+    (out * gout.to(device)).sum().backward()
+    p64 = _req(params, torch.float64)
+    o64 = O.gat_forward(p64, obs.double(), h_prev.double(), noise.double())
+    (o64 * gout.double()).sum().backward()
+    p32 = _req(params)
+    o32 = O.gat_forward(p32, obs, h_prev, noise)
+    (o32 * gout).sum().backward()
+    gscale = lambda k: max(1.0, p64[k].grad.abs().max().item())  # noqa: E731
+    e32 = max((p32[k].grad.double() - p64[k].grad).abs().max().item() / gscale(k) for k in p64)
+    worst = dict(out=_rel(out.detach(), o64.detach()), out_vs_fp32_oracle=_rel(out.detach(), o32.detach()), grad=0.0,
+                 fp32_oracle_out_vs_fp64=_rel(o32.detach(), o64.detach()), fp32_oracle_grad_vs_fp64=e32)
+    assert worst["out"] <= tol, worst
+    gtol = max(tol, 4.0 * e32)              # tau = 0.01 gate conditioning: see check_prediction_learn_vs_oracle
+    for k, p in net.named_parameters():
+        e = (p.grad.double().cpu() - p64[k].grad).abs().max().item() / gscale(k)
+        worst["grad"] = max(worst["grad"], e)
+        assert e <= gtol, (k, e, gtol)
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------ a13: reference-shaped methods
+def check_ippo_reference_shaped_methods(g, device, tol=3e-5):
+    """compute_returns / generate_data / ppo_update / get_value_ippo / eval_action_ippo / _build_inputs_ippo (the reference's
+    per-agent surface, learners/ippo_learner.py:128-225,344-424, controllers/dcntrl_controller.py:61-115) replayed agent by
+    agent, epoch by epoch, land on the reference's post-train parameters."""
+    from iplan_amd.controllers.dcntrl_controller import DcntrlMAC
+    from iplan_amd.learners.ippo_learner import IPPOLearner
+    args = SimpleNamespace(**dict(g["args"], use_cuda=(torch.device(device).type == "cuda")))
+    scheme = synth.make_scheme(args)
+    mac = DcntrlMAC(scheme, {"agents": args.n_agents}, args)
+    for i in range(args.n_agents):
+        mac.agents[i].load_state_dict(g["pre"]["actors"][i])
+        mac.critics[i].load_state_dict(g["pre"]["critics"][i])
+    learner = IPPOLearner(mac, scheme, _Log(), args)
+    f = g["fields"]
+    E, T = f["history"].shape[0], args.episode_limit
+    learner.insert_episode_batch(synth.DictBatch(f, E, T + 1).to(device))
+    torch.manual_seed(0)
+    gat, beh = args.GAT_enable, args.Behavior_enable
+    worst = 0.0
+    for agent_id in range(args.n_agents):
+        batch = learner.buffers[agent_id].get_batch()
+        obs_all = mac._build_inputs_ippo(agent_id, batch, batch["actions_onehot"])
+        rewards, term_all = batch["reward"][:, :-1], batch["terminated_masks"]
+        returns = learner.compute_returns(agent_id, obs_all, rewards, term_all, batch["rnn_states_critic"])
+        ref_x = O.build_inputs_train(agent_id, f["history"][:, :, agent_id], f["attention_latent"][:, :, agent_id] if gat else None,
+                                     f["behavior_latent"][:, :, agent_id] if beh else None, f["actions_onehot"][:, :, agent_id],
+                                     args.n_agents, gat, beh)
+        assert _rel(obs_all, ref_x) < 1e-6
+        obs, term = obs_all[:, :-1], term_all[:, :-1].float()
+        with torch.no_grad():
+            values = mac.get_value_ippo(agent_id, obs, batch["rnn_states_critic"][:, :-1])
+            adv = O.normalise_advantages(returns.cpu(), values.cpu(), term.cpu()).to(device)   # host-side check of the kernel's advantage path
+            old_logp, _ = mac.eval_action_ippo(agent_id, obs, batch["actions"][:, :-1], batch["available_actions"][:, :-1],
+                                               batch["rnn_states_actor"][:, :-1])
+        for _ in range(args.ppo_epoch):
+            for sample in learner.generate_data(obs, batch["rnn_states_actor"][:, :-1], batch["rnn_states_critic"][:, :-1],
+                                                batch["actions"][:, :-1], returns, term, old_logp, adv,
+                                                batch["available_actions"][:, :-1], values, args.num_mini_batch):
+                learner.ppo_update(agent_id, *sample)
+        learner.buffers[agent_id].clear_buffer()
+    assert learner.store.count == 0
+    for i in range(args.n_agents):
+        for name, mods in (("actors", mac.agents), ("critics", mac.critics)):
+            sd = mods[i].state_dict()
+            for k, ref in g["post"][name][i].items():
+                e = _rel(sd[k], ref)
+                worst = max(worst, e)
+                assert e < tol, (name, i, k, e)
+    return worst

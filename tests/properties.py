@@ -94,7 +94,7 @@ def check_behaviour_properties(loop, batch, fd_tol=2e-2):
     rows = lambda k, lo, hi: k[:, :, lo * N:hi * N].contiguous()   # noqa: E731
     _, ge_a, gd_a = _beh_grads(loop, hist[:, :h], mask[:, :h].contiguous(), rows(keep, 0, h), win_norm=wn)
     _, ge_b, gd_b = _beh_grads(loop, hist[:, h:], mask[:, h:].contiguous(), rows(keep, h, E), win_norm=wn)
-    assert rel(ge_a + ge_b, ge) < 2e-5 and rel(gd_a + gd_b, gd) < 2e-5, (rel(ge_a + ge_b, ge), rel(gd_a + gd_b, gd))
+    assert rel(ge_a + ge_b, ge) < 1e-5 and rel(gd_a + gd_b, gd) < 1e-5, (rel(ge_a + ge_b, ge), rel(gd_a + gd_b, gd))
     # directional derivative along the gradient, decoder parameters of every net at once
     arena = loop.behavior.dec_arena
     theta = arena.data.clone()

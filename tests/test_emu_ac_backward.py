@@ -123,4 +123,4 @@ def test_module_level_autograd():
     (o64 * gout.double()).sum().backward()
     for k, p in net.named_parameters():
         err = (p.grad.double() - gp[k].grad).abs().max().item()
-        assert err <= 2e-5 * gp[k].grad.abs().max().item() + 1e-10, (k, err)
+        assert err <= 1e-5 * gp[k].grad.abs().max().item() + 1e-10, (k, err)

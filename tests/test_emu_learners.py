@@ -51,10 +51,10 @@ def check_ippo_train(g, device):
         for name, mods in (("actors", mac.agents), ("critics", mac.critics)):
             sd = mods[i].state_dict()
             for k, ref in g["post"][name][i].items():
-                assert max_rel(sd[k], ref) < 2e-5, (name, i, k, max_rel(sd[k], ref))
+                assert max_rel(sd[k], ref) < 1e-5, (name, i, k, max_rel(sd[k], ref))
     for k, ref in g["stats"].items():
         got = log.stats[k]
-        assert abs(got - ref) <= 2e-5 * max(1.0, abs(ref)), (k, got, ref)
+        assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (k, got, ref)
 
 
 @pytest.mark.parametrize("tag", ["ippo_train", "ippo_train_mpe"])
@@ -114,7 +114,7 @@ def check_behavior_learn(g, device):
             for k, ref in g["clipped"][name][i].items():
                 got = arena.grad_of(i, k).cpu()
                 err = (got.double() - ref.double()).abs().max().item()
-                assert err <= 2e-5 * ref.abs().max().item() + 1e-9, ("clipped grad", name, i, k, err, ref.abs().max().item())
+                assert err <= 1e-5 * ref.abs().max().item() + 1e-9, ("clipped grad", name, i, k, err, ref.abs().max().item())
             sd = mods[i].state_dict()
             for k, ref in g["post"][name][i].items():
                 assert max_rel(sd[k], ref) < 1e-6, ("post", name, i, k, max_rel(sd[k], ref))
@@ -131,48 +131,12 @@ def test_behavior_learn_bptt_in_pieces_emulated(golden, monkeypatch):
     check_behavior_hard_learn(golden("behavior_hard_learn"), "cpu")
 
 
-def test_ippo_reference_shaped_methods_emulated(golden):
+@pytest.mark.parametrize("tag", ["ippo_train_mpe", "ippo_train"])
+def test_ippo_reference_shaped_methods_emulated(golden, tag):
     """compute_returns / generate_data / ppo_update (the reference's per-agent surface) reproduce the fused train():
     replaying the golden run agent by agent, epoch by epoch, lands on the reference's post-train parameters."""
-    from iplan_amd.controllers.dcntrl_controller import DcntrlMAC
-    from iplan_amd.learners.ippo_learner import IPPOLearner
-    from oracle import iplan_oracle as O
-    g = golden("ippo_train_mpe")
-    args = SimpleNamespace(**dict(g["args"], use_cuda=False))
-    scheme = synth.make_scheme(args)
-    mac = DcntrlMAC(scheme, {"agents": args.n_agents}, args)
-    for i in range(args.n_agents):
-        mac.agents[i].load_state_dict(g["pre"]["actors"][i])
-        mac.critics[i].load_state_dict(g["pre"]["critics"][i])
-    learner = IPPOLearner(mac, scheme, RecLogger(), args)
-    f = g["fields"]
-    E, T = f["history"].shape[0], args.episode_limit
-    learner.insert_episode_batch(synth.DictBatch(f, E, T + 1))
-    torch.manual_seed(0)
-    for agent_id in range(args.n_agents):
-        batch = learner.buffers[agent_id].get_batch()
-        obs_all = mac._build_inputs_ippo(agent_id, batch, batch["actions_onehot"])
-        rewards, term_all = batch["reward"][:, :-1], batch["terminated_masks"]
-        returns = learner.compute_returns(agent_id, obs_all, rewards, term_all, batch["rnn_states_critic"])
-        ref_x = O.build_inputs_train(agent_id, f["history"][:, :, agent_id], None, None, f["actions_onehot"][:, :, agent_id],
-                                     args.n_agents, False, False)
-        assert max_rel(obs_all, ref_x) < 1e-6
-        obs, term = obs_all[:, :-1], term_all[:, :-1].float()
-        with torch.no_grad():
-            values = mac.get_value_ippo(agent_id, obs, batch["rnn_states_critic"][:, :-1])
-            adv = O.normalise_advantages(returns, values, term)          # host-side check of the kernel's advantage path
-            old_logp, _ = mac.eval_action_ippo(agent_id, obs, batch["actions"][:, :-1], batch["available_actions"][:, :-1],
-                                               batch["rnn_states_actor"][:, :-1])
-        for _ in range(args.ppo_epoch):
-            for sample in learner.generate_data(obs, batch["rnn_states_actor"][:, :-1], batch["rnn_states_critic"][:, :-1],
-                                                batch["actions"][:, :-1], returns, term, old_logp, adv,
-                                                batch["available_actions"][:, :-1], values, args.num_mini_batch):
-                learner.ppo_update(agent_id, *sample)
-    for i in range(args.n_agents):
-        for name, mods in (("actors", mac.agents), ("critics", mac.critics)):
-            sd = mods[i].state_dict()
-            for k, ref in g["post"][name][i].items():
-                assert max_rel(sd[k], ref) < 3e-5, (name, i, k, max_rel(sd[k], ref))
+    from tests.oracle_checks import check_ippo_reference_shaped_methods
+    check_ippo_reference_shaped_methods(golden(tag), "cpu")
 
 
 def check_behavior_hard_learn(g, device):
@@ -193,7 +157,7 @@ def check_behavior_hard_learn(g, device):
         for name, mods, arena in (("enc", pol.behavior_encoder, pol.enc_arena), ("dec", pol.behavior_decoder, pol.dec_arena)):
             for k, ref in g["clipped"][name][i].items():
                 err = (arena.grad_of(i, k).cpu().double() - ref.double()).abs().max().item()
-                assert err <= 2e-5 * ref.abs().max().item() + 1e-9, ("clipped grad", name, i, k, err)
+                assert err <= 1e-5 * ref.abs().max().item() + 1e-9, ("clipped grad", name, i, k, err)
             sd = mods[i].state_dict()
             for k, ref in g["post"][name][i].items():
                 assert max_rel(sd[k], ref) < 1e-6, ("post", name, i, k)
@@ -224,7 +188,7 @@ def check_behavior_fc_learn(g, device):
         for name, mods, arena in (("enc", pol.behavior_encoder, pol.enc_arena), ("dec", pol.behavior_decoder, pol.dec_arena)):
             for k, ref in g["clipped"][name][i].items():
                 err = (arena.grad_of(i, k).cpu().double() - ref.double()).abs().max().item()
-                assert err <= 2e-5 * ref.abs().max().item() + 1e-9, ("clipped grad", name, i, k, err)
+                assert err <= 1e-5 * ref.abs().max().item() + 1e-9, ("clipped grad", name, i, k, err)
             sd = mods[i].state_dict()
             for k, ref in g["post"][name][i].items():
                 assert max_rel(sd[k], ref) < 1e-6, ("post", name, i, k)
@@ -242,7 +206,7 @@ def test_behavior_fc_learn_emulated(golden):
     check_behavior_fc_learn(golden("behavior_fc_learn"), "cpu")
 
 
-def check_ippo_train_vs_oracle(g, device, mutate=None, tol=2e-5, **arg_overrides):
+def check_ippo_train_vs_oracle(g, device, mutate=None, tol=1e-5, **arg_overrides):
     """IPPOLearner.train against the oracle's per-agent PPO replay (oracle.ppo_train_agent) on the fixture's episode fields,
     optionally mutated -- covers buffer contents the recorded reference run does not (unfilled trailing steps ...)."""
     import copy
@@ -332,3 +296,39 @@ def test_optimizer_load_resets_state_emulated():
     assert set(opt.state_dict()["state"].keys()) == {0}
     opt.load_state_dict(fresh)
     assert opt._steps == 0 and float(m.abs().max()) == 0.0
+
+
+# ---- oracle-driven checks at arbitrary sizes (tests/oracle_checks.py): small sizes here, BASELINE config 2 / 3 / 5 sizes on the GPU
+def _small(**kw):
+    from iplan_amd.config import default_args
+    base = dict(use_cuda=False, max_vehicle_num=5, n_agents=2, episode_limit=9, batch_size_run=3, max_history_len=3,
+                pred_batch_size=6, pred_length=2, buffer_size=4, batch_size=3, ppo_epoch=2)
+    base.update(kw)
+    return default_args("highway", **base)
+
+
+def test_behavior_learn_vs_oracle_emulated():
+    from tests.oracle_checks import check_behavior_learn_vs_oracle
+    w = check_behavior_learn_vs_oracle(_small(), 3, "cpu", seed=3)
+    assert w["grad"] < 1e-5, w
+
+
+@pytest.mark.parametrize("cfg", ["iplan", "gat_only"])
+def test_prediction_learn_vs_oracle_emulated(cfg):
+    from tests.oracle_checks import check_prediction_learn_vs_oracle
+    kw = {} if cfg == "iplan" else dict(Behavior_enable=False)
+    check_prediction_learn_vs_oracle(_small(**kw), 3, "cpu", seed=4)
+
+
+@pytest.mark.parametrize("cfg", ["iplan", "gat_only", "plain"])
+def test_ppo_train_vs_oracle_emulated(cfg):
+    """config 3 (F = N(d+A+Z)+10), config 2 (Behaviour off: F = N(d+A)+10) and config 1 (both off) feature layouts"""
+    from tests.oracle_checks import check_ppo_train_vs_oracle
+    kw = dict(iplan={}, gat_only=dict(Behavior_enable=False), plain=dict(Behavior_enable=False, GAT_enable=False, GAT_use_behavior=False))[cfg]
+    check_ppo_train_vs_oracle(_small(**kw), "cpu", seed=6)
+
+
+def test_gat_fwd_bwd_vs_oracle_emulated():
+    """GAT forward + backward at config 5's input width (D = 128) and a ragged entity count, vs the fp64 oracle"""
+    from tests.oracle_checks import check_gat_fwd_bwd_vs_oracle
+    check_gat_fwd_bwd_vs_oracle(B=2, N=9, D=128, device="cpu", seed=8)

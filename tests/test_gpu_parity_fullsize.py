@@ -1,0 +1,97 @@
+"""GPU parity of what bench.py times, at the sizes it is timed (VERDICT r1 "next" #1):
+
+* the device-resident rollout (SyntheticLoop._rollout_body: write_back / out= launches, two streams) against the oracle
+  stepped the same way -- BASELINE config 3 (32 envs x 5 agents x 55 entities) and config 2 (16 envs, Behaviour off);
+* one agent of each learner at config 3 size against the oracle (fp64 ground truth, fp32 oracle beside it):
+  Behavior_policy.learn at E = 32, IPPOLearner.train on 255 x 90 = 22 950 rows, Prediction_policy.learn at 64 x 55;
+* config 2 (F = 2045) and config 5 (N = 64, D = 128) forward + backward;
+* the reference-shaped per-agent PPO methods (a13) on the GPU.
+Worst errors are appended to gpurun_out/parity_errors.json (copied to profiles/ as the tolerance evidence)."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _log(name, worst):
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "parity_errors.json")
+    data = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            data = json.load(f)
+    data[name] = worst
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+    print(name, worst)
+
+
+def _args(**kw):
+    from iplan_amd.config import default_args
+    return default_args("highway", use_cuda=True, **kw)
+
+
+def test_rollout_body_config3_vs_oracle():
+    from tests.rollout_oracle import check_rollout_body
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    _log("rollout_body_cfg3_E32_T4", check_rollout_body(_args(episode_limit=4, batch_size_run=32), 32, "cuda", seed=21))
+
+
+def test_rollout_body_config2_vs_oracle():
+    from tests.rollout_oracle import check_rollout_body
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    _log("rollout_body_cfg2_E16_T3", check_rollout_body(_args(episode_limit=3, batch_size_run=16, Behavior_enable=False), 16, "cuda", seed=22))
+
+
+def test_behavior_learn_config3_one_agent_vs_oracle():
+    from tests.oracle_checks import check_behavior_learn_vs_oracle
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    _log("behavior_learn_cfg3_E32_agent0", check_behavior_learn_vs_oracle(_args(batch_size_run=32), 32, "cuda", seed=23, agents=(0,)))
+
+
+def test_ppo_train_config3_one_agent_vs_oracle():
+    """255 x 90 = 22 950 rows x F = 2485, two PPO epochs (the second runs on the first one's updated weights)"""
+    from tests.oracle_checks import check_ppo_train_vs_oracle
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    _log("ppo_train_cfg3_22950rows_agent0", check_ppo_train_vs_oracle(_args(ppo_epoch=2), "cuda", seed=24, agents=(0,)))
+
+
+def test_prediction_learn_config3_vs_oracle():
+    from tests.oracle_checks import check_prediction_learn_vs_oracle
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    _log("prediction_learn_cfg3_S64_N55", check_prediction_learn_vs_oracle(_args(batch_size_run=32), 32, "cuda", seed=25, agents=(0, 3)))
+
+
+def test_config2_learners_vs_oracle():
+    """config 2: IPPO-GAT, Behaviour off (F = 55 x 37 + 10 = 2045), 16 envs"""
+    from tests.oracle_checks import check_ppo_train_vs_oracle, check_prediction_learn_vs_oracle
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    a = _args(Behavior_enable=False, batch_size_run=16, buffer_size=16, batch_size=15, ppo_epoch=2)
+    _log("ppo_train_cfg2_F2045_agent1", check_ppo_train_vs_oracle(a, "cuda", seed=26, agents=(1,)))
+    _log("prediction_learn_cfg2", check_prediction_learn_vs_oracle(a, 16, "cuda", seed=27, agents=(2,)))
+
+
+def test_config5_gat_and_behaviour_vs_oracle():
+    """config 5: 64 entities x 63 neighbours x obs_dim 128 -- GAT forward + backward; behaviour encoder / decoder learning at N = 64"""
+    from tests.oracle_checks import check_gat_fwd_bwd_vs_oracle, check_behavior_learn_vs_oracle
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    _log("gat_fwd_bwd_cfg5_N64_D128_B4", check_gat_fwd_bwd_vs_oracle(B=4, N=64, D=128, device="cuda", seed=28))
+    _log("behavior_learn_cfg5_N64", check_behavior_learn_vs_oracle(_args(max_vehicle_num=64, n_agents=2, episode_limit=30, batch_size_run=4),
+                                                                   4, "cuda", seed=29))
+
+
+@pytest.mark.parametrize("tag", ["ippo_train_mpe", "ippo_train"])
+def test_ippo_reference_shaped_methods_gpu(golden, tag):
+    """a13: get_value_ippo / eval_action_ippo / compute_returns / generate_data / ppo_update / _build_inputs_ippo on the GPU"""
+    from tests.oracle_checks import check_ippo_reference_shaped_methods
+    _log("reference_shaped_methods_" + tag, dict(post=check_ippo_reference_shaped_methods(golden(tag), "cuda")))
+
+
+def test_ippo_train_unfilled_trailing_steps_gpu(golden):
+    from tests.test_emu_learners import check_ippo_train_vs_oracle, unfilled_tail
+    _log("ippo_train_unfilled_tail", dict(post=check_ippo_train_vs_oracle(golden("ippo_train"), "cuda", mutate=unfilled_tail)))
