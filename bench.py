@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 from iplan_amd.config import default_args  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32, dense)
+HBM_PEAK_GBS = 8000.0                # HBM3E spec (same guide; ~6.3 TB/s is what a float4 copy achieves)
 # HBM bytes per launch from the committed PMC passes (profiles/r01*_pmc_*.txt), keyed by (kernel, envs per GPU):
 # (2 * FETCH_SIZE + WRITE_SIZE) KiB -> bytes.  Counters cannot be collected from inside bench.py; None = not profiled.
 PMC_TRAFFIC_BYTES = {
@@ -162,7 +163,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--envs", type=int, default=32, help="parallel envs per GPU (config 3: 32)")
+    ap.add_argument("--envs", type=int, default=32, help="parallel envs per GPU in weak-scaling mode (config 3: 32)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): 32 envs per GPU, every rank its own 256-episode PPO buffer.  strong = BASELINE config 4: "
+                         "--total-envs (256) envs in total, sharded over the GPUs, ONE global 256-episode buffer (train() after every "
+                         "rollout, the first 255 episodes trained on), all gradients all-reduced")
+    ap.add_argument("--total-envs", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollout-only", action="store_true", help="diagnostic: time rollout inference without the learners")
     opt = ap.parse_args()
@@ -180,13 +186,27 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    args = default_args("highway", use_cuda=True, batch_size_run=opt.envs)
-    E = opt.envs
+    strong = opt.scaling == "strong"
+    if strong:
+        # config 4: the env rows of ONE 256-env run are sharded over the ranks; rank r stores its own episodes of the global
+        # buffer, the reference's "first batch_size = buffer_size - 1 episodes" drops the last episode of the last rank
+        assert opt.total_envs % world == 0, "--total-envs must be divisible by the number of GPUs"
+        E = opt.total_envs // world
+        base = default_args("highway")
+        drop = base.buffer_size - base.batch_size               # 1: train() uses the first buffer_size - 1 episodes
+        args = default_args("highway", use_cuda=True, batch_size_run=E, buffer_size=E,
+                            batch_size=E - (drop if rank == world - 1 else 0))
+    else:
+        E = opt.envs
+        args = default_args("highway", use_cuda=True, batch_size_run=E)
     from iplan_amd.harness import SyntheticLoop
     loop = SyntheticLoop(args, E, seed=1234 + rank, device=dev)
     if world > 1:
         from iplan_amd.parallel import DataParallel
         DataParallel(dist.group.WORLD).attach(loop)
+        if strong:
+            loop.learner.dp_global_rows = (args.buffer_size * world - drop) * args.episode_limit
+            loop.learner.dp_global_count = args.buffer_size * world * args.episode_limit
     rollouts_per_step = max(1, args.buffer_size // E)
 
     def one_step():
@@ -206,10 +226,10 @@ def main():
     for _ in range(opt.warmup):
         one_step()
     barrier()
-    # roofline timing of the two dominant kernels, live in the timed region: HIP events on the launch stream right
-    # around every beh_dec_bwd launch and every 8th gat_fwd launch (ops.KernelTimers)
+    # roofline timing, live in the timed region: HIP events on the launch stream right around the launches of the kernels that
+    # make up > 5 % of a cycle (ops.KernelTimers; the two per-vector-step kernels are sampled every 8th launch)
     from iplan_amd import ops
-    ops.TIMERS = ops.KernelTimers(every={"gat_fwd_kernel": 8})
+    ops.TIMERS = ops.KernelTimers(every={"gat_fwd_kernel": 8, "ac_fwd_kernel:rollout": 8})
     t0 = time.perf_counter()
     for _ in range(opt.steps):
         one_step()
@@ -223,46 +243,24 @@ def main():
         dt = float(tt.item())
     env_steps = opt.steps * rollouts_per_step * E * args.episode_limit * world
 
-    nA, N, d, Z = args.n_agents, args.max_vehicle_num, args.obs_shape_single, args.latent_dim
-    # (1) gat_fwd_kernel -- rollout GAT_latent_update, the largest share of a training cycle and on its critical path
-    gat_n, gat_s = timed.get("gat_fwd_kernel", (0, float("nan")))
-    flops = gat_algorithmic_flops(nA, E, N, d + Z)
-    # (2) beh_dec_bwd_kernel -- decoder BPTT of Behavior_policy.learn; one learn() launches it BEH_PIECES times (window
-    # ranges, pipelined with the weight-gradient contraction).  SURVEY.md §8(d): decoder V*L*(2(d+Z)*64 + 12*64^2 + 2*64*d)
-    # FLOPs per window forward; the backward-data pass (this kernel) is 1x that, the weight-gradient pass the other 1x.
-    bwd_n, bwd_s = timed.get("beh_dec_bwd_kernel", (0, float("nan")))
-    Hd, Lw = args.decoder_rnn_dim, args.max_history_len
-    J = args.episode_limit - 1 - Lw
-    pieces = max(1, bwd_n // max(1, opt.steps * rollouts_per_step))
-    flops_b = nA * E * N * J * Lw * (2 * (d + Z) * Hd + 12 * Hd * Hd + 2 * Hd * d) / pieces
-
     if rank == 0:
+        mode = (f"config 4 (strong scaling): {opt.total_envs} envs in total = {E} envs/GPU x {world} GPU(s), one global "
+                f"{opt.total_envs}-episode buffer; step = 1 rollout + insert + Behavior_policy.learn + Prediction_policy.learn + "
+                "IPPOLearner.train (15 epochs over the first 255 episodes x 90 rows x 5 agents), gradients all-reduced"
+                if strong else
+                f"{E} envs/GPU x 90 steps; step = {rollouts_per_step} rollouts, each followed by insert + Behavior_policy.learn + "
+                "Prediction_policy.learn, then IPPOLearner.train (15 epochs x 255 x 90 rows x 5 agents)")
+        rl = rooflines(args, E, timed, opt, rollouts_per_step)
         line = {
             "metric": "env-steps/sec (whole node), Hetero-Highway chaotic 5-agent",
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": opt.steps,
             "warmup": opt.warmup, "ms_per_step": dt / opt.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Highway chaotic full iPLAN (Behaviour + GAT + soft update), 5 agents x 55 entities, "
-                                   f"{E} envs/GPU x 90 steps; step = {rollouts_per_step} rollouts, each followed by "
-                                   "insert + Behavior_policy.learn + Prediction_policy.learn, then IPPOLearner.train "
-                                   "(15 epochs x 255 x 90 rows x 5 agents)" + (" [ROLLOUT ONLY diagnostic]" if opt.rollout_only else ""),
-                       "envs_per_gpu": E, "rollouts_per_step": rollouts_per_step, "env_steps_per_step": rollouts_per_step * E * args.episode_limit},
-            # HBM bytes per launch ("traffic") = 2 x FETCH_SIZE + WRITE_SIZE (KiB) of the rocprofv3 --pmc passes committed in
-            # profiles/ (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); measured at this exact shape
-            "roofline": {"kernel": "gat_fwd_kernel", "bound": "mfma", "achieved": flops / gat_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": flops / gat_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": PMC_TRAFFIC_BYTES.get(("gat_fwd_kernel", E)), "us_per_launch": gat_s * 1e6,
-                         "launches_timed": gat_n, "algorithmic_gflop_per_launch": flops / 1e9,
-                         "note": f"rollout GAT_latent_update (5 nets x {E} envs x 55 entities), launched "
-                                 f"{rollouts_per_step * (args.episode_limit + 1)}x per step; timed in the timed region"},
-            "roofline_others": [
-                {"kernel": "beh_dec_bwd_kernel", "bound": "mfma", "achieved": flops_b / bwd_s / 1e12,
-                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops_b / bwd_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                 "traffic": PMC_TRAFFIC_BYTES.get(("beh_dec_bwd_kernel", E)), "us_per_launch": bwd_s * 1e6,
-                 "launches_timed": bwd_n, "algorithmic_gflop_per_launch": flops_b / 1e9,
-                 "note": f"decoder BPTT of Behavior_policy.learn (5 nets x E*55 chains x 79 windows x 10 steps) in {pieces} "
-                         f"window-range launches per learn(), {pieces * rollouts_per_step} per step; runs beside the weight-gradient "
-                         "contraction of the previous piece, timed in the timed region"}],
+            "scaling": opt.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Highway chaotic full iPLAN (Behaviour + GAT + soft update), 5 agents x 55 entities, " + mode
+                                   + (" [ROLLOUT ONLY diagnostic]" if opt.rollout_only else ""),
+                       "envs_per_gpu": E, "rollouts_per_step": rollouts_per_step,
+                       "env_steps_per_step": rollouts_per_step * E * args.episode_limit * world},
+            "roofline": rl[0], "roofline_others": rl[1:],
         }
         if not opt.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, E)
@@ -278,6 +276,62 @@ def main():
         print(json.dumps(clean(line)))
     if world > 1:
         dist.destroy_process_group()
+
+
+def rooflines(args, E, timed, opt, rollouts_per_step):
+    """Roofline entries of every kernel above 5 % of a cycle's kernel time (profiles/r02*_full_cycle_kernel_stats.csv):
+    ALGORITHMIC work per launch (SURVEY.md §8d convention) / the in-situ mean launch duration.  ``traffic`` =
+    HBM bytes per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE KiB), at the config-3 shape only."""
+    nA, N, d, Z = args.n_agents, args.max_vehicle_num, args.obs_shape_single, args.latent_dim
+    Hd, R, Lw, M, T = args.decoder_rnn_dim, args.encoder_rnn_dim, args.max_history_len, args.rnn_hidden_dim, args.episode_limit
+    J = T - 1 - Lw
+    V = E * N
+    F = N * (d + args.attention_dim + Z) + args.n_actions + nA
+    nan = float("nan")
+
+    def entry(kernel, key, bound, work, unit_scale, peak, unit, note, traffic_key=None, work_from_timer=False):
+        n, sec, w = timed.get(key, (0, nan, 0.0))
+        if work_from_timer:
+            work = w
+        ach = work / sec / unit_scale if n else nan
+        return {"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                "traffic": PMC_TRAFFIC_BYTES.get((traffic_key or kernel, E)), "us_per_launch": sec * 1e6 if n else nan,
+                "launches_timed": n, ("algorithmic_gbyte_per_launch" if bound == "hbm" else "algorithmic_gflop_per_launch"): work / 1e9,
+                "note": note}
+
+    def pieces(key):
+        n = timed.get(key, (0, nan, 0.0))[0]
+        learns = max(1, opt.steps * rollouts_per_step * (1 if E <= 128 else -(-E // 128)))
+        return max(1, round(n / learns))
+
+    f_dec = nA * V * J * Lw * (2 * (d + Z) * Hd + 12 * Hd * Hd + 2 * Hd * d)            # decoder, all windows, one pass
+    f_enc = nA * V * J * (Lw * (2 * d * R + 12 * R * R) + 2 * R * Z)                     # encoder, all windows, one pass
+    if E > 128:                                                                         # env-chunked behaviour learning
+        f_dec, f_enc = f_dec * 128 / E, f_enc * 128 / E
+    rows = args.batch_size * T
+    f_ac = nA * 2 * rows * (2 * F * M + 14 * M * M + 2 * M * 3)                          # actor + critic, n_out 5 / 1
+    b_ac = nA * (4.0 * rows * F + 2 * 4.0 * rows * 648)                                  # features once + the saved activations
+    out = [
+        entry("gat_fwd_kernel", "gat_fwd_kernel", "mfma", gat_algorithmic_flops(nA, E, N, d + Z), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
+              f"rollout GAT_latent_update (5 nets x {E} envs x 55 entities), {rollouts_per_step * (T + 1)} launches per step"),
+        entry("beh_dec_bwd_kernel", "beh_dec_bwd_kernel", "mfma", f_dec / pieces("beh_dec_bwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
+              f"decoder BPTT of Behavior_policy.learn (backward-data pass = 1x the forward FLOPs) in {pieces('beh_dec_bwd_kernel')} "
+              "window-range launches per learn(), beside the weight-gradient contraction and the encoder BPTT of the previous range"),
+        entry("beh_dec_fwd_kernel", "beh_dec_fwd_kernel", "mfma", f_dec / pieces("beh_dec_fwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
+              f"decoder forward of Behavior_policy.learn in {pieces('beh_dec_fwd_kernel')} window-range launches, beside the encoder forward"),
+        entry("beh_enc_bwd_kernel", "beh_enc_bwd_kernel", "mfma", 2 * f_enc / pieces("beh_enc_bwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
+              "encoder BPTT with in-kernel weight gradients (2x the forward FLOPs), side stream"),
+        entry("wgrad_partial_kernel (+reduce)", "iplan_wgrad", "hbm", 0.0, 1e9, HBM_PEAK_GBS, "GB/s",
+              "every iplan_wgrad call of the cycle (behaviour decoder, prediction, PPO 64-wide layers): algorithmic bytes = each operand row "
+              "read once, 4 (O + K) bytes per row and problem; mean over the calls", traffic_key="wgrad_partial_kernel", work_from_timer=True),
+        entry("ac_fwd_kernel<PPO>", "ac_fwd_kernel:train", "mfma", f_ac, 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
+              f"actor + critic forward of one PPO epoch ({rows} rows x F = {F}, 5 agents, activations saved); SURVEY.md §8d: AI ~ ridge, so "
+              "both roofs are reported", traffic_key="ac_fwd_kernel:train"),
+        entry("ac_fwd_kernel<PPO> (HBM roof)", "ac_fwd_kernel:train", "hbm", b_ac, 1e9, HBM_PEAK_GBS, "GB/s",
+              "same launches against the HBM roof: gathered features read once for both nets + saved activations written",
+              traffic_key="ac_fwd_kernel:train"),
+    ]
+    return out
 
 
 if __name__ == "__main__":

@@ -380,6 +380,24 @@ typedef struct {
 
 int iplan_ppo_prepare(const IplanPpoPrepareArgs* args, iplan_stream_t stream);
 
+/* iplan_ppo_adv_norm: the advantage normalisation of ippo_learner.py:276-279 over the rows of ALL data-parallel ranks, in
+ * three launches around two sum all-reduces (the caller only moves bytes between them; every arithmetic step is here):
+ *   phase 0:  sum[net]   = sum_i adv[net, i]                              (this rank's rows)       -> all-reduce sum
+ *   phase 1:  sqdev[net] = sum_i (adv[net, i] - sum[net] / count)^2        (sum = global)           -> all-reduce sqdev
+ *   phase 2:  adv[net, i] = (adv[net, i] - mean) / (sqrt(sqdev[net] / (count - 1)) + 1e-5)
+ * count = rows of all ranks.  With one rank this reproduces iplan_ppo_prepare's own normalisation.                    */
+typedef struct {
+    int32_t n_agents, n;         /* n = this rank's rows per agent                                   */
+    int64_t row_stride;          /* per-agent stride of adv                                          */
+    float* adv;                  /* [n_agents, row_stride]                                           */
+    float* sum;                  /* [n_agents]                                                       */
+    float* sqdev;                /* [n_agents]                                                       */
+    float count;                 /* rows per agent over all ranks                                    */
+    int32_t phase;
+} IplanAdvNormArgs;
+
+int iplan_ppo_adv_norm(const IplanAdvNormArgs* args, iplan_stream_t stream);
+
 /* iplan_ppo_loss: ppo_update's losses (:185-197) and cal_value_loss (:128-159) over the first
  * `rows` rows of every agent, plus dLoss/dlogp and d(value_loss_coef * value_loss)/dvalue per row.
  * stats[net][0..4] = policy_loss, value_loss, mean ratio, mean entropy, sum(mask).              */
@@ -546,6 +564,8 @@ typedef struct {
     const float* win_norm;      /* optional [n_nets, J]: per window, sum of the mask over the window's target steps and
                                    the envs of ALL data-parallel ranks (hard update: the one global sum, repeated);
                                    NULL = summed in-kernel over this launch's envs                              */
+    float enc_grad_beta;        /* backward: enc_grad = enc_grad_beta * enc_grad + sum of the wave partials (1 = accumulate
+                                   over several launches on disjoint env chunks, 0 = overwrite)                  */
 } IplanBehArgs;
 
 int iplan_beh_fwd(const IplanBehArgs* args, iplan_stream_t stream);

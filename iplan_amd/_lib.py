@@ -49,7 +49,7 @@ class IplanError(RuntimeError):
 
 # every entry point include/iplan_hip.h declares
 ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step", "iplan_wgrad",
-                "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_loss", "iplan_gat_bwd",
+                "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_adv_norm", "iplan_ppo_loss", "iplan_gat_bwd",
                 "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd", "iplan_mlp3_fwd", "iplan_mlp3_bwd"]
 RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups", "iplan_sizeof"]      # non (args*, stream) signatures
 
@@ -244,6 +244,11 @@ class PpoPrepareArgs(C.Structure):
     ]
 
 
+class AdvNormArgs(C.Structure):
+    _fields_ = [("n_agents", i32), ("n", i32), ("row_stride", i64), ("adv", fp), ("sum", fp), ("sqdev", fp),
+                ("count", C.c_float), ("phase", i32)]
+
+
 class PpoLossArgs(C.Structure):
     _fields_ = [
         ("n_agents", i32), ("rows", i32), ("row_stride", i64),
@@ -299,6 +304,7 @@ class BehArgs(C.Structure):
         ("enc_part", fp), ("enc_grad", fp), ("enc_grad_s_net", i64), ("bwd_phase", i32),
         ("bwd_j_lo", i32), ("bwd_j_hi", i32), ("dec_carry", fp),
         ("fwd_phase", i32), ("fwd_j_lo", i32), ("fwd_j_hi", i32), ("enc_carry", fp), ("win_norm", fp),
+        ("enc_grad_beta", C.c_float),
     ]
 
 
@@ -317,4 +323,4 @@ STRUCT_MIRRORS = {"IplanGatSaved": GatSaved, "IplanGatFwdArgs": GatFwdArgs, "Ipl
                   "IplanEncFwdArgs": EncFwdArgs, "IplanAcNet": AcNet, "IplanAcFeatures": AcFeatures, "IplanAcFwdArgs": AcFwdArgs,
                   "IplanAcBwdArgs": AcBwdArgs, "IplanAdamArgs": AdamArgs, "IplanWgradProblem": WgradProblem,
                   "IplanWgradArgs": WgradArgs, "IplanPpoPrepareArgs": PpoPrepareArgs, "IplanPpoLossArgs": PpoLossArgs,
-                  "IplanPdecArgs": PdecArgs, "IplanBehArgs": BehArgs, "IplanMlp3Args": Mlp3Args}
+                  "IplanPdecArgs": PdecArgs, "IplanBehArgs": BehArgs, "IplanMlp3Args": Mlp3Args, "IplanAdvNormArgs": AdvNormArgs}

@@ -722,7 +722,8 @@ __global__ __launch_bounds__(256) void beh_enc_grad_kernel(IplanBehArgs a) {
     const float* part = a.enc_part + (int64_t)net * tiles * IPLAN_BEH_ENC_PART + src;
     float s = 0.f;
     for (int t = 0; t < tiles; ++t) s += part[(int64_t)t * IPLAN_BEH_ENC_PART];
-    a.enc_grad[(int64_t)net * a.enc_grad_s_net + a.enc_off[which] + rem] = s;
+    float* dst = a.enc_grad + (int64_t)net * a.enc_grad_s_net + a.enc_off[which] + rem;
+    *dst = a.enc_grad_beta != 0.f ? fmaf(a.enc_grad_beta, *dst, s) : s;
 }
 
 static int check_beh(const IplanBehArgs* a, const char* what) {

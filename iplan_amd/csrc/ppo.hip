@@ -57,6 +57,31 @@ __global__ __launch_bounds__(1024) void ppo_prepare_kernel(IplanPpoPrepareArgs a
     for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) adv[i] = (adv[i] - mean) * inv;
 }
 
+// advantage normalisation over the rows of all data-parallel ranks (see the header): partial sums per rank
+__global__ __launch_bounds__(1024) void adv_norm_kernel(IplanAdvNormArgs a) {
+    __shared__ float s_part[16];
+    const int net = (int)blockIdx.x;
+    float* __restrict__ adv = a.adv + (int64_t)net * a.row_stride;
+    const int n = a.n;
+    if (a.phase == 0) {
+        float s = 0.f;
+        for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) s += adv[i];
+        s = block_sum_1024(s, s_part);
+        if (threadIdx.x == 0) a.sum[net] = s;
+        return;
+    }
+    const float mean = a.sum[net] / a.count;
+    if (a.phase == 1) {
+        float q = 0.f;
+        for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) { const float d = adv[i] - mean; q = fmaf(d, d, q); }
+        q = block_sum_1024(q, s_part);
+        if (threadIdx.x == 0) a.sqdev[net] = q;
+        return;
+    }
+    const float inv = 1.0f / (sqrtf(a.sqdev[net] / (a.count - 1.0f)) + 1e-5f);           // th.std_mean: unbiased
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) adv[i] = (adv[i] - mean) * inv;
+}
+
 __device__ __forceinline__ float huber_q(float e, float d) {      // util.py:33-36 (one-sided)
     const float ae = fabsf(e);
     return (ae <= d ? e * e * 0.5f : 0.f) + (e > d ? d * (ae - d * 0.5f) : 0.f);
@@ -139,4 +164,12 @@ extern "C" int iplan_ppo_loss(const IplanPpoLossArgs* a, iplan_stream_t stream) 
         return fail(IPLAN_EINVAL, "iplan_ppo_loss: bad arguments");
     hipLaunchKernelGGL(ppo_loss_kernel, dim3((unsigned)a->n_agents), dim3(1024), 0, (hipStream_t)stream, *a);
     return check_launch("iplan_ppo_loss");
+}
+
+extern "C" int iplan_ppo_adv_norm(const IplanAdvNormArgs* a, iplan_stream_t stream) {
+    using namespace iplan;
+    if (!a || a->n_agents < 1 || a->n < 1 || !a->adv || !a->sum || !a->sqdev || a->phase < 0 || a->phase > 2 || !(a->count >= 2.0f))
+        return fail(IPLAN_EINVAL, "iplan_ppo_adv_norm: bad arguments");
+    hipLaunchKernelGGL(adv_norm_kernel, dim3((unsigned)a->n_agents), dim3(1024), 0, (hipStream_t)stream, *a);
+    return check_launch("iplan_ppo_adv_norm");
 }

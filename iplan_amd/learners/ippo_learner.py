@@ -153,6 +153,10 @@ class IPPOLearner:
                                             weight_decay=self.weight_decay) for n in range(self.n_agents)]
         self.last_train_info = None
         self.dp = None          # optional iplan_amd.parallel.DataParallel (gradient / statistic all-reduce)
+        # data-parallel runs whose ranks hold DIFFERENT numbers of PPO rows (config 4: a global 256-episode buffer of which
+        # the first 255 episodes are trained on -> the last rank drops one): the global row counts, set by the caller
+        self.dp_global_rows = None      # PPO rows of all ranks (default: rows * world)
+        self.dp_global_count = None     # stored (episode, step) entries of all ranks (default: bs * T * world)
 
     def lr_decay(self, episode, episodes):
         for n in range(self.n_agents):
@@ -235,12 +239,18 @@ class IPPOLearner:
         pp.skip_norm = 0 if self.dp is None else 1
         lib.call("iplan_ppo_prepare", pp, stream)
         if self.dp is not None:
-            # data-parallel: advantage mean / unbiased std over ALL ranks' rows (two tiny all-reduces), same formula
-            # as the kernel: (adv - mean) / (std + 1e-5)
-            cnt = float(bs * T * self.dp.world)              # every rank stores the same number of episodes
-            mean = self.dp.all_reduce_sum(adv.sum(dim=1)) / cnt
-            var = self.dp.all_reduce_sum(((adv - mean[:, None]) ** 2).sum(dim=1)) / (cnt - 1.0)
-            adv.sub_(mean[:, None]).mul_((1.0 / (var.sqrt() + 1e-5))[:, None])
+            # data-parallel: advantage mean / unbiased std over ALL ranks' rows -- three launches of iplan_ppo_adv_norm
+            # around two [nA]-float sum all-reduces (the host only moves the partial sums; no arithmetic here)
+            an = L.AdvNormArgs()
+            an.n_agents, an.n, an.row_stride = nA, bs * T, bs * T
+            asum, asq = th.empty(nA, **f32), th.empty(nA, **f32)
+            an.adv, an.sum, an.sqdev = adv.data_ptr(), asum.data_ptr(), asq.data_ptr()
+            an.count = float(self.dp_global_count if self.dp_global_count is not None else bs * T * self.dp.world)
+            for phase, red in ((0, asum), (1, asq), (2, None)):
+                an.phase = phase
+                lib.call("iplan_ppo_adv_norm", an, stream)
+                if red is not None:
+                    self.dp.all_reduce_sum(red)
         # generate_data (:368-424): the first batch_size * T rows
         rows = self.batch_size * T
         spec = self._feature_spec(T, T1, last)
@@ -268,7 +278,7 @@ class IPPOLearner:
             # the losses' denominators over all ranks: sum(mask) of the PPO rows and the row count (entropy mean)
             msum = self.dp.all_reduce_sum(mask[:, :rows].sum(dim=1).contiguous())
             pl.mask_sum = msum.data_ptr()
-            n_rows = float(rows * self.dp.world)
+            n_rows = float(self.dp_global_rows if self.dp_global_rows is not None else rows * self.dp.world)
         for ep in range(self.ppo_epoch):
             out = ops.ac_forward(mac.actor_arena, mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True, **fwd_kw)
             pl.logp, pl.entropy, pl.values = out["logp"].data_ptr(), out["entropy"].data_ptr(), out["values"].data_ptr()

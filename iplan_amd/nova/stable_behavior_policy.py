@@ -1,6 +1,7 @@
 """Behavior_policy (soft update = iPLAN) -- behavioural-incentive inference module (mirror of
 nova/stable_behavior_policy.py:13-312)."""
 import copy
+import os
 
 import numpy as np
 import torch
@@ -125,15 +126,37 @@ class Behavior_policy:
         mask = mask.permute(2, 0, 1).to(torch.float32).contiguous()                # [nA, E, T]
         hist = history.permute(2, 0, 1, 3, 4)                                       # [nA, E, T, N, d] view
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if keep is None else 0
-        fwd = ops.beh_forward(self.enc_arena, self.dec_arena, hist, mask, self.max_history_len, self.latent_dim,
-                              self.soft_update_coef, self.thres_small_variation, a.decoder_dropout, keep=keep, seed=seed,
-                              win_norm=self._global_window_sums(mask))
-        ops.beh_backward(self.enc_arena, self.dec_arena, fwd)
+        E, N = history.shape[0], self.max_vehicle_num
+        chunk = int(getattr(a, "behavior_env_chunk", 0) or os.environ.get("IPLAN_BEH_ENV_CHUNK", "128"))
+        if E <= chunk:
+            fwd = ops.beh_forward(self.enc_arena, self.dec_arena, hist, mask, self.max_history_len, self.latent_dim,
+                                  self.soft_update_coef, self.thres_small_variation, a.decoder_dropout, keep=keep, seed=seed,
+                                  win_norm=self._global_window_sums(mask))
+            ops.beh_backward(self.enc_arena, self.dec_arena, fwd)
+            loss_dev = fwd["loss"]
+        else:
+            # Large batches (config 4's 256 envs on one GPU: 230 GB of BPTT records at once): env chunks run one after the
+            # other -- chains never interact; the loss normalisers are the window mask sums over ALL envs (and ranks), so
+            # the chunk gradients simply add up in the arenas -- and one clip + Adam step follows.
+            wn = self._global_window_sums(mask)
+            if wn is None:
+                wn = ops.beh_window_mask_sums(mask, self.max_history_len)
+            loss_dev = None
+            for c, lo in enumerate(range(0, E, chunk)):
+                hi = min(E, lo + chunk)
+                fwd = ops.beh_forward(self.enc_arena, self.dec_arena, hist[:, lo:hi], mask[:, lo:hi].contiguous(), self.max_history_len,
+                                      self.latent_dim, self.soft_update_coef, self.thres_small_variation, a.decoder_dropout,
+                                      keep=None if keep is None else keep[:, :, lo * N:hi * N].contiguous(),
+                                      seed=seed + 0x9E3779B97F4A7C15 * c & (2 ** 63 - 1), win_norm=wn)
+                ops.beh_backward(self.enc_arena, self.dec_arena, fwd, accumulate=c > 0)
+                part = fwd["loss"] * torch.tensor([1.0, (hi - lo) / E], device=dev)      # the stability statistic is a mean over envs
+                loss_dev = part if loss_dev is None else loss_dev + part
+                del fwd
         if getattr(self, "dp", None) is not None:
             self.dp.all_reduce_grads(self.enc_arena, self.dec_arena)
         sq = step_all(self.behavior_optimizer, self.max_grad_norm if self._use_max_grad_norm else None)
         nA = self.n_agents
-        host = torch.cat([fwd["loss"].reshape(-1), sq.sqrt().reshape(-1)]).cpu()    # ONE host read-back
+        host = torch.cat([loss_dev.reshape(-1), sq.sqrt().reshape(-1)]).cpu()       # ONE host read-back
         loss = host[:2 * nA].reshape(nA, 2).numpy()
         norms = host[2 * nA:].reshape(nA, 2)
         beh = [np.asarray(loss[i, 0]) for i in range(nA)]

@@ -240,7 +240,8 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
     if save:
         out["saved"] = torch.empty(2, n_agents, rows, L.AC_SAVE_FLOATS, **f32)
         a.saved = out["saved"].data_ptr()
-    lib.call("iplan_ac_fwd", a, L.current_stream(dev))
+    _launch("ac_fwd_kernel:train" if save else ("ac_fwd_kernel:rollout" if rows <= 512 else "ac_fwd_kernel:infer"),
+            lambda: lib.call("iplan_ac_fwd", a, L.current_stream(dev)))
     out["_args"] = a
     out["_keep"] = (spec, h_actor, h_critic, avail, q_noise, actions_in, h_out, actions_out, onehot_out, ln_stats)
     return out
@@ -254,35 +255,38 @@ _SIDE_STREAMS = {}
 class KernelTimers:
     """In-situ kernel timing for bench.py's roofline: HIP events recorded on the launch stream right around selected
     launches (every ``every[name]``-th one) while the real workload runs.  ``ops.TIMERS = KernelTimers(...)`` turns
-    it on; ``summary()`` (after a device synchronise) gives {name: (launches timed, mean seconds)}."""
+    it on; ``summary()`` (after a device synchronise) gives {name: (launches timed, mean seconds, mean work)} where
+    ``work`` is whatever the call site passed (algorithmic bytes / FLOPs of that launch; 0 if it passed nothing)."""
 
     def __init__(self, every=None):
         self.every = dict(every or {})
         self.count = {}
         self.spans = {}
 
-    def launch(self, name, fn):
+    def launch(self, name, fn, stream=None, work=0.0):
         n = self.count.get(name, 0)
         self.count[name] = n + 1
         if n % self.every.get(name, 1):
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record(stream)
         fn()
-        e1.record()
-        self.spans.setdefault(name, []).append((e0, e1))
+        e1.record(stream)
+        self.spans.setdefault(name, []).append((e0, e1, float(work)))
 
     def summary(self):
-        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v) / 1e3) for k, v in self.spans.items()}
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b, _ in v) / len(v) / 1e3, sum(w for _, _, w in v) / len(v))
+                for k, v in self.spans.items()}
 
 
 TIMERS = None
 
 
-def _launch(name, fn):
+def _launch(name, fn, stream=None, work=0.0):
+    """``stream``: the torch stream the launch goes to when it is not the current one (events must sit on that stream)."""
     if TIMERS is None:
         return fn()
-    return TIMERS.launch(name, fn)
+    return TIMERS.launch(name, fn, stream, work)
 
 
 def workspace(device, floats, tag="wgrad"):
@@ -342,7 +346,9 @@ class Wgrad:
             need = lib.c.iplan_wgrad_workspace_floats(C.byref(a))
             ws = workspace(dev, need)
             a.workspace, a.workspace_floats = ws.data_ptr(), ws.numel()
-            lib.call("iplan_wgrad", a, stream)
+            # algorithmic HBM bytes: every operand row of every problem read exactly once (4 (O + K) bytes per row)
+            nbytes = 4.0 * self.n_nets * sum(p.n_outer * p.n_inner * (p.O + p.K) for p in chunk)
+            _launch("iplan_wgrad", lambda: lib.call("iplan_wgrad", a, stream), work=nbytes)
 
 
 def _ac_wgrad(w, arena, head_names, saved, dsave, which, n_agents, rows, T, h, h_strides, T_phys, n_out, tiles, ln_part):
@@ -638,7 +644,7 @@ def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p,
             if side is None:
                 lib.call("iplan_beh_fwd", a, stream)
             else:
-                lib.call("iplan_beh_fwd", a, side.cuda_stream)
+                _launch("beh_enc_fwd_kernel", lambda: lib.call("iplan_beh_fwd", a, side.cuda_stream), stream=side)
                 ev = torch.cuda.Event()
                 ev.record(side)
                 enc_done.append(ev)
@@ -646,7 +652,7 @@ def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p,
             if side is not None:
                 main.wait_event(enc_done[k])
             a.fwd_phase, a.fwd_j_lo, a.fwd_j_hi = 2, bounds[k], bounds[k + 1]
-            lib.call("iplan_beh_fwd", a, stream)
+            _launch("beh_dec_fwd_kernel", lambda: lib.call("iplan_beh_fwd", a, stream))
         a.fwd_phase, a.fwd_j_lo, a.fwd_j_hi = 3, 0, 0
         lib.call("iplan_beh_fwd", a, stream)
         a.fwd_phase = 0
@@ -674,8 +680,9 @@ def beh_window_mask_sums(mask, L_win, hard=False):
     return (cs[:, j + 1 + L_win] - cs[:, j + 1]).contiguous()
 
 
-def beh_backward(enc_arena, dec_arena, fwd, lib=None):
-    """BPTT of beh_forward's behaviour loss (behavior_variation_penalty == 0): fills both gradient arenas."""
+def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, lib=None):
+    """BPTT of beh_forward's behaviour loss (behavior_variation_penalty == 0): fills both gradient arenas
+    (``accumulate=True``: adds to them -- launches on disjoint env chunks of one batch, normalised by a shared ``win_norm``)."""
     lib = _lib(lib)
     a = fwd["_args"]
     n_nets, E, N, T, Lw, d, Z = a.n_nets, a.E, a.N, a.T, a.L, a.d, a.Z
@@ -688,6 +695,7 @@ def beh_backward(enc_arena, dec_arena, fwd, lib=None):
     ep = torch.empty(n_nets, tiles, L.BEH_ENC_PART, **f32)
     a.dsave_dec, a.dsave_lat, a.enc_part = dd.data_ptr(), dl.data_ptr(), ep.data_ptr()
     a.enc_grad, a.enc_grad_s_net = enc_arena.grad.data_ptr(), enc_arena.grad.stride(0)
+    a.enc_grad_beta = 1.0 if accumulate else 0.0
     SD, DD = L.BEH_SAVE_DEC, L.BEH_DSAVE_DEC
     n_in = J * Lw
     sd = fwd["saved_dec"].data_ptr()
@@ -730,7 +738,7 @@ def beh_backward(enc_arena, dec_arena, fwd, lib=None):
     for k in range(pieces, 0, -1):
         a.bwd_phase, a.bwd_j_lo, a.bwd_j_hi = 1, bounds[k - 1], bounds[k]
         _launch("beh_dec_bwd_kernel", lambda: lib.call("iplan_beh_bwd", a, stream))
-        beta = 0.0 if k == pieces else 1.0
+        beta = 0.0 if (k == pieces and not accumulate) else 1.0
         if side is None:
             dec_wgrad(bounds[k - 1] * Lw, bounds[k] * Lw, beta)
             a.bwd_phase = 2
@@ -743,7 +751,7 @@ def beh_backward(enc_arena, dec_arena, fwd, lib=None):
             with torch.cuda.stream(side):
                 dec_wgrad(bounds[k - 1] * Lw, bounds[k] * Lw, beta)
             a.bwd_phase = 2
-            lib.call("iplan_beh_bwd", a, side2.cuda_stream)
+            _launch("beh_enc_bwd_kernel", lambda: lib.call("iplan_beh_bwd", a, side2.cuda_stream), stream=side2)
     a.bwd_phase, a.bwd_j_lo, a.bwd_j_hi = 0, 0, 0
     if side is not None:
         for st in (side, side2):

@@ -171,9 +171,16 @@ def check_prediction_learn_vs_oracle(args, E, device, seed=0, tol=1e-5, post_tol
 
 
 # ------------------------------------------------------------------------------------------------ IPPOLearner.train
-def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, terminated_p=0.15, also_fp32=True, agents=None):
+def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, terminated_p=0.15, also_fp32=True, agents=None,
+                              assert_grads=True):
     """insert buffer_size episodes -> train() (ppo_epoch fused epochs) vs oracle.ppo_train_agent, every agent: clipped
-    gradients of the LAST epoch and the post-train parameters."""
+    gradients of the LAST epoch and the post-train parameters.
+    ``assert_grads=False`` (multi-epoch runs at full size): Adam's first steps are sign-like -- lr * g / (|g| + eps) per
+    ENTRY -- so an absolute gradient error of 1e-7 * max|g| on an entry 1000x smaller than the tensor's max moves that
+    weight's update by 1e-4 of lr, and the NEXT epoch's gradient (dominated by curvature x update when the zero-mean
+    advantages cancel the first-order term) inherits it: the fp32 reference itself sits 2e-4 from the fp64 result there
+    (logged as fp32_oracle_grad_vs_fp64).  The per-epoch arithmetic is pinned by the single-epoch run; multi-epoch runs
+    assert the post-train parameters and log the last epoch's gradient distance."""
     from iplan_amd.controllers.dcntrl_controller import DcntrlMAC
     from iplan_amd.learners.ippo_learner import IPPOLearner
     args = SimpleNamespace(**dict(vars(args), use_cuda=(torch.device(device).type == "cuda")))
@@ -212,7 +219,7 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
                 if prm[k].grad is not None:
                     e = _grad_err(arena.grad_of(i, k), prm[k].grad)
                     worst["grad"] = max(worst["grad"], e)
-                    assert e <= gtol, ("clipped grad (last epoch) vs fp64 oracle", name, i, k, e, gtol)
+                    assert e <= gtol or not assert_grads, ("clipped grad (last epoch) vs fp64 oracle", name, i, k, e, gtol)
                 pe = _rel(sd[k], prm[k].detach())
                 worst["post"] = max(worst["post"], pe)
                 assert pe <= ptol, ("post", name, i, k, pe, ptol)

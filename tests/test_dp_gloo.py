@@ -90,6 +90,29 @@ with contextlib.redirect_stdout(io.StringIO()):
 close(loop.mac.actor_arena.data, full.mac.actor_arena.data, "PPO actors")
 close(loop.mac.critic_arena.data, full.mac.critic_arena.data, "PPO critics")
 
+# ---------------------------------------------------------------- config-4 trigger (bench.py --scaling strong): ONE global buffer
+# of EF episodes sharded over the ranks, train() uses the FIRST EF - 1 of them (batch_size = buffer_size - 1,
+# learners/ippo_learner.py:370-372): the last rank drops its last episode, so the ranks hold different row counts
+from iplan_amd.learners.ippo_learner import IPPOLearner
+for a, b in zip(arenas_of(loop), arenas_of(full)):
+    a.data.copy_(b.data)                                            # remove the 1e-6 drift of the steps above
+args_fs = default_args("highway", batch_size_run=EF, buffer_size=EF, batch_size=EF - 1, **kw)
+args_rs = default_args("highway", batch_size_run=ER, buffer_size=ER, batch_size=ER - (1 if rank == world - 1 else 0), **kw)
+lf_s = IPPOLearner(full.mac, full.scheme, full.logger, args_fs)
+lr_s = IPPOLearner(loop.mac, loop.scheme, loop.logger, args_rs)
+lr_s.dp = dp
+lr_s.dp_global_rows, lr_s.dp_global_count = (EF - 1) * T, EF * T
+with contextlib.redirect_stdout(io.StringIO()):
+    lf_s.insert_episode_batch(b_full)
+    lf_s.train(0)
+    lr_s.insert_episode_batch(b_rank)
+    lr_s.train(0)
+close(loop.mac.actor_arena.data, full.mac.actor_arena.data, "PPO actors (strong-mode trigger)")
+close(loop.mac.critic_arena.data, full.mac.critic_arena.data, "PPO critics (strong-mode trigger)")
+for a in (loop.mac.actor_arena, loop.mac.critic_arena):
+    g = gathered(a.data)
+    assert torch.equal(g[0], g[1]), "replicas diverged (strong-mode trigger)"
+
 # ---------------------------------------------------------------- a full synthetic cycle keeps the replicas identical
 calls = []
 orig = dp.all_reduce_grads

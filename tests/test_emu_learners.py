@@ -332,3 +332,12 @@ def test_gat_fwd_bwd_vs_oracle_emulated():
     """GAT forward + backward at config 5's input width (D = 128) and a ragged entity count, vs the fp64 oracle"""
     from tests.oracle_checks import check_gat_fwd_bwd_vs_oracle
     check_gat_fwd_bwd_vs_oracle(B=2, N=9, D=128, device="cpu", seed=8)
+
+
+def test_behavior_learn_env_chunks_vs_oracle_emulated(monkeypatch):
+    """Behavior_policy.learn on env chunks (config 4's 256 envs on one GPU do not fit one launch's BPTT records): the chunk
+    gradients accumulate in the arenas under the all-env window normalisers -- same result as the oracle on the whole batch."""
+    from tests.oracle_checks import check_behavior_learn_vs_oracle
+    monkeypatch.setenv("IPLAN_BEH_ENV_CHUNK", "2")
+    w = check_behavior_learn_vs_oracle(_small(), 5, "cpu", seed=13)
+    assert w["grad"] < 1e-5, w
