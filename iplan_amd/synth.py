@@ -125,3 +125,43 @@ def obs_stream(K, nA, obs_num, d, T, seed, n_ids=14, p_seen=0.6):
                         obs[k, i, j, 1:] = rng.uniform(-1, 1, d)
         steps.append(obs)
     return steps
+
+
+class StubHighwayVecEnv:
+    """Stand-in for envs/env_wrappers.SubprocVecEnv around Heterogeneous_Highway_Env (not installable offline) with the
+    call surface ParallelRunner touches (runners/ippo_parallel_runner.py:90-102, 184): ``reset() -> (state, obs)``,
+    ``step(action_env) -> (state, obs, reward, win_tags, terminated_agent, env_info)``, ``close()``.
+    obs [K, nA, obs_num, 1 + d]: row 0 = the ego (id = agent index + 1), other rows = vehicles of an id pool that come and
+    go; state [K, 1, n_state * (1 + d)].  The stream is pre-generated (it does not react to the actions -- the hot path never
+    looks inside the simulator); ``end_steps[k]``: the step after which env k reports every agent terminated."""
+
+    def __init__(self, K, nA, obs_num, d, n_state, T, seed=0, end_steps=None, n_ids=14, p_seen=0.6):
+        rng = np.random.default_rng(seed)
+        self.K, self.nA, self.T = K, nA, T
+        obs = np.zeros((T + 2, K, nA, obs_num, d + 1))
+        obs[:, :, :, 0, 0] = np.arange(1, nA + 1)
+        obs[:, :, :, 0, 1:] = rng.uniform(-1, 1, (T + 2, K, nA, d))
+        ids = 10 + np.argsort(rng.random((T + 2, K, nA, n_ids)), axis=-1)[..., :obs_num - 1]
+        seen = rng.random((T + 2, K, nA, obs_num - 1)) < p_seen
+        obs[..., 1:, 0] = np.where(seen, ids, 0)
+        obs[..., 1:, 1:] = rng.uniform(-1, 1, (T + 2, K, nA, obs_num - 1, d)) * seen[..., None]
+        self.obs = obs
+        self.state = rng.uniform(-1, 1, (T + 2, K, 1, n_state * (d + 1)))
+        self.reward = rng.normal(size=(T + 2, K, nA))
+        self.end_steps = np.full(K, T + 5) if end_steps is None else np.asarray(end_steps)
+        self.t = 0
+
+    def reset(self):
+        self.t = 0
+        return self.state[0], self.obs[0]
+
+    def step(self, action_env):
+        assert len(action_env) == self.K
+        self.t += 1
+        t = min(self.t, self.T + 1)
+        term = np.repeat((self.t >= self.end_steps)[:, None], self.nA, axis=1)
+        info = [{"speed": np.full(self.nA, 20.0 + k)} for k in range(self.K)]
+        return self.state[t], self.obs[t], self.reward[t], np.zeros((self.K, self.nA)), term, info
+
+    def close(self):
+        pass

@@ -1,0 +1,240 @@
+"""Drop-in proof against the REAL reference objects (runs only where /root/reference exists -- the build container; the
+fixtures under tests/golden/ carry the parity to the GPU box): the reference's own ``EpisodeBatch`` and the reference's own
+``ParallelRunner.run`` loop (runners/ippo_parallel_runner.py:105-281) drive the iplan_amd classes -- DcntrlMAC,
+Behavior_policy, Prediction_policy, IPPOLearner, host-emulated kernels -- through a stub vector env, and the episode they
+produce is compared with the one the all-reference stack produces from the same weights on the same observation stream."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+REF = os.environ.get("IPLAN_REFERENCE", "/root/reference")
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "runners")), reason="the reference tree is not present")
+
+
+class _Log:
+    def __init__(self):
+        self.stats = {}
+
+    def log_stat(self, k, v, t):
+        self.stats[k] = v
+
+
+@pytest.fixture()
+def ref_path():
+    sys.path.insert(0, REF)
+    yield
+    sys.path.remove(REF)
+    for name in list(sys.modules):                     # the reference's top-level package names are generic: unload them
+        if name.split(".")[0] in ("controllers", "learners", "nova", "modules", "components", "runners", "observation_wrapper", "utils", "envs"):
+            mod = sys.modules[name]
+            if getattr(mod, "__file__", None) and str(mod.__file__).startswith(REF):
+                del sys.modules[name]
+
+
+@pytest.fixture()
+def emu():
+    from iplan_amd import _lib as L
+    from tests.emu.emu_lib import get_emu_lib
+    L.use_library_for_tests(get_emu_lib())
+    yield
+    L.use_library_for_tests(None)
+
+
+def _args(**kw):
+    from iplan_amd.config import default_args
+    K, nA, n_other, d = 3, 2, 5, 5            # ParallelRunner.action2env_tuple (:81-83) needs n_actions == n_agents (5 == 5 in Highway)
+    a = default_args("highway", use_cuda=False, batch_size_run=K, n_agents=nA, n_other_vehicles=n_other, max_vehicle_num=n_other + nA,
+                     episode_limit=6, max_history_len=3, buffer_size=K, batch_size=K - 1, ppo_epoch=2, pred_batch_size=4, pred_length=2,
+                     n_obs_vehicles=4, device="cpu", animation_enable=False, n_actions=nA, **kw)
+    a.obs_shape = a.obs_shape_single * a.n_obs_vehicles
+    a.state_shape = a.obs_shape_single * a.max_vehicle_num
+    return a
+
+
+def _scheme_groups_preprocess(args):
+    from components.transforms import OneHot
+    from iplan_amd import synth
+    scheme = synth.make_scheme(args)
+    scheme.pop("actions_onehot")
+    scheme.pop("filled")
+    return scheme, {"agents": args.n_agents}, {"actions": ("actions_onehot", [OneHot(out_dim=args.n_actions)])}
+
+
+def _env(args, seed=0, end_steps=None):
+    from iplan_amd import synth
+    return synth.StubHighwayVecEnv(args.batch_size_run, args.n_agents, args.n_obs_vehicles, args.obs_shape_single, args.max_vehicle_num,
+                                   args.episode_limit, seed=seed, end_steps=end_steps, n_ids=args.max_vehicle_num - 2)
+
+
+def _stack(args, ours):
+    """(mac, behaviour, prediction, learner) from iplan_amd or from the reference, on the reference's scheme"""
+    scheme, groups, _ = _scheme_groups_preprocess(args)
+    full_scheme = dict(scheme, actions_onehot={"vshape": (args.n_actions,), "group": "agents", "dtype": torch.float32},
+                       filled={"vshape": (1,), "dtype": torch.long})
+    if ours:
+        from iplan_amd.controllers.dcntrl_controller import DcntrlMAC
+        from iplan_amd.learners.ippo_learner import IPPOLearner
+        from iplan_amd.nova.prediction_policy import Prediction_policy
+        from iplan_amd.nova.stable_behavior_policy import Behavior_policy
+    else:
+        from controllers.dcntrl_controller import DcntrlMAC
+        from learners.ippo_learner import IPPOLearner
+        from nova.prediction_policy import Prediction_policy
+        from nova.stable_behavior_policy import Behavior_policy
+    log = _Log()
+    mac = DcntrlMAC(full_scheme, groups, args)
+    beh, pred = Behavior_policy(args, log), Prediction_policy(args, log)
+    learner = IPPOLearner(mac, full_scheme, log, args)
+    return mac, beh, pred, learner
+
+
+def _sync_weights(src, dst):
+    (ms, bs, ps, _), (md, bd, pd, _) = src, dst
+    for i in range(len(ms.agents)):
+        md.agents[i].load_state_dict(ms.agents[i].state_dict())
+        md.critics[i].load_state_dict(ms.critics[i].state_dict())
+        bd.behavior_encoder[i].load_state_dict(bs.behavior_encoder[i].state_dict())
+        bd.behavior_decoder[i].load_state_dict(bs.behavior_decoder[i].state_dict())
+        pd.pred_GAT[i].load_state_dict(ps.pred_GAT[i].state_dict())
+        pd.pred_decoder[i].load_state_dict(ps.pred_decoder[i].state_dict())
+
+
+def _run_reference_runner(args, stack, env):
+    from runners.ippo_parallel_runner import ParallelRunner
+    scheme, groups, preprocess = _scheme_groups_preprocess(args)
+    runner = ParallelRunner(args, env, _Log())
+    runner.setup(scheme, groups, preprocess, stack[0], stack[1], stack[2])
+    batch, *_ = runner.run(test_mode=False)
+    return batch, runner
+
+
+def test_reference_parallel_runner_drives_iplan_amd(ref_path, emu):
+    """The reference's ParallelRunner.run + EpisodeBatch with the iplan_amd classes plugged in: the deterministic fields of
+    the episode equal the all-reference run's; the learners then consume the reference's EpisodeBatch unchanged."""
+    args = _args()
+    torch.manual_seed(0)
+    ref = _stack(args, ours=False)
+    mine = _stack(args, ours=True)
+    _sync_weights(ref, mine)
+    end = [args.episode_limit + 5, 4, args.episode_limit + 5]                 # env 1 terminates early
+    torch.manual_seed(1)
+    np.random.seed(1)
+    b_ref, _ = _run_reference_runner(args, ref, _env(args, 3, end))
+    torch.manual_seed(1)
+    np.random.seed(1)
+    b_mine, runner = _run_reference_runner(args, mine, _env(args, 3, end))
+    from components.episode_buffer import EpisodeBatch
+    assert isinstance(b_mine, EpisodeBatch)
+    T1 = args.episode_limit + 1
+    for k in ("history", "state", "obs", "reward", "terminated", "filled", "avail_actions", "speed"):
+        assert torch.equal(b_mine[k], b_ref[k]), k
+    # the behavioural incentive has no random draw on its path: identical up to fp32 round-off at every step
+    assert (b_mine["behavior_latent"] - b_ref["behavior_latent"]).abs().max() < 1e-5
+    assert b_mine["behavior_latent"].abs().sum() > 0 and b_mine["attention_latent"][:, 1:].abs().sum() > 0
+    assert b_mine["actions"].shape == (args.batch_size_run, T1, args.n_agents, 1)
+    assert torch.equal(b_mine["actions_onehot"].sum(-1)[:, :args.episode_limit], torch.ones(args.batch_size_run, args.episode_limit, args.n_agents))
+    # step 0 has no sampled quantity upstream of the actor / critic except the gumbel gate of the first GAT update
+    assert (b_mine["rnn_states_actors"][:, 0] - b_ref["rnn_states_actors"][:, 0]).abs().max() == 0
+    # the learners take the reference's EpisodeBatch as is
+    mac, beh, pred, learner = mine
+    t_env = runner.t_env
+    bl, sl, tl = beh.learn(b_mine, t_env)
+    pl = pred.learn(b_mine, t_env)
+    assert len(bl) == args.n_agents and len(pl) == args.n_agents and all(np.isfinite(float(x)) for x in list(bl) + list(pl))
+    before = [p.detach().clone() for p in mac.agents[0].parameters()]
+    learner.insert_episode_batch(b_mine)
+    learner.train(t_env)
+    assert any((a - b).abs().max() > 0 for a, b in zip(before, mac.agents[0].parameters()))
+
+
+def test_learners_match_reference_on_a_reference_episode_batch(ref_path, emu):
+    """One EpisodeBatch object (the reference's, filled by the reference's runner) through BOTH stacks' learners: post-update
+    parameters of the behaviour nets (injected dropout via a fixed in-kernel seed is not comparable, so dropout is 0 here) and
+    of the PPO actors / critics agree."""
+    args = _args(decoder_dropout=0.0)
+    torch.manual_seed(0)
+    ref = _stack(args, ours=False)
+    mine = _stack(args, ours=True)
+    _sync_weights(ref, mine)
+    torch.manual_seed(2)
+    np.random.seed(2)
+    batch, runner = _run_reference_runner(args, ref, _env(args, 5))
+    batch["terminated"][:] = (torch.rand(batch["terminated"].shape) < 0.5).to(batch["terminated"].dtype)     # give the losses a mask
+    for stack in (ref, mine):
+        stack[1].learn(batch, 0)
+        stack[3].insert_episode_batch(batch)
+        stack[3].train(0)
+    for i in range(args.n_agents):
+        for name in ("behavior_encoder", "behavior_decoder"):
+            for (k, a), (_, b) in zip(getattr(mine[1], name)[i].state_dict().items(), getattr(ref[1], name)[i].state_dict().items()):
+                assert (a - b).abs().max() <= 1e-6 * max(1.0, b.abs().max().item()), (name, i, k)
+        for a_m, a_r in ((mine[0].agents[i], ref[0].agents[i]), (mine[0].critics[i], ref[0].critics[i])):
+            for (k, a), (_, b) in zip(a_m.state_dict().items(), a_r.state_dict().items()):
+                assert (a - b).abs().max() <= 1e-5 * max(1.0, b.abs().max().item()), (i, k, (a - b).abs().max().item())
+
+
+def _run_our_runner(args, stack, env):
+    from iplan_amd.runners.ippo_parallel_runner import ParallelRunner
+    scheme, groups, preprocess = _scheme_groups_preprocess(args)
+    runner = ParallelRunner(args, env, _Log())
+    runner.setup(scheme, groups, preprocess, stack[0], stack[1], stack[2])
+    batch, *_ = runner.run(test_mode=False)
+    return batch, runner
+
+
+def test_device_resident_runner_equals_reference_runner(ref_path, emu):
+    """iplan_amd.runners.ParallelRunner (in-place launches into the episode container, one D2H of the actions per step) vs
+    the reference's ParallelRunner driving the same iplan_amd classes from the same seeds: every field of the episode,
+    sampled actions included; one env terminates early, so later steps store action 0 for it."""
+    args = _args()
+    torch.manual_seed(0)
+    mine = _stack(args, ours=True)
+    end = [args.episode_limit + 5, 3, args.episode_limit + 5]
+    torch.manual_seed(4)
+    np.random.seed(4)
+    b_ref, r_ref = _run_reference_runner(args, mine, _env(args, 7, end))
+    torch.manual_seed(4)
+    np.random.seed(4)
+    b_dev, r_dev = _run_our_runner(args, mine, _env(args, 7, end))
+    from components.episode_buffer import EpisodeBatch
+    assert isinstance(b_dev, EpisodeBatch) and r_dev.t_env == r_ref.t_env and r_dev.t == r_ref.t
+    for k in ("actions", "actions_onehot", "filled", "terminated", "avail_actions"):
+        assert torch.equal(b_dev[k], b_ref[k]), k
+    for k in ("history", "state", "obs", "reward", "speed", "behavior_latent", "attention_latent", "rnn_states_actors", "rnn_states_critics"):
+        assert (b_dev[k].float() - b_ref[k].float()).abs().max() <= 1e-6, (k, (b_dev[k].float() - b_ref[k].float()).abs().max().item())
+
+
+def test_device_resident_runner_all_terminated_break(emu):
+    """No reference tree needed: the built-in episode container; every env terminated -> the loop breaks like
+    ippo_parallel_runner.py:212-214 and the trailing steps stay unfilled (actions 0, one-hot rows all zero)."""
+    from iplan_amd import synth
+    from iplan_amd.controllers.dcntrl_controller import DcntrlMAC
+    from iplan_amd.nova.prediction_policy import Prediction_policy
+    from iplan_amd.nova.stable_behavior_policy import Behavior_policy
+    from iplan_amd.runners.ippo_parallel_runner import ParallelRunner, _dict_batch
+    args = _args()
+    scheme = synth.make_scheme(args)
+    scheme.pop("actions_onehot")
+    scheme.pop("filled")
+
+    class OneHot:                                                 # components/transforms.py:8-21, for the fallback container
+        def __init__(self, out_dim):
+            self.out_dim = out_dim
+
+        def infer_output_info(self, vshape_in, dtype_in):
+            return (self.out_dim,), torch.float32
+    full = dict(scheme, actions_onehot={"vshape": (args.n_actions,), "group": "agents"}, filled={"vshape": (1,), "dtype": torch.long})
+    mac = DcntrlMAC(full, {"agents": args.n_agents}, args)
+    beh, pred = Behavior_policy(args, _Log()), Prediction_policy(args, _Log())
+    runner = ParallelRunner(args, _env(args, 9, [3, 2, 3]), _Log())
+    runner.setup(scheme, {"agents": args.n_agents}, {"actions": ("actions_onehot", [OneHot(args.n_actions)])}, mac, beh, pred)
+    runner.new_batch = lambda: _dict_batch(scheme, {"agents": args.n_agents}, args.batch_size_run, args.episode_limit + 1,
+                                           {"actions": ("actions_onehot", [OneHot(args.n_actions)])}, "cpu")
+    batch, _, _, avg_len = runner.run()
+    assert runner.t == 2 and float(batch["filled"].sum()) == 3 * args.batch_size_run
+    assert batch["actions_onehot"][:, 3:].abs().sum() == 0 and batch["actions"][:, 3:].abs().sum() == 0
+    assert torch.isfinite(batch["attention_latent"]).all() and batch["behavior_latent"][:, 2].abs().sum() > 0
