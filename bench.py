@@ -49,113 +49,20 @@ def gat_algorithmic_flops(n_nets, B, N, D, H=32, A=32):
 
 
 def cpu_baseline(args, E):
-    """The oracle (CPU port of the reference arithmetic, kind "port") timed on this host's cores on a
-    BOUNDED sample of the same workload: a few rollout vector steps at full width plus one
-    Behaviour / Prediction / PPO learner pass on a reduced number of envs / rows, each scaled to
-    seconds per env-step and summed.  Reported beside the GPU number, never mixed into it."""
-    from oracle import iplan_oracle as O
-    from iplan_amd import synth
-    from iplan_amd.modules.agents.ippo_actor import R_Actor
-    from iplan_amd.modules.critics.ippo_critic import R_Critic
-    from iplan_amd.nova.GAT_Net import GAT_Net
-    from iplan_amd.nova.behavior_net import Behavior_Latent_Decoder, EncoderRNN
-    from iplan_amd.nova.prediction_net import Prediction_Decoder
-    # intra-op threads: the path is thousands of small ATen ops; beyond ~16 threads fork/join overhead
-    # dominates (with all 256 hardware threads of the GPU box one vector step took minutes)
+    """The oracle (CPU port of the reference arithmetic, kind "port") timed on this host's cores on a BOUNDED sample of the
+    same workload (oracle/cpu_baseline.py: a rollout vector step at full width plus one Behaviour / Prediction / PPO learner
+    pass on a reduced number of envs / rows; warm-up + best of 3; scaled to seconds per env-step and summed).  Reported beside
+    the GPU number, never mixed into it.  profiles/r02_cpu_baseline_anchor.json ties the oracle's speed to the REAL reference
+    classes timed on identical inputs in the build container (the reference cannot travel to the GPU box)."""
+    from oracle.cpu_baseline import measure
+    # intra-op threads: the path is thousands of small ATen ops; beyond ~16 threads fork/join overhead dominates (with all
+    # 256 hardware threads of the GPU box one vector step took minutes)
     cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    ca = default_args("highway", use_cuda=False)
-    nA, N, d, Z, A, L, T = ca.n_agents, ca.max_vehicle_num, ca.obs_shape_single, ca.latent_dim, ca.attention_dim, ca.max_history_len, ca.episode_limit
-    sd = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}  # noqa: E731
-    req = lambda p: {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in p.items()}  # noqa: E731
-    gat = [sd(GAT_Net(d + Z, ca)) for _ in range(nA)]
-    enc = [sd(EncoderRNN(d, 32, Z, 1)) for _ in range(nA)]
-    bdec = sd(Behavior_Latent_Decoder(d + Z, 64, 1, d, 0.1))
-    pdec = sd(Prediction_Decoder(d, A, 1, d, ca.pred_length, 0.1, 0))
-    F = N * (d + A + Z) + ca.n_actions + nA
-    act = [sd(R_Actor(F, ca)) for _ in range(nA)]
-    cri = [sd(R_Critic(F, ca)) for _ in range(nA)]
-    hist, window = synth.rollout_step_inputs(ca, E, 0)
-    hist, window = torch.as_tensor(hist, dtype=torch.float32), torch.as_tensor(window, dtype=torch.float32)
-    st = dict(att=torch.zeros(E, nA, N, A), lat=torch.full((E, nA, N, Z), 1.0 / Z), eh=torch.zeros(E, 1, nA, N, 32))
-    ha = torch.zeros(E, nA, 64)
-
-    def vector_step():
-        with torch.no_grad():
-            new_att = []
-            for i in range(nA):
-                noise = O.gumbel_noise_like_reference(E * N * (N - 1))
-                new_att.append(O.gat_forward(gat[i], torch.cat([hist[:, i], st["lat"][:, i]], -1),
-                                             st["att"][:, i].reshape(E * N, A), noise).reshape(E, N, A))
-            st["att"] = torch.stack(new_att, 1)
-            st["lat"], st["eh"] = O.latent_update(enc, window, st["eh"], st["lat"], ca.soft_update_coef)
-            x = O.build_inputs_rollout(hist, st["att"], st["lat"], torch.zeros(E, nA, ca.n_actions), nA)
-            for i in range(nA):
-                O.actor_logits(act[i], x[:, i], ha[:, i])
-                O.critic_value(cri[i], x[:, i], ha[:, i])
-
-    def timed(fn, budget, max_n=50):
-        fn()
-        t0, n = time.time(), 0
-        while n < 1 or (time.time() - t0 < budget and n < max_n):
-            fn()
-            n += 1
-        return (time.time() - t0) / n, n
-
-    t_vec, n_vec = timed(vector_step, 6.0)
-    # Behaviour learn: one agent, Eb envs, full episode, forward + backward
-    Eb = 2
-    f = synth.make_episode_fields(ca, Eb, seed=1, terminated_p=0.5)
-
-    def beh_learn():
-        ep, dp = req(enc[0]), req(bdec)
-        _, _, loss = O.behavior_learn_loss(ep, dp, f["history"][:, :-1, 0], f["terminated"][:, :-1, 0, 0].float(), L,
-                                           ca.soft_update_coef, None, 0.0)
-        loss.backward()
-    t0 = time.time()
-    beh_learn()
-    t_beh = time.time() - t0
-    # Prediction learn: one agent, full sample count
-    S = ca.pred_batch_size
-    gen = torch.Generator().manual_seed(2)
-    obs = synth.make_history(gen, (S,), N, d)
-    lat = torch.softmax(torch.randn(S, N, Z, generator=gen), -1)
-    att = torch.randn(S, N, 1, A, generator=gen) * 0.1
-    actual = synth.make_history(gen, (S, N), ca.pred_length, d)
-
-    def pred_learn():
-        gp, dp = req(gat[0]), req(pdec)
-        noise = O.gumbel_noise_like_reference(S * N * (N - 1))
-        loss, _ = O.prediction_loss(gp, dp, obs.unsqueeze(2), att, lat.unsqueeze(2), actual, torch.ones_like(actual), noise,
-                                    None, 0.0, ca.pred_length)
-        loss.backward()
-    t0 = time.time()
-    pred_learn()
-    t_pred = time.time() - t0
-    # PPO: one agent, one epoch (actor + critic forward/backward) on Rp rows
-    Rp = 2048
-    xr = torch.randn(Rp, F)
-    hr = torch.randn(Rp, 64) * 0.1
-    ar = torch.randint(0, ca.n_actions, (Rp, 1))
-
-    def ppo_epoch():
-        ap, cp = req(act[0]), req(cri[0])
-        lp, ent = O.actor_evaluate(ap, xr, hr, ar)
-        v, _ = O.critic_value(cp, xr, hr)
-        (lp.sum() + ent).backward()
-        v.sum().backward()
-    t0 = time.time()
-    ppo_epoch()
-    t_ppo = time.time() - t0
-    per_step = (t_vec / E                                                  # rollout inference
-                + nA * t_beh / (Eb * T)                                    # Behavior_policy.learn
-                + nA * t_pred / (E * T)                                    # Prediction_policy.learn (once per rollout)
-                + nA * ca.ppo_epoch * t_ppo / Rp * (ca.batch_size / ca.buffer_size))   # IPPOLearner.train
-    return dict(value=1.0 / per_step, unit="env-steps/s", cores=cores, kind="port",
-                sample=f"oracle on {cores} threads: {n_vec} rollout vector steps at E={E} ({t_vec:.2f}s each); Behaviour learn fwd+bwd "
-                       f"1 agent x {Eb} envs x full episode ({t_beh:.1f}s); Prediction learn fwd+bwd 1 agent x {S} samples ({t_pred:.1f}s); "
-                       f"one PPO epoch 1 agent x {Rp} rows ({t_ppo:.2f}s); each scaled to s/env-step and summed")
+    # Behaviour learn (the dominant CPU leg) at the FULL env count of one rollout: its per-env cost keeps falling with the
+    # batch (anchor file: behaviour_leg_linearity), so a small-batch sample would understate the CPU path
+    m = measure("oracle", E, cores, Eb=min(E, 32), reps=2)
+    return dict(value=m["value"], unit="env-steps/s", cores=cores, kind="port",
+                sample=m["sample"] + "; oracle-vs-reference speed on identical inputs: profiles/r02_cpu_baseline_anchor.json")
 
 
 def main():

@@ -211,158 +211,274 @@ __global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Decoder kernels: geometry and addressing shared by the forward and the BPTT.
+//
+// QUARTER SPLIT.  A 16-chain tile's GRU64 step is 416 MFMAs; with the weights in LDS (one copy per workgroup) the number of
+// tiles a CU can host decides how evenly the 550 tiles of config 3 spread over the chip.  A tile is shared by FOUR waves,
+// one per SIMD: wave q owns hidden tile q (its r, z, n gate rows: 3 of the 12 row tiles of W_ih / W_hh), needs the whole u
+// and h vectors as B operands and hands its 16 new hidden units to the other three through LDS once per step.  A
+// 768-thread workgroup = 3 tiles x 4 quarters, so a SIMD runs three quarter-waves = 0.75 tile-steps per step (the former
+// half split, 4 tiles x 2 halves on 138 CUs, put a whole tile-step on every SIMD), and 5 x 37 = 185 workgroups leave 71
+// CUs to the encoder / weight-gradient kernels that run beside.
+//
+// ADDRESSING.  Everything a lane touches is a wave-uniform 64-bit base (SGPRs) plus a 32-bit lane byte offset: the records
+// of a tile are [16 chains][J*L steps][cols], so the per-step advance is one scalar add and the column is an immediate.
+// FULL = all 16 chains of the tile exist (every tile when rows % 16 == 0): no predication on any load / store.
+constexpr int DEC_TILES = 3;
+constexpr int DEC_THREADS = 256 * DEC_TILES;
+
+__device__ __forceinline__ int uniform_i(int v) {
+#ifdef IPLAN_HOST_EMULATION
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
+// per-wave view of one chain tile of the decoder kernels
+struct DecTile {
+    int net, rows, tiles, tile, J;
+    bool live, full, valid;
+    int n, g, row, e, ent;
+    uint32_t rec_lane;            // byte offset of this lane's chain inside the tile's block of a per-step record, per float column: x steps*cols*4
+    const char* hist;             // uniform: a.hist + net * h_s_net
+    uint32_t hist_lane;           // (e * h_s_e + ent * d) * 4
+    const char* mask;             // uniform: a.mask + net * E * T
+    uint32_t mask_lane;           // e * T * 4
+    int64_t grow0;                // net * rows + tile * 16  (first chain of the tile)
+};
+__device__ __forceinline__ void dec_tile(const IplanBehArgs& a, DecTile& c, int tile) {
+    const int l = lane_id();
+    c.n = l & 15;
+    c.g = l >> 4;
+    c.net = (int)blockIdx.y;
+    c.rows = a.E * a.N;
+    c.tiles = (c.rows + 15) / 16;
+    c.tile = tile;
+    c.live = tile < c.tiles;
+    c.full = c.live && tile * 16 + 15 < c.rows;
+    c.row = tile * 16 + c.n;
+    c.valid = c.live && c.row < c.rows;
+    const int rr = c.valid ? c.row : 0;
+    c.e = rr / a.N;
+    c.ent = rr - c.e * a.N;
+    c.J = beh_windows(a);
+    c.hist = reinterpret_cast<const char*>(a.hist ? a.hist + (int64_t)c.net * a.h_s_net : nullptr);
+    c.hist_lane = (uint32_t)(((int64_t)c.e * a.h_s_e + (int64_t)c.ent * a.d) * 4);
+    c.mask = reinterpret_cast<const char*>(a.mask ? a.mask + (int64_t)c.net * a.E * a.T : nullptr);
+    c.mask_lane = (uint32_t)(c.e * a.T * 4);
+    c.grow0 = (int64_t)c.net * c.rows + (int64_t)(c.live ? tile : 0) * 16;
+}
+
+template <bool FULL>
+__device__ __forceinline__ f32x4 ld4(const char* __restrict__ base, uint32_t off, bool valid) {
+    if (FULL || valid) return *reinterpret_cast<const f32x4*>(base + off);
+    return splat4(0.f);
+}
+template <bool FULL>
+__device__ __forceinline__ void st4(char* __restrict__ base, uint32_t off, bool valid, f32x4 v) {
+    if (FULL || valid) *reinterpret_cast<f32x4*>(base + off) = v;
+}
+// the lane's (up to 4) entries 4g .. 4g+3 of a dim-wide row that is NOT 16-byte aligned (history rows: d = 5 floats)
+template <bool FULL>
+__device__ __forceinline__ f32x4 ld_row(const char* __restrict__ base, uint32_t off, bool valid, int dim, int g) {
+    f32x4 v = splat4(0.f);
+    if (FULL || valid) {
+        const float* p = reinterpret_cast<const float*>(base + off) + 4 * g;
+        for (int q = 0; q < 4; ++q)
+            if (4 * g + q < dim) v[q] = p[q];
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // decoder forward over the whole episode (+ masked-L1 loss and the stability statistic); also serves
 // Behavior_Latent_Decoder.forward on one explicit window (a.win != NULL)
-__global__ __launch_bounds__(512) void beh_dec_fwd_kernel(IplanBehArgs a) {
+constexpr int XF_H = 0, XF_U = 4, XF_Y = 8, XF_SLOTS = 11;      // exchange slots of a tile: new h | next u | partial y (quarters 1..3)
+
+// (FULL, Q) are template parameters: with the quarter a compile-time constant every LDS fragment address is an immediate and
+// the per-tile register arrays are indexed statically; a wave runs exactly one of the instantiations.
+template <bool FULL, int Q>
+__device__ __forceinline__ void dec_fwd_body(const IplanBehArgs& a, const DecTile& c, const float* __restrict__ s_wih,
+                                             const float* __restrict__ s_whh, const float* __restrict__ s_lin,
+                                             const float* __restrict__ s_out, const float* __restrict__ s_b, float* __restrict__ xch) {
+    constexpr int q = Q;
+    const bool valid = c.valid;
+    const int l = lane_id(), g = c.g, J = c.J, net = c.net;
+    const float inv_keep = 1.0f / (1.0f - a.drop_p);
+    const bool dec_only = a.win != nullptr;
+    const int Lw = a.L;
+    auto put = [&](int slot, f32x4 v) { *reinterpret_cast<f32x4*>(xch + slot * 256 + 4 * l) = v; };
+    auto get = [&](int slot) { return *reinterpret_cast<const f32x4*>(xch + slot * 256 + 4 * l); };
+    const int j_lo = dec_only ? 0 : imax(a.fwd_j_lo, 0), j_hi = (!dec_only && a.fwd_j_hi > 0) ? imin(a.fwd_j_hi, J) : J;
+    // record bases of this tile (uniform) and lane offsets; a step's record starts at step * cols * 4 bytes
+    const int64_t steps_per_chain = (int64_t)J * Lw;
+    char* sd_base = reinterpret_cast<char*>(a.saved_dec + c.grow0 * steps_per_chain * SVD);
+    const uint32_t sd_lane = (uint32_t)((int64_t)c.n * steps_per_chain * SVD * 4) + 16u * (uint32_t)g;
+    const char* sl_base = reinterpret_cast<const char*>(a.saved_lat ? a.saved_lat + c.grow0 * J * SVL : nullptr);
+    const uint32_t sl_lane = (uint32_t)((int64_t)c.n * J * SVL * 4);
+    float* carry = (a.dec_carry && c.live) ? a.dec_carry + ((int64_t)net * c.tiles + c.tile) * 1024 : nullptr;
+    const int64_t grow = c.grow0 + c.n;                      // this lane's chain (single-window mode addressing)
+
+    // The Linear's input row [x_t || latent] as one tile: lane (n, g) holds columns 4g .. 4g+3 (x in [0, d), latent in [d, d+Z))
+    auto latent_shifted = [&](int j) {
+        f32x4 v = splat4(0.f);
+        if (FULL || valid) {
+            const float* lp = dec_only ? a.lat_in + grow * a.Z
+                                       : reinterpret_cast<const float*>(sl_base + sl_lane + (uint32_t)j * (uint32_t)(SVL * 4)) + 16;
+            for (int k = 0; k < 4; ++k) {
+                const int z = 4 * g + k - a.d;
+                if (z >= 0 && z < a.Z) v[k] = lp[z];
+            }
+        }
+        return v;
+    };
+    auto x_of = [&](int j, int t) {
+        if (dec_only) return ld_row<FULL>(reinterpret_cast<const char*>(a.win), (uint32_t)((grow * Lw + t) * a.d * 4), valid, a.d, g);
+        const int st = beh_x_step(a, j, t);
+        if (st < 0) return splat4(0.f);
+        return ld_row<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)st * a.h_s_t * 4), valid, a.d, g);
+    };
+    auto u_own = [&](f32x4 xin) {                            // own tile of ReLU(Linear([x || latent]))
+        f32x4 x1[1];
+        x1[0] = xin;
+        return relu4(dense_tile<1>(s_lin, 24, 16 * q, x1, bfrag_lds(s_b, q)));
+    };
+
+    f32x4 h[DT], u[DT];
+    for (int i = 0; i < DT; ++i) h[i] = dec_only ? ld4<FULL>(reinterpret_cast<const char*>(a.hd_in), (uint32_t)(grow * DHd * 4) + 64u * i + 16u * g, valid)
+                                                 : splat4(0.f);
+    if (j_lo > 0 && carry)
+        for (int i = 0; i < DT; ++i) h[i] = *reinterpret_cast<const f32x4*>(carry + 256 * i + 4 * l);
+    // first step's u: every quarter computes its tile, all four are exchanged
+    f32x4 latsh = latent_shifted(j_lo);
+    f32x4 xin = x_of(j_lo, 0) + latsh;
+    put(XF_U + q, u_own(xin));
+    __syncthreads();
+    for (int i = 0; i < DT; ++i) u[i] = get(XF_U + i);
+    __syncthreads();
+
+    float beh = 0.f, stab = 0.f;
+    const int rows3[3] = {16 * q, DHd + 16 * q, 2 * DHd + 16 * q};                       // r, z, n gate rows of hidden tile q
+    for (int j = j_lo; j < j_hi; ++j) {
+        const float scale = (dec_only || q) ? 0.f : (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS);
+        float err = 0.f;
+        f32x4 latsh_next = latsh;
+        if (j + 1 < j_hi) latsh_next = latent_shifted(j + 1);
+        for (int t = 0; t < Lw; ++t) {
+            const uint32_t so = sd_lane + (uint32_t)(((int64_t)j * Lw + t) * SVD * 4);           // this step's record
+            // next step's Linear input (the first step of the next window uses that window's latent); loads issued early
+            const bool last_t = t + 1 == Lw;
+            const bool has_next = !last_t || j + 1 < j_hi;
+            f32x4 xin_next = splat4(0.f);
+            if (has_next) xin_next = x_of(last_t ? j + 1 : j, last_t ? 0 : t + 1) + (last_t ? latsh_next : latsh);
+            f32x4 nx = splat4(0.f);
+            float m = 0.f;
+            if (q == 0 && !dec_only) {
+                nx = ld_row<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)beh_y_step(a, j, t) * a.h_s_t * 4), valid, a.d, g);
+                if (FULL || valid) m = *reinterpret_cast<const float*>(c.mask + c.mask_lane + 4u * (uint32_t)beh_m_step(a, j, t));
+            }
+            if (q == 0) st4<FULL>(sd_base, so + 4u * SD_X, valid, xin);
+            st4<FULL>(sd_base, so + 4u * (SD_U + 16 * q), valid, u[q]);
+            // gates of hidden tile q
+            f32x4 ai[3], ah[3];
+            ai[0] = bfrag_lds(s_b + 64, q) + bfrag_lds(s_b + 256, q);
+            ai[1] = bfrag_lds(s_b + 64, DT + q) + bfrag_lds(s_b + 256, DT + q);
+            ai[2] = bfrag_lds(s_b + 64, 2 * DT + q);
+            dense_multi<3, DT>(s_wih, DLD, rows3, 0, u, ai);                                 // W_ih u: pre_r, pre_z, gi_n
+            ah[0] = ai[0];
+            ah[1] = ai[1];
+            ah[2] = bfrag_lds(s_b + 256, 2 * DT + q);
+            dense_multi<3, DT>(s_whh, DLD, rows3, 0, h, ah);                                 // + W_hh h: pre_r, pre_z, gh_n
+            const GruGates o = gru_gates(ah[0], ah[1], ai[2], ah[2], h[q]);
+            st4<FULL>(sd_base, so + 4u * (SD_R + 16 * q), valid, o.r);
+            st4<FULL>(sd_base, so + 4u * (SD_Z + 16 * q), valid, o.z);
+            st4<FULL>(sd_base, so + 4u * (SD_N + 16 * q), valid, o.n);
+            st4<FULL>(sd_base, so + 4u * (SD_HN + 16 * q), valid, o.hn);
+            st4<FULL>(sd_base, so + 4u * (SD_H + 16 * q), valid, o.h);
+            const f32x4 km = keep_tile(a, net, j, c.row, t, q, FULL || valid, c.rows);
+            f32x4 act[1];
+            for (int k = 0; k < 4; ++k) act[0][k] = tanh_f(o.h[k]) * (km[k] * inv_keep);
+            st4<FULL>(sd_base, so + 4u * (SD_A + 16 * q), valid, act[0]);
+            // y = W_out act + b: every quarter contracts its own tile, quarter 0 adds the partials up
+            const f32x4 yp = dense_tile_k<1>(s_out, DLD, 0, 16 * q, act, q ? splat4(0.f) : bfrag_lds(s_b + 448, 0));
+            put(XF_H + q, o.h);
+            if (q) put(XF_Y + q - 1, yp);
+            if (has_next) put(XF_U + q, u_own(xin_next));
+            __syncthreads();
+            for (int i = 0; i < DT; ++i) h[i] = (i == q) ? o.h : get(XF_H + i);      // (q is a constant: no select)
+            if (has_next)
+                for (int i = 0; i < DT; ++i) u[i] = get(XF_U + i);
+            f32x4 y = yp;
+            if (q == 0) y = (yp + get(XF_Y)) + (get(XF_Y + 1) + get(XF_Y + 2));
+            __syncthreads();
+            const f32x4 xt = xin;                            // columns >= d hold the latent: masked out below
+            xin = xin_next;
+            if (q) continue;                                 // the rest of the step (output, loss terms) is quarter 0's
+            st4<FULL>(sd_base, so + 4u * SD_Y, valid, y);
+            if (dec_only) {
+                if (FULL || valid) {
+                    float* po = a.pred_out + (grow * Lw + t) * a.d + 4 * g;
+                    for (int k = 0; k < 4; ++k)
+                        if (4 * g + k < a.d) po[k] = y[k];
+                }
+                continue;
+            }
+            // masked L1 against the target window, stability vs the current one (stable_behavior_policy.py:226, 233-240)
+            float d2 = 0.f;
+            for (int k = 0; k < 4; ++k) {
+                if (4 * g + k < a.d) {
+                    err += fabsf(nx[k] - y[k]) * m;
+                    const float df = xt[k] - y[k];
+                    d2 = fmaf(df, df, d2);
+                }
+            }
+            d2 = group_sum(d2);
+            if ((FULL || valid) && g == 0) stab += fmaxf(sqrtf(d2) - a.thres, 0.f);
+        }
+        latsh = latsh_next;
+        if (dec_only) {
+            st4<FULL>(reinterpret_cast<char*>(a.hd_out), (uint32_t)(grow * DHd * 4) + 64u * q + 16u * g, valid, h[q]);
+            return;
+        }
+        beh = fmaf(err, scale, beh);
+    }
+    if (j_hi < J && carry) *reinterpret_cast<f32x4*>(carry + 256 * q + 4 * l) = h[q];
+    beh = chain_sum_b(group_sum(beh)) / (a.hard ? 1.0f : (float)J);
+    stab = chain_sum_b(group_sum(stab)) / (float)a.E / (float)a.L / (float)J;
+    if (l == 0 && q == 0 && c.live) {
+        float* lp = a.loss_part + ((int64_t)net * c.tiles + c.tile) * 2;
+        lp[0] = j_lo > 0 ? lp[0] + beh : beh;             // pieces accumulate
+        lp[1] = j_lo > 0 ? lp[1] + stab : stab;
+    }
+}
+
+__global__ __launch_bounds__(DEC_THREADS) void beh_dec_fwd_kernel(IplanBehArgs a) {
     IPLAN_DYN_LDS(smem);
     float* s_wih = smem;                                    // [192][DLD]
     float* s_whh = s_wih + 3 * DHd * DLD;                   // [192][DLD]
-    float* s_linx = s_whh + 3 * DHd * DLD;                  // [64][24]   W_lin[:, :d]
-    float* s_linz = s_linx + DHd * 24;                      // [64][24]   W_lin[:, d:d+Z]
-    float* s_out = s_linz + DHd * 24;                       // [16][DLD]
+    float* s_lin = s_whh + 3 * DHd * DLD;                   // [64][24]   W_lin, columns [0, d + Z)
+    float* s_out = s_lin + DHd * 24;                        // [16][DLD]
     float* s_b = s_out + 16 * DLD;                          // lin 64 | ih 192 | hh 192 | out 16
-    float* s_xch = s_b + DEC_FWD_BIAS;                      // [8 waves][3 tiles][256]: new h (own tiles) | partial y
+    float* s_xch = s_b + DEC_FWD_BIAS;                      // [DEC_TILES][XF_SLOTS][256]
     const float* __restrict__ PD = a.dec_params + (int64_t)blockIdx.y * a.dec_s_net;
-    const int din = a.d + a.Z;
     stage_matrix(s_wih, DLD, 3 * DHd, PD + a.dec_off[IPLAN_DEC_WIH], 3 * DHd, DHd);
     stage_matrix(s_whh, DLD, 3 * DHd, PD + a.dec_off[IPLAN_DEC_WHH], 3 * DHd, DHd);
-    {   // split the input Linear by source: columns [0, d) act on x_t, [d, d+Z) on the latent
-        const float* Wl = PD + a.dec_off[IPLAN_DEC_LIN_W];
-        for (int idx = (int)threadIdx.x; idx < DHd * 24; idx += (int)blockDim.x) {
-            const int m = idx / 24, cc = idx - m * 24;
-            s_linx[idx] = cc < a.d ? Wl[(int64_t)m * din + cc] : 0.f;
-            s_linz[idx] = cc < a.Z ? Wl[(int64_t)m * din + a.d + cc] : 0.f;
-        }
-    }
+    stage_matrix(s_lin, 24, DHd, PD + a.dec_off[IPLAN_DEC_LIN_W], DHd, a.d + a.Z);
     stage_matrix(s_out, DLD, 16, PD + a.dec_off[IPLAN_DEC_OUT_W], a.d, DHd);
     stage_vector(s_b, 64, PD + a.dec_off[IPLAN_DEC_LIN_B], 64);
     stage_vector(s_b + 64, 192, PD + a.dec_off[IPLAN_DEC_BIH], 192);
     stage_vector(s_b + 256, 192, PD + a.dec_off[IPLAN_DEC_BHH], 192);
     stage_vector(s_b + 448, 16, PD + a.dec_off[IPLAN_DEC_OUT_B], a.d);
     __syncthreads();
-    BehChain c;
-    beh_chain(a, c);                                        // waves without a tile still take part in the block barriers
-    const bool valid = c.valid;
-    const int l = lane_id(), g = c.g, J = c.J, net = c.net, row = c.row, rows = c.rows;
-    const float inv_keep = 1.0f / (1.0f - a.drop_p);
-    const bool dec_only = a.win != nullptr;
-    // Gate split: waves w and w + 4 (same SIMD) share a 16-chain tile; half hf computes hidden tiles 2hf, 2hf+1.
-    // Per-tile register arrays are in ROTATED order: index i <-> hidden tile (2hf + i) & 3, so 0, 1 are the wave's own.
-    const int hf = wave_id() >> 2, own = 2 * hf, kown = 32 * hf, koth = 32 - kown;
-    float* xm = s_xch + wave_id() * 768;
-    const float* xp = s_xch + (wave_id() ^ 4) * 768;
-    auto put = [&](int slot, f32x4 v) { *reinterpret_cast<f32x4*>(xm + slot * 256 + 4 * l) = v; };
-    auto get = [&](int slot) { return *reinterpret_cast<const f32x4*>(xp + slot * 256 + 4 * l); };
-    const int j_lo = dec_only ? 0 : imax(a.fwd_j_lo, 0), j_hi = (!dec_only && a.fwd_j_hi > 0) ? imin(a.fwd_j_hi, J) : J;
-    // carry of the hidden state between pieces: every wave keeps its own two tiles in its half of the tile's slot
-    float* carry = a.dec_carry ? a.dec_carry + (((int64_t)net * c.tiles + imin(c.tile, c.tiles - 1)) * 2) * 512 : nullptr;
-    f32x4 hd[DT];
-    for (int i = 0; i < DT; ++i) hd[i] = dec_only ? vload_a(a.hd_in + c.grow * DHd, valid, (own + i) & 3) : splat4(0.f);
-    if (j_lo > 0 && carry)
-        for (int i = 0; i < DT; ++i) hd[i] = *reinterpret_cast<const f32x4*>(carry + 512 * (hf ^ (i >> 1)) + 256 * (i & 1) + 4 * l);
-    float beh = 0.f, stab = 0.f;
-    for (int j = j_lo; j < j_hi; ++j) {
-        const float scale = (dec_only || hf) ? 0.f : (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS);
-        float err = 0.f;
-        f32x4 lat1[1], zproj[DT];
-        lat1[0] = dec_only ? vload(a.lat_in + c.grow * a.Z, valid, a.Z, 0) : vload_a(a.saved_lat + (c.grow * J + j) * SVL + 16, valid, 0);
-        for (int i = 0; i < DT; ++i) zproj[i] = dense_tile<1>(s_linz, 24, 16 * ((own + i) & 3), lat1, bfrag_lds(s_b, (own + i) & 3));
-        // The record keeps the Linear's input row [x_t || latent] as ONE tile (the weight-gradient contraction then
-        // reads a single operand tile): the latent moved up by d columns, through the wave's exchange area.
-        f32x4 latsh;
-        put(0, lat1[0]);
-        __syncthreads();
-        for (int q = 0; q < 4; ++q) {
-            const int z = 4 * g + q - a.d;
-            latsh[q] = (z >= 0 && z < a.Z) ? xm[64 * (z >> 2) + 4 * c.n + (z & 3)] : 0.f;
-        }
-        __syncthreads();
-        for (int t = 0; t < a.L; ++t) {
-            const f32x4 xt = dec_only ? vload(a.win + (c.grow * a.L + t) * a.d, valid, a.d, 0) : window_x(a, c.hrow, j, t, valid);
-            float* sd = a.saved_dec + ((c.grow * J + j) * a.L + t) * SVD;
-            f32x4 x1[1];
-            x1[0] = xt;
-            if (hf == 0) vstore_a(sd + SD_X, valid, 0, xt + latsh);
-            f32x4 u[DT];
-            // Linear([x_t || latent]) = W[:, :d] x_t + (W[:, d:] latent + b): the latent part is per window
-            for (int i = 0; i < DT; ++i) u[i] = relu4(dense_tile<1>(s_linx, 24, 16 * ((own + i) & 3), x1, zproj[i]));
-            vstore_a(sd + SD_U, valid, own, u[0]);
-            vstore_a(sd + SD_U, valid, own + 1, u[1]);
-            f32x4 hnew[2], act[2];
-            for (int tt = 0; tt < 2; ++tt) {
-                const int T = own + tt;
-                const int grow3[3] = {16 * T, DHd + 16 * T, 2 * DHd + 16 * T};        // r, z, n gate rows of this hidden tile
-                f32x4 ai[3], ah[3];
-                ai[0] = bfrag_lds(s_b + 64, T) + bfrag_lds(s_b + 256, T);
-                ai[1] = bfrag_lds(s_b + 64, DT + T) + bfrag_lds(s_b + 256, DT + T);
-                ai[2] = bfrag_lds(s_b + 64, 2 * DT + T);
-                dense_multi<3, 2>(s_wih, DLD, grow3, kown, u, ai);                     // W_ih u: pre_r, pre_z, gi_n
-                dense_multi<3, 2>(s_wih, DLD, grow3, koth, u + 2, ai);
-                ah[0] = ai[0];
-                ah[1] = ai[1];
-                ah[2] = bfrag_lds(s_b + 256, 2 * DT + T);
-                dense_multi<3, 2>(s_whh, DLD, grow3, kown, hd, ah);                    // + W_hh h: pre_r, pre_z, gh_n
-                dense_multi<3, 2>(s_whh, DLD, grow3, koth, hd + 2, ah);
-                const GruGates o = gru_gates(ah[0], ah[1], ai[2], ah[2], hd[tt]);
-                hnew[tt] = o.h;
-                vstore_a(sd + SD_R, valid, T, o.r);
-                vstore_a(sd + SD_Z, valid, T, o.z);
-                vstore_a(sd + SD_N, valid, T, o.n);
-                vstore_a(sd + SD_HN, valid, T, o.hn);
-                vstore_a(sd + SD_H, valid, T, o.h);
-                const f32x4 km = keep_tile(a, net, j, row, t, T, valid, rows);
-                for (int q = 0; q < 4; ++q) act[tt][q] = tanh_f(o.h[q]) * (km[q] * inv_keep);
-                vstore_a(sd + SD_A, valid, T, act[tt]);
-                put(tt, o.h);
-                IPLAN_SCHED_FENCE();
-            }
-            // y = W_out act + b: each half contracts its own two tiles, the second half hands its partial over
-            const f32x4 yp = dense_tile_k<2>(s_out, DLD, 0, kown, act, hf ? splat4(0.f) : bfrag_lds(s_b + 448, 0));
-            if (hf) put(2, yp);
-            __syncthreads();
-            hd[0] = hnew[0]; hd[1] = hnew[1];
-            hd[2] = get(0); hd[3] = get(1);
-            f32x4 y = yp;
-            if (hf == 0) y = yp + get(2);
-            __syncthreads();
-            if (hf) continue;                               // the rest of the step (output, loss terms) is the first half's
-            vstore_a(sd + SD_Y, valid, 0, y);
-            if (dec_only) {
-                vstore(a.pred_out + (c.grow * a.L + t) * a.d, valid, a.d, 0, y);
-                continue;
-            }
-            // masked L1 against the target window, stability vs the current one (stable_behavior_policy.py:226, 233-240)
-            const f32x4 nx = vload(c.hrow + (int64_t)beh_y_step(a, j, t) * a.h_s_t, valid, a.d, 0);
-            const float m = valid ? c.mrow[beh_m_step(a, j, t)] : 0.f;
-            float d2 = 0.f;
-            for (int q = 0; q < 4; ++q) {
-                if (4 * g + q < a.d) {
-                    err += fabsf(nx[q] - y[q]) * m;
-                    const float df = xt[q] - y[q];
-                    d2 = fmaf(df, df, d2);
-                }
-            }
-            d2 = group_sum(d2);
-            if (valid && g == 0) stab += fmaxf(sqrtf(d2) - a.thres, 0.f);
-        }
-        if (dec_only) {
-            vstore_a(a.hd_out + c.grow * DHd, valid, own, hd[0]);
-            vstore_a(a.hd_out + c.grow * DHd, valid, own + 1, hd[1]);
-            return;
-        }
-        beh = fmaf(err, scale, beh);
-    }
-    if (j_hi < J && carry && c.tile < c.tiles) {
-        *reinterpret_cast<f32x4*>(carry + 512 * hf + 4 * l) = hd[0];
-        *reinterpret_cast<f32x4*>(carry + 512 * hf + 256 + 4 * l) = hd[1];
-    }
-    beh = chain_sum_b(group_sum(beh)) / (a.hard ? 1.0f : (float)J);
-    stab = chain_sum_b(group_sum(stab)) / (float)a.E / (float)a.L / (float)J;
-    if (lane_id() == 0 && hf == 0 && c.tile < c.tiles) {
-        float* lp = a.loss_part + ((int64_t)net * c.tiles + c.tile) * 2;
-        lp[0] = j_lo > 0 ? lp[0] + beh : beh;             // pieces accumulate
-        lp[1] = j_lo > 0 ? lp[1] + stab : stab;
-    }
+    const int w = uniform_i(wave_id()), q = w & 3, ts = w >> 2;
+    DecTile c;
+    dec_tile(a, c, (int)blockIdx.x * DEC_TILES + ts);       // waves without a tile still take part in the block barriers
+    float* xch = s_xch + ts * (XF_SLOTS * 256);
+#define IPLAN_DEC_FWD(F, QQ) dec_fwd_body<F, QQ>(a, c, s_wih, s_whh, s_lin, s_out, s_b, xch)
+    if (c.full) { if (q == 0) IPLAN_DEC_FWD(true, 0); else if (q == 1) IPLAN_DEC_FWD(true, 1); else if (q == 2) IPLAN_DEC_FWD(true, 2); else IPLAN_DEC_FWD(true, 3); }
+    else { if (q == 0) IPLAN_DEC_FWD(false, 0); else if (q == 1) IPLAN_DEC_FWD(false, 1); else if (q == 2) IPLAN_DEC_FWD(false, 2); else IPLAN_DEC_FWD(false, 3); }
+#undef IPLAN_DEC_FWD
 }
 
 __global__ __launch_bounds__(64) void beh_loss_kernel(IplanBehArgs a) {
@@ -382,15 +498,140 @@ __global__ __launch_bounds__(64) void beh_loss_kernel(IplanBehArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// decoder BPTT: row gradients for wgrad.hip (dsave_dec) and d(loss)/d(latent_j) per window (dsave_lat)
-__global__ __launch_bounds__(512) void beh_dec_bwd_kernel(IplanBehArgs a) {
+// decoder BPTT: row gradients for wgrad.hip (dsave_dec) and d(loss)/d(latent_j) per window (dsave_lat).
+// Quarter split as in the forward: wave Q owns hidden tile Q -- its gate gradients [dr dz dn_i dn_h] (lane-local from the
+// forward's record), which it parks in LDS for the other three, and output tile Q of the two backward-data products
+//      du = W_ih^T [dr dz dn_i],    dh_prev = W_hh^T [dr dz dn_h] + z * dh        (K = 192: 12 k-tiles each),
+// two accumulator chains issued alternately.  The NEXT step's record is fetched between the lane-local part and the MFMA part.
+constexpr int XB_SLOTS = 16;                                 // exchange slots of a tile: gate * 4 + quarter, gate = dr | dz | dn_i | dn_h
+
+template <bool FULL, int Q>
+__device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTile& c, const float* __restrict__ s_wihT,
+                                             const float* __restrict__ s_whhT, const float* __restrict__ s_outT,
+                                             const float* __restrict__ s_latT, float* __restrict__ xch) {
+    constexpr int TLD = 3 * DHd + 8;
+    const bool valid = c.valid;
+    const int l = lane_id(), g = c.g, J = c.J, net = c.net, Lw = a.L;
+    const float inv_keep = 1.0f / (1.0f - a.drop_p);
+    auto put = [&](int slot, f32x4 v) { *reinterpret_cast<f32x4*>(xch + slot * 256 + 4 * l) = v; };
+    auto get = [&](int slot) { return *reinterpret_cast<const f32x4*>(xch + slot * 256 + 4 * l); };
+    const int64_t steps_per_chain = (int64_t)J * Lw;
+    const char* sd_base = reinterpret_cast<const char*>(a.saved_dec + c.grow0 * steps_per_chain * SVD);
+    const uint32_t sd_lane = (uint32_t)((int64_t)c.n * steps_per_chain * SVD * 4) + 16u * (uint32_t)g;
+    char* dd_base = reinterpret_cast<char*>(a.dsave_dec + c.grow0 * steps_per_chain * DSD);
+    const uint32_t dd_lane = (uint32_t)((int64_t)c.n * steps_per_chain * DSD * 4) + 16u * (uint32_t)g;
+    char* dl_base = reinterpret_cast<char*>(a.dsave_lat + c.grow0 * J * DSL);
+    const uint32_t dl_lane = (uint32_t)((int64_t)c.n * J * DSL * 4) + 16u * (uint32_t)g;
+
+    // The forward's record of a step (own hidden tile), the loss target and the mask
+    struct StepIn {
+        f32x4 r, z, n, hn, hp, u, y, nx;
+        float m;
+    };
+    auto load_step = [&](int j, int t, StepIn& o) {
+        const uint32_t so = sd_lane + (uint32_t)(((int64_t)j * Lw + t) * SVD * 4);
+        const bool first = (j == 0 && t == 0);
+        o.r = ld4<FULL>(sd_base, so + 4u * (SD_R + 16 * Q), valid);
+        o.z = ld4<FULL>(sd_base, so + 4u * (SD_Z + 16 * Q), valid);
+        o.n = ld4<FULL>(sd_base, so + 4u * (SD_N + 16 * Q), valid);
+        o.hn = ld4<FULL>(sd_base, so + 4u * (SD_HN + 16 * Q), valid);
+        o.u = ld4<FULL>(sd_base, so + 4u * (SD_U + 16 * Q), valid);
+        o.hp = first ? splat4(0.f) : ld4<FULL>(sd_base, so - 4u * SVD + 4u * (SD_H + 16 * Q), valid);
+        o.y = ld4<FULL>(sd_base, so + 4u * SD_Y, valid);
+        o.nx = ld_row<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)beh_y_step(a, j, t) * a.h_s_t * 4), valid, a.d, g);
+        o.m = 0.f;
+        if (FULL || valid) o.m = *reinterpret_cast<const float*>(c.mask + c.mask_lane + 4u * (uint32_t)beh_m_step(a, j, t));
+    };
+    // window range of this launch (the BPTT may run in pieces, see bwd_j_lo / bwd_j_hi in the header)
+    const int j_hi = a.bwd_j_hi > 0 ? imin(a.bwd_j_hi, J) : J, j_lo = imax(a.bwd_j_lo, 0);
+    float* carry = (a.dec_carry && c.live) ? a.dec_carry + ((int64_t)net * c.tiles + c.tile) * 1024 + 256 * Q : nullptr;
+    f32x4 dhd = (j_hi < J && carry) ? *reinterpret_cast<const f32x4*>(carry + 4 * l) : splat4(0.f);
+    StepIn cur;
+    load_step(j_hi - 1, Lw - 1, cur);
+    f32x4 hcur = ld4<FULL>(sd_base, sd_lane + (uint32_t)((((int64_t)(j_hi - 1)) * Lw + (Lw - 1)) * SVD * 4) + 4u * (SD_H + 16 * Q), valid);
+    for (int j = j_hi - 1; j >= j_lo; --j) {
+        const float scale = (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS) / (a.hard ? 1.0f : (float)J);
+        f32x4 dlat = splat4(0.f);                           // d(loss)/d(latent_j) through this window's decoder inputs (own share)
+        for (int t = Lw - 1; t >= 0; --t) {
+            const uint32_t dof = dd_lane + (uint32_t)(((int64_t)j * Lw + t) * DSD * 4);
+            // ---- part A: lane-local, consumes the step's record
+            f32x4 dy[1];
+            for (int k = 0; k < 4; ++k) {
+                float v = 0.f;
+                if ((FULL || valid) && 4 * g + k < a.d) {
+                    const float er = cur.nx[k] - cur.y[k];
+                    v = -((er > 0.f) ? 1.0f : (er < 0.f ? -1.0f : 0.0f)) * cur.m * scale;
+                }
+                dy[0][k] = v;
+            }
+            if (Q == 0) st4<FULL>(dd_base, dof + 4u * DD_DY, valid, dy[0]);
+            const f32x4 da = dense_tile<1>(s_outT, 24, 16 * Q, dy, splat4(0.f));
+            const f32x4 km = keep_tile(a, net, j, c.row, t, Q, FULL || valid, c.rows);
+            f32x4 dht;
+            for (int k = 0; k < 4; ++k) {
+                const float th = tanh_f(hcur[k]);
+                dht[k] = fmaf(da[k] * km[k] * inv_keep, 1.0f - th * th, dhd[k]);
+            }
+            const GruGrads o = gru_gates_bwd(dht, cur.r, cur.z, cur.n, cur.hn, cur.hp);
+            st4<FULL>(dd_base, dof + 4u * (DD_DR + 16 * Q), valid, o.dr);
+            st4<FULL>(dd_base, dof + 4u * (DD_DZ + 16 * Q), valid, o.dz);
+            st4<FULL>(dd_base, dof + 4u * (DD_DNI + 16 * Q), valid, o.dni);
+            st4<FULL>(dd_base, dof + 4u * (DD_DNH + 16 * Q), valid, o.dnh);
+            put(0 * 4 + Q, o.dr);
+            put(1 * 4 + Q, o.dz);
+            put(2 * 4 + Q, o.dni);
+            put(3 * 4 + Q, o.dnh);
+            const f32x4 u_own = cur.u;
+            hcur = cur.hp;                                  // h_{t-1}: the next step's "current" hidden state
+            IPLAN_SCHED_FENCE();
+            if (t > 0) load_step(j, t - 1, cur);
+            else if (j > j_lo) load_step(j - 1, Lw - 1, cur);
+            __syncthreads();
+            // ---- part B: output tile Q of the two backward-data products over all 12 gate k-tiles
+            f32x4 du = splat4(0.f), pd = splat4(0.f);
+            f32x4 fa = wfrag_lds(s_wihT, TLD, 16 * Q, 0), fb = wfrag_lds(s_whhT, TLD, 16 * Q, 0);
+            for (int gate = 0; gate < 3; ++gate)
+                for (int T = 0; T < DT; ++T) {
+                    const int kt = gate * DT + T;                                        // k-tile: columns gate * 64 + 16 T
+                    f32x4 fan = fa, fbn = fb;
+                    if (kt + 1 < 3 * DT) {
+                        fan = wfrag_lds(s_wihT, TLD, 16 * Q, 16 * (kt + 1));
+                        fbn = wfrag_lds(s_whhT, TLD, 16 * Q, 16 * (kt + 1));
+                    }
+                    // B operands: [dr dz dn_i] for W_ih^T, [dr dz dn_h] for W_hh^T (own tile from registers)
+                    const f32x4 bi = (T == Q) ? (gate == 0 ? o.dr : (gate == 1 ? o.dz : o.dni)) : get(gate * 4 + T);
+                    const f32x4 bh = gate < 2 ? bi : ((T == Q) ? o.dnh : get(3 * 4 + T));
+                    for (int k = 0; k < 4; ++k) {
+                        du = mfma4(fa[k], bi[k], du);
+                        pd = mfma4(fb[k], bh[k], pd);
+                    }
+                    fa = fan;
+                    fb = fbn;
+                }
+            f32x4 dup[1];
+            for (int k = 0; k < 4; ++k) dup[0][k] = u_own[k] > 0.f ? du[k] : 0.f;
+            st4<FULL>(dd_base, dof + 4u * (DD_DU + 16 * Q), valid, dup[0]);
+            dhd = o.dh_direct + pd;
+            dlat = dense_tile_k<1>(s_latT, DLD, 0, 16 * Q, dup, dlat);                    // through the tiled latent input
+            __syncthreads();
+        }
+        // d(loss)/d(latent_j): sum of the four quarters' shares
+        if (Q) put(Q - 1, dlat);
+        __syncthreads();
+        if (Q == 0) st4<FULL>(dl_base, dl_lane + (uint32_t)j * (uint32_t)(DSL * 4), valid, (dlat + get(0)) + (get(1) + get(2)));
+        __syncthreads();
+    }
+    if (j_lo > 0 && carry) *reinterpret_cast<f32x4*>(carry + 4 * l) = dhd;
+}
+
+__global__ __launch_bounds__(DEC_THREADS) void beh_dec_bwd_kernel(IplanBehArgs a) {
     IPLAN_DYN_LDS(smem);
     constexpr int TLD = 3 * DHd + 8;                        // 200: ld % 16 == 8 -> conflict-free ds_read_b128 fragments
     float* s_wihT = smem;                                   // [64][200]   W_ih^T
     float* s_whhT = s_wihT + DHd * TLD;                     // [64][200]
     float* s_outT = s_whhT + DHd * TLD;                     // [64][24]    W_out^T (cols = d)
     float* s_latT = s_outT + DHd * 24;                      // [16][DLD]   W_lin[:, d:d+Z]^T
-    float* s_xch = s_latT + 16 * DLD;                       // [8 waves][4 tiles][256]: partial du | partial dh for the partner's tiles
+    float* s_xch = s_latT + 16 * DLD;                       // [DEC_TILES][XB_SLOTS][256]
     const float* __restrict__ PD = a.dec_params + (int64_t)blockIdx.y * a.dec_s_net;
     const int din = a.d + a.Z;
     stage_matrix_t(s_wihT, TLD, DHd, PD + a.dec_off[IPLAN_DEC_WIH], 3 * DHd, DHd);
@@ -404,124 +645,14 @@ __global__ __launch_bounds__(512) void beh_dec_bwd_kernel(IplanBehArgs a) {
         }
     }
     __syncthreads();
-    BehChain c;
-    beh_chain(a, c);                                        // waves without a tile still take part in the block barriers
-    const bool valid = c.valid;
-    const int l = lane_id(), g = c.g, J = c.J, net = c.net, row = c.row, rows = c.rows;
-    const float inv_keep = 1.0f / (1.0f - a.drop_p);
-    // Gate split (see beh_dec_fwd_kernel): this wave owns hidden tiles own, own + 1 -- their gate gradients, their
-    // share (6 of the 12 k-tiles) of the two transposed products, and after the exchange their rows of du and dh.
-    const int hf = wave_id() >> 2, own = 2 * hf, kown = 32 * hf;
-    float* xm = s_xch + wave_id() * 1024;
-    const float* xp = s_xch + (wave_id() ^ 4) * 1024;
-    auto put = [&](int slot, f32x4 v) { *reinterpret_cast<f32x4*>(xm + slot * 256 + 4 * l) = v; };
-    auto get = [&](int slot) { return *reinterpret_cast<const f32x4*>(xp + slot * 256 + 4 * l); };
-
-    // The forward's record of a step (gates + previous hidden state of the own tiles), the loss target and the mask.
-    // The NEXT step's record is fetched between the lane-local part and the MFMA part of the current step.
-    struct StepIn {
-        f32x4 r[2], z[2], n[2], hn[2], hp[2];
-        f32x4 y, nx;
-        float m;
-    };
-    auto load_step = [&](int j, int t, StepIn& o) {
-        const int64_t step = (c.grow * J + j) * a.L + t;
-        const bool first = (j == 0 && t == 0);
-        const float* sd = a.saved_dec + step * SVD;
-        for (int tt = 0; tt < 2; ++tt) {
-            o.r[tt] = vload_a(sd + SD_R, valid, own + tt);
-            o.z[tt] = vload_a(sd + SD_Z, valid, own + tt);
-            o.n[tt] = vload_a(sd + SD_N, valid, own + tt);
-            o.hn[tt] = vload_a(sd + SD_HN, valid, own + tt);
-            o.hp[tt] = vload_a(sd - SVD + SD_H, valid && !first, own + tt);
-        }
-        o.y = vload_a(sd + SD_Y, valid, 0);
-        o.nx = vload(c.hrow + (int64_t)beh_y_step(a, j, t) * a.h_s_t, valid, a.d, 0);
-        o.m = valid ? c.mrow[beh_m_step(a, j, t)] : 0.f;
-    };
-    // window range of this launch (the BPTT may run in pieces, see bwd_j_lo / bwd_j_hi in the header)
-    const int j_hi = a.bwd_j_hi > 0 ? imin(a.bwd_j_hi, J) : J, j_lo = imax(a.bwd_j_lo, 0);
-    float* carry = a.dec_carry ? a.dec_carry + ((((int64_t)net * c.tiles + imin(c.tile, c.tiles - 1)) * 2 + hf) * 512) : nullptr;
-    f32x4 dhd[2], hcur[2];
-    for (int tt = 0; tt < 2; ++tt)
-        dhd[tt] = (j_hi < J && carry) ? *reinterpret_cast<const f32x4*>(carry + 256 * tt + 4 * l) : splat4(0.f);
-    StepIn cur;
-    load_step(j_hi - 1, a.L - 1, cur);
-    for (int tt = 0; tt < 2; ++tt) hcur[tt] = vload_a(a.saved_dec + ((c.grow * J + (j_hi - 1)) * a.L + (a.L - 1)) * SVD + SD_H, valid, own + tt);
-    int od[DT];
-    for (int i = 0; i < DT; ++i) od[i] = 16 * ((own + i) & 3);                             // output tiles in rotated order
-    for (int j = j_hi - 1; j >= j_lo; --j) {
-        const float scale = (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS) / (a.hard ? 1.0f : (float)J);
-        f32x4 dlat = splat4(0.f);                           // d(loss)/d(latent_j) through this window's decoder inputs (own share)
-        for (int t = a.L - 1; t >= 0; --t) {
-            const int64_t step = (c.grow * J + j) * a.L + t;
-            float* dd_ = a.dsave_dec + step * DSD;
-            f32x4 du_[2];
-            for (int tt = 0; tt < 2; ++tt) du_[tt] = vload_a(a.saved_dec + step * SVD + SD_U, valid, own + tt);
-            // ---- part A: lane-local, consumes the step's record
-            f32x4 dy[1];
-            for (int q = 0; q < 4; ++q) {
-                float v = 0.f;
-                if (valid && 4 * g + q < a.d) {
-                    const float er = cur.nx[q] - cur.y[q];
-                    v = -((er > 0.f) ? 1.0f : (er < 0.f ? -1.0f : 0.0f)) * cur.m * scale;
-                }
-                dy[0][q] = v;
-            }
-            if (hf == 0) vstore_a(dd_ + DD_DY, valid, 0, dy[0]);
-            f32x4 dg[8], ddir[2];                          // [dr | dz | dn_i | dn_h] of the own tiles
-            for (int tt = 0; tt < 2; ++tt) {
-                const int T = own + tt;
-                const f32x4 da = dense_tile<1>(s_outT, 24, 16 * T, dy, splat4(0.f));
-                const f32x4 km = keep_tile(a, net, j, row, t, T, valid, rows);
-                f32x4 dht;
-                for (int q = 0; q < 4; ++q) {
-                    const float th = tanh_f(hcur[tt][q]);
-                    dht[q] = fmaf(da[q] * km[q] * inv_keep, 1.0f - th * th, dhd[tt][q]);
-                }
-                const GruGrads o = gru_gates_bwd(dht, cur.r[tt], cur.z[tt], cur.n[tt], cur.hn[tt], cur.hp[tt]);
-                vstore_a(dd_ + DD_DR, valid, T, o.dr);
-                vstore_a(dd_ + DD_DZ, valid, T, o.dz);
-                vstore_a(dd_ + DD_DNI, valid, T, o.dni);
-                vstore_a(dd_ + DD_DNH, valid, T, o.dnh);
-                dg[tt] = o.dr; dg[2 + tt] = o.dz; dg[4 + tt] = o.dni; dg[6 + tt] = o.dnh;
-                ddir[tt] = o.dh_direct;
-                hcur[tt] = cur.hp[tt];                     // h_{t-1}: the next step's "current" hidden state
-            }
-            IPLAN_SCHED_FENCE();
-            if (t > 0) load_step(j, t - 1, cur);
-            else if (j > j_lo) load_step(j - 1, a.L - 1, cur);
-            IPLAN_SCHED_FENCE();
-            // ---- part B: this half's k-tiles of the backward-data products, all four output tiles
-            f32x4 du[DT], pd[DT];
-            for (int i = 0; i < DT; ++i) { du[i] = splat4(0.f); pd[i] = splat4(0.f); }
-            dense_multi<DT, 2>(s_wihT, TLD, od, kown, dg, du);                              // W_ih^T [dr dz dn_i]
-            dense_multi<DT, 2>(s_wihT, TLD, od, DHd + kown, dg + 2, du);
-            dense_multi<DT, 2>(s_wihT, TLD, od, 2 * DHd + kown, dg + 4, du);
-            put(0, du[2]); put(1, du[3]);
-            IPLAN_SCHED_FENCE();
-            dense_multi<DT, 2>(s_whhT, TLD, od, kown, dg, pd);                              // W_hh^T [dr dz | dn_h]
-            dense_multi<DT, 2>(s_whhT, TLD, od, DHd + kown, dg + 2, pd);
-            dense_multi<DT, 2>(s_whhT, TLD, od, 2 * DHd + kown, dg + 6, pd);
-            put(2, pd[2]); put(3, pd[3]);
-            __syncthreads();
-            f32x4 dup[2];
-            for (int tt = 0; tt < 2; ++tt) {
-                const f32x4 dut = du[tt] + get(tt);
-                for (int q = 0; q < 4; ++q) dup[tt][q] = du_[tt][q] > 0.f ? dut[q] : 0.f;
-                vstore_a(dd_ + DD_DU, valid, own + tt, dup[tt]);
-                dhd[tt] = ddir[tt] + (pd[tt] + get(2 + tt));
-            }
-            __syncthreads();
-            dlat = dense_tile_k<2>(s_latT, DLD, 0, kown, dup, dlat);                        // through the tiled latent input
-        }
-        if (hf) put(0, dlat);
-        __syncthreads();
-        if (hf == 0) vstore_a(a.dsave_lat + (c.grow * J + j) * DSL, valid, 0, dlat + get(0));
-        __syncthreads();
-    }
-    if (j_lo > 0 && carry && c.tile < c.tiles)
-        for (int tt = 0; tt < 2; ++tt) *reinterpret_cast<f32x4*>(carry + 256 * tt + 4 * l) = dhd[tt];
+    const int w = uniform_i(wave_id()), q = w & 3, ts = w >> 2;
+    DecTile c;
+    dec_tile(a, c, (int)blockIdx.x * DEC_TILES + ts);       // waves without a tile still take part in the block barriers
+    float* xch = s_xch + ts * (XB_SLOTS * 256);
+#define IPLAN_DEC_BWD(F, QQ) dec_bwd_body<F, QQ>(a, c, s_wihT, s_whhT, s_outT, s_latT, xch)
+    if (c.full) { if (q == 0) IPLAN_DEC_BWD(true, 0); else if (q == 1) IPLAN_DEC_BWD(true, 1); else if (q == 2) IPLAN_DEC_BWD(true, 2); else IPLAN_DEC_BWD(true, 3); }
+    else { if (q == 0) IPLAN_DEC_BWD(false, 0); else if (q == 1) IPLAN_DEC_BWD(false, 1); else if (q == 2) IPLAN_DEC_BWD(false, 2); else IPLAN_DEC_BWD(false, 3); }
+#undef IPLAN_DEC_BWD
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -753,15 +884,16 @@ extern "C" int iplan_beh_fwd(const IplanBehArgs* a, iplan_stream_t stream) {
                                                  (a->fwd_j_hi > 0 && a->fwd_j_hi <= a->fwd_j_lo)))
         return fail(IPLAN_EINVAL, "iplan_beh_fwd: a window range needs enc_carry, dec_carry and 0 <= fwd_j_lo < fwd_j_hi");
     const int tiles = (a->E * a->N + 15) / 16;
-    const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets);
+    const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets);                       // encoder: 4 tiles per workgroup
+    const dim3 dgrid((unsigned)((tiles + DEC_TILES - 1) / DEC_TILES), (unsigned)a->n_nets);  // decoder: 3 tiles x 4 quarter-waves
     const int ph = a->win ? 2 : a->fwd_phase;
     if (ph == 0 || ph == 1) hipLaunchKernelGGL(beh_enc_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
     if (ph == 0 || ph == 2) {
-        const size_t lds = sizeof(float) * (2 * 3 * DHd * DLD + 2 * DHd * 24 + 16 * DLD + DEC_FWD_BIAS + 8 * 3 * 256);
+        const size_t lds = sizeof(float) * (2 * 3 * DHd * DLD + DHd * 24 + 16 * DLD + DEC_FWD_BIAS + DEC_TILES * XF_SLOTS * 256);
 #ifndef IPLAN_HOST_EMULATION
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_dec_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
-        hipLaunchKernelGGL(beh_dec_fwd_kernel, grid, dim3(512), lds, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL(beh_dec_fwd_kernel, dgrid, dim3(DEC_THREADS), lds, (hipStream_t)stream, *a);
     }
     if (!a->win && (ph == 0 || ph == 3)) hipLaunchKernelGGL(beh_loss_kernel, dim3((unsigned)a->n_nets), dim3(64), 0, (hipStream_t)stream, *a);
     return check_launch("iplan_beh_fwd");
@@ -779,11 +911,12 @@ extern "C" int iplan_beh_bwd(const IplanBehArgs* a, iplan_stream_t stream) {
         return fail(IPLAN_EINVAL, "iplan_beh_bwd: a window range needs bwd_phase 1 (+ dec_carry) or 2 (+ enc_carry) and 0 <= bwd_j_lo < bwd_j_hi");
     const int tiles = (a->E * a->N + 15) / 16;
     const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets);
-    const size_t lds = sizeof(float) * (2 * DHd * (3 * DHd + 8) + DHd * 24 + 16 * DLD + 8 * 4 * 256);
+    const dim3 dgrid((unsigned)((tiles + DEC_TILES - 1) / DEC_TILES), (unsigned)a->n_nets);
+    const size_t lds = sizeof(float) * (2 * DHd * (3 * DHd + 8) + DHd * 24 + 16 * DLD + DEC_TILES * XB_SLOTS * 256);
 #ifndef IPLAN_HOST_EMULATION
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_dec_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
-    if (a->bwd_phase != 2) hipLaunchKernelGGL(beh_dec_bwd_kernel, grid, dim3(512), lds, (hipStream_t)stream, *a);
+    if (a->bwd_phase != 2) hipLaunchKernelGGL(beh_dec_bwd_kernel, dgrid, dim3(DEC_THREADS), lds, (hipStream_t)stream, *a);
     if (a->bwd_phase != 1) {
         hipLaunchKernelGGL(beh_enc_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
         if (a->bwd_j_lo <= 0) {                             // the last (or only) piece: reduce the wave partials
