@@ -600,6 +600,30 @@ typedef struct {
 int iplan_mlp3_fwd(const IplanMlp3Args* args, iplan_stream_t stream);
 int iplan_mlp3_bwd(const IplanMlp3Args* args, iplan_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * nova/Seq2Seq.py:41-70 -- Seq2Seq.forward (encoder GRU over the input sequence from a zero state, then pred_length
+ * autoregressive decoder steps  y_t = Linear(Dropout(tanh(GRU(y_{t-1}, h))))  from last_location, optionally teacher forced).
+ * nn.GRU semantics, batch_first, `layers` stacked layers (1..4) of width H in {32, 64}; rows = N*V.  Inference only.
+ * enc_off / dec_off: per layer l  [4l + 0..3] = weight_ih_l<l> [3H, In_l], weight_hh_l<l> [3H, H], bias_ih_l<l>, bias_hh_l<l>
+ * (In_0 = input_size for the encoder, output_size for the decoder; In_l = H above); lin_off = decoder.linear.weight [O, H], .bias.
+ */
+#define IPLAN_S2S_MAX_LAYERS 4
+typedef struct {
+    int32_t rows, T_in, In, H, layers, P, O;
+    const float* x;             /* [rows, T_in, In]                                                     */
+    const float* last;          /* [rows, O]   last_location                                            */
+    const float* teacher;       /* [rows, P, O] or NULL                                                 */
+    const int32_t* coins;       /* [P] 1 = feed teacher[:, t] into step t + 1 (teacher != NULL), or NULL */
+    const float* keep;          /* [P, rows, H] dropout keep flags of the decoder output, or NULL (no dropout) */
+    float drop_p;
+    const float* params;
+    int64_t enc_off[4 * IPLAN_S2S_MAX_LAYERS], dec_off[4 * IPLAN_S2S_MAX_LAYERS], lin_off[2];
+    float* out;                 /* [rows, P, O]                                                         */
+    float* hidden_out;          /* optional [layers, rows, H]: the decoder's final hidden state         */
+} IplanSeq2SeqArgs;
+
+int iplan_seq2seq_fwd(const IplanSeq2SeqArgs* args, iplan_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

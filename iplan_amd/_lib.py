@@ -50,7 +50,7 @@ class IplanError(RuntimeError):
 # every entry point include/iplan_hip.h declares
 ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step", "iplan_wgrad",
                 "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_adv_norm", "iplan_ppo_loss", "iplan_gat_bwd",
-                "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd", "iplan_mlp3_fwd", "iplan_mlp3_bwd"]
+                "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd", "iplan_mlp3_fwd", "iplan_mlp3_bwd", "iplan_seq2seq_fwd"]
 RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups", "iplan_sizeof"]      # non (args*, stream) signatures
 
 
@@ -318,9 +318,17 @@ class Mlp3Args(C.Structure):
     ]
 
 
+class Seq2SeqArgs(C.Structure):
+    _fields_ = [
+        ("rows", i32), ("T_in", i32), ("In", i32), ("H", i32), ("layers", i32), ("P", i32), ("O", i32),
+        ("x", fp), ("last", fp), ("teacher", fp), ("coins", fp), ("keep", fp), ("drop_p", C.c_float), ("params", fp),
+        ("enc_off", i64 * 16), ("dec_off", i64 * 16), ("lin_off", i64 * 2), ("out", fp), ("hidden_out", fp),
+    ]
+
+
 # ctypes mirror -> C struct name (checked against iplan_sizeof() of the loaded library by tests/test_abi.py)
 STRUCT_MIRRORS = {"IplanGatSaved": GatSaved, "IplanGatFwdArgs": GatFwdArgs, "IplanGatBwdArgs": GatBwdArgs,
                   "IplanEncFwdArgs": EncFwdArgs, "IplanAcNet": AcNet, "IplanAcFeatures": AcFeatures, "IplanAcFwdArgs": AcFwdArgs,
                   "IplanAcBwdArgs": AcBwdArgs, "IplanAdamArgs": AdamArgs, "IplanWgradProblem": WgradProblem,
                   "IplanWgradArgs": WgradArgs, "IplanPpoPrepareArgs": PpoPrepareArgs, "IplanPpoLossArgs": PpoLossArgs,
-                  "IplanPdecArgs": PdecArgs, "IplanBehArgs": BehArgs, "IplanMlp3Args": Mlp3Args, "IplanAdvNormArgs": AdvNormArgs}
+                  "IplanPdecArgs": PdecArgs, "IplanBehArgs": BehArgs, "IplanMlp3Args": Mlp3Args, "IplanAdvNormArgs": AdvNormArgs, "IplanSeq2SeqArgs": Seq2SeqArgs}

@@ -1,0 +1,115 @@
+// nova/Seq2Seq.py:41-70 -- Seq2Seq.forward on the wave-tile GRU idiom: one wave owns 16 rows (N*V chains) for the whole
+// call; the encoder GRU stack consumes the T_in input steps from a zero state, then pred_length autoregressive decoder
+// steps feed the previous prediction (or the teacher's location) back in.  Hidden states of all layers stay in registers
+// in the D layout; weights are read as MFMA A fragments straight from L1/L2 (the whole model is < 200 KB).
+// The reference never calls this module on its training path: it is built for API completeness
+// (same constructor / forward / state_dict), inference only.
+#include "api_util.h"
+#include "gru_tile.h"
+
+namespace iplan {
+
+// one GRU layer step: x = `xt` input tiles of real width `in_dim`, weights [3H, in_dim] / [3H, H] in global memory
+template <int HT>
+__device__ __forceinline__ void gru_layer_step(const float* __restrict__ Wih, const float* __restrict__ Whh,
+                                               const float* __restrict__ bih, const float* __restrict__ bhh, int in_dim,
+                                               const f32x4 (&x)[4], int xt, f32x4 (&h)[HT]) {
+    constexpr int H = 16 * HT;
+    f32x4 hnew[HT];
+    for (int t = 0; t < HT; ++t) {
+        f32x4 pr = bfrag(bih, 3 * H, t) + bfrag(bhh, 3 * H, t);
+        f32x4 pz = bfrag(bih, 3 * H, HT + t) + bfrag(bhh, 3 * H, HT + t);
+        f32x4 gi = bfrag(bih, 3 * H, 2 * HT + t), gh = bfrag(bhh, 3 * H, 2 * HT + t);
+        for (int T = 0; T < xt; ++T) {
+            pr = mma_block(wfrag(Wih, in_dim, 3 * H, in_dim, 16 * t, 16 * T), x[T], pr);
+            pz = mma_block(wfrag(Wih, in_dim, 3 * H, in_dim, H + 16 * t, 16 * T), x[T], pz);
+            gi = mma_block(wfrag(Wih, in_dim, 3 * H, in_dim, 2 * H + 16 * t, 16 * T), x[T], gi);
+        }
+        for (int T = 0; T < HT; ++T) {
+            pr = mma_block(wfrag_a(Whh, H, 3 * H, 16 * t, 16 * T), h[T], pr);
+            pz = mma_block(wfrag_a(Whh, H, 3 * H, H + 16 * t, 16 * T), h[T], pz);
+            gh = mma_block(wfrag_a(Whh, H, 3 * H, 2 * H + 16 * t, 16 * T), h[T], gh);
+        }
+        hnew[t] = gru_gates(pr, pz, gi, gh, h[t]).h;
+    }
+    for (int t = 0; t < HT; ++t) h[t] = hnew[t];
+}
+
+template <int HT>
+__global__ __launch_bounds__(256) void seq2seq_fwd_kernel(IplanSeq2SeqArgs a) {
+    constexpr int H = 16 * HT;
+    const int l = lane_id(), g = l >> 4;
+    const int row = ((int)blockIdx.x * 4 + wave_id()) * 16 + (l & 15);
+    const bool valid = row < a.rows;
+    const float* __restrict__ P = a.params;
+    f32x4 h[IPLAN_S2S_MAX_LAYERS][HT];
+    for (int L = 0; L < IPLAN_S2S_MAX_LAYERS; ++L)
+        for (int t = 0; t < HT; ++t) h[L][t] = splat4(0.f);
+    const int xt_in = (a.In + 15) / 16;
+    // ---- encoder: (N*V, T, C) -> hidden (L, N*V, H)
+    for (int t = 0; t < a.T_in; ++t) {
+        f32x4 x[4];
+        for (int T = 0; T < 4; ++T) x[T] = T < xt_in ? vload(a.x + ((int64_t)row * a.T_in + t) * a.In, valid, a.In, T) : splat4(0.f);
+#pragma unroll
+        for (int L = 0; L < IPLAN_S2S_MAX_LAYERS; ++L) {                                  // (unrolled: h[L] is indexed statically)
+            if (L >= a.layers) break;
+            const int in_dim = L ? H : a.In;
+            gru_layer_step<HT>(P + a.enc_off[4 * L], P + a.enc_off[4 * L + 1], P + a.enc_off[4 * L + 2], P + a.enc_off[4 * L + 3],
+                               in_dim, x, L ? HT : xt_in, h[L]);
+            for (int T = 0; T < 4; ++T) x[T] = T < HT ? h[L][T] : splat4(0.f);           // the layer above reads this layer's output
+        }
+    }
+    // ---- decoder: pred_length autoregressive steps from last_location
+    const float inv_keep = a.keep ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    f32x4 yin = vload(a.last + (int64_t)row * a.O, valid, a.O, 0);
+    for (int t = 0; t < a.P; ++t) {
+        f32x4 x[4];
+        x[0] = yin;
+        for (int T = 1; T < 4; ++T) x[T] = splat4(0.f);
+#pragma unroll
+        for (int L = 0; L < IPLAN_S2S_MAX_LAYERS; ++L) {
+            if (L >= a.layers) break;
+            const int in_dim = L ? H : a.O;
+            gru_layer_step<HT>(P + a.dec_off[4 * L], P + a.dec_off[4 * L + 1], P + a.dec_off[4 * L + 2], P + a.dec_off[4 * L + 3],
+                               in_dim, x, L ? HT : 1, h[L]);
+            for (int T = 0; T < 4; ++T) x[T] = T < HT ? h[L][T] : splat4(0.f);
+        }
+        f32x4 act[HT];
+        for (int T = 0; T < HT; ++T) {
+            f32x4 km = splat4(1.0f);
+            if (a.keep) km = vload(a.keep + ((int64_t)t * a.rows + row) * H, valid, H, T);
+            for (int q = 0; q < 4; ++q) act[T][q] = tanh_f(x[T][q]) * (km[q] * inv_keep);   // x = the top layer's new hidden state
+        }
+        const f32x4 y = dense_tile_g<HT>(P + a.lin_off[0], H, a.O, H, 0, act, bfrag(P + a.lin_off[1], a.O, 0));
+        vstore(a.out + ((int64_t)row * a.P + t) * a.O, valid, a.O, 0, y);
+        yin = y;
+        if (a.teacher && a.coins && a.coins[t]) yin = vload(a.teacher + ((int64_t)row * a.P + t) * a.O, valid, a.O, 0);
+        if (!valid) yin = splat4(0.f);
+        for (int q = 0; q < 4; ++q)
+            if (4 * g + q >= a.O) yin[q] = 0.f;
+    }
+    if (a.hidden_out) {
+#pragma unroll
+        for (int L = 0; L < IPLAN_S2S_MAX_LAYERS; ++L) {
+            if (L >= a.layers) break;
+            for (int T = 0; T < HT; ++T) vstore(a.hidden_out + ((int64_t)L * a.rows + row) * H, valid, H, T, h[L][T]);
+        }
+    }
+}
+
+}  // namespace iplan
+
+extern "C" int iplan_seq2seq_fwd(const IplanSeq2SeqArgs* a, iplan_stream_t stream) {
+    using namespace iplan;
+    if (!a) return fail(IPLAN_EINVAL, "iplan_seq2seq_fwd: null args");
+    if (a->rows < 1 || a->T_in < 1 || a->In < 1 || a->In > 64 || a->layers < 1 || a->layers > IPLAN_S2S_MAX_LAYERS || a->P < 1 ||
+        a->O < 1 || a->O > 16 || (a->H != 32 && a->H != 64))
+        return fail(IPLAN_EINVAL, "iplan_seq2seq_fwd: unsupported dims rows=%d T=%d In=%d H=%d layers=%d P=%d O=%d (In <= 64, O <= 16, H in {32, 64})",
+                    a->rows, a->T_in, a->In, a->H, a->layers, a->P, a->O);
+    if (!a->x || !a->last || !a->params || !a->out) return fail(IPLAN_EINVAL, "iplan_seq2seq_fwd: null tensor pointer");
+    if (a->keep && (a->drop_p < 0.f || a->drop_p >= 1.f)) return fail(IPLAN_EINVAL, "iplan_seq2seq_fwd: dropout p=%f", a->drop_p);
+    const dim3 grid((unsigned)((a->rows + 63) / 64));
+    if (a->H == 32) hipLaunchKernelGGL(seq2seq_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(seq2seq_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    return check_launch("iplan_seq2seq_fwd");
+}

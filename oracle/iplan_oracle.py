@@ -539,3 +539,36 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
             stats.append(dict(policy_loss=float(pol.detach()), value_loss=float(vl.detach()), entropy=float(ent.detach()), ratio=float(ratio.detach().mean()),
                               actor_grad_norm=norms[0], critic_grad_norm=norms[1]))
     return dict(returns=rets, adv=adv, old_logp=old_logp, values_all=v_all, stats=stats)
+
+
+# ----------------------------------------------------------------------------------------------
+# a19 Seq2Seq.forward (nova/Seq2Seq.py:52-70): stacked-GRU encoder from a zero state, autoregressive decoder
+# ----------------------------------------------------------------------------------------------
+def seq2seq_forward(p, in_data, last_location, pred_length, teacher=None, coins=None, drop_masks=None, drop_p=0.0):
+    """p: Seq2Seq state_dict; in_data [R,T,C], last_location [R,1,O], teacher [R,P,O] / coins [P] bools (teacher forcing of the
+    NEXT step's input) or None, drop_masks [P, R, 1, H] keep flags or None -> [R, P, O]."""
+    layers = sum(1 for k in p if k.startswith("encoder.rnn.weight_ih_l"))
+    H = p["encoder.rnn.weight_hh_l0"].shape[1]
+    R = in_data.shape[0]
+    h = [torch.zeros(R, H, dtype=in_data.dtype) for _ in range(layers)]
+    for t in range(in_data.shape[1]):
+        x = in_data[:, t]
+        for k in range(layers):
+            h[k] = gru_cell(x, h[k], p[f"encoder.rnn.weight_ih_l{k}"], p[f"encoder.rnn.weight_hh_l{k}"],
+                            p[f"encoder.rnn.bias_ih_l{k}"], p[f"encoder.rnn.bias_hh_l{k}"])
+            x = h[k]
+    y = last_location[:, 0]
+    outs = []
+    for t in range(pred_length):
+        x = y
+        for k in range(layers):
+            h[k] = gru_cell(x, h[k], p[f"decoder.rnn.weight_ih_l{k}"], p[f"decoder.rnn.weight_hh_l{k}"],
+                            p[f"decoder.rnn.bias_ih_l{k}"], p[f"decoder.rnn.bias_hh_l{k}"])
+            x = h[k]
+        a = torch.tanh(x)
+        if drop_masks is not None:
+            a = a * drop_masks[t].reshape(R, H) / (1.0 - drop_p)
+        out = a @ p["decoder.linear.weight"].t() + p["decoder.linear.bias"]
+        outs.append(out)
+        y = teacher[:, t] if (teacher is not None and coins is not None and coins[t]) else out
+    return torch.stack(outs, dim=1)

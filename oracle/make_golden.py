@@ -538,6 +538,7 @@ def main():
     golden_obs_wrapper()
     golden_behavior_fc_learn()
     golden_wrappers()
+    golden_seq2seq()
     print("all golden fixtures written to", GOLD)
 
 
@@ -665,5 +666,42 @@ def golden_wrappers(seed=90):
                     pred=tuple(t.clone() for t in out)), os.path.join(GOLD, "wrappers.pt"))
 
 
+def golden_seq2seq(seed=95):
+    """nova/Seq2Seq.py: the reference class (2 layers x 64, teacher forcing 0.5, dropout active) and a 1 x 32 variant."""
+    from nova.Seq2Seq import Seq2Seq
+    print("seq2seq")
+    cases = []
+    for tag, (C, H, layers, P, No, ratio) in (("l2h64", (4, 64, 2, 6, 2, 0.5)), ("l1h32", (7, 32, 1, 4, 3, 0.0))):
+        torch.manual_seed(seed)
+        net = Seq2Seq(C, H, layers, P, num_node=5, output_size=No, dropout=0.5, teacher_forcing_ratio=ratio)
+        gen = torch.Generator().manual_seed(seed + 1)
+        R, T = 35, 6
+        x = torch.rand(R, T, C, generator=gen) * 2 - 1
+        last = torch.rand(R, 1, No, generator=gen) * 2 - 1
+        teacher = torch.rand(R, P, No, generator=gen) * 2 - 1
+        patch()
+        torch.manual_seed(seed + 2)
+        np.random.seed(seed + 3)
+        with torch.no_grad():
+            out = net(x, last, teacher)
+        masks = torch.stack(REC["dropout"])                                # [P, R, 1, H]
+        unpatch()
+        np.random.seed(seed + 3)
+        coins = [bool(np.random.random() < ratio) for _ in range(P)]
+        p = sd(net)
+        o = O.seq2seq_forward(p, x, last, P, teacher, coins, masks, 0.5)
+        check(f"seq2seq {tag}", o, out, 1e-5)
+        cases.append(dict(tag=tag, dims=dict(C=C, H=H, layers=layers, P=P, O=No, ratio=ratio, R=R, T=T), params=p, x=x, last=last,
+                          teacher=teacher, masks=masks, coins=coins, np_seed=seed + 3, out=out))
+        seed += 10
+    torch.save(cases, os.path.join(GOLD, "seq2seq.pt"))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:                                     # python oracle/make_golden.py golden_seq2seq ...: selected fixtures only
+        os.makedirs(GOLD, exist_ok=True)
+        torch.set_num_threads(4)
+        for name in sys.argv[1:]:
+            globals()[name]()
+    else:
+        main()

@@ -271,3 +271,25 @@ def test_device_resident_rollout_matches_oracle_emulated(cfg):
                         max_history_len=3, **kw)
     worst = check_rollout_body(args, 3, "cpu", seed=5)
     assert max(worst.values()) < 1e-5
+
+
+def check_seq2seq(golden, device):
+    """nova/Seq2Seq.py forward (a19): same constructor / state_dict / random draws as the reference class, outputs recorded from it"""
+    import numpy as np
+    from iplan_amd.nova.Seq2Seq import Seq2Seq
+    for g in golden("seq2seq"):
+        d = g["dims"]
+        net = Seq2Seq(d["C"], d["H"], d["layers"], d["P"], num_node=5, output_size=d["O"], dropout=0.5, teacher_forcing_ratio=d["ratio"])
+        assert list(net.state_dict().keys()) == list(g["params"].keys())
+        net.load_state_dict(g["params"])
+        np.random.seed(g["np_seed"])
+        with torch.no_grad():
+            out = net(g["x"].to(device), g["last"].to(device), g["teacher"].to(device), keep=g["masks"].reshape(d["P"], d["R"], d["H"]).to(device))
+        assert out.shape == g["out"].shape and rel_err(out.cpu(), g["out"]) < 1e-5, (g["tag"], rel_err(out.cpu(), g["out"]))
+        x4 = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)          # the reshape helpers (N, C, T, V)
+        assert net.reshape_for_rnn(x4).shape == (10, 4, 3)
+        assert torch.equal(net.reshape_from_rnn(net.reshape_for_rnn(x4)), x4)
+
+
+def test_seq2seq_forward_emulated(golden):
+    check_seq2seq(golden, "cpu")

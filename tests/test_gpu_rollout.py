@@ -36,3 +36,8 @@ def test_decoder_modules_match_reference(golden):
 def test_reference_checkpoint_matches(golden, tmp_path):
     from tests.test_emu_kernels import check_reference_checkpoint
     check_reference_checkpoint(golden, "cuda", tmp_path)
+
+
+def test_seq2seq_forward_matches_reference(golden):
+    from tests.test_emu_kernels import check_seq2seq
+    check_seq2seq(golden, "cuda")
