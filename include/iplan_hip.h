@@ -275,6 +275,7 @@ typedef struct {
     float lr, beta1, beta2, eps;
     float bc1[IPLAN_MAX_NETS];      /* 1 - beta1^step   per net                                   */
     float bc2_sqrt[IPLAN_MAX_NETS]; /* sqrt(1 - beta2^step)                                       */
+    float weight_decay;         /* torch.optim.Adam's L2 form: g <- g + weight_decay * p, after the clip (0 = off) */
 } IplanAdamArgs;
 
 int iplan_adam_step(const IplanAdamArgs* args, iplan_stream_t stream);
@@ -566,6 +567,10 @@ typedef struct {
                                    NULL = summed in-kernel over this launch's envs                              */
     float enc_grad_beta;        /* backward: enc_grad = enc_grad_beta * enc_grad + sum of the wave partials (1 = accumulate
                                    over several launches on disjoint env chunks, 0 = overwrite)                  */
+    float penalty;              /* backward: behavior_variation_penalty -- weight of the stability term
+                                   mean_j sum_{chain, t} max(||x_t - y_t||_2 - thres, 0) / (E_norm L) in the differentiated loss
+                                   (nova/stable_behavior_policy.py:238-246); 0 = the shipped configuration       */
+    int32_t E_norm;             /* envs the stability term is averaged over (all chunks / ranks); 0 = E           */
 } IplanBehArgs;
 
 int iplan_beh_fwd(const IplanBehArgs* args, iplan_stream_t stream);

@@ -193,7 +193,7 @@ class AdamArgs(C.Structure):
         ("sqnorm", fp), ("sqnorm_stride", i32), ("sqnorm_slot", i32),
         ("max_norm", C.c_float), ("write_clipped", i32),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-        ("bc1", C.c_float * MAX_NETS), ("bc2_sqrt", C.c_float * MAX_NETS),
+        ("bc1", C.c_float * MAX_NETS), ("bc2_sqrt", C.c_float * MAX_NETS), ("weight_decay", C.c_float),
     ]
 
 
@@ -304,7 +304,7 @@ class BehArgs(C.Structure):
         ("enc_part", fp), ("enc_grad", fp), ("enc_grad_s_net", i64), ("bwd_phase", i32),
         ("bwd_j_lo", i32), ("bwd_j_hi", i32), ("dec_carry", fp),
         ("fwd_phase", i32), ("fwd_j_lo", i32), ("fwd_j_hi", i32), ("enc_carry", fp), ("win_norm", fp),
-        ("enc_grad_beta", C.c_float),
+        ("enc_grad_beta", C.c_float), ("penalty", C.c_float), ("E_norm", i32),
     ]
 
 

@@ -525,7 +525,7 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
 
     // The forward's record of a step (own hidden tile), the loss target and the mask
     struct StepIn {
-        f32x4 r, z, n, hn, hp, u, y, nx;
+        f32x4 r, z, n, hn, hp, u, y, nx, xc;
         float m;
     };
     auto load_step = [&](int j, int t, StepIn& o) {
@@ -541,7 +541,14 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
         o.nx = ld_row<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)beh_y_step(a, j, t) * a.h_s_t * 4), valid, a.d, g);
         o.m = 0.f;
         if (FULL || valid) o.m = *reinterpret_cast<const float*>(c.mask + c.mask_lane + 4u * (uint32_t)beh_m_step(a, j, t));
+        o.xc = splat4(0.f);
+        if (a.penalty != 0.f) {                             // the stability term compares the prediction with the CURRENT window's step
+            const int st = beh_x_step(a, j, t);
+            if (st >= 0) o.xc = ld_row<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)st * a.h_s_t * 4), valid, a.d, g);
+        }
     };
+    // stability term (stable_behavior_policy.py:238-246): penalty / J * sum max(||x_t - y_t|| - thres, 0) / (E L)
+    const float pen = a.penalty / (float)J / (float)(a.E_norm > 0 ? a.E_norm : a.E) / (float)Lw;
     // window range of this launch (the BPTT may run in pieces, see bwd_j_lo / bwd_j_hi in the header)
     const int j_hi = a.bwd_j_hi > 0 ? imin(a.bwd_j_hi, J) : J, j_lo = imax(a.bwd_j_lo, 0);
     float* carry = (a.dec_carry && c.live) ? a.dec_carry + ((int64_t)net * c.tiles + c.tile) * 1024 + 256 * Q : nullptr;
@@ -563,6 +570,17 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
                     v = -((er > 0.f) ? 1.0f : (er < 0.f ? -1.0f : 0.0f)) * cur.m * scale;
                 }
                 dy[0][k] = v;
+            }
+            if (a.penalty != 0.f) {                         // d/dy of max(||x - y||_2 - thres, 0): -(x - y) / ||x - y|| where active
+                float d2 = 0.f;
+                f32x4 df;
+                for (int k = 0; k < 4; ++k) {
+                    df[k] = (4 * g + k < a.d) ? cur.xc[k] - cur.y[k] : 0.f;
+                    d2 = fmaf(df[k], df[k], d2);
+                }
+                const float nrm = sqrtf(group_sum(d2));
+                if ((FULL || valid) && nrm > a.thres)
+                    for (int k = 0; k < 4; ++k) dy[0][k] -= pen * df[k] / nrm;
             }
             if (Q == 0) st4<FULL>(dd_base, dof + 4u * DD_DY, valid, dy[0]);
             const f32x4 da = dense_tile<1>(s_outT, 24, 16 * Q, dy, splat4(0.f));

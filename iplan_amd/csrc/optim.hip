@@ -36,8 +36,9 @@ __global__ __launch_bounds__(256) void adam_kernel(IplanAdamArgs a) {
     const float bc1 = a.bc1[net], bc2s = a.bc2_sqrt[net];
     const float step_size = a.lr / bc1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float g = a.grad[base + i] * scale;
+        float g = a.grad[base + i] * scale;
         if (a.write_clipped) a.grad[base + i] = g;
+        if (a.weight_decay != 0.f) g = fmaf(a.weight_decay, a.param[base + i], g);
         const float m = a.exp_avg[base + i] * a.beta1 + (1.0f - a.beta1) * g;
         const float v = a.exp_avg_sq[base + i] * a.beta2 + (1.0f - a.beta2) * g * g;
         a.exp_avg[base + i] = m;

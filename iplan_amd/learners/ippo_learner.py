@@ -140,10 +140,10 @@ class IPPOLearner:
         self._use_gae = args.use_gae
         self.gae_lambda = args.gae_lambda
         self._use_max_grad_norm = args.use_max_grad_norm
-        if (args.num_mini_batch != 1 or not args.use_gae or not args.use_huber_loss or not args.use_clipped_value_loss
+        if (not args.use_gae or not args.use_huber_loss or not args.use_clipped_value_loss
                 or not args.use_value_active_masks or not args.use_policy_active_masks):
-            raise NotImplementedError("iplan_amd implements the reference's shipped PPO configuration "
-                                      "(config/algs/ippo.yaml: 1 minibatch, GAE, clipped Huber value loss, active masks)")
+            raise NotImplementedError("iplan_amd implements the reference's shipped PPO loss configuration "
+                                      "(config/algs/ippo.yaml: GAE, clipped Huber value loss, active masks)")
 
         self.actor_params = mac.parameters()
         self.critic_params = mac.critic_parameters()
@@ -263,6 +263,10 @@ class IPPOLearner:
             tmp[:, :rows] = old_logp
             old_logp = tmp
 
+        if self.num_mini_batch > 1:
+            fin = self._train_minibatches(t_env, rows, last, ln_stats, old_logp, adv, returns, vpred, mask)
+            return fin if defer else (fin() and None)
+
         pl = L.PpoLossArgs()
         pl.n_agents, pl.rows, pl.row_stride = nA, rows, bs * T
         pl.old_logp, pl.adv, pl.value_preds = old_logp.data_ptr(), adv.data_ptr(), vpred.data_ptr()
@@ -308,6 +312,79 @@ class IPPOLearner:
                     self.logger.log_stat(self.log_prefix + k, v, t_env)
             return train_info
         return finish if defer else (finish() and None)
+
+    def _train_minibatches(self, t_env, rows, last, ln_stats, old_logp, adv, returns, vpred, mask):
+        """num_mini_batch > 1 (generate_data, learners/ippo_learner.py:368-424): every epoch draws a fresh ``randperm`` of the
+        rows per agent and steps the optimisers once per minibatch.  A minibatch is a set of INDEPENDENT rows (stored GRU
+        states, one step each), so the epoch's rows are gathered once, in permuted order, into contiguous per-agent staging
+        tensors (index plumbing: what the reference's ``obs[indices]`` does on the assembled 229 MB tensor, here on the raw
+        fields) and the fused kernels run on row ranges of those.  The permutations are drawn in the reference's order
+        (agent-major, one per epoch) from torch's global CPU generator."""
+        a, d, nA, mac = self.args, self.store.data, self.n_agents, self.mac
+        if self.dp is not None:
+            raise NotImplementedError("num_mini_batch > 1 is not wired into the data-parallel path")
+        dev = self.device
+        f32 = dict(dtype=th.float32, device=dev)
+        T, T1, nmb = self.episode_limit, self.episode_limit + 1, self.num_mini_batch
+        mbs = rows // nmb
+        perms = th.stack([th.stack([th.randperm(rows) for _ in range(self.ppo_epoch)]) for _ in range(nA)]).to(dev)   # [nA, epochs, rows]
+        ag = th.arange(nA, device=dev)[:, None]
+        lib = L.get_lib()
+        stream = L.current_stream(dev)
+        max_norm = self.max_grad_norm if self._use_max_grad_norm else None
+        stats = th.zeros(self.ppo_epoch * nmb, nA, 8, **f32)
+        norms = th.zeros(self.ppo_epoch * nmb, 2, nA, **f32)
+        widths = mac._widths()
+        avail_all = d["avail_actions"] if d["avail_actions"].dtype == th.int32 else d["avail_actions"].to(th.int32)
+        for ep in range(self.ppo_epoch):
+            idx = perms[:, ep, :mbs * nmb]                                   # [nA, n] rows of this epoch, minibatch-major
+            e_i, t_i = idx // T, idx % T
+            n = idx.shape[1]
+            src = [(d[k][e_i, t_i, ag].reshape(nA, n, -1).contiguous(), w) for k, w in widths]            # [nA, n, N*w]
+            la = last[e_i, t_i, ag].contiguous()                               # [nA, n] int32
+            ha, hc = d["rnn_states_actors"][e_i, t_i, ag].contiguous(), d["rnn_states_critics"][e_i, t_i, ag].contiguous()
+            av = avail_all[e_i, t_i, ag].contiguous()
+            ac = d["actions"][e_i, t_i, ag].contiguous()                       # [nA, n, 1] int64
+            lns = ln_stats.reshape(nA, -1, 2)[ag, e_i * T1 + t_i].contiguous()   # [nA, n, 2]
+            g = lambda x: x[ag, idx].contiguous()                             # noqa: E731  -- [nA, bs*T] per-row quantities
+            olp, adv_g, ret_g, vp_g, msk_g = g(old_logp), g(adv), g(returns), g(vpred), g(mask)
+            for i in range(nmb):
+                lo, hi = i * mbs, (i + 1) * mbs
+                spec = ops.AcFeatureSpec(a.max_vehicle_num, [(t[:, lo:hi], w, t.stride(0), t.stride(1)) for t, w in src],
+                                         n_actions=a.n_actions if a.obs_last_action else 0, last_action=la[:, lo:hi],
+                                         la_strides=(la.stride(0), 1), n_id=nA if a.obs_agent_id else 0, T=1, T_phys=1)
+                out = ops.ac_forward(mac.actor_arena, mac.critic_arena, 2, spec, mbs, nA, h_actor=ha[:, lo:hi], h_critic=hc[:, lo:hi],
+                                     h_strides=(ha.stride(0), ha.stride(1)), avail=av[:, lo:hi], avail_strides=(av.stride(0), av.stride(1)),
+                                     mode=2, actions_in=ac[:, lo:hi], act_strides=(ac.stride(0), ac.stride(1)), n_actions=a.n_actions,
+                                     ksplit=1, want_h=False, ln_stats=lns[:, lo:hi], ln_stats_mode=2, save=True, want_entropy=True)
+                pl = L.PpoLossArgs()
+                pl.n_agents, pl.rows, pl.row_stride = nA, mbs, n
+                pl.old_logp, pl.adv, pl.value_preds = olp[:, lo:hi].data_ptr(), adv_g[:, lo:hi].data_ptr(), vp_g[:, lo:hi].data_ptr()
+                pl.returns, pl.mask = ret_g[:, lo:hi].data_ptr(), msk_g[:, lo:hi].data_ptr()
+                pl.clip, pl.huber_delta, pl.value_loss_coef = self.clip_param, self.huber_delta, self.value_loss_coef
+                g_logp, g_v = th.empty(nA, mbs, **f32), th.empty(nA, mbs, **f32)
+                pl.g_logp, pl.g_values = g_logp.data_ptr(), g_v.data_ptr()
+                pl.logp, pl.entropy, pl.values = out["logp"].data_ptr(), out["entropy"].data_ptr(), out["values"].data_ptr()
+                k = ep * nmb + i
+                pl.stats = stats[k].data_ptr()
+                lib.call("iplan_ppo_loss", pl, stream)
+                ops.ac_backward(out, mac.actor_arena, mac.critic_arena, g_logp=g_logp, g_entropy=-self.entropy_coef / float(mbs), g_values=g_v)
+                norms[k, 0] = step_all(self.actor_optimizers, max_norm)[:, 0]
+                norms[k, 1] = step_all(self.critic_optimizers, max_norm)[:, 0]
+        self.store.clear()
+        st_d = stats.mean(dim=(0, 1))
+        nr_d = norms.sqrt().mean(dim=(0, 2)) if max_norm is not None else th.zeros(2, device=dev)
+
+        def finish():
+            st, nr = st_d.cpu(), nr_d.cpu()
+            train_info = {"value_loss": float(st[1]), "policy_loss": float(st[0]), "dist_entropy": float(st[3]),
+                          "actor_grad_norm": float(nr[0]), "critic_grad_norm": float(nr[1]), "ratio": float(st[2])}
+            self.last_train_info = train_info
+            if t_env - self.log_stats_t >= self.args.learner_log_interval:
+                for kk, v in train_info.items():
+                    self.logger.log_stat(self.log_prefix + kk, v, t_env)
+            return train_info
+        return finish
 
     # ------------------------------------------------------------------ reference-shaped single-agent methods
     # The fused train() above is the production path.  The methods below keep the reference's per-agent,

@@ -107,6 +107,11 @@ class Behavior_policy:
             return None
         return dp.all_reduce_sum(ops.beh_window_mask_sums(mask, self.max_history_len, hard=hard))
 
+    def _global_envs(self, E):
+        """envs the stability statistic is averaged over: this process's, times the data-parallel world size"""
+        dp = getattr(self, "dp", None)
+        return E * (dp.world if dp is not None else 1)
+
     def learn(self, batch, t_env, keep=None):
         """nova/stable_behavior_policy.py:161-279 for all agents at once: ONE persistent forward launch
         walks every (env, entity) chain through the T-1-L windows (decoder + encoder GRUs, soft latent
@@ -116,9 +121,6 @@ class Behavior_policy:
         generator seeded from torch's RNG.  Returns (behavior_loss, stability_loss, total_loss) lists."""
         a = self.args
         dev = self.device
-        if self.behavior_variation_penalty != 0:
-            raise NotImplementedError("iplan_amd implements iPLAN's shipped behavior_variation_penalty = 0 "
-                                      "(the stability term is reported, not differentiated)")
         history = batch["history"][:, :-1].to(device=dev, dtype=torch.float32)     # [E, T, nA, N, d]
         term = batch["terminated"][:, :-1].to(dev)                                 # [E, T, nA, 1]
         # mask polarity is env dependent in the reference (:190-193)
@@ -132,7 +134,7 @@ class Behavior_policy:
             fwd = ops.beh_forward(self.enc_arena, self.dec_arena, hist, mask, self.max_history_len, self.latent_dim,
                                   self.soft_update_coef, self.thres_small_variation, a.decoder_dropout, keep=keep, seed=seed,
                                   win_norm=self._global_window_sums(mask))
-            ops.beh_backward(self.enc_arena, self.dec_arena, fwd)
+            ops.beh_backward(self.enc_arena, self.dec_arena, fwd, penalty=self.behavior_variation_penalty, E_norm=self._global_envs(E))
             loss_dev = fwd["loss"]
         else:
             # Large batches (config 4's 256 envs on one GPU: 230 GB of BPTT records at once): env chunks run one after the
@@ -148,7 +150,8 @@ class Behavior_policy:
                                       self.latent_dim, self.soft_update_coef, self.thres_small_variation, a.decoder_dropout,
                                       keep=None if keep is None else keep[:, :, lo * N:hi * N].contiguous(),
                                       seed=seed + 0x9E3779B97F4A7C15 * c & (2 ** 63 - 1), win_norm=wn)
-                ops.beh_backward(self.enc_arena, self.dec_arena, fwd, accumulate=c > 0)
+                ops.beh_backward(self.enc_arena, self.dec_arena, fwd, accumulate=c > 0, penalty=self.behavior_variation_penalty,
+                                 E_norm=self._global_envs(E))
                 part = fwd["loss"] * torch.tensor([1.0, (hi - lo) / E], device=dev)      # the stability statistic is a mean over envs
                 loss_dev = part if loss_dev is None else loss_dev + part
                 del fwd

@@ -233,7 +233,8 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
     if h_out is not None:
         a.ho_s_net, a.ho_s_row = h_out[2]
     if ln_stats is not None and ln_stats_mode:
-        assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.shape[0] == n_agents and ln_stats.shape[2] == 2
+        assert (ln_stats.dtype == torch.float32 and ln_stats.shape[0] == n_agents and ln_stats.shape[2] == 2
+                and ln_stats.stride(2) == 1 and ln_stats.stride(1) == 2)          # rows contiguous (a row range of a larger buffer is fine)
         a.ln_stats, a.ln_stats_s_net, a.ln_stats_mode = ln_stats.data_ptr(), ln_stats.stride(0), ln_stats_mode
     if phase_clocks is not None:
         a.phase_clocks = phase_clocks.data_ptr()
@@ -680,7 +681,7 @@ def beh_window_mask_sums(mask, L_win, hard=False):
     return (cs[:, j + 1 + L_win] - cs[:, j + 1]).contiguous()
 
 
-def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, lib=None):
+def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_norm=0, lib=None):
     """BPTT of beh_forward's behaviour loss (behavior_variation_penalty == 0): fills both gradient arenas
     (``accumulate=True``: adds to them -- launches on disjoint env chunks of one batch, normalised by a shared ``win_norm``)."""
     lib = _lib(lib)
@@ -696,6 +697,7 @@ def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, lib=None):
     a.dsave_dec, a.dsave_lat, a.enc_part = dd.data_ptr(), dl.data_ptr(), ep.data_ptr()
     a.enc_grad, a.enc_grad_s_net = enc_arena.grad.data_ptr(), enc_arena.grad.stride(0)
     a.enc_grad_beta = 1.0 if accumulate else 0.0
+    a.penalty, a.E_norm = float(penalty), int(E_norm)      # behavior_variation_penalty: the stability term's weight in the loss
     SD, DD = L.BEH_SAVE_DEC, L.BEH_DSAVE_DEC
     n_in = J * Lw
     sd = fwd["saved_dec"].data_ptr()

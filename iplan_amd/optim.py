@@ -35,7 +35,7 @@ def grad_sqnorm(arena, nets, out, slot, lib=None):
         raise L.IplanError("iplan_grad_sqnorm: " + lib.c.iplan_last_error().decode())
 
 
-def adam_launch(arena, nets, steps, lr, betas, eps, sqnorm, slot, max_norm, write_clipped=True, lib=None):
+def adam_launch(arena, nets, steps, lr, betas, eps, sqnorm, slot, max_norm, write_clipped=True, weight_decay=0.0, lib=None):
     lib = lib or L.get_lib()
     m, v = _moments(arena)
     n0, cnt = nets
@@ -52,6 +52,7 @@ def adam_launch(arena, nets, steps, lr, betas, eps, sqnorm, slot, max_norm, writ
     a.max_norm = max_norm
     a.write_clipped = 1 if write_clipped else 0
     a.lr, a.beta1, a.beta2, a.eps = lr, betas[0], betas[1], eps
+    a.weight_decay = weight_decay
     for k in range(cnt):
         a.bc1[k] = 1.0 - betas[0] ** steps[k]
         a.bc2_sqrt[k] = math.sqrt(1.0 - betas[1] ** steps[k])
@@ -61,8 +62,6 @@ def adam_launch(arena, nets, steps, lr, betas, eps, sqnorm, slot, max_norm, writ
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, slices, lr, eps=1e-8, weight_decay=0, betas=(0.9, 0.999)):
         """slices: list of (arena, net) whose parameters this optimiser owns, in param order."""
-        if weight_decay != 0:
-            raise NotImplementedError("FusedAdam implements the reference's weight_decay = 0 configuration")
         self.slices = slices
         params = []
         for arena, net in slices:
@@ -88,7 +87,7 @@ class FusedAdam(torch.optim.Optimizer):
                 grad_sqnorm(arena, (net, 1), self._sq, k)
                 sq = self._sq
             adam_launch(arena, (net, 1), [self._steps], g["lr"], g["betas"], g["eps"], sq, k,
-                        max_norm if max_norm is not None else 0.0)
+                        max_norm if max_norm is not None else 0.0, weight_decay=g["weight_decay"])
 
     def grad_norms(self):
         """Pre-clip L2 norms of the slices (device tensor; read it lazily to avoid a sync)."""
@@ -136,7 +135,7 @@ class FusedAdam(torch.optim.Optimizer):
             m.copy_(st["exp_avg"])
             v.copy_(st["exp_avg_sq"])
             self._steps = int(float(st["step"]))
-        for k in ("lr", "betas", "eps"):
+        for k in ("lr", "betas", "eps", "weight_decay"):
             if k in sd["param_groups"][0]:
                 self.param_groups[0][k] = sd["param_groups"][0][k]
 
@@ -158,5 +157,5 @@ def step_all(optimizers, max_norm):
         if max_norm is not None:
             grad_sqnorm(arena, (0, n), sq, k)
         adam_launch(arena, (0, n), steps, g["lr"], g["betas"], g["eps"], sq if max_norm is not None else None, k,
-                    max_norm if max_norm is not None else 0.0)
+                    max_norm if max_norm is not None else 0.0, weight_decay=g["weight_decay"])
     return sq      # [n_agents, n_slices] squared pre-clip norms

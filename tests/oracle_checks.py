@@ -195,17 +195,25 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
     learner.batch_size_run = E
     learner.insert_episode_batch(batch)
     assert learner.buffers[0].can_sample()
+    torch.manual_seed(seed + 77)                               # generate_data's randperm draws (num_mini_batch > 1)
     learner.train(0)
+    index_lists = None
+    if args.num_mini_batch > 1:
+        torch.manual_seed(seed + 77)
+        rows, nmb = args.batch_size * args.episode_limit, args.num_mini_batch
+        mbs = rows // nmb
+        perms = [[torch.randperm(rows) for _ in range(args.ppo_epoch)] for _ in range(args.n_agents)]   # the reference's order
+        index_lists = [[[p[i * mbs:(i + 1) * mbs] for i in range(nmb)] for p in pa] for pa in perms]
     worst = dict(grad=0.0, post=0.0, fp32_oracle_grad_vs_fp64=0.0, fp32_oracle_post_vs_fp64=0.0)
     f64 = {k: (v.double() if v.is_floating_point() else v) for k, v in fields.items()}
     for i in (range(args.n_agents) if agents is None else agents):
         # ground truth = the oracle in fp64; the fp32 oracle (= the reference's arithmetic) is run beside it (when
         # ``also_fp32``) to record how far the reference's own fp32 rounding sits from it
         ap, cp = _req(pre["actors"][i], torch.float64), _req(pre["critics"][i], torch.float64)
-        O.ppo_train_agent(i, ap, cp, f64, args)
+        O.ppo_train_agent(i, ap, cp, f64, args, row_index_lists=None if index_lists is None else index_lists[i])
         if also_fp32:
             a32, c32 = _req(pre["actors"][i]), _req(pre["critics"][i])
-            O.ppo_train_agent(i, a32, c32, fields, args)
+            O.ppo_train_agent(i, a32, c32, fields, args, row_index_lists=None if index_lists is None else index_lists[i])
             for p32, p64 in ((a32, ap), (c32, cp)):
                 for k in p64:
                     if p64[k].grad is not None:

@@ -341,3 +341,40 @@ def test_behavior_learn_env_chunks_vs_oracle_emulated(monkeypatch):
     monkeypatch.setenv("IPLAN_BEH_ENV_CHUNK", "2")
     w = check_behavior_learn_vs_oracle(_small(), 5, "cpu", seed=13)
     assert w["grad"] < 1e-5, w
+
+
+def test_behavior_learn_with_stability_penalty_vs_oracle_emulated():
+    """behavior_variation_penalty != 0 (nova/stable_behavior_policy.py:238-246): the stability term is differentiated too"""
+    from tests.oracle_checks import check_behavior_learn_vs_oracle
+    w = check_behavior_learn_vs_oracle(_small(behavior_variation_penalty=0.3, thres_small_variation=0.05), 3, "cpu", seed=17)
+    assert w["grad"] < 1e-5, w
+
+
+def test_adam_weight_decay_emulated():
+    """weight_decay != 0 (torch.optim.Adam's L2 form, applied after the clip) against torch.optim.Adam itself"""
+    from iplan_amd.arena import ParamArena
+    from iplan_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    mods = [torch.nn.Linear(6, 4)]
+    ref = torch.nn.Linear(6, 4)
+    ref.load_state_dict(mods[0].state_dict())
+    arena = ParamArena(mods, "cpu")
+    opt = FusedAdam([(arena, 0)], lr=1e-2, eps=1e-5, weight_decay=0.05)
+    topt = torch.optim.Adam(ref.parameters(), lr=1e-2, eps=1e-5, weight_decay=0.05)
+    for step in range(3):
+        grads = [torch.randn_like(p) * 3 for p in ref.parameters()]
+        for p, q, gq in zip(mods[0].parameters(), ref.parameters(), grads):
+            p.grad.copy_(gq)
+            q.grad = gq.clone()
+        opt.step(max_norm=1.0)
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        topt.step()
+        for p, q in zip(mods[0].parameters(), ref.parameters()):
+            assert max_rel(p.detach(), q.detach()) < 1e-6
+
+
+def test_ppo_minibatches_vs_oracle_emulated():
+    """num_mini_batch > 1 (generate_data's randperm split, one optimiser step per minibatch): same permutations as the
+    reference draws them, post-train parameters and last-step gradients vs the oracle"""
+    from tests.oracle_checks import check_ppo_train_vs_oracle
+    check_ppo_train_vs_oracle(_small(num_mini_batch=3, ppo_epoch=2, episode_limit=10, batch_size=3), "cpu", seed=31)

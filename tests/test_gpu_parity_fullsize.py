@@ -98,3 +98,14 @@ def test_ippo_reference_shaped_methods_gpu(golden, tag):
 def test_ippo_train_unfilled_trailing_steps_gpu(golden):
     from tests.test_emu_learners import check_ippo_train_vs_oracle, unfilled_tail
     _log("ippo_train_unfilled_tail", dict(post=check_ippo_train_vs_oracle(golden("ippo_train"), "cuda", mutate=unfilled_tail)))
+
+
+def test_lifted_restrictions_vs_oracle_gpu():
+    """configurations the reference accepts beyond its shipped YAMLs: num_mini_batch > 1 (randperm minibatches),
+    behavior_variation_penalty != 0 (stability term differentiated), weight_decay != 0"""
+    from tests.oracle_checks import check_ppo_train_vs_oracle, check_behavior_learn_vs_oracle
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    a = _args(max_vehicle_num=9, n_agents=2, episode_limit=12, batch_size_run=4, buffer_size=6, batch_size=5, ppo_epoch=2, num_mini_batch=3)
+    _log("ppo_minibatches_3x2", check_ppo_train_vs_oracle(a, "cuda", seed=41))
+    b = _args(max_vehicle_num=9, n_agents=2, episode_limit=20, batch_size_run=4, behavior_variation_penalty=0.3, thres_small_variation=0.05)
+    _log("behavior_learn_penalty_0.3", check_behavior_learn_vs_oracle(b, 4, "cuda", seed=42))
