@@ -247,6 +247,13 @@ typedef struct {
     int32_t ln_stats_mode;
     int64_t* phase_clocks;      /* optional profiling aid: wall_clock64 of workgroup (0,0,0) at entry, after the
                                    LayerNorm statistics, after the fc1 contraction, at the end of the tail; NULL = off */
+    /* optional pre-packed fc1 operands (iplan_ac_pack_fc1): fc1.weight and feature_norm.{weight,bias} of every net in the
+     * kernels' own K order and MFMA fragment order, so that a wave's fragment load is ONE contiguous 1 KiB block instead of
+     * 64 scattered 64-byte pieces of a row-major [64, F] matrix (the rollout contraction was bound by exactly that:
+     * profiles/r02b_notes.md).  NULL = read the arena in place.  The caller repacks after every weight update.          */
+    const float* packed_actor;
+    const float* packed_critic;
+    int64_t packed_s_net;
 } IplanAcFwdArgs;
 
 int iplan_ac_fwd(const IplanAcFwdArgs* args, iplan_stream_t stream);
@@ -348,6 +355,19 @@ typedef struct {
     float* critic_grad;
     int64_t actor_grad_s_net, critic_grad_s_net;
 } IplanAcBwdArgs;
+
+/* iplan_ac_pack_fc1: packed[net] = { Wp [KT][4 o-tiles][64 lanes][4] | gamma_p [KT][16] | beta_p [KT][16] }, KT = iplan_ac_kpad / 16:
+ * Wp[T][oo][lane (n, g)][q] = fc1.weight[16 oo + n][column of k-order position 16 T + 4 g + q] (0 past a block's end).      */
+typedef struct {
+    int32_t n_nets;
+    IplanAcFeatures feat;        /* only N, w[], n_actions, n_id are read                             */
+    const float* params;
+    int64_t params_s_net, off_w1, off_fn_w, off_fn_b;
+    float* packed;
+    int64_t packed_s_net;        /* >= iplan_ac_packed_floats(feat)                                   */
+} IplanAcPackArgs;
+int64_t iplan_ac_packed_floats(const IplanAcFeatures* feat);
+int iplan_ac_pack_fc1(const IplanAcPackArgs* args, iplan_stream_t stream);
 
 int iplan_ac_kpad(const IplanAcFeatures* feat);   /* padded length of the kernels' source-major feature order */
 int iplan_ac_fc1_groups(const IplanAcFeatures* feat); /* wave jobs along the feature axis of iplan_ac_bwd_fc1 (the caller

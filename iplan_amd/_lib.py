@@ -50,8 +50,8 @@ class IplanError(RuntimeError):
 # every entry point include/iplan_hip.h declares
 ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step", "iplan_wgrad",
                 "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_adv_norm", "iplan_ppo_loss", "iplan_gat_bwd",
-                "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd", "iplan_mlp3_fwd", "iplan_mlp3_bwd", "iplan_seq2seq_fwd"]
-RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups", "iplan_sizeof"]      # non (args*, stream) signatures
+                "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd", "iplan_mlp3_fwd", "iplan_mlp3_bwd", "iplan_seq2seq_fwd", "iplan_ac_pack_fc1"]
+RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups", "iplan_sizeof", "iplan_ac_packed_floats"]      # non (args*, stream) signatures
 
 
 class Lib:
@@ -73,6 +73,8 @@ class Lib:
             getattr(cdll, name).restype = C.c_int
         cdll.iplan_sizeof.restype = C.c_size_t
         cdll.iplan_sizeof.argtypes = [C.c_char_p]
+        cdll.iplan_ac_packed_floats.restype = C.c_int64
+        cdll.iplan_ac_packed_floats.argtypes = [C.c_void_p]
         cdll.iplan_wgrad_workspace_floats.restype = C.c_size_t
         cdll.iplan_wgrad_workspace_floats.argtypes = [C.c_void_p]
 
@@ -179,7 +181,13 @@ class AcFwdArgs(C.Structure):
         ("ho_s_net", i64), ("ho_s_row", i64), ("ao_s_net", i64), ("ao_s_row", i64),
         ("onehot_out", fp), ("oh_s_net", i64), ("oh_s_row", i64),
         ("ln_stats", fp), ("ln_stats_s_net", i64), ("ln_stats_mode", i32), ("phase_clocks", fp),
+        ("packed_actor", fp), ("packed_critic", fp), ("packed_s_net", i64),
     ]
+
+
+class AcPackArgs(C.Structure):
+    _fields_ = [("n_nets", i32), ("feat", AcFeatures), ("params", fp), ("params_s_net", i64), ("off_w1", i64), ("off_fn_w", i64),
+                ("off_fn_b", i64), ("packed", fp), ("packed_s_net", i64)]
 
 
 # ---- optimiser -------------------------------------------------------------------------------------
@@ -331,4 +339,4 @@ STRUCT_MIRRORS = {"IplanGatSaved": GatSaved, "IplanGatFwdArgs": GatFwdArgs, "Ipl
                   "IplanEncFwdArgs": EncFwdArgs, "IplanAcNet": AcNet, "IplanAcFeatures": AcFeatures, "IplanAcFwdArgs": AcFwdArgs,
                   "IplanAcBwdArgs": AcBwdArgs, "IplanAdamArgs": AdamArgs, "IplanWgradProblem": WgradProblem,
                   "IplanWgradArgs": WgradArgs, "IplanPpoPrepareArgs": PpoPrepareArgs, "IplanPpoLossArgs": PpoLossArgs,
-                  "IplanPdecArgs": PdecArgs, "IplanBehArgs": BehArgs, "IplanMlp3Args": Mlp3Args, "IplanAdvNormArgs": AdvNormArgs, "IplanSeq2SeqArgs": Seq2SeqArgs}
+                  "IplanPdecArgs": PdecArgs, "IplanBehArgs": BehArgs, "IplanMlp3Args": Mlp3Args, "IplanAdvNormArgs": AdvNormArgs, "IplanSeq2SeqArgs": Seq2SeqArgs, "IplanAcPackArgs": AcPackArgs}

@@ -26,6 +26,7 @@ class ParamArena:
             off += (v.numel() + 3) // 4 * 4           # keep every tensor 16-byte aligned
         self.size = off
         self.trainable = {k: v.requires_grad for k, v in named}
+        self.version = 0          # bumped by every KERNEL-side write to ``data`` (Adam, collectives); torch-side writes bump data._version
         self.data = torch.zeros(self.n_nets, self.size, dtype=torch.float32, device=device)
         self.grad = torch.zeros_like(self.data)
         for i, m in enumerate(self.modules):
@@ -35,6 +36,11 @@ class ParamArena:
                 p.data = view
                 p.grad = self.grad[i, self.offsets[k]:self.offsets[k] + p.numel()].view(p.shape) \
                     if p.requires_grad else None
+            # module.load_state_dict copies into the views through ``.data`` (its own version counter): tell derived caches
+            m.register_load_state_dict_post_hook(lambda module, incompatible_keys: self._bump())
+
+    def _bump(self):
+        self.version += 1
 
     @property
     def net_stride(self):

@@ -34,6 +34,7 @@ class DcntrlMAC:
         for i in range(self.n_agents):
             self.agents[i].attach(self.actor_arena, i)
             self.critics[i].attach(self.critic_arena, i)
+        self.fc1_pack = ops.Fc1Pack(self.actor_arena, self.critic_arena)     # fragment-major fc1 operands, repacked when stale
         self.agent_output_type = args.agent_output_type
         self.hidden_states = None
         self.input_scheme = scheme
@@ -98,7 +99,8 @@ class DcntrlMAC:
         o = ops.ac_forward(self.actor_arena, self.critic_arena, 2, spec, E, nA, h_actor=ha, h_critic=hc,
                            h_strides=(ha.stride(1), ha.stride(0)), avail=avail,
                            avail_strides=(avail.stride(1), avail.stride(0)),
-                           mode=0 if test_mode else 1, q_noise=q_noise, n_actions=a.n_actions, phase_clocks=phase_clocks, **wb)
+                           mode=0 if test_mode else 1, q_noise=q_noise, n_actions=a.n_actions, phase_clocks=phase_clocks,
+                           packed=self.fc1_pack.get(spec), **wb)
         values = o["values"].t()                                          # [E, nA]
         logps = [o["logp"][i].reshape(E, 1) for i in range(nA)]
         if write_back:

@@ -41,6 +41,11 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     const KMap km = make_kmap(ft);
     const int F = km.NW + km.n_actions + km.n_id;
     const int KT = km.kt0[4];
+    // pre-packed fc1 operands (iplan_ac_pack_fc1): fragment-major weights, k-ordered LayerNorm(F) parameters
+    const float* __restrict__ pkw = which ? a.packed_critic : a.packed_actor;
+    if (pkw) pkw += (int64_t)net * a.packed_s_net;
+    const float* __restrict__ pkg = pkw ? pkw + (int64_t)KT * 1024 : nullptr;
+    const float* __restrict__ pkb = pkw ? pkg + (int64_t)KT * 16 : nullptr;
     // k-tiles are dealt round-robin to the ks cooperating waves (tile T belongs to wave T % ks): the slow tiles
     // (the gathered history block) are spread evenly instead of landing on one straggler wave
     const int T_lo = part, T_hi = KT, T_st = ks;
@@ -147,9 +152,15 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     };
     auto kload = [&](int T, KOps& o) {
         o.kt = ktile(km, T);
+        for (int t = 0; t < RT; ++t) o.x[t] = kfeat(km, o.kt, src[t], vld[t], last[t], net);
+        if (pkw) {
+            o.gm = *reinterpret_cast<const f32x4*>(pkg + T * 16 + 4 * g);
+            o.bt = *reinterpret_cast<const f32x4*>(pkb + T * 16 + 4 * g);
+            for (int oo = 0; oo < AT; ++oo) o.wf[oo] = *reinterpret_cast<const f32x4*>(pkw + ((int64_t)(T * AT + oo) * 64 + l) * 4);
+            return;
+        }
         o.gm = kcols(o.kt, fnw);
         o.bt = kcols(o.kt, fnb);
-        for (int t = 0; t < RT; ++t) o.x[t] = kfeat(km, o.kt, src[t], vld[t], last[t], net);
         for (int oo = 0; oo < AT; ++oo) o.wf[oo] = kcols(o.kt, W1 + (int64_t)(16 * oo + n) * F);
     };
     // folded variant of the normalisation: B operand = gamma o x (plus the [gamma beta] columns), statistics on the side
@@ -189,13 +200,19 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         f32x4 gm, bt, x[RT], wf[AT];
     };
     auto fload = [&](int T, int s, FOps& o) {
-        const int wS = km.w[s];
         const int f0 = 16 * (T - km.kt0[s]) + 4 * g;
+        for (int t = 0; t < RT; ++t) o.x[t] = ldu4(src[t][s] + f0);
+        if (pkw) {                                          // one contiguous 1 KiB block per fragment, 64 B for gamma / beta
+            o.gm = *reinterpret_cast<const f32x4*>(pkg + T * 16 + 4 * g);
+            o.bt = *reinterpret_cast<const f32x4*>(pkb + T * 16 + 4 * g);
+            for (int oo = 0; oo < AT; ++oo) o.wf[oo] = *reinterpret_cast<const f32x4*>(pkw + ((int64_t)(T * AT + oo) * 64 + l) * 4);
+            return;
+        }
+        const int wS = km.w[s];
         const int e = f0 / wS;
         const int c0 = e * km.W + km.off[s] + (f0 - e * wS);
         o.gm = ldu4(fnw + c0);
         o.bt = ldu4(fnb + c0);
-        for (int t = 0; t < RT; ++t) o.x[t] = ldu4(src[t][s] + f0);
         for (int oo = 0; oo < AT; ++oo) o.wf[oo] = ldu4(W1 + (int64_t)(16 * oo + n) * F + c0);
     };
     auto fmma = [&](const FOps& o) {
@@ -429,7 +446,45 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     if (clk) a.phase_clocks[3] = IPLAN_CLOCK();
 }
 
+// fc1.weight / feature_norm.{weight, bias} -> the forward kernels' K order and MFMA fragment order (see the header)
+__global__ __launch_bounds__(256) void ac_pack_fc1_kernel(IplanAcPackArgs a) {
+    const int T = (int)blockIdx.x, net = (int)blockIdx.y;
+    const KMap km = make_kmap(a.feat);
+    const int F = km.NW + km.n_actions + km.n_id, KT = km.kt0[4];
+    const float* __restrict__ P = a.params + (int64_t)net * a.params_s_net;
+    float* __restrict__ out = a.packed + (int64_t)net * a.packed_s_net;
+    for (int idx = (int)threadIdx.x; idx < 1024; idx += (int)blockDim.x) {
+        const int q = idx & 3, lane = (idx >> 2) & 63, oo = idx >> 8;
+        const int n = lane & 15, g = lane >> 4;
+        const KTile kt = ktile_at(km, T, 4 * g);
+        out[(int64_t)T * 1024 + idx] = q < kt.nv ? P[a.off_w1 + (int64_t)(16 * oo + n) * F + kt.c[q]] : 0.f;
+    }
+    if (threadIdx.x < 16) {
+        const int g = (int)threadIdx.x >> 2, q = (int)threadIdx.x & 3;
+        const KTile kt = ktile_at(km, T, 4 * g);
+        out[(int64_t)KT * 1024 + T * 16 + threadIdx.x] = q < kt.nv ? P[a.off_fn_w + kt.c[q]] : 0.f;
+        out[(int64_t)KT * 1040 + T * 16 + threadIdx.x] = q < kt.nv ? P[a.off_fn_b + kt.c[q]] : 0.f;
+    }
+}
+
 }  // namespace iplan
+
+extern "C" int64_t iplan_ac_packed_floats(const IplanAcFeatures* ft) {
+    if (!ft) return 0;
+    int t = 0;
+    for (int s = 0; s < 3; ++s) t += (ft->N * ft->w[s] + 15) / 16;
+    t += (ft->n_actions + ft->n_id + 15) / 16;
+    return (int64_t)t * (1024 + 32);
+}
+
+extern "C" int iplan_ac_pack_fc1(const IplanAcPackArgs* a, iplan_stream_t stream) {
+    using namespace iplan;
+    if (!a || a->n_nets < 1 || !a->params || !a->packed || a->packed_s_net < iplan_ac_packed_floats(&a->feat))
+        return fail(IPLAN_EINVAL, "iplan_ac_pack_fc1: bad arguments");
+    const int KT = (int)(iplan_ac_packed_floats(&a->feat) / (1024 + 32));
+    hipLaunchKernelGGL(ac_pack_fc1_kernel, dim3((unsigned)KT, (unsigned)a->n_nets), dim3(256), 0, (hipStream_t)stream, *a);
+    return check_launch("iplan_ac_pack_fc1");
+}
 
 extern "C" int iplan_ac_fwd(const IplanAcFwdArgs* a, iplan_stream_t stream) {
     using namespace iplan;

@@ -607,25 +607,29 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
             __syncthreads();
             // ---- part B: output tile Q of the two backward-data products over all 12 gate k-tiles
             f32x4 du = splat4(0.f), pd = splat4(0.f);
+            // k-tile kt = gate * 4 + T (columns gate * 64 + 16 T): B operands [dr dz dn_i] for W_ih^T, [dr dz dn_h] for W_hh^T,
+            // the own tile from registers, the others from the exchange slots; operands of k-tile kt + 1 are read from LDS
+            // while k-tile kt's MFMAs issue
+            auto b_ih = [&](int kt) { const int gate = kt >> 2, T = kt & 3;
+                                      return (T == Q) ? (gate == 0 ? o.dr : (gate == 1 ? o.dz : o.dni)) : get(gate * 4 + T); };
+            auto b_hn = [&](int T) { return (T == Q) ? o.dnh : get(3 * 4 + T); };
             f32x4 fa = wfrag_lds(s_wihT, TLD, 16 * Q, 0), fb = wfrag_lds(s_whhT, TLD, 16 * Q, 0);
-            for (int gate = 0; gate < 3; ++gate)
-                for (int T = 0; T < DT; ++T) {
-                    const int kt = gate * DT + T;                                        // k-tile: columns gate * 64 + 16 T
-                    f32x4 fan = fa, fbn = fb;
-                    if (kt + 1 < 3 * DT) {
-                        fan = wfrag_lds(s_wihT, TLD, 16 * Q, 16 * (kt + 1));
-                        fbn = wfrag_lds(s_whhT, TLD, 16 * Q, 16 * (kt + 1));
-                    }
-                    // B operands: [dr dz dn_i] for W_ih^T, [dr dz dn_h] for W_hh^T (own tile from registers)
-                    const f32x4 bi = (T == Q) ? (gate == 0 ? o.dr : (gate == 1 ? o.dz : o.dni)) : get(gate * 4 + T);
-                    const f32x4 bh = gate < 2 ? bi : ((T == Q) ? o.dnh : get(3 * 4 + T));
-                    for (int k = 0; k < 4; ++k) {
-                        du = mfma4(fa[k], bi[k], du);
-                        pd = mfma4(fb[k], bh[k], pd);
-                    }
-                    fa = fan;
-                    fb = fbn;
+            f32x4 bi = b_ih(0), bh = bi;
+#pragma unroll
+            for (int kt = 0; kt < 3 * DT; ++kt) {
+                f32x4 fan = fa, fbn = fb, bin = bi, bhn = bh;
+                if (kt + 1 < 3 * DT) {
+                    fan = wfrag_lds(s_wihT, TLD, 16 * Q, 16 * (kt + 1));
+                    fbn = wfrag_lds(s_whhT, TLD, 16 * Q, 16 * (kt + 1));
+                    bin = b_ih(kt + 1);
+                    bhn = (kt + 1) < 2 * DT ? bin : b_hn((kt + 1) & 3);
                 }
+                for (int k = 0; k < 4; ++k) {
+                    du = mfma4(fa[k], bi[k], du);
+                    pd = mfma4(fb[k], bh[k], pd);
+                }
+                fa = fan; fb = fbn; bi = bin; bh = bhn;
+            }
             f32x4 dup[1];
             for (int k = 0; k < 4; ++k) dup[0][k] = u_own[k] > 0.f ? du[k] : 0.f;
             st4<FULL>(dd_base, dof + 4u * (DD_DU + 16 * Q), valid, dup[0]);

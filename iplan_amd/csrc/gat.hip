@@ -50,7 +50,14 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
     const bool valid = node < N;
     const int64_t sb = (int64_t)net * a.B + b;
     const IplanGatSaved& sv = a.saved;
-    int64_t* clk = a.phase_clocks ? a.phase_clocks + (int64_t)blockIdx.x * 5 : nullptr;
+#ifdef GAT_P3_CLOCKS                   // profiling build (scripts/build_variants.sh): 6 more clocks inside phase 3
+    constexpr int CLK_STRIDE = 12;
+#define GAT_SUBCLK(i) do { if (clk && threadIdx.x == 0) clk[i] = IPLAN_CLOCK(); } while (0)
+#else
+    constexpr int CLK_STRIDE = 5;
+#define GAT_SUBCLK(i) do {} while (0)
+#endif
+    int64_t* clk = a.phase_clocks ? a.phase_clocks + (int64_t)blockIdx.x * CLK_STRIDE : nullptr;
     if (clk && threadIdx.x == 0) clk[0] = IPLAN_CLOCK();
 
     const float* bih = P + a.off[dir ? IPLAN_GAT_R_BIH : IPLAN_GAT_F_BIH];
@@ -227,6 +234,7 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
                 gz0[T][q] = ok ? gz[0] : 0.f;
                 gz1[T][q] = ok ? gz[1] : 0.f;
             }
+        GAT_SUBCLK(5);
         f32x4 sc[4];
         for (int T = 0; T < 4; ++T) sc[T] = splat4(0.f);
         for (int ks = 0; ks < GH / 4; ++ks) {
@@ -234,6 +242,7 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
             for (int T = 0; T < 4; ++T)
                 if (T < NT) sc[T] = mfma4(s_k[16 * T + n][4 * ks + g], qv, sc[T]);
         }
+        GAT_SUBCLK(6);
         float m = -INFINITY;
         for (int T = 0; T < 4; ++T)
             for (int q = 0; q < 4; ++q) {
@@ -254,6 +263,7 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
                 den += e;
             }
         den = group_sum(den);
+        GAT_SUBCLK(7);
         for (int T = 0; T < 4; ++T)
             for (int q = 0; q < 4; ++q) {
                 const int j = 16 * T + 4 * g + q;
@@ -273,6 +283,7 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
                 }
                 w[T][q] = ok ? soft * hard : 0.f;            // no renormalisation (GAT_Net.py:132)
             }
+        GAT_SUBCLK(8);
         for (int ct = 0; ct < 2; ++ct) {
             f32x4 xa = splat4(0.f);
             for (int T = 0; T < 4; ++T)
@@ -291,6 +302,7 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
             }
         }
     }
+    GAT_SUBCLK(9);
     __syncthreads();
     if (clk && threadIdx.x == 0) clk[3] = IPLAN_CLOCK();
 

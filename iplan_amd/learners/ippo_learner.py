@@ -224,7 +224,7 @@ class IPPOLearner:
         # computes them once and all 1 + 15 x 2 later passes re-use them
         ln_stats = th.empty(nA, bs * T1, 2, **f32)
         v_all = ops.ac_forward(None, mac.critic_arena, 1, spec_all, bs * T1, nA, h_critic=hc, h_strides=hs,
-                               ksplit=1, want_h=False, ln_stats=ln_stats, ln_stats_mode=1)["values"]
+                               ksplit=1, want_h=False, ln_stats=ln_stats, ln_stats_mode=1, packed=mac.fc1_pack.get(spec_all))["values"]
         rw, tm = d["reward"], d["terminated"]
         pp = L.PpoPrepareArgs()
         pp.n_agents, pp.bs, pp.T = nA, bs, T
@@ -257,7 +257,7 @@ class IPPOLearner:
         fwd_kw = dict(h_actor=ha, h_critic=hc, h_strides=hs, avail=avail, avail_strides=av_s, mode=2,
                       actions_in=actions, act_strides=act_s, n_actions=n_act, ksplit=1, want_h=False,
                       ln_stats=ln_stats, ln_stats_mode=2)
-        old_logp = ops.ac_forward(mac.actor_arena, None, 0, spec, rows, nA, **fwd_kw)["logp"]
+        old_logp = ops.ac_forward(mac.actor_arena, None, 0, spec, rows, nA, packed=mac.fc1_pack.get(spec), **fwd_kw)["logp"]
         if bs * T != rows:                                   # pad to the [nA, bs*T] stride of adv / returns
             tmp = th.zeros(nA, bs * T, **f32)
             tmp[:, :rows] = old_logp
@@ -284,7 +284,8 @@ class IPPOLearner:
             pl.mask_sum = msum.data_ptr()
             n_rows = float(self.dp_global_rows if self.dp_global_rows is not None else rows * self.dp.world)
         for ep in range(self.ppo_epoch):
-            out = ops.ac_forward(mac.actor_arena, mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True, **fwd_kw)
+            out = ops.ac_forward(mac.actor_arena, mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True,
+                                 packed=mac.fc1_pack.get(spec), **fwd_kw)         # repacked after every Adam step
             pl.logp, pl.entropy, pl.values = out["logp"].data_ptr(), out["entropy"].data_ptr(), out["values"].data_ptr()
             pl.stats = stats[ep].data_ptr()
             lib.call("iplan_ppo_loss", pl, stream)
@@ -356,7 +357,8 @@ class IPPOLearner:
                 out = ops.ac_forward(mac.actor_arena, mac.critic_arena, 2, spec, mbs, nA, h_actor=ha[:, lo:hi], h_critic=hc[:, lo:hi],
                                      h_strides=(ha.stride(0), ha.stride(1)), avail=av[:, lo:hi], avail_strides=(av.stride(0), av.stride(1)),
                                      mode=2, actions_in=ac[:, lo:hi], act_strides=(ac.stride(0), ac.stride(1)), n_actions=a.n_actions,
-                                     ksplit=1, want_h=False, ln_stats=lns[:, lo:hi], ln_stats_mode=2, save=True, want_entropy=True)
+                                     ksplit=1, want_h=False, ln_stats=lns[:, lo:hi], ln_stats_mode=2, save=True, want_entropy=True,
+                                     packed=mac.fc1_pack.get(spec))
                 pl = L.PpoLossArgs()
                 pl.n_agents, pl.rows, pl.row_stride = nA, mbs, n
                 pl.old_logp, pl.adv, pl.value_preds = olp[:, lo:hi].data_ptr(), adv_g[:, lo:hi].data_ptr(), vp_g[:, lo:hi].data_ptr()

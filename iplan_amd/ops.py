@@ -165,7 +165,8 @@ def _fill_acnet(dst, arena, order, n_out):
 def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=None, h_critic=None,
                h_strides=(0, 0), avail=None, avail_strides=(0, 0), mode=0, q_noise=None, actions_in=None,
                act_strides=(0, 0), n_actions=5, ksplit=None, save=False, want_probs=False, want_entropy=False,
-               want_h=True, h_out=None, actions_out=None, onehot_out=None, ln_stats=None, ln_stats_mode=0, phase_clocks=None, lib=None):
+               want_h=True, h_out=None, actions_out=None, onehot_out=None, ln_stats=None, ln_stats_mode=0, phase_clocks=None,
+               packed=None, lib=None):
     """Fused actor (which=0) / critic (1) / both (2) forward for all agents.
     Returns a dict with the requested outputs, each laid out [n_agents, rows, ...].
     Optional in-place destinations (rollout: write straight into the episode buffer):
@@ -238,14 +239,53 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
         a.ln_stats, a.ln_stats_s_net, a.ln_stats_mode = ln_stats.data_ptr(), ln_stats.stride(0), ln_stats_mode
     if phase_clocks is not None:
         a.phase_clocks = phase_clocks.data_ptr()
+    if packed is not None:                                 # FusedFc1Pack.get(): fragment-major fc1 operands of both arenas
+        pa, pc = packed
+        if which != 1:
+            a.packed_actor, a.packed_s_net = pa.data_ptr(), pa.stride(0)
+        if which != 0:
+            a.packed_critic, a.packed_s_net = pc.data_ptr(), pc.stride(0)
     if save:
         out["saved"] = torch.empty(2, n_agents, rows, L.AC_SAVE_FLOATS, **f32)
         a.saved = out["saved"].data_ptr()
     _launch("ac_fwd_kernel:train" if save else ("ac_fwd_kernel:rollout" if rows <= 512 else "ac_fwd_kernel:infer"),
             lambda: lib.call("iplan_ac_fwd", a, L.current_stream(dev)))
     out["_args"] = a
-    out["_keep"] = (spec, h_actor, h_critic, avail, q_noise, actions_in, h_out, actions_out, onehot_out, ln_stats)
+    out["_keep"] = (spec, h_actor, h_critic, avail, q_noise, actions_in, h_out, actions_out, onehot_out, ln_stats, packed)
     return out
+
+
+class Fc1Pack:
+    """fc1.weight + feature_norm.{weight, bias} of the actor and critic arenas in the forward kernels' own K order and MFMA
+    fragment order (iplan_ac_pack_fc1).  ``get(spec)`` repacks only when an arena changed since the last pack (torch-side
+    writes bump ``arena.data._version``, kernel-side writes -- Adam -- bump ``arena.version``) or the feature layout differs."""
+
+    def __init__(self, actor_arena, critic_arena):
+        self.arenas = (actor_arena, critic_arena)
+        self.buf = [None, None]
+        self.key = [None, None]
+
+    def get(self, spec, lib=None):
+        if os.environ.get("IPLAN_NO_FC1_PACK"):             # A/B knob: read the arena in place (scattered fragment loads)
+            return None
+        lib = _lib(lib)
+        a = L.AcPackArgs()
+        spec.fill(a.feat)
+        floats = int(lib.c.iplan_ac_packed_floats(C.byref(a.feat)))
+        sig = (spec.N, tuple(s[1] for s in spec.sources), spec.n_actions, spec.n_id)
+        for k, (arena, order) in enumerate(zip(self.arenas, (L.ACTOR_PARAM_ORDER, L.CRITIC_PARAM_ORDER))):
+            key = (arena.data._version, arena.version, sig)
+            if self.key[k] == key:
+                continue
+            if self.buf[k] is None or self.buf[k].shape[1] != floats:
+                self.buf[k] = torch.empty(arena.n_nets, floats, dtype=torch.float32, device=arena.data.device)
+            a.n_nets = arena.n_nets
+            a.params, a.params_s_net = arena.data.data_ptr(), arena.net_stride
+            a.off_w1, a.off_fn_w, a.off_fn_b = (arena.off(n) for n in ("base.mlp.fc1.0.weight", "base.feature_norm.weight", "base.feature_norm.bias"))
+            a.packed, a.packed_s_net = self.buf[k].data_ptr(), floats
+            lib.call("iplan_ac_pack_fc1", a, L.current_stream(arena.data.device))
+            self.key[k] = key
+        return self.buf[0], self.buf[1]
 
 
 # ---- weight gradients ----------------------------------------------------------------------------------

@@ -57,6 +57,7 @@ def adam_launch(arena, nets, steps, lr, betas, eps, sqnorm, slot, max_norm, writ
         a.bc1[k] = 1.0 - betas[0] ** steps[k]
         a.bc2_sqrt[k] = math.sqrt(1.0 - betas[1] ** steps[k])
     lib.call("iplan_adam_step", a, L.current_stream(arena.data.device))
+    arena.version += 1                                      # derived caches (ops.Fc1Pack) repack on the next use
 
 
 class FusedAdam(torch.optim.Optimizer):

@@ -28,6 +28,7 @@ class DataParallel:
 
     def broadcast_arena(self, arena, src=0):
         dist.broadcast(arena.data, src=src, group=self.group)
+        arena.version += 1
 
     def attach(self, loop):
         """Hook a SyntheticLoop-like object (``.mac``, ``.learner``, ``.behavior``, ``.prediction``): replicas

@@ -89,6 +89,15 @@ if not want or "ac_train_parts" in want:
     g1 = torch.randn(nA, rows, device=dev)
     tm("ac_backward(all)", lambda: ops.ac_backward(fo, loop.mac.actor_arena, loop.mac.critic_arena, g_logp=g1, g_entropy=-1e-6, g_values=g1), n=5)
 
+if "gat_phases12" in set(sys.argv[1:]):           # libraries built with -DGAT_P3_CLOCKS only
+    clk = torch.zeros(nA * E, 12, dtype=torch.int64, device=dev)
+    ops.gat_forward(loop.prediction.gat_arena, hist, lat, hid, noise, out=out, phase_clocks=clk)
+    torch.cuda.synchronize()
+    c = clk.cpu().double()
+    seq = c[:, [0, 1, 2, 5, 6, 7, 8, 9, 3, 4]]
+    print("gat clocks x10 ns, mean per WG: entry->p1->p2->[noise issued]->[score GEMM]->[softmax]->[gate]->[aggregate]->barrier->p4:",
+          (seq[:, 1:] - seq[:, :-1]).mean(0).tolist())
+
 if "gat_phases" in set(sys.argv[1:]):
     clk = torch.zeros(nA * E, 5, dtype=torch.int64, device=dev)
     ops.gat_forward(loop.prediction.gat_arena, hist, lat, hid, noise, out=out, phase_clocks=clk)
