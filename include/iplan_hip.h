@@ -356,7 +356,8 @@ typedef struct {
     int64_t actor_grad_s_net, critic_grad_s_net;
 } IplanAcBwdArgs;
 
-/* iplan_ac_pack_fc1: packed[net] = { Wp [KT][4 o-tiles][64 lanes][4] | gamma_p [KT][16] | beta_p [KT][16] }, KT = iplan_ac_kpad / 16:
+/* iplan_ac_pack_fc1: packed[net] = { Wp [KT][4 o-tiles][64 lanes][4] | gamma_p [KT][16] | beta_p [KT][16] | W gamma [64] | W beta [64] },
+ * KT = iplan_ac_kpad / 16 (the last two: fc1.weight x feature_norm.{weight, bias}, operands of the folded LayerNorm(F)):
  * Wp[T][oo][lane (n, g)][q] = fc1.weight[16 oo + n][column of k-order position 16 T + 4 g + q] (0 past a block's end).      */
 typedef struct {
     int32_t n_nets;

@@ -26,6 +26,19 @@ template <int RT>
 __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     __shared__ float s_red[8][16], s_red2[8][16], s_cc[8][2][AM];
     __shared__ __attribute__((aligned(16))) f32x4 s_acc[8][AT][64];
+    // Rollout shape (RT == 1, the 8 waves of a workgroup share ONE 16-row tile): the 64-wide tail runs in a single wave and
+    // was a chain of ~10 dependent stages, each waiting ~1 us for its weight fragments from L2 (15 us of a 52 us launch).
+    // All 8 waves therefore stage fc2 / GRU W_ih / head weights into LDS at kernel entry (the loads land during the fc1
+    // contraction) and share out the 12 tiles of  W_hh h + b_hh  (it does not depend on fc1); the tail wave then reads
+    // everything from LDS.  The streaming instantiation (RT == 2, one wave per tile pair) keeps reading L1/L2.
+    constexpr int TLDW = AM + 8;                                                  // conflict-free ds_read_b128 fragments
+#ifdef AC_NO_STAGED_TAIL                // A/B builds (scripts/build_variants.sh)
+    constexpr bool STAGED_BUILD = false;
+#else
+    constexpr bool STAGED_BUILD = RT == 1;
+#endif
+    __shared__ __attribute__((aligned(16))) float s_tw[STAGED_BUILD ? (AM + 3 * AM + 16) * TLDW : 4];      // fc2 | W_ih | head rows
+    __shared__ __attribute__((aligned(16))) f32x4 s_gh[STAGED_BUILD ? 3 * AT : 1][64];
 
     const int net = (int)blockIdx.y;
     const int which = a.which == 2 ? (int)blockIdx.z : a.which;       // 0 actor, 1 critic
@@ -46,6 +59,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     if (pkw) pkw += (int64_t)net * a.packed_s_net;
     const float* __restrict__ pkg = pkw ? pkw + (int64_t)KT * 1024 : nullptr;
     const float* __restrict__ pkb = pkw ? pkg + (int64_t)KT * 16 : nullptr;
+    const float* __restrict__ pkc = pkw ? pkb + (int64_t)KT * 16 : nullptr;      // (W gamma)[64] | (W beta)[64]
     // k-tiles are dealt round-robin to the ks cooperating waves (tile T belongs to wave T % ks): the slow tiles
     // (the gathered history block) are spread evenly instead of landing on one straggler wave
     const int T_lo = part, T_hi = KT, T_st = ks;
@@ -66,6 +80,27 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
             if (ft.last_action) last[t] = ft.last_action[(int64_t)net * ft.la_s_net + prr[t] * ft.la_s_row];
             else if (ft.last_action64) last[t] = (int)ft.last_action64[(int64_t)net * ft.la64_s_net + prr[t] * ft.la64_s_row];
         }
+    }
+
+    const bool staged = STAGED_BUILD && ks == 8 && groups == 1 && a.saved == nullptr;    // (training launches keep the gate records)
+    if (STAGED_BUILD && staged) {
+        // (a) 4352 16-byte chunks of [fc2.weight 64x64 | rnn.weight_ih 192x64 | head n_out x 64 (zero padded to 16 rows)]
+        const float* Wsrc[3] = {P + nw.off[IPLAN_AC_FC2_W], P + nw.off[IPLAN_AC_WIH], P + nw.off[IPLAN_AC_HEAD_W]};
+        for (int c = (int)threadIdx.x; c < (AM + 3 * AM + 16) * 16; c += 512) {
+            const int r = c >> 4, c4 = c & 15;
+            f32x4 v = splat4(0.f);
+            if (r < AM) v = *reinterpret_cast<const f32x4*>(Wsrc[0] + r * AM + 4 * c4);
+            else if (r < 4 * AM) v = *reinterpret_cast<const f32x4*>(Wsrc[1] + (r - AM) * AM + 4 * c4);
+            else if (r - 4 * AM < nw.n_out) v = *reinterpret_cast<const f32x4*>(Wsrc[2] + (r - 4 * AM) * AM + 4 * c4);
+            *reinterpret_cast<f32x4*>(&s_tw[r * TLDW + 4 * c4]) = v;
+        }
+        // (b) gh tile t = W_hh[16 t .. 16 t + 15] h + b_hh: tiles w and w + 8 of the 12
+        const float* hsrc0 = which ? a.h_critic : a.h_actor;
+        const float* hrow0 = hsrc0 + (int64_t)net * a.hs_net + prr[0] * a.hs_row;
+        f32x4 h0[AT];
+        for (int t = 0; t < AT; ++t) h0[t] = vload(hrow0, vld[0], AM, t);
+        for (int t = w; t < 3 * AT; t += 8)
+            s_gh[t][l] = dense_tile_ga<AT>(P + nw.off[IPLAN_AC_WHH], AM, 3 * AM, 16 * t, h0, bfrag_a(P + nw.off[IPLAN_AC_BHH], t));
     }
 
     // ---- LayerNorm(F) statistics, two passes (mean, then centred second moment) over L2-resident rows
@@ -177,10 +212,11 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         }
         for (int oo = 0; oo < AT; ++oo) {
             accs[0][oo] = mma_block(wf[oo], xg, accs[0][oo]);
-            for (int q = 0; q < 4; ++q) {                      // wf[oo] = W[16 oo + n][4g .. 4g+3] of this k-tile
-                c1a[oo] = fmaf(wf[oo][q], gz[q], c1a[oo]);
-                c2a[oo] = fmaf(wf[oo][q], bz[q], c2a[oo]);
-            }
+            if (!pkc)                                          // (packed operands carry W gamma, W beta precomputed)
+                for (int q = 0; q < 4; ++q) {                  // wf[oo] = W[16 oo + n][4g .. 4g+3] of this k-tile
+                    c1a[oo] = fmaf(wf[oo][q], gz[q], c1a[oo]);
+                    c2a[oo] = fmaf(wf[oo][q], bz[q], c2a[oo]);
+                }
         }
     };
     auto kmma = [&](const KOps& o) {
@@ -273,10 +309,11 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
             fsx = group_sum(fsx);
             fsxx = group_sum(fsxx);
             if (g == 0) { s_red[w][n] = fsx; s_red2[w][n] = fsxx; }
-            for (int t = 0; t < AT; ++t) {
-                const float c1 = group_sum(c1a[t]), c2 = group_sum(c2a[t]);
-                if (g == 0) { s_cc[w][0][16 * t + n] = c1; s_cc[w][1][16 * t + n] = c2; }
-            }
+            if (!pkc)
+                for (int t = 0; t < AT; ++t) {
+                    const float c1 = group_sum(c1a[t]), c2 = group_sum(c2a[t]);
+                    if (g == 0) { s_cc[w][0][16 * t + n] = c1; s_cc[w][1][16 * t + n] = c2; }
+                }
             __syncthreads();
             if (part == 0) {
                 float sx = 0.f, sxx = 0.f;
@@ -287,7 +324,8 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
                     for (int q = 0; q < 4; ++q) {
                         const int o = 16 * t + 4 * g + q;
                         float c1 = 0.f, c2 = 0.f;
-                        for (int p2 = 0; p2 < ks; ++p2) { c1 += s_cc[w + p2][0][o]; c2 += s_cc[w + p2][1][o]; }
+                        if (pkc) { c1 = pkc[o]; c2 = pkc[AM + o]; }
+                        else for (int p2 = 0; p2 < ks; ++p2) { c1 += s_cc[w + p2][0][o]; c2 += s_cc[w + p2][1][o]; }
                         accs[0][t][q] = rstd[0] * (accs[0][t][q] - mu[0] * c1) + c2;
                     }
             }
@@ -316,7 +354,8 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     if (sv) for (int t = 0; t < AT; ++t) vstore(sv + AM, valid, AM, t, f[t]);   // f1
     f32x4 f2[AT];
     for (int t = 0; t < AT; ++t) {
-        f2[t] = relu4(dense_tile_ga<AT>(P + nw.off[IPLAN_AC_FC2_W], AM, AM, 16 * t, f, bfrag_a(P + nw.off[IPLAN_AC_FC2_B], t)));
+        if (STAGED_BUILD && staged) f2[t] = relu4(dense_tile<AT>(s_tw, TLDW, 16 * t, f, bfrag_a(P + nw.off[IPLAN_AC_FC2_B], t)));
+        else f2[t] = relu4(dense_tile_ga<AT>(P + nw.off[IPLAN_AC_FC2_W], AM, AM, 16 * t, f, bfrag_a(P + nw.off[IPLAN_AC_FC2_B], t)));
         if (sv) vstore(sv + 2 * AM, valid, AM, t, f2[t]);             // a2
     }
     layer_norm_tiles<AT>(f2, P + nw.off[IPLAN_AC_LN2_W], P + nw.off[IPLAN_AC_LN2_B], &mu2, &rs2);
@@ -332,6 +371,14 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         const float* bi = P + nw.off[IPLAN_AC_BIH];
         const float* bh = P + nw.off[IPLAN_AC_BHH];
         for (int t = 0; t < AT; ++t) {
+            if (STAGED_BUILD && staged) {                    // W_ih from LDS, W_hh h + b_hh precomputed by the 8 waves
+                const float* sWi = s_tw + AM * TLDW;
+                const f32x4 pr_s = dense_tile<AT>(sWi, TLDW, 16 * t, f2, bfrag_a(bi, t) + s_gh[t][l]);
+                const f32x4 pz_s = dense_tile<AT>(sWi, TLDW, AM + 16 * t, f2, bfrag_a(bi, AT + t) + s_gh[AT + t][l]);
+                const f32x4 gn_s = dense_tile<AT>(sWi, TLDW, 2 * AM + 16 * t, f2, bfrag_a(bi, 2 * AT + t));
+                hnew[t] = gru_gates(pr_s, pz_s, gn_s, s_gh[2 * AT + t][l], h[t]).h;
+                continue;
+            }
             f32x4 prr = bfrag_a(bi, t) + bfrag_a(bh, t);
             f32x4 pz = bfrag_a(bi, AT + t) + bfrag_a(bh, AT + t);
             f32x4 gn = bfrag_a(bi, 2 * AT + t);
@@ -369,7 +416,9 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     }
     // ---- head
     const int n_out = nw.n_out;
-    const f32x4 lg = dense_tile_ga<AT>(P + nw.off[IPLAN_AC_HEAD_W], AM, n_out, 0, hnew, bfrag(P + nw.off[IPLAN_AC_HEAD_B], n_out, 0));
+    const f32x4 lg = (STAGED_BUILD && staged)
+        ? dense_tile<AT>(s_tw + 4 * AM * TLDW, TLDW, 0, hnew, bfrag(P + nw.off[IPLAN_AC_HEAD_B], n_out, 0))
+        : dense_tile_ga<AT>(P + nw.off[IPLAN_AC_HEAD_W], AM, n_out, 0, hnew, bfrag(P + nw.off[IPLAN_AC_HEAD_B], n_out, 0));
     const int64_t orow = (int64_t)net * a.rows + (valid ? r : 0);
     if (which == 1) {
         if (valid && g == 0 && a.values) a.values[orow] = lg[0];
@@ -467,6 +516,31 @@ __global__ __launch_bounds__(256) void ac_pack_fc1_kernel(IplanAcPackArgs a) {
     }
 }
 
+// (W gamma)[o], (W beta)[o] of fc1 / feature_norm for the folded LayerNorm(F) of the rollout forward
+// (fc1(LN(x)) = rstd (W (gamma o x) - mu W gamma) + W beta): one workgroup per net, fixed summation order
+__global__ __launch_bounds__(256) void ac_pack_wgamma_kernel(IplanAcPackArgs a) {
+    __shared__ float s_p[2][4][AM];
+    const int net = (int)blockIdx.x;
+    const KMap km = make_kmap(a.feat);
+    const int F = km.NW + km.n_actions + km.n_id, KT = km.kt0[4];
+    const float* __restrict__ P = a.params + (int64_t)net * a.params_s_net;
+    const int o = (int)threadIdx.x & 63, part = (int)threadIdx.x >> 6;
+    float c1 = 0.f, c2 = 0.f;
+    for (int c = part; c < F; c += 4) {
+        const float wv = P[a.off_w1 + (int64_t)o * F + c];
+        c1 = fmaf(wv, P[a.off_fn_w + c], c1);
+        c2 = fmaf(wv, P[a.off_fn_b + c], c2);
+    }
+    s_p[0][part][o] = c1;
+    s_p[1][part][o] = c2;
+    __syncthreads();
+    if (part == 0) {
+        float* out = a.packed + (int64_t)net * a.packed_s_net + (int64_t)KT * 1056;
+        out[o] = (s_p[0][0][o] + s_p[0][1][o]) + (s_p[0][2][o] + s_p[0][3][o]);
+        out[AM + o] = (s_p[1][0][o] + s_p[1][1][o]) + (s_p[1][2][o] + s_p[1][3][o]);
+    }
+}
+
 }  // namespace iplan
 
 extern "C" int64_t iplan_ac_packed_floats(const IplanAcFeatures* ft) {
@@ -474,15 +548,16 @@ extern "C" int64_t iplan_ac_packed_floats(const IplanAcFeatures* ft) {
     int t = 0;
     for (int s = 0; s < 3; ++s) t += (ft->N * ft->w[s] + 15) / 16;
     t += (ft->n_actions + ft->n_id + 15) / 16;
-    return (int64_t)t * (1024 + 32);
+    return (int64_t)t * (1024 + 32) + 2 * 64;              // + W gamma, W beta
 }
 
 extern "C" int iplan_ac_pack_fc1(const IplanAcPackArgs* a, iplan_stream_t stream) {
     using namespace iplan;
     if (!a || a->n_nets < 1 || !a->params || !a->packed || a->packed_s_net < iplan_ac_packed_floats(&a->feat))
         return fail(IPLAN_EINVAL, "iplan_ac_pack_fc1: bad arguments");
-    const int KT = (int)(iplan_ac_packed_floats(&a->feat) / (1024 + 32));
+    const int KT = (int)((iplan_ac_packed_floats(&a->feat) - 128) / (1024 + 32));
     hipLaunchKernelGGL(ac_pack_fc1_kernel, dim3((unsigned)KT, (unsigned)a->n_nets), dim3(256), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(ac_pack_wgamma_kernel, dim3((unsigned)a->n_nets), dim3(256), 0, (hipStream_t)stream, *a);
     return check_launch("iplan_ac_pack_fc1");
 }
 
