@@ -102,10 +102,40 @@ __device__ __forceinline__ float window_mask_sum(const IplanBehArgs& a, int net,
     return wave_sum(s) * (float)(a.N * a.d);
 }
 
-// x_t of window j for this lane's chain: history[e, j-(L-1)+t] or zeros (right-aligned window)
+// Zeroing a loaded value is a bitwise AND with an all-ones / zero lane mask, NOT `cond ? loaded : 0`: the compiler turns a
+// select whose operand is a load back into a branch around the load (and then waits for it on the spot).
+__device__ __forceinline__ float keep_if(bool ok, float v) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & (ok ? 0xFFFFFFFFu : 0u));
+}
+__device__ __forceinline__ f32x4 zero_unless(bool ok, f32x4 v) {
+    const uint32_t m = ok ? 0xFFFFFFFFu : 0u;
+    f32x4 r;
+    for (int q = 0; q < 4; ++q) r[q] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)v[q]) & m);
+    return r;
+}
+// entries 4g .. 4g+3 of a dim-wide row behind a per-lane pointer (any alignment), indices clamped to the row, NOT masked
+__device__ __forceinline__ f32x4 ld_row_raw(const float* __restrict__ row, int dim, int g) {
+    f32x4 v;
+    for (int q = 0; q < 4; ++q) {
+        const int i = 4 * g + q;
+        v[q] = row[i < dim ? i : dim - 1];
+    }
+    return v;
+}
+// ... `use` = false gives zeros
+__device__ __forceinline__ f32x4 ld_row_p(const float* __restrict__ row, int dim, int g, bool use) {
+    f32x4 v;
+    for (int q = 0; q < 4; ++q) {
+        const int i = 4 * g + q;
+        v[q] = keep_if(use && i < dim, row[i < dim ? i : dim - 1]);
+    }
+    return v;
+}
+
+// x_t of window j for this lane's chain: history[e, j-(L-1)+t] or zeros (right-aligned window); branch-free (see ld4 below)
 __device__ __forceinline__ f32x4 window_x(const IplanBehArgs& a, const float* __restrict__ hrow, int j, int t, bool valid) {
     const int st = beh_x_step(a, j, t);
-    return vload(hrow + (int64_t)(st < 0 ? 0 : st) * a.h_s_t, valid && st >= 0, a.d, 0);
+    return ld_row_p(hrow + (int64_t)(st < 0 ? 0 : st) * a.h_s_t, a.d, lane_id() >> 4, valid && st >= 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -270,23 +300,49 @@ __device__ __forceinline__ void dec_tile(const IplanBehArgs& a, DecTile& c, int 
     c.grow0 = (int64_t)c.net * c.rows + (int64_t)(c.live ? tile : 0) * 16;
 }
 
+// Loads are BRANCH-FREE: a lane that has nothing to fetch reads a clamped (in-bounds) address and the result is replaced by
+// zeros with a select.  A load under `if (lane condition)` becomes an exec-masked block, and the compiler's wait-count
+// placement around those blocks put `s_waitcnt vmcnt(0)` right behind the record prefetch of the BPTT step -- every step
+// then sat out a full HBM round trip plus the drain of its own row-gradient stores (profiles/r02d_notes.md).
 template <bool FULL>
 __device__ __forceinline__ f32x4 ld4(const char* __restrict__ base, uint32_t off, bool valid) {
-    if (FULL || valid) return *reinterpret_cast<const f32x4*>(base + off);
-    return splat4(0.f);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(base + ((FULL || valid) ? off : 0u));
+    return FULL ? v : zero_unless(valid, v);
+}
+// fetch only (clamped address, NO masking): for prefetches whose values are masked where they are consumed -- an AND
+// right behind the load would pull the wait for it up to the load
+template <bool FULL>
+__device__ __forceinline__ f32x4 ld4_raw(const char* __restrict__ base, uint32_t off, bool valid) {
+    return *reinterpret_cast<const f32x4*>(base + ((FULL || valid) ? off : 0u));
+}
+template <bool FULL>
+__device__ __forceinline__ f32x4 ld_row_raw(const char* __restrict__ base, uint32_t off, bool valid, int dim, int g) {
+    const uint32_t o = (FULL || valid) ? off : 0u;
+    f32x4 v;
+    for (int q = 0; q < 4; ++q) {
+        const int i = 4 * g + q;
+        v[q] = *reinterpret_cast<const float*>(base + (o + 4u * (uint32_t)(i < dim ? i : dim - 1)));
+    }
+    return v;
+}
+template <bool FULL>
+__device__ __forceinline__ float ld1(const char* __restrict__ base, uint32_t off, bool valid) {
+    const float v = *reinterpret_cast<const float*>(base + ((FULL || valid) ? off : 0u));
+    return FULL ? v : keep_if(valid, v);
 }
 template <bool FULL>
 __device__ __forceinline__ void st4(char* __restrict__ base, uint32_t off, bool valid, f32x4 v) {
     if (FULL || valid) *reinterpret_cast<f32x4*>(base + off) = v;
 }
-// the lane's (up to 4) entries 4g .. 4g+3 of a dim-wide row that is NOT 16-byte aligned (history rows: d = 5 floats)
+// the lane's (up to 4) entries 4g .. 4g+3 of a dim-wide row that is NOT 16-byte aligned (history rows: d = 5 floats);
+// `use` = false gives zeros (the address must still be a readable row)
 template <bool FULL>
-__device__ __forceinline__ f32x4 ld_row(const char* __restrict__ base, uint32_t off, bool valid, int dim, int g) {
-    f32x4 v = splat4(0.f);
-    if (FULL || valid) {
-        const float* p = reinterpret_cast<const float*>(base + off) + 4 * g;
-        for (int q = 0; q < 4; ++q)
-            if (4 * g + q < dim) v[q] = p[q];
+__device__ __forceinline__ f32x4 ld_row(const char* __restrict__ base, uint32_t off, bool valid, int dim, int g, bool use = true) {
+    const uint32_t o = (FULL || valid) ? off : 0u;          // (uniform base + 32-bit lane offset: the saddr form of global_load)
+    f32x4 v;
+    for (int q = 0; q < 4; ++q) {
+        const int i = 4 * g + q;
+        v[q] = keep_if(use && (FULL || valid) && i < dim, *reinterpret_cast<const float*>(base + (o + 4u * (uint32_t)(i < dim ? i : dim - 1))));
     }
     return v;
 }
@@ -321,23 +377,20 @@ __device__ __forceinline__ void dec_fwd_body(const IplanBehArgs& a, const DecTil
     const int64_t grow = c.grow0 + c.n;                      // this lane's chain (single-window mode addressing)
 
     // The Linear's input row [x_t || latent] as one tile: lane (n, g) holds columns 4g .. 4g+3 (x in [0, d), latent in [d, d+Z))
-    auto latent_shifted = [&](int j) {
-        f32x4 v = splat4(0.f);
-        if (FULL || valid) {
-            const float* lp = dec_only ? a.lat_in + grow * a.Z
-                                       : reinterpret_cast<const float*>(sl_base + sl_lane + (uint32_t)j * (uint32_t)(SVL * 4)) + 16;
-            for (int k = 0; k < 4; ++k) {
-                const int z = 4 * g + k - a.d;
-                if (z >= 0 && z < a.Z) v[k] = lp[z];
-            }
+    auto latent_shifted = [&](int j) {                       // (branch-free loads, see ld4)
+        const float* lp = dec_only ? a.lat_in + ((FULL || valid) ? grow : c.grow0) * a.Z
+                                   : reinterpret_cast<const float*>(sl_base + ((FULL || valid) ? sl_lane : 0u) + (uint32_t)j * (uint32_t)(SVL * 4)) + 16;
+        f32x4 v;
+        for (int k = 0; k < 4; ++k) {
+            const int z = 4 * g + k - a.d;
+            v[k] = keep_if((FULL || valid) && z >= 0 && z < a.Z, lp[z < 0 ? 0 : (z < a.Z ? z : a.Z - 1)]);
         }
         return v;
     };
     auto x_of = [&](int j, int t) {
         if (dec_only) return ld_row<FULL>(reinterpret_cast<const char*>(a.win), (uint32_t)((grow * Lw + t) * a.d * 4), valid, a.d, g);
-        const int st = beh_x_step(a, j, t);
-        if (st < 0) return splat4(0.f);
-        return ld_row<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)st * a.h_s_t * 4), valid, a.d, g);
+        const int st = beh_x_step(a, j, t);                  // < 0: left of the episode start (zeros)
+        return ld_row<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)(st < 0 ? 0 : st) * a.h_s_t * 4), valid, a.d, g, st >= 0);
     };
     auto u_own = [&](f32x4 xin) {                            // own tile of ReLU(Linear([x || latent]))
         f32x4 x1[1];
@@ -376,7 +429,7 @@ __device__ __forceinline__ void dec_fwd_body(const IplanBehArgs& a, const DecTil
             float m = 0.f;
             if (q == 0 && !dec_only) {
                 nx = ld_row<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)beh_y_step(a, j, t) * a.h_s_t * 4), valid, a.d, g);
-                if (FULL || valid) m = *reinterpret_cast<const float*>(c.mask + c.mask_lane + 4u * (uint32_t)beh_m_step(a, j, t));
+                m = ld1<FULL>(c.mask, c.mask_lane + 4u * (uint32_t)beh_m_step(a, j, t), valid);
             }
             if (q == 0) st4<FULL>(sd_base, so + 4u * SD_X, valid, xin);
             st4<FULL>(sd_base, so + 4u * (SD_U + 16 * q), valid, u[q]);
@@ -405,13 +458,13 @@ __device__ __forceinline__ void dec_fwd_body(const IplanBehArgs& a, const DecTil
             put(XF_H + q, o.h);
             if (q) put(XF_Y + q - 1, yp);
             if (has_next) put(XF_U + q, u_own(xin_next));
-            __syncthreads();
+            IPLAN_LDS_BARRIER();                             // (record stores stay in flight across the barrier)
             for (int i = 0; i < DT; ++i) h[i] = (i == q) ? o.h : get(XF_H + i);      // (q is a constant: no select)
             if (has_next)
                 for (int i = 0; i < DT; ++i) u[i] = get(XF_U + i);
             f32x4 y = yp;
             if (q == 0) y = (yp + get(XF_Y)) + (get(XF_Y + 1) + get(XF_Y + 2));
-            __syncthreads();
+            IPLAN_LDS_BARRIER();
             const f32x4 xt = xin;                            // columns >= d hold the latent: masked out below
             xin = xin_next;
             if (q) continue;                                 // the rest of the step (output, loss terms) is quarter 0's
@@ -527,24 +580,38 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
     struct StepIn {
         f32x4 r, z, n, hn, hp, u, y, nx, xc;
         float m;
+        bool first, has_xc;
     };
+    // straight-line fetch: no lane- or step-dependent branch around a load, no masking (mask_step does that at the top of
+    // the step that consumes the record, one MFMA phase later)
     auto load_step = [&](int j, int t, StepIn& o) {
         const uint32_t so = sd_lane + (uint32_t)(((int64_t)j * Lw + t) * SVD * 4);
-        const bool first = (j == 0 && t == 0);
-        o.r = ld4<FULL>(sd_base, so + 4u * (SD_R + 16 * Q), valid);
-        o.z = ld4<FULL>(sd_base, so + 4u * (SD_Z + 16 * Q), valid);
-        o.n = ld4<FULL>(sd_base, so + 4u * (SD_N + 16 * Q), valid);
-        o.hn = ld4<FULL>(sd_base, so + 4u * (SD_HN + 16 * Q), valid);
-        o.u = ld4<FULL>(sd_base, so + 4u * (SD_U + 16 * Q), valid);
-        o.hp = first ? splat4(0.f) : ld4<FULL>(sd_base, so - 4u * SVD + 4u * (SD_H + 16 * Q), valid);
-        o.y = ld4<FULL>(sd_base, so + 4u * SD_Y, valid);
-        o.nx = ld_row<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)beh_y_step(a, j, t) * a.h_s_t * 4), valid, a.d, g);
-        o.m = 0.f;
-        if (FULL || valid) o.m = *reinterpret_cast<const float*>(c.mask + c.mask_lane + 4u * (uint32_t)beh_m_step(a, j, t));
+        o.first = (j == 0 && t == 0);
+        o.r = ld4_raw<FULL>(sd_base, so + 4u * (SD_R + 16 * Q), valid);
+        o.z = ld4_raw<FULL>(sd_base, so + 4u * (SD_Z + 16 * Q), valid);
+        o.n = ld4_raw<FULL>(sd_base, so + 4u * (SD_N + 16 * Q), valid);
+        o.hn = ld4_raw<FULL>(sd_base, so + 4u * (SD_HN + 16 * Q), valid);
+        o.u = ld4_raw<FULL>(sd_base, so + 4u * (SD_U + 16 * Q), valid);
+        o.hp = ld4_raw<FULL>(sd_base, (o.first ? so : so - 4u * SVD) + 4u * (SD_H + 16 * Q), valid);   // h_{-1} = 0
+        o.y = ld4_raw<FULL>(sd_base, so + 4u * SD_Y, valid);
+        o.nx = ld_row_raw<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)beh_y_step(a, j, t) * a.h_s_t * 4), valid, a.d, g);
+        o.m = *reinterpret_cast<const float*>(c.mask + c.mask_lane + 4u * (uint32_t)beh_m_step(a, j, t));
+        o.has_xc = false;
         o.xc = splat4(0.f);
         if (a.penalty != 0.f) {                             // the stability term compares the prediction with the CURRENT window's step
             const int st = beh_x_step(a, j, t);
-            if (st >= 0) o.xc = ld_row<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)st * a.h_s_t * 4), valid, a.d, g);
+            o.has_xc = st >= 0;
+            o.xc = ld_row_raw<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)(st < 0 ? 0 : st) * a.h_s_t * 4), valid, a.d, g);
+        }
+    };
+    auto mask_step = [&](StepIn& o) {
+        o.hp = zero_unless(!o.first, o.hp);
+        for (int k = 0; k < 4; ++k) o.xc[k] = keep_if(o.has_xc && 4 * g + k < a.d, o.xc[k]);
+        if (!FULL) {
+            o.r = zero_unless(valid, o.r); o.z = zero_unless(valid, o.z); o.n = zero_unless(valid, o.n);
+            o.hn = zero_unless(valid, o.hn); o.u = zero_unless(valid, o.u); o.hp = zero_unless(valid, o.hp);
+            o.y = zero_unless(valid, o.y); o.nx = zero_unless(valid, o.nx); o.xc = zero_unless(valid, o.xc);
+            o.m = keep_if(valid, o.m);
         }
     };
     // stability term (stable_behavior_policy.py:238-246): penalty / J * sum max(||x_t - y_t|| - thres, 0) / (E L)
@@ -562,6 +629,7 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
         for (int t = Lw - 1; t >= 0; --t) {
             const uint32_t dof = dd_lane + (uint32_t)(((int64_t)j * Lw + t) * DSD * 4);
             // ---- part A: lane-local, consumes the step's record
+            mask_step(cur);
             f32x4 dy[1];
             for (int k = 0; k < 4; ++k) {
                 float v = 0.f;
@@ -582,7 +650,10 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
                 if ((FULL || valid) && nrm > a.thres)
                     for (int k = 0; k < 4; ++k) dy[0][k] -= pen * df[k] / nrm;
             }
-            if (Q == 0) st4<FULL>(dd_base, dof + 4u * DD_DY, valid, dy[0]);
+#ifndef BWD_ABL
+#define BWD_ABL 0                        // timing ablations (scripts/build_variants.sh): 1 no dd stores, 2 no record prefetch,
+#endif                                   // 3 no part-B MFMAs, 4 no second barrier, 5 no first barrier (results are WRONG under them)
+            if (Q == 0 && BWD_ABL != 1) st4<FULL>(dd_base, dof + 4u * DD_DY, valid, dy[0]);
             const f32x4 da = dense_tile<1>(s_outT, 24, 16 * Q, dy, splat4(0.f));
             const f32x4 km = keep_tile(a, net, j, c.row, t, Q, FULL || valid, c.rows);
             f32x4 dht;
@@ -591,10 +662,12 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
                 dht[k] = fmaf(da[k] * km[k] * inv_keep, 1.0f - th * th, dhd[k]);
             }
             const GruGrads o = gru_gates_bwd(dht, cur.r, cur.z, cur.n, cur.hn, cur.hp);
-            st4<FULL>(dd_base, dof + 4u * (DD_DR + 16 * Q), valid, o.dr);
-            st4<FULL>(dd_base, dof + 4u * (DD_DZ + 16 * Q), valid, o.dz);
-            st4<FULL>(dd_base, dof + 4u * (DD_DNI + 16 * Q), valid, o.dni);
-            st4<FULL>(dd_base, dof + 4u * (DD_DNH + 16 * Q), valid, o.dnh);
+            if (BWD_ABL != 1) {
+                st4<FULL>(dd_base, dof + 4u * (DD_DR + 16 * Q), valid, o.dr);
+                st4<FULL>(dd_base, dof + 4u * (DD_DZ + 16 * Q), valid, o.dz);
+                st4<FULL>(dd_base, dof + 4u * (DD_DNI + 16 * Q), valid, o.dni);
+                st4<FULL>(dd_base, dof + 4u * (DD_DNH + 16 * Q), valid, o.dnh);
+            }
             put(0 * 4 + Q, o.dr);
             put(1 * 4 + Q, o.dz);
             put(2 * 4 + Q, o.dni);
@@ -602,9 +675,11 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
             const f32x4 u_own = cur.u;
             hcur = cur.hp;                                  // h_{t-1}: the next step's "current" hidden state
             IPLAN_SCHED_FENCE();
-            if (t > 0) load_step(j, t - 1, cur);
-            else if (j > j_lo) load_step(j - 1, Lw - 1, cur);
-            __syncthreads();
+            if (BWD_ABL != 2) {                              // the last step re-reads its own record (no branch around the loads)
+                const bool wrap = t == 0, more = j > j_lo;
+                load_step(wrap && more ? j - 1 : j, wrap ? (more ? Lw - 1 : 0) : t - 1, cur);
+            }
+            if (BWD_ABL != 5) IPLAN_LDS_BARRIER();           // (the record prefetch and the row-gradient stores stay in flight)
             // ---- part B: output tile Q of the two backward-data products over all 12 gate k-tiles
             f32x4 du = splat4(0.f), pd = splat4(0.f);
             // k-tile kt = gate * 4 + T (columns gate * 64 + 16 T): B operands [dr dz dn_i] for W_ih^T, [dr dz dn_h] for W_hh^T,
@@ -624,24 +699,26 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
                     bin = b_ih(kt + 1);
                     bhn = (kt + 1) < 2 * DT ? bin : b_hn((kt + 1) & 3);
                 }
-                for (int k = 0; k < 4; ++k) {
-                    du = mfma4(fa[k], bi[k], du);
-                    pd = mfma4(fb[k], bh[k], pd);
-                }
+                if (BWD_ABL != 3)
+                    for (int k = 0; k < 4; ++k) {
+                        du = mfma4(fa[k], bi[k], du);
+                        pd = mfma4(fb[k], bh[k], pd);
+                    }
+                else { du += fa * bi; pd += fb * bh; }
                 fa = fan; fb = fbn; bi = bin; bh = bhn;
             }
             f32x4 dup[1];
             for (int k = 0; k < 4; ++k) dup[0][k] = u_own[k] > 0.f ? du[k] : 0.f;
-            st4<FULL>(dd_base, dof + 4u * (DD_DU + 16 * Q), valid, dup[0]);
+            if (BWD_ABL != 1) st4<FULL>(dd_base, dof + 4u * (DD_DU + 16 * Q), valid, dup[0]);
             dhd = o.dh_direct + pd;
             dlat = dense_tile_k<1>(s_latT, DLD, 0, 16 * Q, dup, dlat);                    // through the tiled latent input
-            __syncthreads();
+            if (BWD_ABL != 4) IPLAN_LDS_BARRIER();
         }
         // d(loss)/d(latent_j): sum of the four quarters' shares
         if (Q) put(Q - 1, dlat);
-        __syncthreads();
+        IPLAN_LDS_BARRIER();
         if (Q == 0) st4<FULL>(dl_base, dl_lane + (uint32_t)j * (uint32_t)(DSL * 4), valid, (dlat + get(0)) + (get(1) + get(2)));
-        __syncthreads();
+        IPLAN_LDS_BARRIER();
     }
     if (j_lo > 0 && carry) *reinterpret_cast<f32x4*>(carry + 4 * l) = dhd;
 }
@@ -729,6 +806,45 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
         for (int t = 0; t < ET; ++t) dhe[t] = *reinterpret_cast<const f32x4*>(carry + 256 * t + 4 * l);
         dlat = *reinterpret_cast<const f32x4*>(carry + 512 + 4 * l);
     }
+    // The forward's record of a step.  Loads are branch-free (see ld4): a lane without a chain reads chain 0 of its net.
+    struct EncIn {
+        f32x4 r[ET], z[ET], n[ET], hn[ET], u[ET], hp[ET], x;
+        bool first, has_x;
+    };
+    const bool ok = valid && live;
+    const float* rec0 = a.saved_enc + c.grow * J * a.L * SVE + 4 * g;          // this lane's column group of its chain's first record
+    // fetch only: the values are masked where they are consumed (mask_step) -- an AND behind the load would pull the wait for
+    // it up to the load
+    auto load_step = [&](int j, int t, EncIn& o) {
+        const int64_t step = (int64_t)j * a.L + t;
+        o.first = step == 0;
+        const float* se = rec0 + step * SVE;
+        const float* sp = o.first ? se : se - SVE;                             // h_{-1} = 0
+        for (int T = 0; T < ET; ++T) {
+            o.hp[T] = *reinterpret_cast<const f32x4*>(sp + SE_H + 16 * T);
+            o.u[T] = *reinterpret_cast<const f32x4*>(se + SE_U + 16 * T);
+            o.r[T] = *reinterpret_cast<const f32x4*>(se + SE_R + 16 * T);
+            o.z[T] = *reinterpret_cast<const f32x4*>(se + SE_Z + 16 * T);
+            o.n[T] = *reinterpret_cast<const f32x4*>(se + SE_N + 16 * T);
+            o.hn[T] = *reinterpret_cast<const f32x4*>(se + SE_HN + 16 * T);
+        }
+        const int st = beh_x_step(a, j, t);
+        o.has_x = st >= 0;
+        o.x = ld_row_raw(c.hrow + (int64_t)(st < 0 ? 0 : st) * a.h_s_t, a.d, g);
+    };
+    auto mask_step = [&](EncIn& o) {
+        for (int T = 0; T < ET; ++T) {
+            o.hp[T] = zero_unless(ok && !o.first, o.hp[T]);
+            o.u[T] = zero_unless(ok, o.u[T]);
+            o.r[T] = zero_unless(ok, o.r[T]);
+            o.z[T] = zero_unless(ok, o.z[T]);
+            o.n[T] = zero_unless(ok, o.n[T]);
+            o.hn[T] = zero_unless(ok, o.hn[T]);
+        }
+        for (int q = 0; q < 4; ++q) o.x[q] = keep_if(ok && o.has_x && 4 * g + q < a.d, o.x[q]);
+    };
+    EncIn cur;
+    load_step(j_hi - 1, a.L - 1, cur);
     for (int j = j_hi - 1; j >= j_lo; --j) {
         // ---- latent update + head backward (dlat = d(loss)/d(latent_{j+1}) on entry)
         f32x4 dlog[1], hL[ET];
@@ -751,25 +867,21 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
             }
             // dW_out += dlogit^T h_L
             park(0, dlog[0]); park(1, hL[0]); park(2, hL[1]);
-            __syncthreads();
+            IPLAN_LDS_BARRIER();
             for (int s4 = 0; s4 < 4; ++s4) {
                 const float av = pick(0, s4);
                 aOut[0] = mfma4(av, pick(1, s4), aOut[0]);
                 aOut[1] = mfma4(av, pick(2, s4), aOut[1]);
             }
-            __syncthreads();
+            IPLAN_LDS_BARRIER();
         }
         for (int t = a.L - 1; t >= 0; --t) {
-            const int64_t step = (c.grow * J + j) * a.L + t;
-            const bool first = (j == 0 && t == 0);
-            const float* se = a.saved_enc + step * SVE;
-            const bool ok = valid && live;
             f32x4 dg[4 * ET], dd[ET], u[ET], hp[ET];
+            mask_step(cur);
             for (int T = 0; T < ET; ++T) {
-                hp[T] = vload_a(se - SVE + SE_H, ok && !first, T);
-                u[T] = vload_a(se + SE_U, ok, T);
-                const GruGrads o = gru_gates_bwd(dhe[T], vload_a(se + SE_R, ok, T), vload_a(se + SE_Z, ok, T),
-                                                 vload_a(se + SE_N, ok, T), vload_a(se + SE_HN, ok, T), hp[T]);
+                hp[T] = cur.hp[T];
+                u[T] = cur.u[T];
+                const GruGrads o = gru_gates_bwd(dhe[T], cur.r[T], cur.z[T], cur.n[T], cur.hn[T], hp[T]);
                 dg[T] = o.dr; dg[ET + T] = o.dz; dg[2 * ET + T] = o.dni; dg[3 * ET + T] = o.dnh;
                 dd[T] = o.dh_direct;
             }
@@ -785,10 +897,14 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
                 bU[T] += dup[T];
             }
             // ---- weight gradients of this step
-            const f32x4 xt = window_x(a, c.hrow, j, t, ok);
             for (int k = 0; k < 8; ++k) park(k, dg[k]);
-            park(8, dup[0]); park(9, dup[1]); park(10, u[0]); park(11, u[1]); park(12, hp[0]); park(13, hp[1]); park(14, xt);
-            __syncthreads();
+            park(8, dup[0]); park(9, dup[1]); park(10, u[0]); park(11, u[1]); park(12, hp[0]); park(13, hp[1]); park(14, cur.x);
+            IPLAN_SCHED_FENCE();
+            {   // the next step's record is fetched under this step's 104 weight-gradient MFMAs (the last step re-reads its own)
+                const bool wrap = t == 0, more = j > j_lo;
+                load_step(wrap && more ? j - 1 : j, wrap ? (more ? a.L - 1 : 0) : t - 1, cur);
+            }
+            IPLAN_LDS_BARRIER();
             for (int s4 = 0; s4 < 4; ++s4) {
                 const float u0 = pick(10, s4), u1 = pick(11, s4), h0 = pick(12, s4), h1 = pick(13, s4), xv = pick(14, s4);
                 for (int o = 0; o < 6; ++o) {
@@ -802,7 +918,7 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
                 aLin[0] = mfma4(pick(8, s4), xv, aLin[0]);
                 aLin[1] = mfma4(pick(9, s4), xv, aLin[1]);
             }
-            __syncthreads();
+            IPLAN_LDS_BARRIER();
         }
     }
     if (!live) return;

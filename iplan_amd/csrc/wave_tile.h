@@ -41,6 +41,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define IPLAN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// Workgroup barrier that orders LDS traffic ONLY: `__syncthreads()` is fence + barrier, and the fence drains vmcnt -- every
+// global load / store in flight (the BPTT kernels prefetch the next step's record and stream their row gradients) is waited
+// for at every barrier, i.e. the HBM latency the prefetch was meant to hide is paid in full once or twice per step
+// (ablations in profiles/r02d_notes.md: the decoder BPTT spent 45 % of its time on its loads, 26 % on its stores).  The step
+// loops exchange data between waves through LDS alone, so they wait for their own LDS operations and nothing else.
+#ifdef IPLAN_HOST_EMULATION
+#define IPLAN_LDS_BARRIER() __syncthreads()
+#else
+#define IPLAN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 namespace iplan {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }

@@ -101,11 +101,14 @@ class Behavior_policy:
         return curr, nxt, m_curr, m_next
 
     def _global_window_sums(self, mask, hard=False):
-        """Data-parallel runs: the loss normalisers (mask sums per window) over ALL ranks' envs; None otherwise."""
+        """The loss normalisers (mask sums per window), over ALL ranks' envs in data-parallel runs.  Always handed to the
+        kernels: their in-kernel fallback re-sums E x L mask entries per window in every wave (a dependent-load loop that
+        cost the decoder kernels about a tenth of their time at 110 envs)."""
         dp = getattr(self, "dp", None)
-        if dp is None:
+        if dp is None and os.environ.get("IPLAN_BEH_KERNEL_WINSUM"):             # (timing experiments: the in-kernel sums)
             return None
-        return dp.all_reduce_sum(ops.beh_window_mask_sums(mask, self.max_history_len, hard=hard))
+        wn = ops.beh_window_mask_sums(mask, self.max_history_len, hard=hard)
+        return wn if dp is None else dp.all_reduce_sum(wn)
 
     def _global_envs(self, E):
         """envs the stability statistic is averaged over: this process's, times the data-parallel world size"""
@@ -141,8 +144,6 @@ class Behavior_policy:
             # other -- chains never interact; the loss normalisers are the window mask sums over ALL envs (and ranks), so
             # the chunk gradients simply add up in the arenas -- and one clip + Adam step follows.
             wn = self._global_window_sums(mask)
-            if wn is None:
-                wn = ops.beh_window_mask_sums(mask, self.max_history_len)
             loss_dev = None
             for c, lo in enumerate(range(0, E, chunk)):
                 hi = min(E, lo + chunk)

@@ -92,15 +92,18 @@ class ParallelRunner:
 
     # ------------------------------------------------------------------------------------------ host <-> device plumbing
     def _to_dev(self, name, array, dtype):
-        """numpy -> device through a pinned staging buffer (asynchronous on the current stream)."""
+        """numpy -> device through a pinned staging buffer (asynchronous on the current stream).  The dtype conversion is a
+        single-threaded numpy copy straight into the pinned pages (a torch copy_ of a few hundred KB fans out over every host
+        core: 0.9 ms per call on a 256-core box, profiles/r02b_runner_host_in_loop.txt)."""
         a = np.asarray(array)
         if self.device.type != "cuda":
             return torch.as_tensor(a).to(dtype)
         buf = self._pin.get(name)
-        if buf is None or buf.shape != a.shape or buf.dtype != dtype:
-            buf = self._pin[name] = torch.empty(a.shape, dtype=dtype, pin_memory=True)
-        buf.copy_(torch.as_tensor(a))                                   # host-side cast into the pinned buffer
-        return buf.to(self.device, non_blocking=True)
+        if buf is None or buf[0].shape != a.shape or buf[0].dtype != dtype:
+            t = torch.empty(a.shape, dtype=dtype, pin_memory=True)
+            buf = self._pin[name] = (t, t.numpy())
+        np.copyto(buf[1], a, casting="unsafe")
+        return buf[0].to(self.device, non_blocking=True)
 
     def _field(self, key):
         return self.batch[key]                                          # [E, T1, ...] tensor of the episode container

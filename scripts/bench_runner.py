@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--envs", type=int, default=32)
     opt = ap.parse_args()
     E = opt.envs
+    torch.set_num_threads(min(8, os.cpu_count() or 1))     # host work is small-array numpy / torch ops: no 256-thread fan-out
     args = default_args("highway", use_cuda=True, batch_size_run=E, n_obs_vehicles=15, device="cuda", animation_enable=False)
     args.obs_shape = args.obs_shape_single * args.n_obs_vehicles
     args.state_shape = args.obs_shape_single * args.max_vehicle_num

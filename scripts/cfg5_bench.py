@@ -27,16 +27,22 @@ PEAK = 157.3  # TFLOP/s fp32 MFMA (MI355X_MICROARCH.md)
 
 
 def timed(fn, n, warm=1):
+    """mean GPU time of fn() over n calls, each bracketed by its own events with a device synchronise in between: the BPTT
+    records of one call at these sizes are tens of GB that the caching allocator can only hand back once the side streams that
+    touched them are idle -- without the synchronise the next call pays hipMalloc for all of it (a benchmark artefact: the
+    training loop re-uses the blocks)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    tot = 0.0
     for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e-3
+        e1.record()
+        torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1)
+    return tot / n * 1e-3
 
 
 def gat_flops(n_nets, B, N, D, H=32, A=32):
