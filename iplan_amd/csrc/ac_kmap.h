@@ -14,7 +14,7 @@ namespace iplan {
 // math), and the matching weight / LayerNorm columns are  e*W + off_s + k  -- 4 consecutive columns
 // whenever w_s % 4 == 0 (attention 32, behaviour 8), per-element otherwise (history 5).
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ f32x4 ldu4(const float* __restrict__ p) { return *reinterpret_cast<const f32x4_u*>(p); }
+__device__ __forceinline__ f32x4 ldu4(const float* __restrict__ p) { return *(const IPLAN_GLOBAL_AS f32x4_u*)p; }
 
 struct KMap {
     int kt0[5];        // first k-tile of block 0..3, and the total
@@ -99,7 +99,7 @@ __device__ __forceinline__ f32x4 kfeat(const KMap& k, const KTile& kt, const flo
     if (kt.s < 3) {
         const float* p = src[kt.s] + kt.f0;
         if (kt.nv == 4) v = ldu4(p);
-        else for (int q = 0; q < 4; ++q) if (q < kt.nv) v[q] = p[q];
+        else for (int q = 0; q < 4; ++q) if (q < kt.nv) v[q] = as_global(p)[q];
     } else {
         for (int q = 0; q < 4; ++q) {
             const int idx = kt.f0 + q;
@@ -113,7 +113,7 @@ __device__ __forceinline__ f32x4 kfeat(const KMap& k, const KTile& kt, const flo
 __device__ __forceinline__ f32x4 kcols(const KTile& kt, const float* __restrict__ vec) {
     f32x4 v = splat4(0.f);
     if (kt.nv == 4 && kt.contig) return ldu4(vec + kt.c[0]);
-    for (int q = 0; q < 4; ++q) if (q < kt.nv) v[q] = vec[kt.c[q]];
+    for (int q = 0; q < 4; ++q) if (q < kt.nv) v[q] = as_global(vec)[kt.c[q]];
     return v;
 }
 

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     const IplanAcNet& nw = which ? a.critic : a.actor;
     const float* __restrict__ P = nw.params + (int64_t)net * nw.params_s_net;
     const IplanAcFeatures& ft = a.feat;
-    const int l = lane_id(), w = wave_id(), n = l & 15, g = l >> 4;
+    const int l = lane_id(), w = uniform_i(wave_id()), n = l & 15, g = l >> 4;
     const int ks = RT == 1 ? a.ksplit : 1;
     const int groups = 8 / ks;
     const int part = w % ks;
@@ -265,19 +265,40 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     constexpr int PF = AC_PF;
     for (int s = 0; s < 4; ++s) {
         // this wave's tiles of block s: T in [b_lo, b_hi) with T % T_st == part; the fast ones are below f_hi
-        const int b_end = imin(T_hi, km.kt0[s + 1]);
-        int b_lo = km.kt0[s] + ((part - km.kt0[s]) % T_st + T_st) % T_st;           // first owned tile of the block
+        // (km's arrays are indexed by the loop counter and live in scratch: what comes back is a VGPR, and loop bounds in
+        // VGPRs make every branch below a divergent one -- exec-masked loads, wait counters drained at each join.  Through
+        // SGPRs the ring keeps its PF k-tiles of loads in flight.)
+        const int kt0s = uniform_i(km.kt0[s]);
+        const int b_end = imin(T_hi, uniform_i(km.kt0[s + 1]));
+        const int b_lo = kt0s + ((part - kt0s) % T_st + T_st) % T_st;               // first owned tile of the block
         if (b_lo >= b_end) continue;
         int f_hi = b_lo;
-        if (s < 3 && (km.w[s] & 3) == 0 && src[0][s] != nullptr) f_hi = imin(b_end, km.kt0[s] + km.len[s] / 16);
+        if (s < 3 && (uniform_i(km.w[s]) & 3) == 0 && uniform_i(ft.w[s]) > 0) f_hi = imin(b_end, kt0s + uniform_i(km.len[s]) / 16);
         int T_slow = b_lo;
         if (f_hi > b_lo) {
             FOps ring[PF];
-            for (int i = 0; i < PF; ++i)
-                if (b_lo + i * T_st < f_hi) fload(b_lo + i * T_st, s, ring[i]);
+            int T = b_lo;
+            // Steady state: while a whole round of PF tiles AND their PF successors exist, every load of the round is
+            // unconditional -- only then does the number of loads in flight not depend on the path taken, and only then can
+            // the compiler wait for the OLDEST ring slot alone (vmcnt(2 slots)) instead of draining everything (vmcnt(0))
+            // at the top of each round.  The ragged end of the block runs through the guarded round below.
+            if (b_lo + (2 * PF - 1) * T_st < f_hi) {
+                for (int i = 0; i < PF; ++i) fload(b_lo + i * T_st, s, ring[i]);
+                IPLAN_SCHED_FENCE();
+                for (; T + (2 * PF - 1) * T_st < f_hi; T += PF * T_st) {
+                    for (int i = 0; i < PF; ++i) {
+                        fmma(ring[i]);
+                        IPLAN_SCHED_FENCE();
+                        fload(T + (i + PF) * T_st, s, ring[i]);
+                        IPLAN_SCHED_FENCE();
+                    }
+                }
+            } else {
+                for (int i = 0; i < PF; ++i)
+                    if (b_lo + i * T_st < f_hi) fload(b_lo + i * T_st, s, ring[i]);
+            }
             IPLAN_SCHED_FENCE();                            // keep the prefetches where they are: the scheduler would
-            int T = b_lo;                                   // otherwise sink every load next to its use
-            for (; T < f_hi; T += PF * T_st) {
+            for (; T < f_hi; T += PF * T_st) {              // otherwise sink every load next to its use
                 for (int i = 0; i < PF; ++i) {
                     if (T + i * T_st < f_hi) {
                         fmma(ring[i]);

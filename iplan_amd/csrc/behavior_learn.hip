@@ -257,13 +257,6 @@ __global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
 constexpr int DEC_TILES = 3;
 constexpr int DEC_THREADS = 256 * DEC_TILES;
 
-__device__ __forceinline__ int uniform_i(int v) {
-#ifdef IPLAN_HOST_EMULATION
-    return v;
-#else
-    return __builtin_amdgcn_readfirstlane(v);
-#endif
-}
 
 // per-wave view of one chain tile of the decoder kernels
 struct DecTile {
@@ -326,23 +319,20 @@ __device__ __forceinline__ f32x4 ld_row_raw(const char* __restrict__ base, uint3
     return v;
 }
 template <bool FULL>
-__device__ __forceinline__ float ld1(const char* __restrict__ base, uint32_t off, bool valid) {
-    const float v = *reinterpret_cast<const float*>(base + ((FULL || valid) ? off : 0u));
-    return FULL ? v : keep_if(valid, v);
-}
-template <bool FULL>
 __device__ __forceinline__ void st4(char* __restrict__ base, uint32_t off, bool valid, f32x4 v) {
     if (FULL || valid) *reinterpret_cast<f32x4*>(base + off) = v;
 }
-// the lane's (up to 4) entries 4g .. 4g+3 of a dim-wide row that is NOT 16-byte aligned (history rows: d = 5 floats);
-// `use` = false gives zeros (the address must still be a readable row)
+// the lane's (up to 4) entries 4g .. 4g+3 of a dim-wide row that is NOT 16-byte aligned (history rows: d = 5 floats).
+// Predicated variant (loads under lane conditions).  The decoder FORWARD keeps it: its history loads have a whole MFMA phase
+// between issue and use either way, and the clamped-index / mask arithmetic of the branch-free form cost it 5 % (same-box A/B,
+// profiles/r02d_notes.md).
 template <bool FULL>
-__device__ __forceinline__ f32x4 ld_row(const char* __restrict__ base, uint32_t off, bool valid, int dim, int g, bool use = true) {
-    const uint32_t o = (FULL || valid) ? off : 0u;          // (uniform base + 32-bit lane offset: the saddr form of global_load)
-    f32x4 v;
-    for (int q = 0; q < 4; ++q) {
-        const int i = 4 * g + q;
-        v[q] = keep_if(use && (FULL || valid) && i < dim, *reinterpret_cast<const float*>(base + (o + 4u * (uint32_t)(i < dim ? i : dim - 1))));
+__device__ __forceinline__ f32x4 ld_row_br(const char* __restrict__ base, uint32_t off, bool valid, int dim, int g) {
+    f32x4 v = splat4(0.f);
+    if (FULL || valid) {
+        const float* p = reinterpret_cast<const float*>(base + off) + 4 * g;
+        for (int q = 0; q < 4; ++q)
+            if (4 * g + q < dim) v[q] = p[q];
     }
     return v;
 }
@@ -377,20 +367,23 @@ __device__ __forceinline__ void dec_fwd_body(const IplanBehArgs& a, const DecTil
     const int64_t grow = c.grow0 + c.n;                      // this lane's chain (single-window mode addressing)
 
     // The Linear's input row [x_t || latent] as one tile: lane (n, g) holds columns 4g .. 4g+3 (x in [0, d), latent in [d, d+Z))
-    auto latent_shifted = [&](int j) {                       // (branch-free loads, see ld4)
-        const float* lp = dec_only ? a.lat_in + ((FULL || valid) ? grow : c.grow0) * a.Z
-                                   : reinterpret_cast<const float*>(sl_base + ((FULL || valid) ? sl_lane : 0u) + (uint32_t)j * (uint32_t)(SVL * 4)) + 16;
-        f32x4 v;
-        for (int k = 0; k < 4; ++k) {
-            const int z = 4 * g + k - a.d;
-            v[k] = keep_if((FULL || valid) && z >= 0 && z < a.Z, lp[z < 0 ? 0 : (z < a.Z ? z : a.Z - 1)]);
+    auto latent_shifted = [&](int j) {
+        f32x4 v = splat4(0.f);
+        if (FULL || valid) {
+            const float* lp = dec_only ? a.lat_in + grow * a.Z
+                                       : reinterpret_cast<const float*>(sl_base + sl_lane + (uint32_t)j * (uint32_t)(SVL * 4)) + 16;
+            for (int k = 0; k < 4; ++k) {
+                const int z = 4 * g + k - a.d;
+                if (z >= 0 && z < a.Z) v[k] = lp[z];
+            }
         }
         return v;
     };
     auto x_of = [&](int j, int t) {
-        if (dec_only) return ld_row<FULL>(reinterpret_cast<const char*>(a.win), (uint32_t)((grow * Lw + t) * a.d * 4), valid, a.d, g);
-        const int st = beh_x_step(a, j, t);                  // < 0: left of the episode start (zeros)
-        return ld_row<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)(st < 0 ? 0 : st) * a.h_s_t * 4), valid, a.d, g, st >= 0);
+        if (dec_only) return ld_row_br<FULL>(reinterpret_cast<const char*>(a.win), (uint32_t)((grow * Lw + t) * a.d * 4), valid, a.d, g);
+        const int st = beh_x_step(a, j, t);
+        if (st < 0) return splat4(0.f);
+        return ld_row_br<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)st * a.h_s_t * 4), valid, a.d, g);
     };
     auto u_own = [&](f32x4 xin) {                            // own tile of ReLU(Linear([x || latent]))
         f32x4 x1[1];
@@ -428,8 +421,8 @@ __device__ __forceinline__ void dec_fwd_body(const IplanBehArgs& a, const DecTil
             f32x4 nx = splat4(0.f);
             float m = 0.f;
             if (q == 0 && !dec_only) {
-                nx = ld_row<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)beh_y_step(a, j, t) * a.h_s_t * 4), valid, a.d, g);
-                m = ld1<FULL>(c.mask, c.mask_lane + 4u * (uint32_t)beh_m_step(a, j, t), valid);
+                nx = ld_row_br<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)beh_y_step(a, j, t) * a.h_s_t * 4), valid, a.d, g);
+                if (FULL || valid) m = *reinterpret_cast<const float*>(c.mask + c.mask_lane + 4u * (uint32_t)beh_m_step(a, j, t));
             }
             if (q == 0) st4<FULL>(sd_base, so + 4u * SD_X, valid, xin);
             st4<FULL>(sd_base, so + 4u * (SD_U + 16 * q), valid, u[q]);

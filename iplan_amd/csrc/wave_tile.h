@@ -163,6 +163,28 @@ __device__ __forceinline__ f32x4 bfrag(const float* __restrict__ b, int dim, int
     return v;
 }
 
+// Pointers that went through a local array (indexed at run time -> scratch) come back as GENERIC pointers: loads through
+// them are flat_load, which counts on vmcnt AND lgkmcnt and forces `s_waitcnt vmcnt(0) lgkmcnt(0)` before any use -- a
+// software-pipelined ring of loads is then drained completely every round.  Everything the kernels read is global memory.
+#ifdef IPLAN_HOST_EMULATION
+#define IPLAN_GLOBAL_AS
+#else
+#define IPLAN_GLOBAL_AS __attribute__((address_space(1)))
+#endif
+template <class T>
+__device__ __forceinline__ const IPLAN_GLOBAL_AS T* as_global(const T* p) { return (const IPLAN_GLOBAL_AS T*)p; }
+
+// A wave-uniform value the compiler cannot prove uniform (anything derived from threadIdx.x, like the wave index): through
+// an SGPR.  Branches and loop bounds on it become scalar branches -- with a "divergent" condition every load inside turns
+// into an exec-masked block and the wait counters are drained at each join.
+__device__ __forceinline__ int uniform_i(int v) {
+#ifdef IPLAN_HOST_EMULATION
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
 // Load tile t of a per-chain vector from a row pointer (one row per chain); `valid` = chain exists.
 __device__ __forceinline__ f32x4 vload(const float* __restrict__ row, bool valid, int dim, int t) {
     const int c = 16 * t + 4 * (lane_id() >> 4);

@@ -86,6 +86,19 @@ if not want or "ac_train_parts" in want:
     tm("ac_fwd_train(infer)", lambda: ops.ac_forward(loop.mac.actor_arena, loop.mac.critic_arena, 2, spec, rows, nA, **kw), n=5)
     tm("ac_fwd_train(save)", lambda: ops.ac_forward(loop.mac.actor_arena, loop.mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True, **kw), n=5)
     fo = ops.ac_forward(loop.mac.actor_arena, loop.mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True, **kw)
+    # what a PPO epoch launches: cached LayerNorm(F) statistics (mode 2) and the pre-packed fc1 operands
+    lns = torch.empty(nA, args.batch_size * (T + 1), 2, device=dev)
+    pk = loop.mac.fc1_pack.get(spec)
+    ops.ac_forward(loop.mac.actor_arena, loop.mac.critic_arena, 2, spec, rows, nA, ln_stats=lns, ln_stats_mode=1, packed=pk, **kw)
+    tm("ac_fwd_train(epoch form)", lambda: ops.ac_forward(loop.mac.actor_arena, loop.mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True,
+                                                          ln_stats=lns, ln_stats_mode=2, packed=pk, **kw), n=5)
+    clk = torch.zeros(4, dtype=torch.int64, device=dev)
+    for _ in range(2):
+        ops.ac_forward(loop.mac.actor_arena, loop.mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True, ln_stats=lns, ln_stats_mode=2,
+                       packed=pk, phase_clocks=clk, **kw)
+    torch.cuda.synchronize()
+    cc = clk.cpu().double()
+    print("ac_fwd (epoch form) phases of wave 0 of WG 0, x10 ns: stats, fc1 contraction, tail (2 row tiles) =", (cc[1:] - cc[:-1]).tolist())
     g1 = torch.randn(nA, rows, device=dev)
     tm("ac_backward(all)", lambda: ops.ac_backward(fo, loop.mac.actor_arena, loop.mac.critic_arena, g_logp=g1, g_entropy=-1e-6, g_values=g1), n=5)
 
