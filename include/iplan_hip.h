@@ -366,6 +366,8 @@ typedef struct {
     int64_t params_s_net, off_w1, off_fn_w, off_fn_b;
     float* packed;
     int64_t packed_s_net;        /* >= iplan_ac_packed_floats(feat)                                   */
+    int32_t parts;               /* 0 = everything; 1 = Wp | gamma_p | beta_p only (all the streaming forward of a PPO
+                                    epoch reads); 2 = W gamma | W beta only (operands of the rollout's folded form)    */
 } IplanAcPackArgs;
 int64_t iplan_ac_packed_floats(const IplanAcFeatures* feat);
 int iplan_ac_pack_fc1(const IplanAcPackArgs* args, iplan_stream_t stream);

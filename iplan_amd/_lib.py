@@ -187,7 +187,7 @@ class AcFwdArgs(C.Structure):
 
 class AcPackArgs(C.Structure):
     _fields_ = [("n_nets", i32), ("feat", AcFeatures), ("params", fp), ("params_s_net", i64), ("off_w1", i64), ("off_fn_w", i64),
-                ("off_fn_b", i64), ("packed", fp), ("packed_s_net", i64)]
+                ("off_fn_b", i64), ("packed", fp), ("packed_s_net", i64), ("parts", i32)]
 
 
 # ---- optimiser -------------------------------------------------------------------------------------

@@ -100,7 +100,7 @@ class DcntrlMAC:
                            h_strides=(ha.stride(1), ha.stride(0)), avail=avail,
                            avail_strides=(avail.stride(1), avail.stride(0)),
                            mode=0 if test_mode else 1, q_noise=q_noise, n_actions=a.n_actions, phase_clocks=phase_clocks,
-                           packed=self.fc1_pack.get(spec), **wb)
+                           packed=self.fc1_pack.get(spec, fold=E <= 512), **wb)
         values = o["values"].t()                                          # [E, nA]
         logps = [o["logp"][i].reshape(E, 1) for i in range(nA)]
         if write_back:

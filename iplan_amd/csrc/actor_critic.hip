@@ -25,19 +25,23 @@ constexpr int AT = AM / 16;            // 4 tiles
 template <int RT>
 __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     __shared__ float s_red[8][16], s_red2[8][16], s_cc[8][2][AM];
-    __shared__ __attribute__((aligned(16))) f32x4 s_acc[8][AT][64];
+    __shared__ __attribute__((aligned(16))) f32x4 s_acc[RT == 1 ? 8 : 1][AT][64];          // (cross-wave K reduction: rollout shape only)
     // Rollout shape (RT == 1, the 8 waves of a workgroup share ONE 16-row tile): the 64-wide tail runs in a single wave and
     // was a chain of ~10 dependent stages, each waiting ~1 us for its weight fragments from L2 (15 us of a 52 us launch).
     // All 8 waves therefore stage fc2 / GRU W_ih / head weights into LDS at kernel entry (the loads land during the fc1
     // contraction) and share out the 12 tiles of  W_hh h + b_hh  (it does not depend on fc1); the tail wave then reads
     // everything from LDS.  The streaming instantiation (RT == 2, one wave per tile pair) keeps reading L1/L2.
     constexpr int TLDW = AM + 8;                                                  // conflict-free ds_read_b128 fragments
+    // The streaming instantiation (RT == 2, one wave per tile pair, 8 independent waves) stages the same weights PLUS W_hh
+    // (464 rows, 131 KiB: one workgroup per CU either way at 199 registers) -- its tail read 133 KB of weight fragments per
+    // row tile from L1/L2, each fragment load followed by its wait: 112 us of a wave's 357 us (phase clocks, profiles/r02d_notes.md).
 #ifdef AC_NO_STAGED_TAIL                // A/B builds (scripts/build_variants.sh)
-    constexpr bool STAGED_BUILD = false;
+    constexpr bool STAGED_BUILD = false, STAGED2 = false;
 #else
-    constexpr bool STAGED_BUILD = RT == 1;
+    constexpr bool STAGED_BUILD = RT == 1, STAGED2 = RT == 2;
 #endif
-    __shared__ __attribute__((aligned(16))) float s_tw[STAGED_BUILD ? (AM + 3 * AM + 16) * TLDW : 4];      // fc2 | W_ih | head rows
+    constexpr int TW_ROWS = STAGED2 ? AM + 3 * AM + 16 + 3 * AM : (STAGED_BUILD ? AM + 3 * AM + 16 : 0);
+    __shared__ __attribute__((aligned(16))) float s_tw[TW_ROWS ? TW_ROWS * TLDW : 4];      // fc2 | W_ih | head rows (| W_hh)
     __shared__ __attribute__((aligned(16))) f32x4 s_gh[STAGED_BUILD ? 3 * AT : 1][64];
 
     const int net = (int)blockIdx.y;
@@ -101,6 +105,19 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         for (int t = 0; t < AT; ++t) h0[t] = vload(hrow0, vld[0], AM, t);
         for (int t = w; t < 3 * AT; t += 8)
             s_gh[t][l] = dense_tile_ga<AT>(P + nw.off[IPLAN_AC_WHH], AM, 3 * AM, 16 * t, h0, bfrag_a(P + nw.off[IPLAN_AC_BHH], t));
+    }
+
+    if (STAGED2) {      // 7424 16-byte chunks: [fc2 64 | rnn.weight_ih 192 | head n_out (zero padded to 16) | rnn.weight_hh 192] x 64
+        const float* Wsrc[4] = {P + nw.off[IPLAN_AC_FC2_W], P + nw.off[IPLAN_AC_WIH], P + nw.off[IPLAN_AC_HEAD_W], P + nw.off[IPLAN_AC_WHH]};
+        for (int c = (int)threadIdx.x; c < TW_ROWS * 16; c += 512) {
+            const int r = c >> 4, c4 = c & 15;
+            f32x4 v = splat4(0.f);
+            if (r < AM) v = *reinterpret_cast<const f32x4*>(Wsrc[0] + r * AM + 4 * c4);
+            else if (r < 4 * AM) v = *reinterpret_cast<const f32x4*>(Wsrc[1] + (r - AM) * AM + 4 * c4);
+            else if (r < 4 * AM + 16) { if (r - 4 * AM < nw.n_out) v = *reinterpret_cast<const f32x4*>(Wsrc[2] + (r - 4 * AM) * AM + 4 * c4); }
+            else v = *reinterpret_cast<const f32x4*>(Wsrc[3] + (r - 4 * AM - 16) * AM + 4 * c4);
+            *reinterpret_cast<f32x4*>(&s_tw[r * TLDW + 4 * c4]) = v;
+        }
     }
 
     // ---- LayerNorm(F) statistics, two passes (mean, then centred second moment) over L2-resident rows
@@ -353,6 +370,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         }
     }
     if (clk) a.phase_clocks[2] = IPLAN_CLOCK();
+    if (STAGED2) __syncthreads();                               // the staged tail weights (every wave gets here: ks == 1)
     if (part != 0) return;
 
   for (int rt = 0; rt < RT; ++rt) {
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     if (sv) for (int t = 0; t < AT; ++t) vstore(sv + AM, valid, AM, t, f[t]);   // f1
     f32x4 f2[AT];
     for (int t = 0; t < AT; ++t) {
-        if (STAGED_BUILD && staged) f2[t] = relu4(dense_tile<AT>(s_tw, TLDW, 16 * t, f, bfrag_a(P + nw.off[IPLAN_AC_FC2_B], t)));
+        if (STAGED2 || (STAGED_BUILD && staged)) f2[t] = relu4(dense_tile<AT>(s_tw, TLDW, 16 * t, f, bfrag_a(P + nw.off[IPLAN_AC_FC2_B], t)));
         else f2[t] = relu4(dense_tile_ga<AT>(P + nw.off[IPLAN_AC_FC2_W], AM, AM, 16 * t, f, bfrag_a(P + nw.off[IPLAN_AC_FC2_B], t)));
         if (sv) vstore(sv + 2 * AM, valid, AM, t, f2[t]);             // a2
     }
@@ -404,12 +422,21 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
             f32x4 pz = bfrag_a(bi, AT + t) + bfrag_a(bh, AT + t);
             f32x4 gn = bfrag_a(bi, 2 * AT + t);
             f32x4 hn = bfrag_a(bh, 2 * AT + t);
+            if (STAGED2) {
+                const float* sWi = s_tw + AM * TLDW;
+                const float* sWh = s_tw + (4 * AM + 16) * TLDW;
+                prr = dense_tile<AT>(sWh, TLDW, 16 * t, h, dense_tile<AT>(sWi, TLDW, 16 * t, f2, prr));
+                pz = dense_tile<AT>(sWh, TLDW, AM + 16 * t, h, dense_tile<AT>(sWi, TLDW, AM + 16 * t, f2, pz));
+                gn = dense_tile<AT>(sWi, TLDW, 2 * AM + 16 * t, f2, gn);
+                hn = dense_tile<AT>(sWh, TLDW, 2 * AM + 16 * t, h, hn);
+            } else {
             prr = dense_tile_ga<AT>(Wi, AM, 3 * AM, 16 * t, f2, prr);
             prr = dense_tile_ga<AT>(Wh, AM, 3 * AM, 16 * t, h, prr);
             pz = dense_tile_ga<AT>(Wi, AM, 3 * AM, AM + 16 * t, f2, pz);
             pz = dense_tile_ga<AT>(Wh, AM, 3 * AM, AM + 16 * t, h, pz);
             gn = dense_tile_ga<AT>(Wi, AM, 3 * AM, 2 * AM + 16 * t, f2, gn);
             hn = dense_tile_ga<AT>(Wh, AM, 3 * AM, 2 * AM + 16 * t, h, hn);
+            }
             const GruGates o = gru_gates(prr, pz, gn, hn, h[t]);
             hnew[t] = o.h;
             if (sv) {
@@ -437,7 +464,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     }
     // ---- head
     const int n_out = nw.n_out;
-    const f32x4 lg = (STAGED_BUILD && staged)
+    const f32x4 lg = (STAGED2 || (STAGED_BUILD && staged))
         ? dense_tile<AT>(s_tw + 4 * AM * TLDW, TLDW, 0, hnew, bfrag(P + nw.off[IPLAN_AC_HEAD_B], n_out, 0))
         : dense_tile_ga<AT>(P + nw.off[IPLAN_AC_HEAD_W], AM, n_out, 0, hnew, bfrag(P + nw.off[IPLAN_AC_HEAD_B], n_out, 0));
     const int64_t orow = (int64_t)net * a.rows + (valid ? r : 0);
@@ -538,27 +565,28 @@ __global__ __launch_bounds__(256) void ac_pack_fc1_kernel(IplanAcPackArgs a) {
 }
 
 // (W gamma)[o], (W beta)[o] of fc1 / feature_norm for the folded LayerNorm(F) of the rollout forward
-// (fc1(LN(x)) = rstd (W (gamma o x) - mu W gamma) + W beta): one workgroup per net, fixed summation order
+// (fc1(LN(x)) = rstd (W (gamma o x) - mu W gamma) + W beta).  grid (n_nets, 8): a workgroup owns 8 output rows, 32 threads
+// per row stride the K axis together (coalesced), partial sums meet in LDS in a fixed order.
 __global__ __launch_bounds__(256) void ac_pack_wgamma_kernel(IplanAcPackArgs a) {
-    __shared__ float s_p[2][4][AM];
+    __shared__ float s_p[2][8][32];
     const int net = (int)blockIdx.x;
     const KMap km = make_kmap(a.feat);
     const int F = km.NW + km.n_actions + km.n_id, KT = km.kt0[4];
     const float* __restrict__ P = a.params + (int64_t)net * a.params_s_net;
-    const int o = (int)threadIdx.x & 63, part = (int)threadIdx.x >> 6;
+    const int part = (int)threadIdx.x & 31, ro = (int)threadIdx.x >> 5, o = (int)blockIdx.y * 8 + ro;
     float c1 = 0.f, c2 = 0.f;
-    for (int c = part; c < F; c += 4) {
+    for (int c = part; c < F; c += 32) {
         const float wv = P[a.off_w1 + (int64_t)o * F + c];
         c1 = fmaf(wv, P[a.off_fn_w + c], c1);
         c2 = fmaf(wv, P[a.off_fn_b + c], c2);
     }
-    s_p[0][part][o] = c1;
-    s_p[1][part][o] = c2;
+    s_p[0][ro][part] = c1;
+    s_p[1][ro][part] = c2;
     __syncthreads();
-    if (part == 0) {
-        float* out = a.packed + (int64_t)net * a.packed_s_net + (int64_t)KT * 1056;
-        out[o] = (s_p[0][0][o] + s_p[0][1][o]) + (s_p[0][2][o] + s_p[0][3][o]);
-        out[AM + o] = (s_p[1][0][o] + s_p[1][1][o]) + (s_p[1][2][o] + s_p[1][3][o]);
+    if (part < 2) {                                           // part 0: W gamma, part 1: W beta
+        float s = 0.f;
+        for (int k = 0; k < 32; ++k) s += s_p[part][ro][k];
+        a.packed[(int64_t)net * a.packed_s_net + (int64_t)KT * 1056 + part * AM + o] = s;
     }
 }
 
@@ -577,8 +605,9 @@ extern "C" int iplan_ac_pack_fc1(const IplanAcPackArgs* a, iplan_stream_t stream
     if (!a || a->n_nets < 1 || !a->params || !a->packed || a->packed_s_net < iplan_ac_packed_floats(&a->feat))
         return fail(IPLAN_EINVAL, "iplan_ac_pack_fc1: bad arguments");
     const int KT = (int)((iplan_ac_packed_floats(&a->feat) - 128) / (1024 + 32));
-    hipLaunchKernelGGL(ac_pack_fc1_kernel, dim3((unsigned)KT, (unsigned)a->n_nets), dim3(256), 0, (hipStream_t)stream, *a);
-    hipLaunchKernelGGL(ac_pack_wgamma_kernel, dim3((unsigned)a->n_nets), dim3(256), 0, (hipStream_t)stream, *a);
+    if (a->parts < 0 || a->parts > 2) return fail(IPLAN_EINVAL, "iplan_ac_pack_fc1: parts must be 0, 1 or 2");
+    if (a->parts != 2) hipLaunchKernelGGL(ac_pack_fc1_kernel, dim3((unsigned)KT, (unsigned)a->n_nets), dim3(256), 0, (hipStream_t)stream, *a);
+    if (a->parts != 1) hipLaunchKernelGGL(ac_pack_wgamma_kernel, dim3((unsigned)a->n_nets, AM / 8), dim3(256), 0, (hipStream_t)stream, *a);
     return check_launch("iplan_ac_pack_fc1");
 }
 

@@ -239,8 +239,10 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
         a.ln_stats, a.ln_stats_s_net, a.ln_stats_mode = ln_stats.data_ptr(), ln_stats.stride(0), ln_stats_mode
     if phase_clocks is not None:
         a.phase_clocks = phase_clocks.data_ptr()
-    if packed is not None:                                 # FusedFc1Pack.get(): fragment-major fc1 operands of both arenas
+    if packed is not None:                                 # Fc1Pack.get(): fragment-major fc1 operands of both arenas
         pa, pc = packed
+        if a.ksplit > 1 and a.ln_stats_mode == 0:           # the folded form reads W gamma / W beta from the pack
+            assert getattr(packed, "fold", False), "rollout-shaped launch needs Fc1Pack.get(spec, fold=True)"
         if which != 1:
             a.packed_actor, a.packed_s_net = pa.data_ptr(), pa.stride(0)
         if which != 0:
@@ -255,17 +257,25 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
     return out
 
 
+class _Packed(tuple):
+    """(actor buffer, critic buffer) of Fc1Pack.get; ``fold`` says whether the W gamma / W beta tail is current"""
+    fold = False
+
+
 class Fc1Pack:
     """fc1.weight + feature_norm.{weight, bias} of the actor and critic arenas in the forward kernels' own K order and MFMA
     fragment order (iplan_ac_pack_fc1).  ``get(spec)`` repacks only when an arena changed since the last pack (torch-side
-    writes bump ``arena.data._version``, kernel-side writes -- Adam -- bump ``arena.version``) or the feature layout differs."""
+    writes bump ``arena.data._version``, kernel-side writes -- Adam -- bump ``arena.version``) or the feature layout differs.
+    ``fold=True`` also brings W gamma / W beta up to date (the rollout's folded LayerNorm(F) reads them; the streaming
+    forward of a PPO epoch does not, and a repack after each of its 30 Adam steps would spend more on them than on the
+    fragments)."""
 
     def __init__(self, actor_arena, critic_arena):
         self.arenas = (actor_arena, critic_arena)
         self.buf = [None, None]
-        self.key = [None, None]
+        self.key = [[None, None], [None, None]]             # per arena: key of the fragment part, of the W gamma / W beta part
 
-    def get(self, spec, lib=None):
+    def get(self, spec, fold=False, lib=None):
         if os.environ.get("IPLAN_NO_FC1_PACK"):             # A/B knob: read the arena in place (scattered fragment loads)
             return None
         lib = _lib(lib)
@@ -275,17 +285,23 @@ class Fc1Pack:
         sig = (spec.N, tuple(s[1] for s in spec.sources), spec.n_actions, spec.n_id)
         for k, (arena, order) in enumerate(zip(self.arenas, (L.ACTOR_PARAM_ORDER, L.CRITIC_PARAM_ORDER))):
             key = (arena.data._version, arena.version, sig)
-            if self.key[k] == key:
-                continue
             if self.buf[k] is None or self.buf[k].shape[1] != floats:
                 self.buf[k] = torch.empty(arena.n_nets, floats, dtype=torch.float32, device=arena.data.device)
+                self.key[k] = [None, None]
+            todo = [p for p, need in ((0, True), (1, fold)) if need and self.key[k][p] != key]
+            if not todo:
+                continue
             a.n_nets = arena.n_nets
             a.params, a.params_s_net = arena.data.data_ptr(), arena.net_stride
             a.off_w1, a.off_fn_w, a.off_fn_b = (arena.off(n) for n in ("base.mlp.fc1.0.weight", "base.feature_norm.weight", "base.feature_norm.bias"))
             a.packed, a.packed_s_net = self.buf[k].data_ptr(), floats
+            a.parts = 0 if len(todo) == 2 else todo[0] + 1
             lib.call("iplan_ac_pack_fc1", a, L.current_stream(arena.data.device))
-            self.key[k] = key
-        return self.buf[0], self.buf[1]
+            for p in todo:
+                self.key[k][p] = key
+        out = _Packed((self.buf[0], self.buf[1]))
+        out.fold = all(self.key[k][1] == self.key[k][0] for k in range(2))
+        return out
 
 
 # ---- weight gradients ----------------------------------------------------------------------------------

@@ -98,6 +98,26 @@ def check_rollout_step(g, device):
             assert ha.shape == (1, E, nA, 64)
             assert rel_err(torch.as_tensor(ha), ref["h_actor"]) < 1e-5
             assert rel_err(torch.as_tensor(hc), ref["h_critic"]) < 1e-5
+    # Pre-packed fc1 operands (iplan_ac_pack_fc1, incl. the lazily packed W gamma / W beta of the folded form) against the
+    # arenas read in place (what a C-ABI caller without a pack gets) -- also right after the weights change under the cache.
+    import os
+
+    def both():
+        packed = mac.select_actions_ippo(batch, t, test_mode=True)
+        os.environ["IPLAN_NO_FC1_PACK"] = "1"
+        try:
+            plain = mac.select_actions_ippo(batch, t, test_mode=True)
+        finally:
+            del os.environ["IPLAN_NO_FC1_PACK"]
+        return packed, plain
+
+    first, _ = both()
+    for arena in (mac.actor_arena, mac.critic_arena):
+        arena.data.mul_(0.75)                                   # torch-side write: bumps data._version
+    (v1, a1, lp1, ha1, hc1), (v2, a2, lp2, ha2, hc2) = both()
+    assert rel_err(torch.as_tensor(v1), torch.as_tensor(v2)) < 2e-6 and np.array_equal(a1, a2)
+    assert rel_err(torch.as_tensor(ha1), torch.as_tensor(ha2)) < 2e-6 and rel_err(torch.as_tensor(hc1), torch.as_tensor(hc2)) < 2e-6
+    assert rel_err(torch.as_tensor(first[0]), torch.as_tensor(v1)) > 1e-3      # (the weights did change)
 
 
 def test_rollout_step_emulated(golden):
