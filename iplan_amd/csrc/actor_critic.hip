@@ -43,6 +43,11 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     constexpr int TW_ROWS = STAGED2 ? AM + 3 * AM + 16 + 3 * AM : (STAGED_BUILD ? AM + 3 * AM + 16 : 0);
     __shared__ __attribute__((aligned(16))) float s_tw[TW_ROWS ? TW_ROWS * TLDW : 4];      // fc2 | W_ih | head rows (| W_hh)
     __shared__ __attribute__((aligned(16))) f32x4 s_gh[STAGED_BUILD ? 3 * AT : 1][64];
+    // the tail's parameter VECTORS (biases, LayerNorm gamma / beta): 26 of them per row tile, each a dependent ~1 us L2 round
+    // trip when read where it is used (37 of the 50 us a row tile's tail took in the streaming form)
+    constexpr int TP_FC1B = 0, TP_LN1W = 64, TP_LN1B = 128, TP_FC2B = 192, TP_LN2W = 256, TP_LN2B = 320, TP_BIH = 384, TP_BHH = 576,
+                  TP_LN3W = 768, TP_LN3B = 832, TP_HEADB = 896, TP_FLOATS = 912;
+    __shared__ __attribute__((aligned(16))) float s_tp[TW_ROWS ? TP_FLOATS : 4];
 
     const int net = (int)blockIdx.y;
     const int which = a.which == 2 ? (int)blockIdx.z : a.which;       // 0 actor, 1 critic
@@ -117,6 +122,18 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
             else if (r < 4 * AM + 16) { if (r - 4 * AM < nw.n_out) v = *reinterpret_cast<const f32x4*>(Wsrc[2] + (r - 4 * AM) * AM + 4 * c4); }
             else v = *reinterpret_cast<const f32x4*>(Wsrc[3] + (r - 4 * AM - 16) * AM + 4 * c4);
             *reinterpret_cast<f32x4*>(&s_tw[r * TLDW + 4 * c4]) = v;
+        }
+    }
+
+    const bool lds_tail = STAGED2 || (STAGED_BUILD && staged);
+    if (TW_ROWS && lds_tail) {
+        const int tp_off[11] = {TP_FC1B, TP_LN1W, TP_LN1B, TP_FC2B, TP_LN2W, TP_LN2B, TP_BIH, TP_BHH, TP_LN3W, TP_LN3B, TP_HEADB};
+        const int tp_src[11] = {IPLAN_AC_FC1_B, IPLAN_AC_LN1_W, IPLAN_AC_LN1_B, IPLAN_AC_FC2_B, IPLAN_AC_LN2_W, IPLAN_AC_LN2_B, IPLAN_AC_BIH,
+                                IPLAN_AC_BHH, IPLAN_AC_LN3_W, IPLAN_AC_LN3_B, IPLAN_AC_HEAD_B};
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const int len = k == 10 ? 16 : ((k == 6 || k == 7) ? 3 * AM : AM), have = k == 10 ? nw.n_out : len;
+            for (int i = (int)threadIdx.x; i < len; i += 512) s_tp[tp_off[k] + i] = i < have ? P[nw.off[tp_src[k]] + i] : 0.f;
         }
     }
 
@@ -384,44 +401,47 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     // ---- 64-wide tail, one wave per row tile
     float* sv = a.saved ? a.saved + (((int64_t)which * a.n_agents + net) * a.rows + (valid ? r : 0)) * IPLAN_AC_SAVE_FLOATS : nullptr;
     float mu1, rs1, mu2, rs2, mu3, rs3;
-    f32x4 f[AT];
-    for (int t = 0; t < AT; ++t) {
-        f[t] = relu4(acc[t] + bfrag_a(P + nw.off[IPLAN_AC_FC1_B], t));
-        if (sv) vstore(sv, valid, AM, t, f[t]);                       // a1
-    }
-    layer_norm_tiles<AT>(f, P + nw.off[IPLAN_AC_LN1_W], P + nw.off[IPLAN_AC_LN1_B], &mu1, &rs1);
-    if (sv) for (int t = 0; t < AT; ++t) vstore(sv + AM, valid, AM, t, f[t]);   // f1
-    f32x4 f2[AT];
-    for (int t = 0; t < AT; ++t) {
-        if (STAGED2 || (STAGED_BUILD && staged)) f2[t] = relu4(dense_tile<AT>(s_tw, TLDW, 16 * t, f, bfrag_a(P + nw.off[IPLAN_AC_FC2_B], t)));
-        else f2[t] = relu4(dense_tile_ga<AT>(P + nw.off[IPLAN_AC_FC2_W], AM, AM, 16 * t, f, bfrag_a(P + nw.off[IPLAN_AC_FC2_B], t)));
-        if (sv) vstore(sv + 2 * AM, valid, AM, t, f2[t]);             // a2
-    }
-    layer_norm_tiles<AT>(f2, P + nw.off[IPLAN_AC_LN2_W], P + nw.off[IPLAN_AC_LN2_B], &mu2, &rs2);
-    if (sv) for (int t = 0; t < AT; ++t) vstore(sv + 3 * AM, valid, AM, t, f2[t]);  // f2
-    // GRU step (rnn.py:24-27) from the stored hidden state
+    // tile t of a parameter vector: LDS copy (tail staged) or the arena (two loads in two branches, never a mixed pointer)
+    auto pv = [&](int tp, int which_vec, int t) { return (TW_ROWS && lds_tail) ? bfrag_a(s_tp + tp, t) : bfrag_a(P + nw.off[which_vec], t); };
+    // the row's stored hidden state is fetched first: it lands while fc1's epilogue, fc2 and two LayerNorms run
     const float* hsrc = which ? a.h_critic : a.h_actor;
     const float* hrow = hsrc + (int64_t)net * a.hs_net + pr * a.hs_row;
     f32x4 h[AT], hnew[AT];
     for (int t = 0; t < AT; ++t) h[t] = vload(hrow, valid, AM, t);
+    f32x4 f[AT], gmv[AT], btv[AT];
+    for (int t = 0; t < AT; ++t) {
+        f[t] = relu4(acc[t] + pv(TP_FC1B, IPLAN_AC_FC1_B, t));
+        if (sv) vstore(sv, valid, AM, t, f[t]);                       // a1
+    }
+    for (int t = 0; t < AT; ++t) { gmv[t] = pv(TP_LN1W, IPLAN_AC_LN1_W, t); btv[t] = pv(TP_LN1B, IPLAN_AC_LN1_B, t); }
+    layer_norm_tiles_f<AT>(f, gmv, btv, &mu1, &rs1);
+    if (sv) for (int t = 0; t < AT; ++t) vstore(sv + AM, valid, AM, t, f[t]);   // f1
+    f32x4 f2[AT];
+    for (int t = 0; t < AT; ++t) {
+        if (lds_tail) f2[t] = relu4(dense_tile<AT>(s_tw, TLDW, 16 * t, f, pv(TP_FC2B, IPLAN_AC_FC2_B, t)));
+        else f2[t] = relu4(dense_tile_ga<AT>(P + nw.off[IPLAN_AC_FC2_W], AM, AM, 16 * t, f, bfrag_a(P + nw.off[IPLAN_AC_FC2_B], t)));
+        if (sv) vstore(sv + 2 * AM, valid, AM, t, f2[t]);             // a2
+    }
+    for (int t = 0; t < AT; ++t) { gmv[t] = pv(TP_LN2W, IPLAN_AC_LN2_W, t); btv[t] = pv(TP_LN2B, IPLAN_AC_LN2_B, t); }
+    layer_norm_tiles_f<AT>(f2, gmv, btv, &mu2, &rs2);
+    if (sv) for (int t = 0; t < AT; ++t) vstore(sv + 3 * AM, valid, AM, t, f2[t]);  // f2
+    // GRU step (rnn.py:24-27) from the stored hidden state
     {
         const float* Wi = P + nw.off[IPLAN_AC_WIH];
         const float* Wh = P + nw.off[IPLAN_AC_WHH];
-        const float* bi = P + nw.off[IPLAN_AC_BIH];
-        const float* bh = P + nw.off[IPLAN_AC_BHH];
         for (int t = 0; t < AT; ++t) {
             if (STAGED_BUILD && staged) {                    // W_ih from LDS, W_hh h + b_hh precomputed by the 8 waves
                 const float* sWi = s_tw + AM * TLDW;
-                const f32x4 pr_s = dense_tile<AT>(sWi, TLDW, 16 * t, f2, bfrag_a(bi, t) + s_gh[t][l]);
-                const f32x4 pz_s = dense_tile<AT>(sWi, TLDW, AM + 16 * t, f2, bfrag_a(bi, AT + t) + s_gh[AT + t][l]);
-                const f32x4 gn_s = dense_tile<AT>(sWi, TLDW, 2 * AM + 16 * t, f2, bfrag_a(bi, 2 * AT + t));
+                const f32x4 pr_s = dense_tile<AT>(sWi, TLDW, 16 * t, f2, bfrag_a(s_tp + TP_BIH, t) + s_gh[t][l]);
+                const f32x4 pz_s = dense_tile<AT>(sWi, TLDW, AM + 16 * t, f2, bfrag_a(s_tp + TP_BIH, AT + t) + s_gh[AT + t][l]);
+                const f32x4 gn_s = dense_tile<AT>(sWi, TLDW, 2 * AM + 16 * t, f2, bfrag_a(s_tp + TP_BIH, 2 * AT + t));
                 hnew[t] = gru_gates(pr_s, pz_s, gn_s, s_gh[2 * AT + t][l], h[t]).h;
                 continue;
             }
-            f32x4 prr = bfrag_a(bi, t) + bfrag_a(bh, t);
-            f32x4 pz = bfrag_a(bi, AT + t) + bfrag_a(bh, AT + t);
-            f32x4 gn = bfrag_a(bi, 2 * AT + t);
-            f32x4 hn = bfrag_a(bh, 2 * AT + t);
+            f32x4 prr = pv(TP_BIH, IPLAN_AC_BIH, t) + pv(TP_BHH, IPLAN_AC_BHH, t);
+            f32x4 pz = pv(TP_BIH, IPLAN_AC_BIH, AT + t) + pv(TP_BHH, IPLAN_AC_BHH, AT + t);
+            f32x4 gn = pv(TP_BIH, IPLAN_AC_BIH, 2 * AT + t);
+            f32x4 hn = pv(TP_BHH, IPLAN_AC_BHH, 2 * AT + t);
             if (STAGED2) {
                 const float* sWi = s_tw + AM * TLDW;
                 const float* sWh = s_tw + (4 * AM + 16) * TLDW;
@@ -454,7 +474,8 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
                                  : hout + ((int64_t)net * a.rows + (valid ? r : 0)) * AM;
         for (int t = 0; t < AT; ++t) vstore(orow, valid, AM, t, hnew[t]);
     }
-    layer_norm_tiles<AT>(hnew, P + nw.off[IPLAN_AC_LN3_W], P + nw.off[IPLAN_AC_LN3_B], &mu3, &rs3);
+    for (int t = 0; t < AT; ++t) { gmv[t] = pv(TP_LN3W, IPLAN_AC_LN3_W, t); btv[t] = pv(TP_LN3B, IPLAN_AC_LN3_B, t); }
+    layer_norm_tiles_f<AT>(hnew, gmv, btv, &mu3, &rs3);
     if (sv) {
         for (int t = 0; t < AT; ++t) vstore(sv + 9 * AM, valid, AM, t, hnew[t]);      // f3
         if (valid && g == 0) {
@@ -464,8 +485,8 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     }
     // ---- head
     const int n_out = nw.n_out;
-    const f32x4 lg = (STAGED2 || (STAGED_BUILD && staged))
-        ? dense_tile<AT>(s_tw + 4 * AM * TLDW, TLDW, 0, hnew, bfrag(P + nw.off[IPLAN_AC_HEAD_B], n_out, 0))
+    const f32x4 lg = lds_tail
+        ? dense_tile<AT>(s_tw + 4 * AM * TLDW, TLDW, 0, hnew, bfrag_a(s_tp + TP_HEADB, 0))
         : dense_tile_ga<AT>(P + nw.off[IPLAN_AC_HEAD_W], AM, n_out, 0, hnew, bfrag(P + nw.off[IPLAN_AC_HEAD_B], n_out, 0));
     const int64_t orow = (int64_t)net * a.rows + (valid ? r : 0);
     if (which == 1) {

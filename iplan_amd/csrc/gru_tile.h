@@ -182,4 +182,21 @@ __device__ __forceinline__ void layer_norm_tiles(f32x4 (&v)[DT], const float* __
     if (rstd_out) *rstd_out = rstd;
 }
 
+// same, with gamma / beta handed over as fragments (callers that hold the parameter vectors in LDS)
+template <int DT>
+__device__ __forceinline__ void layer_norm_tiles_f(f32x4 (&v)[DT], const f32x4 (&gm)[DT], const f32x4 (&bt)[DT], float* mean_out, float* rstd_out) {
+    constexpr float inv = 1.0f / (16 * DT);
+    float s = 0.f;
+    for (int t = 0; t < DT; ++t) s += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
+    const float mu = group_sum(s) * inv;
+    float q = 0.f;
+    for (int t = 0; t < DT; ++t)
+        for (int k = 0; k < 4; ++k) { const float d = v[t][k] - mu; q = fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(group_sum(q) * inv + 1e-5f);
+    for (int t = 0; t < DT; ++t)
+        for (int k = 0; k < 4; ++k) v[t][k] = (v[t][k] - mu) * rstd * gm[t][k] + bt[t][k];
+    if (mean_out) *mean_out = mu;
+    if (rstd_out) *rstd_out = rstd;
+}
+
 }  // namespace iplan
