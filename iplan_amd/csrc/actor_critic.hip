@@ -49,8 +49,25 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
                   TP_LN3W = 768, TP_LN3B = 832, TP_HEADB = 896, TP_FLOATS = 912;
     __shared__ __attribute__((aligned(16))) float s_tp[TW_ROWS ? TP_FLOATS : 4];
 
-    const int net = (int)blockIdx.y;
-    const int which = a.which == 2 ? (int)blockIdx.z : a.which;       // 0 actor, 1 critic
+    // XCD-aware placement (speed only, any placement is correct): workgroup b runs on XCD b % 8 and every (net, actor|critic)
+    // pair has its own 0.64 MB of fc1 weights.  In launch order a pair's row tiles land on all 8 XCDs and every XCD's 4 MB
+    // L2 sees all 10 pairs (6.4 MB: the fragments come from the Infinity Cache instead, profiles/r02d: 20 MB fetched per
+    // rollout launch for 9.6 MB of unique bytes).  The remap hands XCD k a CONTIGUOUS range of the pair-major work list.
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
+#ifndef AC_NO_XCD_REMAP
+    {
+        const int X = (int)gridDim.x, G = X * (int)gridDim.y * (int)gridDim.z;
+        const int b = bx + X * (by + (int)gridDim.y * bz);
+        const int k = b & 7, slot = b >> 3, q8 = G >> 3, r8 = G & 7;
+        const int item = k * q8 + (k < r8 ? k : r8) + slot;                        // bijective: XCD k owns q8 (+1 if k < r8) items
+        bx = item % X;
+        const int pair = item / X;
+        by = pair % (int)gridDim.y;
+        bz = pair / (int)gridDim.y;
+    }
+#endif
+    const int net = by;
+    const int which = a.which == 2 ? bz : a.which;                    // 0 actor, 1 critic
     const IplanAcNet& nw = which ? a.critic : a.actor;
     const float* __restrict__ P = nw.params + (int64_t)net * nw.params_s_net;
     const IplanAcFeatures& ft = a.feat;
@@ -58,7 +75,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     const int ks = RT == 1 ? a.ksplit : 1;
     const int groups = 8 / ks;
     const int part = w % ks;
-    const bool clk = a.phase_clocks && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
+    const bool clk = a.phase_clocks && bx == 0 && by == 0 && bz == 0 && threadIdx.x == 0;
     if (clk) a.phase_clocks[0] = IPLAN_CLOCK();
     const KMap km = make_kmap(ft);
     const int F = km.NW + km.n_actions + km.n_id;
@@ -78,7 +95,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     int64_t prr[RT];
     const float* src[RT][3];
     for (int t = 0; t < RT; ++t) {
-        const int tile = ((int)blockIdx.x * groups + w / ks) * RT + t;
+        const int tile = (bx * groups + w / ks) * RT + t;
         rr[t] = tile * 16 + n;
         vld[t] = rr[t] < a.rows;
         prr[t] = vld[t] ? (int64_t)(rr[t] / ft.T) * ft.T_phys + (rr[t] % ft.T) : 0;
