@@ -36,9 +36,21 @@ FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md (v
 HBM_PEAK_GBS = 8000.0                # HBM3E spec (same guide; ~6.3 TB/s is what a float4 copy achieves)
 # HBM bytes per launch from the committed PMC passes (profiles/r01*_pmc_*.txt), keyed by (kernel, envs per GPU):
 # (2 * FETCH_SIZE + WRITE_SIZE) KiB -> bytes.  Counters cannot be collected from inside bench.py; None = not profiled.
+def _kib(fetch, write):
+    """HBM bytes of one launch from rocprofv3's FETCH_SIZE / WRITE_SIZE (KiB per dispatch, separate --pmc passes): on gfx950
+    FETCH_SIZE counts 128-byte requests as 64 bytes (MI355X_MICROARCH.md, HBM section) -> 2 x FETCH_SIZE + WRITE_SIZE."""
+    return int((2 * fetch + write) * 1024)
+
+
+# per launch at the config-3 shape (E = 32), profiles/r02d_pmc_{rollout,behaviour_learn,ppo_train}.txt (avg / dispatch)
 PMC_TRAFFIC_BYTES = {
-    ("gat_fwd_kernel", 32): int((2 * 5173.6 + 1759.0) * 1024),             # profiles/r01g_pmc_*.txt
-    ("beh_dec_bwd_kernel", 32): int((2 * 1045886.8 + 1676182.8) * 1024),   # per window-range launch (6 per BPTT)
+    ("gat_fwd_kernel", 32): _kib(5170.9, 1100.0),
+    ("beh_dec_bwd_kernel", 32): _kib(1009023.9, 1591471.0),       # per window-range launch (6 per BPTT)
+    ("beh_dec_fwd_kernel", 32): _kib(59320.4, 3293253.1),         # per window-range launch (4 per forward)
+    ("beh_enc_bwd_kernel", 32): _kib(470541.9, 17301.0),          # per window-range launch (6 per BPTT)
+    # one iplan_wgrad call on a decoder BPTT piece = wide + two thin partial kernels + the reduction
+    ("iplan_wgrad:beh_dec", 32): _kib(1341424.0 + 254499.5 + 254747.9 + 39447.8, 49726.1 + 18393.5 + 19241.9 + 542.7),
+    ("ac_fwd_kernel:train", 32): _kib(1287791.2, 960691.1),       # actor + critic forward of a PPO epoch (one launch)
 }
 
 
@@ -228,9 +240,10 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
               f"decoder forward of Behavior_policy.learn in {pieces('beh_dec_fwd_kernel')} window-range launches, beside the encoder forward"),
         entry("beh_enc_bwd_kernel", "beh_enc_bwd_kernel", "mfma", 2 * f_enc / pieces("beh_enc_bwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
               "encoder BPTT with in-kernel weight gradients (2x the forward FLOPs), side stream"),
-        entry("wgrad_partial_kernel (+reduce)", "iplan_wgrad", "hbm", 0.0, 1e9, HBM_PEAK_GBS, "GB/s",
-              "every iplan_wgrad call of the cycle (behaviour decoder, prediction, PPO 64-wide layers): algorithmic bytes = each operand row "
-              "read once, 4 (O + K) bytes per row and problem; mean over the calls", traffic_key="wgrad_partial_kernel", work_from_timer=True),
+        entry("wgrad_partial_kernel (+reduce)", "iplan_wgrad:beh_dec", "hbm", 0.0, 1e9, HBM_PEAK_GBS, "GB/s",
+              "the iplan_wgrad call on each decoder-BPTT window range of Behavior_policy.learn (4 problems: W_out, W_ih, W_hh, W_lin; 3 partial "
+              "kernels + reduction, side stream): algorithmic bytes = each operand row read once, 4 (O + K) bytes per row and problem",
+              traffic_key="iplan_wgrad:beh_dec", work_from_timer=True),
         entry("ac_fwd_kernel<PPO>", "ac_fwd_kernel:train", "mfma", f_ac, 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
               f"actor + critic forward of one PPO epoch ({rows} rows x F = {F}, 5 agents, activations saved); SURVEY.md §8d: AI ~ ridge, so "
               "both roofs are reported", traffic_key="ac_fwd_kernel:train"),

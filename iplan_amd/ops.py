@@ -361,10 +361,11 @@ def workspace(device, floats, tag="wgrad"):
 class Wgrad:
     """Batch of dW = dY^T X problems (include/iplan_hip.h: IplanWgradProblem) written into a gradient arena."""
 
-    def __init__(self, grad, n_nets):
+    def __init__(self, grad, n_nets, tag="iplan_wgrad"):
         self.grad, self.n_nets = grad, n_nets
         self.problems = []
         self._keep = []
+        self.tag = tag                                      # KernelTimers key of the launches (bench.py's roofline entries)
 
     def add(self, dy, dy_strides, O, n_outer, n_inner, x=None, x_strides=(0, 0, 0), K=0, dw_off=-1, db_off=-1,
             dw_ld=None, dw_col0=0, seg=None, x_col0=0, x_shift=0, x0=None, x0_strides=(0, 0), beta=0.0, scale=1.0):
@@ -405,7 +406,7 @@ class Wgrad:
             a.workspace, a.workspace_floats = ws.data_ptr(), ws.numel()
             # algorithmic HBM bytes: every operand row of every problem read exactly once (4 (O + K) bytes per row)
             nbytes = 4.0 * self.n_nets * sum(p.n_outer * p.n_inner * (p.O + p.K) for p in chunk)
-            _launch("iplan_wgrad", lambda: lib.call("iplan_wgrad", a, stream), work=nbytes)
+            _launch(self.tag, lambda: lib.call("iplan_wgrad", a, stream), work=nbytes)
 
 
 def _ac_wgrad(w, arena, head_names, saved, dsave, which, n_agents, rows, T, h, h_strides, T_phys, n_out, tiles, ln_part):
@@ -763,7 +764,7 @@ def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_nor
 
     def dec_wgrad(s0, s1, beta):
         """decoder weight gradients over the rows of steps [s0, s1) of every chain (accumulating when beta = 1)"""
-        w = Wgrad(dec_arena.grad, n_nets)
+        w = Wgrad(dec_arena.grad, n_nets, tag="iplan_wgrad:beh_dec")
         ddp, sdp, n = dd.data_ptr() + 4 * s0 * DD, sd + 4 * s0 * SD, s1 - s0
         w.add(ddp, dd_st, d, rows, n, x=sdp + 4 * 416, x_strides=sd_st, K=H, beta=beta,
               dw_off=off("decoder.out.weight"), db_off=off("decoder.out.bias"))
