@@ -102,17 +102,6 @@ __device__ __forceinline__ float window_mask_sum(const IplanBehArgs& a, int net,
     return wave_sum(s) * (float)(a.N * a.d);
 }
 
-// Zeroing a loaded value is a bitwise AND with an all-ones / zero lane mask, NOT `cond ? loaded : 0`: the compiler turns a
-// select whose operand is a load back into a branch around the load (and then waits for it on the spot).
-__device__ __forceinline__ float keep_if(bool ok, float v) {
-    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & (ok ? 0xFFFFFFFFu : 0u));
-}
-__device__ __forceinline__ f32x4 zero_unless(bool ok, f32x4 v) {
-    const uint32_t m = ok ? 0xFFFFFFFFu : 0u;
-    f32x4 r;
-    for (int q = 0; q < 4; ++q) r[q] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)v[q]) & m);
-    return r;
-}
 // entries 4g .. 4g+3 of a dim-wide row behind a per-lane pointer (any alignment), indices clamped to the row, NOT masked
 __device__ __forceinline__ f32x4 ld_row_raw(const float* __restrict__ row, int dim, int g) {
     f32x4 v;
@@ -517,6 +506,7 @@ __global__ __launch_bounds__(DEC_THREADS) void beh_dec_fwd_kernel(IplanBehArgs a
     stage_vector(s_b + 256, 192, PD + a.dec_off[IPLAN_DEC_BHH], 192);
     stage_vector(s_b + 448, 16, PD + a.dec_off[IPLAN_DEC_OUT_B], a.d);
     __syncthreads();
+    // (rotating the quarters over the SIMDs per tile -- quarter 0 carries a tile's extra work -- measured 2 % slower)
     const int w = uniform_i(wave_id()), q = w & 3, ts = w >> 2;
     DecTile c;
     dec_tile(a, c, (int)blockIdx.x * DEC_TILES + ts);       // waves without a tile still take part in the block barriers
@@ -737,6 +727,7 @@ __global__ __launch_bounds__(DEC_THREADS) void beh_dec_bwd_kernel(IplanBehArgs a
         }
     }
     __syncthreads();
+    // (rotating the quarters over the SIMDs per tile -- quarter 0 carries a tile's extra work -- measured 2 % slower)
     const int w = uniform_i(wave_id()), q = w & 3, ts = w >> 2;
     DecTile c;
     dec_tile(a, c, (int)blockIdx.x * DEC_TILES + ts);       // waves without a tile still take part in the block barriers

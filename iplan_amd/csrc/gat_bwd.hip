@@ -58,6 +58,9 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
     float* __restrict__ ndy = a.node_dy + sb * N * DY;
     float* __restrict__ hpart = a.hard_part + sb * IPLAN_GAT_HARD_PART;
 
+    // optional phase clocks of workgroup 0 (slots 8..14 of the forward's profiling buffer: entry, A, B, C, D, E, F)
+    int64_t* __restrict__ clk = (f.phase_clocks && blockIdx.x == 0 && threadIdx.x == 0) ? f.phase_clocks + 8 : nullptr;
+    if (clk) clk[0] = IPLAN_CLOCK();
     // q, k, v of the scene -> LDS
     for (int idx = (int)threadIdx.x; idx < N * 3 * BH; idx += (int)blockDim.x) {
         const int nd = idx / (3 * BH), c = idx - nd * 3 * BH;
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
         }
     }
     __syncthreads();
+    if (clk) clk[1] = IPLAN_CLOCK();
 
     // ---------------------------------------------------------------- B: attention backward per ego
     {
@@ -136,6 +140,7 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
         hpart[8 * BH] = t;
     }
 
+    if (clk) clk[2] = IPLAN_CLOCK();
     // ---------------------------------------------------------------- C: dk_j, dv_j per node
     for (int j = w; j < N; j += 8) {
         const int c = l & 31, hf = l >> 5;
@@ -154,6 +159,7 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
         }
     }
 
+    if (clk) clk[3] = IPLAN_CLOCK();
     // ---------------------------------------------------------------- D: BPTT through the pair GRU
     float* __restrict__ dgru_base = a.dgru + ((((int64_t)net * 2 + dir) * f.B + b) * N) * (int64_t)(N - 1) * (4 * BH);
     if (tile_live) {
@@ -164,39 +170,73 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
         const float* Wh = P + f.off[IPLAN_GAT_HARD_W];                              // [2][2H]
         f32x4 wdiff[2];
         for (int T = 0; T < 2; ++T) wdiff[T] = bfrag(Wh + 2 * BH + dir * BH, BH, T) - bfrag(Wh + dir * BH, BH, T);
-        const float* gbase = sv.gru + ((((int64_t)net * 2 + dir) * f.B + b) * N + node) * (int64_t)(N - 1) * (5 * BH);
-        float* dbase = dgru_base + (int64_t)node * (N - 1) * (4 * BH);
+        // The forward's record of a pair step (h_s, r, z, n, hn) and of the step the forward came from (h of it = h_prev).
+        // Fetched one step ahead with plain 16-byte loads -- the former predicated, alignment-checked loads each ended in a
+        // full wait: twelve serial L2 / HBM round trips per step (8.6 us per step, profiles/r02e_notes.md).  A lane without a
+        // chain (the ragged last tile) is a CLONE of the scene's last node: it loads, computes and stores exactly what that
+        // node's lane does (same values to the same addresses), so nothing in the step loop is predicated; only the sums
+        // over the 16 chains below leave the clones out.
+        const int cnode = imin(node, N - 1);
+        const float* gbase = sv.gru + ((((int64_t)net * 2 + dir) * f.B + b) * N + cnode) * (int64_t)(N - 1) * (5 * BH) + 4 * g;
+        float* dbase = dgru_base + (int64_t)cnode * (N - 1) * (4 * BH) + 4 * g;
+        struct PairIn {
+            f32x4 hs[2], r[2], z[2], nn[2], hn[2], hp[2];
+            float dd;
+            bool has_prev;
+        };
+        auto load_step = [&](int it, PairIn& o, bool first) {
+            const int s = dir ? it : (N - 2 - it);                 // reverse of the forward visiting order
+            const int sp = dir ? s + 1 : s - 1;                    // the step the forward came from
+            o.has_prev = sp >= 0 && sp <= N - 2;
+            const float* row = gbase + (int64_t)s * (5 * BH);
+            const float* prow = gbase + (int64_t)(o.has_prev ? sp : s) * (5 * BH);
+            for (int T = 0; T < 2; ++T) {
+                if (first) o.hs[T] = *reinterpret_cast<const f32x4*>(row + 16 * T);      // later: the previous step's hp
+                o.r[T] = *reinterpret_cast<const f32x4*>(row + BH + 16 * T);
+                o.z[T] = *reinterpret_cast<const f32x4*>(row + 2 * BH + 16 * T);
+                o.nn[T] = *reinterpret_cast<const f32x4*>(row + 3 * BH + 16 * T);
+                o.hn[T] = *reinterpret_cast<const f32x4*>(row + 4 * BH + 16 * T);
+                o.hp[T] = *reinterpret_cast<const f32x4*>(prow + 16 * T);
+            }
+            o.dd = s_dd[cnode][s];
+        };
         f32x4 dh[2], da[6], hacc[2];
         for (int T = 0; T < 2; ++T) { dh[T] = splat4(0.f); hacc[T] = splat4(0.f); }
         for (int t = 0; t < 6; ++t) da[t] = splat4(0.f);
+        PairIn cur;
+        load_step(0, cur, true);
         for (int it = 0; it < N - 1; ++it) {
-            const int s = dir ? it : (N - 2 - it);                 // reverse of the forward visiting order
-            const int sp = dir ? s + 1 : s - 1;                    // the step the forward came from
-            const bool has_prev = sp >= 0 && sp <= N - 2;
-            const float* row = gbase + (int64_t)s * (5 * BH);
-            const float* prow = gbase + (int64_t)sp * (5 * BH);
-            const float dd = valid ? s_dd[node][s] : 0.f;
+            const int s = dir ? it : (N - 2 - it);
+            const float dd = cur.dd;
             f32x4 dgh[6];
             f32x4 dhd[2];
+            GruGrads o2[2];
             for (int T = 0; T < 2; ++T) {
-                const f32x4 hs = vload(row, valid, BH, T);
-                const f32x4 hp = vload(prow, valid && has_prev, BH, T);
+                const f32x4 hs = cur.hs[T];
+                const f32x4 hp = zero_unless(cur.has_prev, cur.hp[T]);
                 f32x4 dht;
                 for (int q = 0; q < 4; ++q) {
                     dht[q] = fmaf(wdiff[T][q], dd, dh[T][q]);
                     hacc[T][q] = fmaf(dd, hs[q], hacc[T][q]);
                 }
-                const GruGrads o = gru_gates_bwd(dht, vload(row + BH, valid, BH, T), vload(row + 2 * BH, valid, BH, T),
-                                                 vload(row + 3 * BH, valid, BH, T), vload(row + 4 * BH, valid, BH, T), hp);
-                float* drow = dbase + (int64_t)s * (4 * BH);
-                vstore(drow, valid, BH, T, o.dr);
-                vstore(drow + BH, valid, BH, T, o.dz);
-                vstore(drow + 2 * BH, valid, BH, T, o.dni);
-                vstore(drow + 3 * BH, valid, BH, T, o.dnh);
-                da[T] += o.dr; da[2 + T] += o.dz; da[4 + T] += o.dni;
-                dgh[T] = o.dr; dgh[2 + T] = o.dz; dgh[4 + T] = o.dnh;
-                dhd[T] = o.dh_direct;
+                o2[T] = gru_gates_bwd(dht, cur.r[T], cur.z[T], cur.nn[T], cur.hn[T], hp);
+                da[T] += o2[T].dr; da[2 + T] += o2[T].dz; da[4 + T] += o2[T].dni;
+                dgh[T] = o2[T].dr; dgh[2 + T] = o2[T].dz; dgh[4 + T] = o2[T].dnh;
+                dhd[T] = o2[T].dh_direct;
             }
+            float* drow = dbase + (int64_t)s * (4 * BH);
+            for (int T = 0; T < 2; ++T) {
+                *reinterpret_cast<f32x4*>(drow + 16 * T) = o2[T].dr;
+                *reinterpret_cast<f32x4*>(drow + BH + 16 * T) = o2[T].dz;
+                *reinterpret_cast<f32x4*>(drow + 2 * BH + 16 * T) = o2[T].dni;
+                *reinterpret_cast<f32x4*>(drow + 3 * BH + 16 * T) = o2[T].dnh;
+            }
+            IPLAN_SCHED_FENCE();
+            // next step's record under this step's 48 MFMAs; its h is this step's h_prev (the BPTT walks the forward's order
+            // backwards), already in registers
+            for (int T = 0; T < 2; ++T) cur.hs[T] = cur.hp[T];
+            load_step(it + 1 < N - 1 ? it + 1 : it, cur, false);
+            IPLAN_SCHED_FENCE();
             for (int T = 0; T < 2; ++T) {
                 f32x4 acc = dhd[T];
                 for (int t = 0; t < 6; ++t) acc = mma_block(whT[T][t], dgh[t], acc);
@@ -207,31 +247,43 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
         for (int t = 0; t < 6; ++t) vstore(arow, valid, 3 * BH, t, da[t]);
         for (int T = 0; T < 2; ++T)
             for (int q = 0; q < 4; ++q) {
-                const float sum = chain_sum16(hacc[T][q]);
+                const float sum = chain_sum16(valid ? hacc[T][q] : 0.f);
                 if (n == 0) hpart[(dir * 4 + tile) * BH + 16 * T + 4 * g + q] = sum;
             }
     } else {
         if (l < BH) hpart[(dir * 4 + tile) * BH + l] = 0.f;
     }
     __syncthreads();
+    if (clk) clk[4] = IPLAN_CLOCK();
 
     // ---------------------------------------------------------------- E: d(W_b h_j) gather per node
+    // node j is seen by ego i != j at pair step s = j - (j > i); the egos are enumerated as i = u + (u >= j), u = 0 .. N-2 (no
+    // branch), 18 rows fetched per batch before any of them is added (the former load-add-load chain was one L2 round trip
+    // per row: 400 us per scene), summed in the same order as before
     for (int p = w; p < 2 * N; p += 8) {
         const int j = p >> 1, d2 = p & 1;
-        const float* base = a.dgru + ((((int64_t)net * 2 + d2) * f.B + b) * N) * (int64_t)(N - 1) * (4 * BH);
+        const float* base = a.dgru + ((((int64_t)net * 2 + d2) * f.B + b) * N) * (int64_t)(N - 1) * (4 * BH) + l;
         float a0 = 0.f, a1 = 0.f;
-        for (int i = 0; i < N; ++i) {
-            if (i == j) continue;
-            const int s = j - (j > i ? 1 : 0);
-            const float* row = base + ((int64_t)i * (N - 1) + s) * (4 * BH);
-            a0 += row[l];
-            if (l < 32) a1 += row[64 + l];
+        constexpr int UB = 18;
+        for (int u0 = 0; u0 < N - 1; u0 += UB) {
+            float v0[UB], v1[UB];
+            for (int k = 0; k < UB; ++k) {
+                const int u = imin(u0 + k, N - 2);
+                const int i = u + (u >= j ? 1 : 0);
+                const int s = i < j ? j - 1 : j;
+                const float* row = base + ((int64_t)i * (N - 1) + s) * (4 * BH);
+                v0[k] = row[0];
+                v1[k] = row[64];                                   // (lanes >= 32 read the dnh columns: unused)
+            }
+            for (int k = 0; k < UB; ++k)
+                if (u0 + k < N - 1) { a0 += v0[k]; a1 += v1[k]; }
         }
         float* brow = ndy + (int64_t)j * DY + DY_DB + d2 * DY_DIR;
         brow[l] = a0;
         if (l < 32) brow[64 + l] = a1;
     }
     __syncthreads();
+    if (clk) clk[5] = IPLAN_CLOCK();
 
     // ---------------------------------------------------------------- F: node projections backward
     if (tile_live) {
@@ -279,6 +331,7 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
     } else {
         __syncthreads();
     }
+    if (clk) clk[6] = IPLAN_CLOCK();
 }
 
 }  // namespace iplan

@@ -174,6 +174,17 @@ __device__ __forceinline__ f32x4 bfrag(const float* __restrict__ b, int dim, int
 template <class T>
 __device__ __forceinline__ const IPLAN_GLOBAL_AS T* as_global(const T* p) { return (const IPLAN_GLOBAL_AS T*)p; }
 
+// Zeroing a loaded value is a bitwise AND with an all-ones / zero lane mask, NOT `cond ? loaded : 0`: the compiler turns a
+// select whose operand is a load back into a branch around the load (and then waits for it on the spot).
+__device__ __forceinline__ float keep_if(bool ok, float v) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & (ok ? 0xFFFFFFFFu : 0u));
+}
+__device__ __forceinline__ f32x4 zero_unless(bool ok, f32x4 v) {
+    const uint32_t m = ok ? 0xFFFFFFFFu : 0u;
+    f32x4 r;
+    for (int q = 0; q < 4; ++q) r[q] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)v[q]) & m);
+    return r;
+}
 // A wave-uniform value the compiler cannot prove uniform (anything derived from threadIdx.x, like the wave index): through
 // an SGPR.  Branches and loop bounds on it become scalar branches -- with a "divergent" condition every load inside turns
 // into an exec-masked block and the wait counters are drained at each join.

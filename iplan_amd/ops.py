@@ -502,7 +502,7 @@ def ac_backward(fwd, actor_arena, critic_arena, g_logp=None, g_entropy=0.0, g_va
     return dict(dsave=dsave, ln_part=ln_part)
 
 
-def gat_backward(arena, saved, g_out, lib=None):
+def gat_backward(arena, saved, g_out, phase_clocks=None, lib=None):
     """Backward of a ``gat_forward(..., save=True)`` launch.  g_out [n_nets, B, N, A] (first two dims may
     be strided).  Fills arena.grad (every GAT parameter of every net)."""
     lib = _lib(lib)
@@ -520,7 +520,11 @@ def gat_backward(arena, saved, g_out, lib=None):
     node_dy = torch.empty(n_nets, B * N, L.GAT_NODE_DY, **f32)
     hard_part = torch.empty(n_nets, B, L.GAT_HARD_PART, **f32)
     a.dgru, a.node_dy, a.hard_part = dgru.data_ptr(), node_dy.data_ptr(), hard_part.data_ptr()
+    if phase_clocks is not None:                            # int64 [>= 15]: workgroup 0's clocks land in slots 8..14
+        assert phase_clocks.dtype == torch.int64 and phase_clocks.numel() >= 15
+        a.fwd.phase_clocks = phase_clocks.data_ptr()
     lib.call("iplan_gat_bwd", a, L.current_stream(dev))
+    a.fwd.phase_clocks = fa.phase_clocks
 
     w = Wgrad(arena.grad, n_nets)
     off = arena.off

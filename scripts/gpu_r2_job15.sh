@@ -1,0 +1,17 @@
+#!/bin/bash
+# quarter rotation A/B (old = build/abl/lib_norotate.so) + gat_bwd phase clocks
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"; O=gpurun_out; export TMPDIR=/tmp
+OLD=$R/build/abl/lib_norotate.so
+run() { ( cd /tmp && env ${3:-X=1} IPLAN_BEH_SERIAL=1 IPLAN_HIP_LIB=$2 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/abl/$1" -o mb -- python "$R/scripts/microbench.py" behavior_learn > "$R/$O/abl/$1.log" 2>&1 )
+  echo "== $1 (serial)"; grep -E "beh_dec|beh_enc" $(find "$O/abl/$1" -name "*kernel_stats.csv") | awk -F, '{printf "%s calls %s avg_us %.1f\n",$1,$2,$4/1000}'; }
+mkdir -p $O/abl
+run norotate $OLD > $O/abl_summary.txt
+run rotate $R/iplan_amd/libiplan_hip.so >> $O/abl_summary.txt
+for i in 1 2; do
+IPLAN_HIP_LIB=$OLD timeout 200 python scripts/microbench.py behavior_learn > $O/ab_old$i.log 2>&1
+timeout 200 python scripts/microbench.py behavior_learn > $O/ab_new$i.log 2>&1
+done
+grep -H "behavior_learn" $O/ab_old*.log $O/ab_new*.log >> $O/abl_summary.txt
+timeout 200 python scripts/microbench.py gat_bwd_phases 2>&1 | grep -i "gat" >> $O/abl_summary.txt
+rm -rf $O/abl/*/

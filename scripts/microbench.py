@@ -111,6 +111,27 @@ if "gat_phases12" in set(sys.argv[1:]):           # libraries built with -DGAT_P
     print("gat clocks x10 ns, mean per WG: entry->p1->p2->[noise issued]->[score GEMM]->[softmax]->[gate]->[aggregate]->barrier->p4:",
           (seq[:, 1:] - seq[:, :-1]).mean(0).tolist())
 
+if "gat_bwd_phases" in set(sys.argv[1:]):     # training-form GAT (Prediction_policy.learn's shape: 64 sampled scenes per net)
+    S = 64
+    ar = loop.prediction.gat_arena
+    ob = torch.rand(nA, S, N, hist.shape[-1], device=dev) * 2 - 1
+    la = torch.rand(nA, S, N, lat.shape[-1], device=dev)
+    hi = torch.randn(nA, S, N, 32, device=dev) * 0.1
+    from iplan_amd.nova.GAT_Net import gumbel_noise
+    nz = gumbel_noise((nA, S, N, N - 1, 2), dev)
+    go = torch.randn(nA, S, N, 32, device=dev)
+
+    def fb(clk=None):
+        o, saved = ops.gat_forward(ar, ob, la, hi, nz, save=True)
+        ops.gat_backward(ar, saved, go, phase_clocks=clk)
+    tm("gat_fwd(save)+bwd+wgrad S=64", fb, n=5)
+    tm("gat_fwd(save) S=64", lambda: ops.gat_forward(ar, ob, la, hi, nz, save=True), n=5)
+    clk = torch.zeros(16, dtype=torch.int64, device=dev)
+    fb(clk)
+    torch.cuda.synchronize()
+    c = clk.cpu().double()[8:15]
+    print("gat_bwd phases of WG 0, x10 ns: A cell', B attention', C dk dv, D pair-GRU BPTT, E gather, F projections' =", (c[1:] - c[:-1]).tolist())
+
 if "gat_phases" in set(sys.argv[1:]):
     clk = torch.zeros(nA * E, 5, dtype=torch.int64, device=dev)
     ops.gat_forward(loop.prediction.gat_arena, hist, lat, hid, noise, out=out, phase_clocks=clk)
