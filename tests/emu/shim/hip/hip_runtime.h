@@ -53,8 +53,23 @@ struct Wave {
     int ia[64];
 };
 
+// Context switch.  glibc's swapcontext saves / restores the signal mask with a system call on every switch (half of the
+// emulator's CPU time was spent in the kernel); on x86-64 a fiber switch here is the callee-saved registers and the stack
+// pointer (tests/emu/emu_runtime.cpp), elsewhere ucontext.
+#if defined(__x86_64__)
+#define IPLAN_EMU_FAST_SWITCH 1
+struct Ctx {
+    void* sp = nullptr;
+};
+extern "C" void iplan_emu_switch(Ctx* from, Ctx* to);
+inline void switch_ctx(Ctx* from, Ctx* to) { iplan_emu_switch(from, to); }
+#else
+typedef ucontext_t Ctx;
+inline void switch_ctx(Ctx* from, Ctx* to) { swapcontext(from, to); }
+#endif
+
 struct Fiber {
-    ucontext_t ctx;
+    Ctx ctx;
     std::vector<char> stack;
     dim3 tid;
     int lane = 0, wave = 0;
@@ -66,14 +81,14 @@ struct Block {
     std::vector<Fiber> fibers;
     std::vector<Wave> waves;
     int alive = 0, arrived = 0, gen = 0;
-    ucontext_t sched;
+    Ctx sched;
     std::function<void()> body;
 };
 
 extern Block* g_block;
 extern Fiber* g_cur;
 
-inline void yield_() { swapcontext(&g_cur->ctx, &g_block->sched); }
+inline void yield_() { switch_ctx(&g_cur->ctx, &g_block->sched); }
 
 inline void block_sync() {
     Block* b = g_block;

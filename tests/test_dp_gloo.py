@@ -29,7 +29,7 @@ from iplan_amd.parallel import DataParallel
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 EF, ER = 4, 2                                                       # envs of the union / of one rank
-kw = dict(use_cuda=False, max_vehicle_num=3, n_agents=2, episode_limit=9, ppo_epoch=2, pred_batch_size=3, max_history_len=3)
+kw = dict(use_cuda=False, max_vehicle_num=3, n_agents=2, episode_limit=8, ppo_epoch=2, pred_batch_size=3, max_history_len=2)
 args_f = default_args("highway", batch_size_run=EF, buffer_size=EF, batch_size=EF, **kw)
 args_r = default_args("highway", batch_size_run=ER, buffer_size=ER, batch_size=ER, **kw)
 nA, N, T, Lw, P = args_f.n_agents, args_f.max_vehicle_num, args_f.episode_limit, args_f.max_history_len, args_f.pred_length
