@@ -449,22 +449,29 @@ int iplan_ppo_loss(const IplanPpoLossArgs* args, iplan_stream_t stream);
 /* ------------------------------------------------------------------------------------------
  * Backward of GAT_Net.forward (autograd under loss.backward() at nova/prediction_policy.py:228) for
  * every (net, env) scene in one launch: GRUCell', gated soft attention', gumbel gate', BPTT through
- * the bidirectional pair GRU, node projections'.  Emits row-level pre-activation gradients; the
- * weight gradients are iplan_wgrad contractions over them (host assembles the problem list).
+ * the bidirectional pair GRU (its recurrent weight / bias gradients accumulated in-kernel), node
+ * projections'.  Emits node-level pre-activation gradients; their weight gradients are iplan_wgrad
+ * contractions over them (host assembles the problem list).
  * node_dy row layout (floats): ENC 0 (H) | DA_fwd 32 | DB_fwd 128 | DA_rev 224 | DB_rev 320 (3H each)
  *                              | DQ 416 | DK 448 | DV 480 (A each) | CELL 512 (dr dz dn_i dn_h, 4A).
  * hard_part row (per scene): [dir][tile<4][H] partial sums of dDelta * h, then sum(dDelta) at 8H.
  */
 #define IPLAN_GAT_NODE_DY 640
 #define IPLAN_GAT_HARD_PART (8 * IPLAN_GAT_HIDDEN + 16)
+#define IPLAN_GAT_WHH_PART (3 * IPLAN_GAT_HIDDEN * IPLAN_GAT_HIDDEN + 3 * IPLAN_GAT_HIDDEN)   /* dW_hh [3H, H] | db_hh [3H] */
 
 typedef struct {
     IplanGatFwdArgs fwd;        /* descriptor of the forward launch (saved.* all non-NULL)           */
     const float* g_out;         /* dLoss/d out, rows of A floats: (net,b,i)                          */
     int64_t g_s_net, g_s_b;
-    float* dgru;                /* [n_nets, 2, B*N, N-1, 4H]   dr dz dn_i dn_h per pair step         */
+    float* dgru;                /* scratch [n_nets, 2, B*N, N-1, 3H] (kernel-private layout)         */
     float* node_dy;             /* [n_nets, B*N, IPLAN_GAT_NODE_DY]                                  */
     float* hard_part;           /* [n_nets, B, IPLAN_GAT_HARD_PART]                                  */
+    float* whh_part;            /* scratch [n_nets, B, 2, 4, IPLAN_GAT_WHH_PART]                     */
+    float* grad;                /* gradient arena: hard_bi_GRU.weight_hh_l0{,_reverse} and bias_hh_l0{,_reverse} are
+                                   WRITTEN here (at fwd.off[...]); all other GAT gradients are iplan_wgrad contractions
+                                   over node_dy / hard_part assembled by the host                                    */
+    int64_t grad_s_net;
 } IplanGatBwdArgs;
 
 int iplan_gat_bwd(const IplanGatBwdArgs* args, iplan_stream_t stream);

@@ -270,11 +270,12 @@ class PpoLossArgs(C.Structure):
 # ---- GAT backward --------------------------------------------------------------------------------------
 GAT_NODE_DY = 640
 GAT_HARD_PART = 8 * 32 + 16
+GAT_WHH_PART = 3 * 32 * 32 + 3 * 32
 
 
 class GatBwdArgs(C.Structure):
     _fields_ = [("fwd", GatFwdArgs), ("g_out", fp), ("g_s_net", i64), ("g_s_b", i64),
-                ("dgru", fp), ("node_dy", fp), ("hard_part", fp)]
+                ("dgru", fp), ("node_dy", fp), ("hard_part", fp), ("whh_part", fp), ("grad", fp), ("grad_s_net", i64)]
 
 
 # ---- prediction decoder ------------------------------------------------------------------------------

@@ -6,12 +6,13 @@
 //   C  per node (wave):    the scatter side dk_j, dv_j as gathers over the N-1 egos that see j
 //   D  BPTT of the bidirectional pair GRU: wave (dir, tile) walks its 16 ego chains backwards,
 //      W_hh^T in registers as MFMA A fragments, gate math lane-local, the hard-gate gradient
-//      injected per step; the per-step gate gradients stream to HBM (they are the dY operand of
-//      the W_hh weight-gradient contraction, wgrad.hip)
+//      injected per step; dW_hh / db_hh accumulate in-kernel (12 register tiles, operands turned through
+//      LDS); the input-side gate gradients [dr dz dn_i] go to a scratch laid out for phase E
 //   E  per node: d(W_b h_j) = gather-sum of the pair-step gradients of the egos that saw j
 //   F  node projections': dh_enc = W_a^T da + W_b^T db + W_q^T dq + W_k^T dk + W_v^T dv, ReLU'
-// Only row-level pre-activation gradients leave the kernel; every weight gradient is a dY^T X
-// contraction over them (node level for everything except W_hh).
+// Node-level pre-activation gradients leave the kernel (their weight gradients are dY^T X contractions,
+// wgrad.hip); the pair-level W_hh gradient is accumulated here -- streaming the pair-step gradients out
+// and back in for it was a third of the kernel pair's HBM traffic.
 #include "api_util.h"
 #include "gru_tile.h"
 
@@ -36,11 +37,17 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
     __shared__ float s_k[BNP][BQS];
     __shared__ float s_v[BNP][BQS];
     __shared__ float s_dx[BNP][BQS];
-    __shared__ float s_ds[BNP][BNP];
-    __shared__ float s_w[BNP][BNP];
+    // d score and soft*hard per (ego, step) for phases B / C; phase D re-uses the 32 KB for W_hh^T of both directions
+    // ([H][3H + 8]: conflict-free ds_read_b128 fragments) -- in registers they put the step loop 24 VGPRs over budget
+    __shared__ __attribute__((aligned(16))) float s_sw[2][BNP][BNP];
+    float (*s_ds)[BNP] = s_sw[0];
+    float (*s_w)[BNP] = s_sw[1];
+    constexpr int WLD = 3 * BH + 8;
+    static_assert(2 * BH * WLD <= 2 * BNP * BNP, "W_hh^T copies must fit the score buffers");
     __shared__ float s_dd[BNP][BNP];
     __shared__ __attribute__((aligned(16))) f32x4 s_acc[4][2][64];
     __shared__ float s_red[8];
+    __shared__ __attribute__((aligned(16))) float s_turn[8][8][256];       // per wave: 6 gate-gradient tiles + 2 h_prev tiles (phase D)
 
     const IplanGatFwdArgs& f = a.fwd;
     const IplanGatSaved& sv = f.saved;
@@ -159,14 +166,21 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
         }
     }
 
+    __syncthreads();                                                // phases B / C are done with the score buffers
+    {
+        float* swT = &s_sw[0][0][0];
+        stage_matrix_t(swT, WLD, BH, P + f.off[IPLAN_GAT_F_WHH], 3 * BH, BH);
+        stage_matrix_t(swT + BH * WLD, WLD, BH, P + f.off[IPLAN_GAT_R_WHH], 3 * BH, BH);
+    }
+    __syncthreads();
     if (clk) clk[3] = IPLAN_CLOCK();
     // ---------------------------------------------------------------- D: BPTT through the pair GRU
-    float* __restrict__ dgru_base = a.dgru + ((((int64_t)net * 2 + dir) * f.B + b) * N) * (int64_t)(N - 1) * (4 * BH);
+    // dgru: kernel-private scratch, [net][dir][scene][neighbour j][u][3H] with u = the ego's index among the N-1 egos that
+    // see j (i = u + (u >= j)): phase D scatters a pair step's [dr dz dn_i] to its NEIGHBOUR's block, phase E then sums each
+    // block over u as one contiguous stream
+    float* __restrict__ dgru_base = a.dgru + ((((int64_t)net * 2 + dir) * f.B + b) * N) * (int64_t)(N - 1) * (3 * BH);
     if (tile_live) {
-        const float* Whh = P + f.off[dir ? IPLAN_GAT_R_WHH : IPLAN_GAT_F_WHH];     // [3H][H]
-        f32x4 whT[2][6];
-        for (int T = 0; T < 2; ++T)
-            for (int t = 0; t < 6; ++t) whT[T][t] = wfrag_t(Whh, BH, 3 * BH, BH, 16 * T, 16 * t);
+        const float* swT = &s_sw[0][0][0] + dir * (BH * WLD);                      // W_hh^T [H][3H] of this direction
         const float* Wh = P + f.off[IPLAN_GAT_HARD_W];                              // [2][2H]
         f32x4 wdiff[2];
         for (int T = 0; T < 2; ++T) wdiff[T] = bfrag(Wh + 2 * BH + dir * BH, BH, T) - bfrag(Wh + dir * BH, BH, T);
@@ -178,7 +192,14 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
         // over the 16 chains below leave the clones out.
         const int cnode = imin(node, N - 1);
         const float* gbase = sv.gru + ((((int64_t)net * 2 + dir) * f.B + b) * N + cnode) * (int64_t)(N - 1) * (5 * BH) + 4 * g;
-        float* dbase = dgru_base + (int64_t)cnode * (N - 1) * (4 * BH) + 4 * g;
+        float (*turn)[256] = s_turn[w];
+        // a parked tile is [16 chains][16 columns], chain r's columns rotated by 4 (r >> 1) (conflict-free ds_write_b128 /
+        // ds_read_b32, as in beh_enc_bwd_kernel); pick = operand element [chain 4 s + g][column n]
+        auto park = [&](int slot, f32x4 v) { *reinterpret_cast<f32x4*>(&turn[slot][n * 16 + ((4 * g + 4 * (n >> 1)) & 15)]) = v; };
+        auto pick = [&](int slot, int s4) { const int r = 4 * s4 + g; return turn[slot][r * 16 + ((n + 4 * (r >> 1)) & 15)]; };
+        f32x4 aW[6][2], bNh[2];                                     // dW_hh [3H x H] in 12 register tiles; lane-local sums of dn_h
+        for (int t = 0; t < 6; ++t) { aW[t][0] = splat4(0.f); aW[t][1] = splat4(0.f); }   // (db_hh's r, z parts = the da sums below)
+        bNh[0] = splat4(0.f); bNh[1] = splat4(0.f);
         struct PairIn {
             f32x4 hs[2], r[2], z[2], nn[2], hn[2], hp[2];
             float dd;
@@ -224,13 +245,20 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
                 dgh[T] = o2[T].dr; dgh[2 + T] = o2[T].dz; dgh[4 + T] = o2[T].dnh;
                 dhd[T] = o2[T].dh_direct;
             }
-            float* drow = dbase + (int64_t)s * (4 * BH);
-            for (int T = 0; T < 2; ++T) {
-                *reinterpret_cast<f32x4*>(drow + 16 * T) = o2[T].dr;
-                *reinterpret_cast<f32x4*>(drow + BH + 16 * T) = o2[T].dz;
-                *reinterpret_cast<f32x4*>(drow + 2 * BH + 16 * T) = o2[T].dni;
-                *reinterpret_cast<f32x4*>(drow + 3 * BH + 16 * T) = o2[T].dnh;
+            {   // the pair's input-side gate gradients go to the neighbour's block
+                const int j = s + (s >= cnode ? 1 : 0), u = cnode - (cnode > j ? 1 : 0);
+                float* drow = dgru_base + ((int64_t)j * (N - 1) + u) * (3 * BH) + 4 * g;
+                for (int T = 0; T < 2; ++T) {
+                    *reinterpret_cast<f32x4*>(drow + 16 * T) = o2[T].dr;
+                    *reinterpret_cast<f32x4*>(drow + BH + 16 * T) = o2[T].dz;
+                    *reinterpret_cast<f32x4*>(drow + 2 * BH + 16 * T) = o2[T].dni;
+                }
             }
+            // dW_hh += [dr dz dn_h]^T h_prev over the tile's 16 chains (clones contribute zero): operands turned through LDS
+            for (int t = 0; t < 6; ++t) park(t, dgh[t]);
+            bNh[0] += dgh[4]; bNh[1] += dgh[5];
+            for (int T = 0; T < 2; ++T) park(6 + T, zero_unless(valid && cur.has_prev, cur.hp[T]));
+            IPLAN_WAVE_SYNC();
             IPLAN_SCHED_FENCE();
             // next step's record under this step's 48 MFMAs; its h is this step's h_prev (the BPTT walks the forward's order
             // backwards), already in registers
@@ -239,9 +267,30 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
             IPLAN_SCHED_FENCE();
             for (int T = 0; T < 2; ++T) {
                 f32x4 acc = dhd[T];
-                for (int t = 0; t < 6; ++t) acc = mma_block(whT[T][t], dgh[t], acc);
+                for (int t = 0; t < 6; ++t) acc = mma_block(wfrag_lds(swT, WLD, 16 * T, 16 * t), dgh[t], acc);
                 dh[T] = acc;
             }
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float h0 = pick(6, s4), h1 = pick(7, s4);
+                for (int t = 0; t < 6; ++t) {
+                    const float av = pick(t, s4);
+                    aW[t][0] = mfma4(av, h0, aW[t][0]);
+                    aW[t][1] = mfma4(av, h1, aW[t][1]);
+                }
+            }
+            IPLAN_WAVE_SYNC();
+        }
+        {   // this wave's partial of dW_hh / db_hh (reduced over scenes and tiles by gat_whh_grad_kernel, fixed order)
+            float* part = a.whh_part + (((sb * 2 + dir) * 4 + tile) * (int64_t)IPLAN_GAT_WHH_PART);
+            for (int t = 0; t < 6; ++t)
+                for (int T = 0; T < 2; ++T)
+                    for (int q = 0; q < 4; ++q) part[(16 * t + 4 * g + q) * BH + 16 * T + n] = aW[t][T][q];
+            for (int t = 0; t < 6; ++t)
+                for (int q = 0; q < 4; ++q) {
+                    const float v = t < 4 ? da[t][q] : bNh[t - 4][q];       // sum over steps of dr | dz | dn_h of this lane's chain
+                    const float sum = chain_sum16(valid ? v : 0.f);
+                    if (n == 0) part[3 * BH * BH + 16 * t + 4 * g + q] = sum;
+                }
         }
         float* arow = ndy + (int64_t)node * DY + DY_DA + dir * DY_DIR;
         for (int t = 0; t < 6; ++t) vstore(arow, valid, 3 * BH, t, da[t]);
@@ -257,23 +306,19 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
     if (clk) clk[4] = IPLAN_CLOCK();
 
     // ---------------------------------------------------------------- E: d(W_b h_j) gather per node
-    // node j is seen by ego i != j at pair step s = j - (j > i); the egos are enumerated as i = u + (u >= j), u = 0 .. N-2 (no
-    // branch), 18 rows fetched per batch before any of them is added (the former load-add-load chain was one L2 round trip
-    // per row: 400 us per scene), summed in the same order as before
+    // node j's block holds the N-1 egos that see it, in ego order: a column sum over contiguous rows, 18 rows in flight
     for (int p = w; p < 2 * N; p += 8) {
         const int j = p >> 1, d2 = p & 1;
-        const float* base = a.dgru + ((((int64_t)net * 2 + d2) * f.B + b) * N) * (int64_t)(N - 1) * (4 * BH) + l;
+        const float* base = a.dgru + (((((int64_t)net * 2 + d2) * f.B + b) * N + j) * (int64_t)(N - 1)) * (3 * BH);
+        const int c1 = 64 + (l & 31);                              // (lanes >= 32 repeat lanes < 32)
         float a0 = 0.f, a1 = 0.f;
         constexpr int UB = 18;
         for (int u0 = 0; u0 < N - 1; u0 += UB) {
             float v0[UB], v1[UB];
             for (int k = 0; k < UB; ++k) {
-                const int u = imin(u0 + k, N - 2);
-                const int i = u + (u >= j ? 1 : 0);
-                const int s = i < j ? j - 1 : j;
-                const float* row = base + ((int64_t)i * (N - 1) + s) * (4 * BH);
-                v0[k] = row[0];
-                v1[k] = row[64];                                   // (lanes >= 32 read the dnh columns: unused)
+                const float* row = base + (int64_t)imin(u0 + k, N - 2) * (3 * BH);
+                v0[k] = row[l];
+                v1[k] = row[c1];
             }
             for (int k = 0; k < UB; ++k)
                 if (u0 + k < N - 1) { a0 += v0[k]; a1 += v1[k]; }
@@ -334,6 +379,23 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
     if (clk) clk[6] = IPLAN_CLOCK();
 }
 
+// hard_bi_GRU.weight_hh_l0{,_reverse} / bias_hh gradients <- sum of the wave partials over scenes and live tiles, fixed order.
+// grid: (ceil(IPLAN_GAT_WHH_PART / 256), n_nets * 2)
+__global__ __launch_bounds__(256) void gat_whh_grad_kernel(IplanGatBwdArgs a) {
+    const IplanGatFwdArgs& f = a.fwd;
+    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e >= 3 * BH * BH + 3 * BH) return;
+    const int net = (int)blockIdx.y >> 1, dir = (int)blockIdx.y & 1;
+    const int tiles = (f.N + 15) / 16;
+    float sum = 0.f;
+    for (int b = 0; b < f.B; ++b)
+        for (int t = 0; t < tiles; ++t)
+            sum += a.whh_part[((((int64_t)net * f.B + b) * 2 + dir) * 4 + t) * (int64_t)IPLAN_GAT_WHH_PART + e];
+    float* g = a.grad + (int64_t)net * a.grad_s_net;
+    if (e < 3 * BH * BH) g[f.off[dir ? IPLAN_GAT_R_WHH : IPLAN_GAT_F_WHH] + e] = sum;
+    else g[f.off[dir ? IPLAN_GAT_R_BHH : IPLAN_GAT_F_BHH] + (e - 3 * BH * BH)] = sum;
+}
+
 }  // namespace iplan
 
 extern "C" int iplan_gat_bwd(const IplanGatBwdArgs* a, iplan_stream_t stream) {
@@ -345,10 +407,12 @@ extern "C" int iplan_gat_bwd(const IplanGatBwdArgs* a, iplan_stream_t stream) {
     const IplanGatSaved& s = f.saved;
     if (!s.h_enc || !s.gru || !s.qkv || !s.soft || !s.hard || !s.x || !s.cell)
         return fail(IPLAN_EINVAL, "iplan_gat_bwd: the forward launch did not save its activations");
-    if (!a->g_out || !a->dgru || !a->node_dy || !a->hard_part || !f.h_prev || !f.params)
+    if (!a->g_out || !a->dgru || !a->node_dy || !a->hard_part || !a->whh_part || !a->grad || !f.h_prev || !f.params)
         return fail(IPLAN_EINVAL, "iplan_gat_bwd: null tensor pointer");
     if (!aligned16(a->g_out) || (a->g_s_net & 3) || (a->g_s_b & 3) || !aligned16(a->dgru) || !aligned16(a->node_dy))
         return fail(IPLAN_EALIGN, "iplan_gat_bwd: g_out / dgru / node_dy must be 16-byte aligned");
     hipLaunchKernelGGL(gat_bwd_kernel, dim3((unsigned)(f.n_nets * f.B)), dim3(512), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(gat_whh_grad_kernel, dim3((unsigned)((IPLAN_GAT_WHH_PART + 255) / 256), (unsigned)(f.n_nets * 2)), dim3(256), 0,
+                       (hipStream_t)stream, *a);
     return check_launch("iplan_gat_bwd");
 }

@@ -37,8 +37,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 #ifdef IPLAN_HOST_EMULATION
 #define IPLAN_SCHED_FENCE() do {} while (0)
+#define IPLAN_WAVE_SYNC() iplan_emu::wave_sync()         /* lanes are fibres: LDS hand-offs inside a wave need a rendezvous */
 #else
 #define IPLAN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define IPLAN_WAVE_SYNC() __builtin_amdgcn_wave_barrier()  /* a wave's LDS accesses execute in order: nothing to wait for */
 #endif
 
 // Workgroup barrier that orders LDS traffic ONLY: `__syncthreads()` is fence + barrier, and the fence drains vmcnt -- every

@@ -516,7 +516,9 @@ def gat_backward(arena, saved, g_out, phase_clocks=None, lib=None):
     a.fwd = fa
     a.g_out = g_out.data_ptr()
     a.g_s_net, a.g_s_b = _nb_strides(g_out, N * A)
-    dgru = torch.empty(n_nets, 2, B * N, N - 1, 4 * H, **f32)
+    dgru = torch.empty(n_nets, 2, B * N, N - 1, 3 * H, **f32)           # kernel-private scratch
+    whh_part = torch.empty(n_nets, B, 2, 4, L.GAT_WHH_PART, **f32)
+    a.whh_part, a.grad, a.grad_s_net = whh_part.data_ptr(), arena.grad.data_ptr(), arena.grad.stride(0)
     node_dy = torch.empty(n_nets, B * N, L.GAT_NODE_DY, **f32)
     hard_part = torch.empty(n_nets, B, L.GAT_HARD_PART, **f32)
     a.dgru, a.node_dy, a.hard_part = dgru.data_ptr(), node_dy.data_ptr(), hard_part.data_ptr()
@@ -548,11 +550,7 @@ def gat_backward(arena, saved, g_out, phase_clocks=None, lib=None):
               dw_off=off("hard_bi_GRU.weight_ih_l0" + sfx), dw_ld=2 * H, db_off=off("hard_bi_GRU.bias_ih_l0" + sfx))
         w.add(nd + 4 * (128 + dr * 192), nst, 3 * H, B, N, x=he, x_strides=hst, K=H,
               dw_off=off("hard_bi_GRU.weight_ih_l0" + sfx), dw_ld=2 * H, dw_col0=H)
-        # recurrent weights: pair level, previous state = the neighbouring pair step of the same ego
-        w.add(dgru.data_ptr() + 4 * dr * (B * N * P1 * 4 * H), (2 * B * N * P1 * 4 * H, P1 * 4 * H, 4 * H), 3 * H, B * N, P1,
-              x=gru.data_ptr() + 4 * dr * (B * N * P1 * 5 * H), x_strides=(2 * B * N * P1 * 5 * H, P1 * 5 * H, 5 * H), K=H,
-              dw_off=off("hard_bi_GRU.weight_hh_l0" + sfx), db_off=off("hard_bi_GRU.bias_hh_l0" + sfx),
-              seg=(2 * H, 0, 3 * H), x_shift=(1 if dr else -1))
+        # (recurrent weights hard_bi_GRU.weight_hh / bias_hh: accumulated by the backward kernel itself)
         # hard_encoding.weight[c][dr*H : (dr+1)*H] = -/+ sum dDelta * h  (per-scene partials from the kernel)
         for c, sc in ((0, -1.0), (1, 1.0)):
             w.add(hard_part.data_ptr() + 4 * dr * 4 * H, (B * L.GAT_HARD_PART, L.GAT_HARD_PART, H), H, B, 4,
