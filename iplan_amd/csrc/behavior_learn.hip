@@ -111,22 +111,6 @@ __device__ __forceinline__ f32x4 ld_row_raw(const float* __restrict__ row, int d
     }
     return v;
 }
-// ... `use` = false gives zeros
-__device__ __forceinline__ f32x4 ld_row_p(const float* __restrict__ row, int dim, int g, bool use) {
-    f32x4 v;
-    for (int q = 0; q < 4; ++q) {
-        const int i = 4 * g + q;
-        v[q] = keep_if(use && i < dim, row[i < dim ? i : dim - 1]);
-    }
-    return v;
-}
-
-// x_t of window j for this lane's chain: history[e, j-(L-1)+t] or zeros (right-aligned window); branch-free (see ld4 below)
-__device__ __forceinline__ f32x4 window_x(const IplanBehArgs& a, const float* __restrict__ hrow, int j, int t, bool valid) {
-    const int st = beh_x_step(a, j, t);
-    return ld_row_p(hrow + (int64_t)(st < 0 ? 0 : st) * a.h_s_t, a.d, lane_id() >> 4, valid && st >= 0);
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // shared prologue of the four kernels
 struct BehChain {
@@ -185,12 +169,25 @@ __global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
         for (int t = 0; t < ET; ++t) he[t] = *reinterpret_cast<const f32x4*>(carry + 256 * t + 4 * l);
         lat = *reinterpret_cast<const f32x4*>(carry + 512 + 4 * l);
     }
+    // x_t is fetched one step ahead (raw, from a clamped row) and masked where it is consumed: the load has a whole GRU step
+    // to land instead of being waited for at the top of every one of the 790 steps
+    auto x_fetch = [&](int j, int t, bool& has) {
+        const int st = beh_x_step(a, j, t);
+        has = st >= 0;
+        return ld_row_raw(c.hrow + (int64_t)(st < 0 ? 0 : st) * a.h_s_t, a.d, g);
+    };
+    bool x_has = false;
+    f32x4 x_raw = x_fetch(j_lo, 0, x_has);
     for (int j = j_lo; j < j_hi; ++j) {
         float* sl = a.saved_lat + (c.grow * J + j) * SVL;
         vstore_a(sl + 16, valid, 0, lat);                      // the latent the decoder uses in window j
         for (int t = 0; t < a.L; ++t) {
             f32x4 x1[1];
-            x1[0] = window_x(a, c.hrow, j, t, valid);
+            for (int q = 0; q < 4; ++q) x1[0][q] = keep_if(valid && x_has && 4 * g + q < a.d, x_raw[q]);
+            {
+                const bool last_t = t + 1 == a.L, more = j + 1 < j_hi;
+                x_raw = x_fetch(last_t && more ? j + 1 : j, last_t ? (more ? 0 : t) : t + 1, x_has);
+            }
             float* se = a.saved_enc + ((c.grow * J + j) * a.L + t) * SVE;
             f32x4 ue[ET];
             for (int T = 0; T < ET; ++T) {
