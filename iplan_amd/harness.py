@@ -4,6 +4,8 @@ environment and observation_wrapper replaced by pre-generated observation tensor
 are not installable offline).  Everything stays device resident: the only thing a real
 runner would need back on the host per step is the [E, nA] action array.
 """
+import os
+
 import torch
 
 from . import synth
@@ -32,6 +34,17 @@ class SyntheticLoop:
         self.behavior = Behavior_policy(args, self.logger) if args.Behavior_enable else None
         self.learner = IPPOLearner(self.mac, self.scheme, self.logger, args)
         self.t_env = 0
+        # Behavior_policy.learn(defer_decoder=True): decoder weight gradients + optimiser step beside the next rollout
+        # (IPLAN_NO_DEFER_DECODER=1: everything inside learn(), for A/B timing)
+        import inspect
+        self.defer_decoder = (self.behavior is not None and torch.device(device).type == "cuda"
+                              and not os.environ.get("IPLAN_NO_DEFER_DECODER")
+                              and "defer_decoder" in inspect.signature(self.behavior.learn).parameters)
+        # IPLAN_DEFER_CUS=k (opt-in): the deferred work on a stream masked to k CUs.  In isolation (learn + the rollout after
+        # it) 64 CUs is the best arrangement measured (42.7 ms in line, 42.1 deferred, 38.8 deferred on 64 CUs); inside the
+        # full cycle the masked stream made things WORSE (525 ms against 410 ms unmasked, 420 ms in line; cause not found:
+        # profiles/r02e_notes.md), so the default is the plain side stream.
+        self._defer_cus = int(os.environ.get("IPLAN_DEFER_CUS", "0")) if not os.environ.get("IPLAN_NO_CU_MASK") else 0
         gen = torch.Generator().manual_seed(seed + 1)
         T1, nA, N = args.episode_limit + 1, args.n_agents, args.max_vehicle_num
         d, L = args.obs_shape_single, args.max_history_len
@@ -178,10 +191,29 @@ class SyntheticLoop:
         Behavior_policy.learn -> Prediction_policy.learn -> IPPOLearner.train (acts when the buffer is
         full).  Warm-up gates (Behavior_warmup / GAT_warmup) are treated as already passed: the timed
         workload is the steady state.  Returns the number of env transitions produced."""
+        dev = torch.device(self.device)
+        if dev.type == "cuda" and self.defer_decoder and self._defer_cus > 0 and not getattr(self, "_in_work", False):
+            # CU-masked streams are BLOCKING streams (the extension takes no flags): they synchronise implicitly with the
+            # legacy default stream.  The cycle therefore runs on a non-blocking stream of its own, so that the masked decoder
+            # stream really runs beside it.
+            if getattr(self, "_work", None) is None:
+                self._work = torch.cuda.Stream(dev)
+            outer = torch.cuda.current_stream(dev)
+            if outer.cuda_stream == 0:
+                self._work.wait_stream(outer)
+                self._in_work = True
+                try:
+                    with torch.cuda.stream(self._work):
+                        n = self.cycle()
+                finally:
+                    self._in_work = False
+                outer.wait_stream(self._work)
+                return n
+        # (the rollout itself is NOT masked to the complement: measured slower -- it can use the decoder update's CUs again
+        # as soon as that is done; the update's long-lived 372-register waves keep other workgroups off its CUs meanwhile)
         batch = self.rollout()
         self.t_env += self.E * self.args.episode_limit
         self.learner.insert_episode_batch(batch)
-        dev = torch.device(self.device)
         # (Data-parallel runs overlap the learners too: the host issues the gradient all-reduces in the same order on
         # every rank -- prediction, PPO epochs, behaviour -- and RCCL runs them in that order on its own stream,
         # each behind the event of the stream that produced its gradients.)
@@ -214,7 +246,8 @@ class SyntheticLoop:
                 done.record(strm)
             fins.append((f, done))
         if self.behavior is not None:
-            self.behavior.learn(batch, self.t_env)
+            # the decoder's weight-gradient contraction + optimiser step run on beside the next rollout (see learn())
+            self.behavior.learn(batch, self.t_env, **({"defer_decoder": True} if self.defer_decoder else {}))
         for f, done in fins:
             main.wait_event(done)
             if f is not None:

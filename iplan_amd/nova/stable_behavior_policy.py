@@ -1,6 +1,7 @@
 """Behavior_policy (soft update = iPLAN) -- behavioural-incentive inference module (mirror of
 nova/stable_behavior_policy.py:13-312)."""
 import copy
+import contextlib
 import os
 
 import numpy as np
@@ -9,6 +10,7 @@ import torch
 from .. import ops
 from ..arena import ParamArena
 from ..optim import FusedAdam, step_all
+from ..streams import masked_stream
 from .behavior_net import Behavior_Latent_Decoder, EncoderRNN
 from .prediction_policy import _as_dev
 
@@ -115,15 +117,35 @@ class Behavior_policy:
         dp = getattr(self, "dp", None)
         return E * (dp.world if dp is not None else 1)
 
-    def learn(self, batch, t_env, keep=None):
+    def join_decoder(self):
+        """Make the current stream wait for a decoder update that ``learn(..., defer_decoder=True)`` left running on the side
+        stream (no-op otherwise).  Everything that reads or writes the decoder's parameters calls this first."""
+        ev = getattr(self, "_dec_done", None)
+        if ev is not None:
+            # HOST wait, not just a stream wait: the update holds the previous call's 23 GB of BPTT records (record_stream);
+            # until its event has completed the caching allocator cannot hand those blocks to this call and would go to
+            # hipMalloc for fresh ones (+13 ms per call, measured)
+            ev.synchronize()
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            self._dec_done = None
+
+    def learn(self, batch, t_env, keep=None, defer_decoder=False):
         """nova/stable_behavior_policy.py:161-279 for all agents at once: ONE persistent forward launch
         walks every (env, entity) chain through the T-1-L windows (decoder + encoder GRUs, soft latent
         update, masked L1), ONE backward launch does the BPTT, then weight-gradient contractions,
         separate clipping of the encoder and decoder groups and Adam.  ``keep`` (uint8 dropout keep flags
         [nA, J, E*N, L, 64]) may be injected; by default the kernel draws them from a counter-based
-        generator seeded from torch's RNG.  Returns (behavior_loss, stability_loss, total_loss) lists."""
+        generator seeded from torch's RNG.  Returns (behavior_loss, stability_loss, total_loss) lists.
+
+        ``defer_decoder=True`` (device-resident training loops): the DECODER's weight-gradient contraction, gradient
+        all-reduce, clip and Adam step are enqueued on a side stream and this call returns once the encoder is updated.
+        Nothing outside behaviour learning reads the decoder (the rollout uses the encoder only), so that work -- the largest
+        bandwidth-bound item of a ``learn`` -- runs beside the next rollout, whose kernels leave 96 of the 256 CUs idle; the
+        next ``learn`` (and save / load) waits for it.  Same arithmetic, same order of optimiser steps; the logged decoder
+        gradient norm is the previous call's."""
         a = self.args
         dev = self.device
+        self.join_decoder()
         history = batch["history"][:, :-1].to(device=dev, dtype=torch.float32)     # [E, T, nA, N, d]
         term = batch["terminated"][:, :-1].to(dev)                                 # [E, T, nA, 1]
         # mask polarity is env dependent in the reference (:190-193)
@@ -137,9 +159,12 @@ class Behavior_policy:
             fwd = ops.beh_forward(self.enc_arena, self.dec_arena, hist, mask, self.max_history_len, self.latent_dim,
                                   self.soft_update_coef, self.thres_small_variation, a.decoder_dropout, keep=keep, seed=seed,
                                   win_norm=self._global_window_sums(mask))
-            ops.beh_backward(self.enc_arena, self.dec_arena, fwd, penalty=self.behavior_variation_penalty, E_norm=self._global_envs(E))
+            defer = bool(defer_decoder)
+            bwd = ops.beh_backward(self.enc_arena, self.dec_arena, fwd, penalty=self.behavior_variation_penalty,
+                                   E_norm=self._global_envs(E), defer_dec_wgrad=defer)
             loss_dev = fwd["loss"]
         else:
+            defer = False
             # Large batches (config 4's 256 envs on one GPU: 230 GB of BPTT records at once): env chunks run one after the
             # other -- chains never interact; the loss normalisers are the window mask sums over ALL envs (and ranks), so
             # the chunk gradients simply add up in the arenas -- and one clip + Adam step follows.
@@ -156,13 +181,42 @@ class Behavior_policy:
                 part = fwd["loss"] * torch.tensor([1.0, (hi - lo) / E], device=dev)      # the stability statistic is a mean over envs
                 loss_dev = part if loss_dev is None else loss_dev + part
                 del fwd
-        if getattr(self, "dp", None) is not None:
-            self.dp.all_reduce_grads(self.enc_arena, self.dec_arena)
-        sq = step_all(self.behavior_optimizer, self.max_grad_norm if self._use_max_grad_norm else None)
+        max_norm = self.max_grad_norm if self._use_max_grad_norm else None
         nA = self.n_agents
-        host = torch.cat([loss_dev.reshape(-1), sq.sqrt().reshape(-1)]).cpu()       # ONE host read-back
-        loss = host[:2 * nA].reshape(nA, 2).numpy()
-        norms = host[2 * nA:].reshape(nA, 2)
+        if E <= chunk and defer:
+            # encoder now (the next rollout needs it) ...
+            if getattr(self, "dp", None) is not None:
+                self.dp.all_reduce_grads(self.enc_arena)
+            sq = step_all(self.behavior_optimizer, max_norm, slices=(0,))
+            steps = self.behavior_optimizer[0].last_steps
+            prev_dec = getattr(self, "_dec_sq", None)
+            # ... decoder on the side stream, same optimiser step
+            on_gpu = torch.device(dev).type == "cuda"
+            if on_gpu and getattr(self, "_dec_stream", None) is None:
+                # plain side stream by default; IPLAN_DEFER_CUS=k restricts it to k CUs (see harness.py / profiles/r02e_notes.md)
+                self._dec_stream = masked_stream(dev, int(os.environ.get("IPLAN_DEFER_CUS", "0")))
+            ds = self._dec_stream if on_gpu else None                   # (CPU / emulator: same code, run in line)
+            bwd["dec_wgrad"](ds)
+            with (torch.cuda.stream(ds) if on_gpu else contextlib.nullcontext()):
+                if getattr(self, "dp", None) is not None:
+                    self.dp.all_reduce_grads(self.dec_arena)
+                sq_d = step_all(self.behavior_optimizer, max_norm, slices=(1,), steps=steps)
+                self._dec_sq = sq_d[:, 1].clone()
+                if on_gpu:
+                    self._dec_done = torch.cuda.Event()
+                    self._dec_done.record(ds)
+            del bwd
+            dec_col = prev_dec if prev_dec is not None else torch.zeros(nA, device=dev)
+            host = torch.cat([loss_dev.reshape(-1), sq[:, 0].sqrt(), dec_col.sqrt()]).cpu()      # ONE host read-back
+            loss = host[:2 * nA].reshape(nA, 2).numpy()
+            norms = host[2 * nA:].reshape(2, nA).t()
+        else:
+            if getattr(self, "dp", None) is not None:
+                self.dp.all_reduce_grads(self.enc_arena, self.dec_arena)
+            sq = step_all(self.behavior_optimizer, max_norm)
+            host = torch.cat([loss_dev.reshape(-1), sq.sqrt().reshape(-1)]).cpu()       # ONE host read-back
+            loss = host[:2 * nA].reshape(nA, 2).numpy()
+            norms = host[2 * nA:].reshape(nA, 2)
         beh = [np.asarray(loss[i, 0]) for i in range(nA)]
         stab = [np.asarray(loss[i, 1]) for i in range(nA)]
         total = [np.asarray(loss[i, 0] + self.behavior_variation_penalty * loss[i, 1]) for i in range(nA)]
@@ -177,12 +231,14 @@ class Behavior_policy:
 
     # ---------------------------------------------------------------------------- checkpoints
     def save_models(self, path):
+        self.join_decoder()
         for i in range(self.n_agents):
             torch.save(self.behavior_encoder[i].state_dict(), f"{path}/behavior_encoder_{i}.th")
             torch.save(self.behavior_decoder[i].state_dict(), f"{path}/behavior_decoder_{i}.th")
             torch.save(self.behavior_optimizer[i].state_dict(), f"{path}/behavior_optimizer_{i}_opt.th")
 
     def load_models(self, paths, load_optimisers=False):
+        self.join_decoder()
         if len(paths) == 1:
             paths = [copy.copy(paths[0]) for _ in range(self.n_agents)]
         for i in range(self.n_agents):

@@ -740,9 +740,12 @@ def beh_window_mask_sums(mask, L_win, hard=False):
     return (cs[:, j + 1 + L_win] - cs[:, j + 1]).contiguous()
 
 
-def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_norm=0, lib=None):
-    """BPTT of beh_forward's behaviour loss (behavior_variation_penalty == 0): fills both gradient arenas
-    (``accumulate=True``: adds to them -- launches on disjoint env chunks of one batch, normalised by a shared ``win_norm``)."""
+def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_norm=0, defer_dec_wgrad=False, lib=None):
+    """BPTT of beh_forward's behaviour loss: fills both gradient arenas (``accumulate=True``: adds to them -- launches on
+    disjoint env chunks of one batch, normalised by a shared ``win_norm``).
+    ``defer_dec_wgrad=True``: the DECODER's weight-gradient contraction is not launched; the returned dict carries
+    ``"dec_wgrad"``, a callable ``(stream)`` that enqueues it (one call over all steps) on ``stream`` behind the BPTT.  The
+    caller decides where that work runs -- nothing but the decoder's own optimiser step depends on it."""
     lib = _lib(lib)
     a = fwd["_args"]
     n_nets, E, N, T, Lw, d, Z = a.n_nets, a.E, a.N, a.T, a.L, a.d, a.Z
@@ -790,6 +793,8 @@ def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_nor
         main = torch.cuda.current_stream(dev)
         side = _SIDE_STREAMS.setdefault((str(dev), main.cuda_stream), torch.cuda.Stream(dev))
         side2 = _SIDE_STREAMS.setdefault((str(dev), main.cuda_stream, 2), torch.cuda.Stream(dev))
+    if defer_dec_wgrad and side is None and dev.type == "cuda":
+        main = torch.cuda.current_stream(dev)
     pieces = max(1, min(_beh_pieces("BWD", 6 if side is not None else 1), J))
     bounds = [round(J * k / pieces) for k in range(pieces + 1)]
     carry = torch.empty(n_nets, tiles, 2, 512, **f32)
@@ -801,29 +806,49 @@ def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_nor
         _launch("beh_dec_bwd_kernel", lambda: lib.call("iplan_beh_bwd", a, stream))
         beta = 0.0 if (k == pieces and not accumulate) else 1.0
         if side is None:
-            dec_wgrad(bounds[k - 1] * Lw, bounds[k] * Lw, beta)
+            if not defer_dec_wgrad:
+                dec_wgrad(bounds[k - 1] * Lw, bounds[k] * Lw, beta)
             a.bwd_phase = 2
             lib.call("iplan_beh_bwd", a, stream)
         else:
             ev = torch.cuda.Event()
             ev.record(main)
-            side.wait_event(ev)
             side2.wait_event(ev)
-            with torch.cuda.stream(side):
-                dec_wgrad(bounds[k - 1] * Lw, bounds[k] * Lw, beta)
+            if not defer_dec_wgrad:
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    dec_wgrad(bounds[k - 1] * Lw, bounds[k] * Lw, beta)
             a.bwd_phase = 2
             _launch("beh_enc_bwd_kernel", lambda: lib.call("iplan_beh_bwd", a, side2.cuda_stream), stream=side2)
     a.bwd_phase, a.bwd_j_lo, a.bwd_j_hi = 0, 0, 0
+    out = dict(dsave_dec=dd, dsave_lat=dl, enc_part=ep)
+    if defer_dec_wgrad:
+        ev_bptt = None
+        if dev.type == "cuda":
+            ev_bptt = torch.cuda.Event()
+            ev_bptt.record(main)                                         # every decoder BPTT range is behind this
+
+        def run_dec_wgrad(strm=None):
+            if strm is None or dev.type != "cuda":
+                dec_wgrad(0, J * Lw, 1.0 if accumulate else 0.0)
+                return
+            strm.wait_event(ev_bptt)
+            with torch.cuda.stream(strm):
+                dec_wgrad(0, J * Lw, 1.0 if accumulate else 0.0)
+            for t in (dd, fwd["saved_dec"]):
+                t.record_stream(strm)
+        out["dec_wgrad"] = run_dec_wgrad
     if side is not None:
-        for st in (side, side2):
+        for st in ((side2,) if defer_dec_wgrad else (side, side2)):
             ev_done = torch.cuda.Event()
             ev_done.record(st)
             main.wait_event(ev_done)
-        for t in (dd, carry, fwd["saved_dec"]):                         # touched by the side streams: keep the allocator honest
-            t.record_stream(side)
+        if not defer_dec_wgrad:
+            for t in (dd, carry, fwd["saved_dec"]):                     # touched by the side streams: keep the allocator honest
+                t.record_stream(side)
         for t in (dl, ep, ecarry, fwd["saved_enc"], fwd["saved_lat"]):
             t.record_stream(side2)
-    return dict(dsave_dec=dd, dsave_lat=dl, enc_part=ep)
+    return out
 
 
 def bdec_forward(enc_arena, dec_arena, window, latent, hidden, drop_p=0.0, keep=None, seed=0, lib=None):

@@ -141,20 +141,26 @@ class FusedAdam(torch.optim.Optimizer):
                 self.param_groups[0][k] = sd["param_groups"][0][k]
 
 
-def step_all(optimizers, max_norm):
+def step_all(optimizers, max_norm, slices=None, steps=None):
     """Advance the per-agent optimisers of a learner together: one norm launch and one Adam launch
-    per arena for ALL agents (they must own net i of the same arenas, i = position in the list)."""
+    per arena for ALL agents (they must own net i of the same arenas, i = position in the list).
+    ``slices`` restricts the call to some of the optimisers' arenas (indices into ``FusedAdam.slices``); a later call for
+    the remaining arenas of the SAME optimiser step passes the ``steps`` this one returned through ``last_steps``."""
     first = optimizers[0]
     n = len(optimizers)
-    for o in optimizers:
-        o._steps += 1
-    steps = [o._steps for o in optimizers]
+    if steps is None:
+        for o in optimizers:
+            o._steps += 1
+        steps = [o._steps for o in optimizers]
+    first.last_steps = steps
     g = first.param_groups[0]
     dev = first.slices[0][0].data.device
     if getattr(first, "_sq_all", None) is None or first._sq_all.shape[0] != n:
         first._sq_all = torch.zeros(n, len(first.slices), dtype=torch.float32, device=dev)
     sq = first._sq_all
     for k, (arena, _) in enumerate(first.slices):
+        if slices is not None and k not in slices:
+            continue
         if max_norm is not None:
             grad_sqnorm(arena, (0, n), sq, k)
         adam_launch(arena, (0, n), steps, g["lr"], g["betas"], g["eps"], sq if max_norm is not None else None, k,

@@ -148,3 +148,42 @@ if "ac_phases" in set(sys.argv[1:]):
     torch.cuda.synchronize()
     c = clk.cpu().double()
     print("ac_fwd (rollout) phases of WG 0, x10 ns: stats, contraction, tail =", (c[1:] - c[:-1]).tolist())
+
+if "defer_overlap" in set(sys.argv[1:]):
+    # critical path of Behavior_policy.learn with the decoder update in line / deferred, and the rollout that follows it
+    def seq(defer, n=4):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        tl = tr = 0.0
+        for it in range(n + 1):
+            torch.cuda.synchronize()
+            ev[0].record()
+            loop.behavior.learn(batch, 0, **({"defer_decoder": True} if defer else {}))
+            ev[1].record()
+            loop.rollout()
+            ev[2].record()
+            torch.cuda.synchronize()
+            if it:
+                tl += ev[0].elapsed_time(ev[1]) / n
+                tr += ev[1].elapsed_time(ev[2]) / n
+        return tl, tr
+    work = torch.cuda.Stream(dev)          # (CU-masked streams are blocking streams: keep off the legacy default stream)
+    for defer in (False, True, True):
+        with torch.cuda.stream(work):
+            tl, tr = seq(defer)
+        print(f"defer_decoder={defer}: learn (main stream) {tl:.2f} ms, following rollout {tr:.2f} ms, sum {tl + tr:.2f} ms")
+
+if "masked_wgrad" in set(sys.argv[1:]):
+    # the deferred decoder update alone (nothing else on the GPU) on streams restricted to k CUs
+    from iplan_amd.streams import masked_stream
+    for k in (0, 128, 96, 64):
+        loop.behavior._dec_stream = masked_stream(dev, k) if k else torch.cuda.Stream(dev)
+        ts = []
+        for it in range(3):
+            loop.behavior.join_decoder()
+            torch.cuda.synchronize()
+            loop.behavior.learn(batch, 0, defer_decoder=True)
+            torch.cuda.current_stream().synchronize()
+            t0 = time.perf_counter()
+            loop.behavior._dec_stream.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        print(f"deferred decoder update on {k or 256} CUs: {min(ts[1:]):.2f} ms after learn() returned (host clock)")

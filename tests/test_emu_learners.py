@@ -343,6 +343,19 @@ def test_behavior_learn_env_chunks_vs_oracle_emulated(monkeypatch):
     assert w["grad"] < 1e-5, w
 
 
+def test_behavior_learn_deferred_decoder_vs_oracle_emulated():
+    """learn(defer_decoder=True): the decoder's weight gradients / clip / Adam leave the call (side stream on the GPU, in line
+    here) -- same gradients and post-step parameters as the oracle, for two consecutive calls"""
+    from tests.oracle_checks import check_behavior_learn_vs_oracle
+    w = check_behavior_learn_vs_oracle(_small(), 3, "cpu", seed=19, learn_kwargs=dict(defer_decoder=True))
+    assert w["grad"] < 1e-5 and w["post"] < 1e-6, w
+
+
+def test_behavior_learn_deferred_twice_equals_inline_emulated():
+    from tests.oracle_checks import check_deferred_equals_inline
+    check_deferred_equals_inline(_small(), 3, "cpu")
+
+
 def test_behavior_learn_with_stability_penalty_vs_oracle_emulated():
     """behavior_variation_penalty != 0 (nova/stable_behavior_policy.py:238-246): the stability term is differentiated too"""
     from tests.oracle_checks import check_behavior_learn_vs_oracle

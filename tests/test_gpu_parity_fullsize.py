@@ -109,3 +109,14 @@ def test_lifted_restrictions_vs_oracle_gpu():
     _log("ppo_minibatches_3x2", check_ppo_train_vs_oracle(a, "cuda", seed=41))
     b = _args(max_vehicle_num=9, n_agents=2, episode_limit=20, batch_size_run=4, behavior_variation_penalty=0.3, thres_small_variation=0.05)
     _log("behavior_learn_penalty_0.3", check_behavior_learn_vs_oracle(b, 4, "cuda", seed=42))
+
+
+def test_deferred_decoder_update_gpu():
+    """Behavior_policy.learn(defer_decoder=True), the form the benchmark loop uses: decoder weight gradients / all-reduce /
+    clip / Adam on a side stream beside whatever follows.  Same gradients and parameters as the oracle, and two consecutive
+    deferred calls end where two in-line calls end (parameters and Adam step counts)."""
+    from tests.oracle_checks import check_behavior_learn_vs_oracle, check_deferred_equals_inline
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    b = _args(max_vehicle_num=9, n_agents=2, episode_limit=20, batch_size_run=4)
+    _log("behavior_learn_deferred_decoder", check_behavior_learn_vs_oracle(b, 4, "cuda", seed=43, learn_kwargs=dict(defer_decoder=True)))
+    check_deferred_equals_inline(b, 4, "cuda")
