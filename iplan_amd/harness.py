@@ -40,10 +40,10 @@ class SyntheticLoop:
         self.defer_decoder = (self.behavior is not None and torch.device(device).type == "cuda"
                               and not os.environ.get("IPLAN_NO_DEFER_DECODER")
                               and "defer_decoder" in inspect.signature(self.behavior.learn).parameters)
-        # IPLAN_DEFER_CUS=k (opt-in): the deferred work on a stream masked to k CUs.  In isolation (learn + the rollout after
-        # it) 64 CUs is the best arrangement measured (42.7 ms in line, 42.1 deferred, 38.8 deferred on 64 CUs); inside the
-        # full cycle the masked stream made things WORSE (525 ms against 410 ms unmasked, 420 ms in line; cause not found:
-        # profiles/r02e_notes.md), so the default is the plain side stream.
+        # IPLAN_DEFER_CUS=k (opt-in): the deferred work on a stream masked to k CUs.  At k = 64 the cycle is as fast as with the
+        # plain side stream (413 vs 414 ms) and the rollout's kernels no longer queue behind the contraction (in-situ gat_fwd
+        # 189 us instead of 271 us), but the optimum is narrow (48 CUs: 492 ms, 80 CUs: 435 ms -- the update has to fit inside
+        # one rollout without squeezing it), so the default is the plain side stream (profiles/r02e_notes.md).
         self._defer_cus = int(os.environ.get("IPLAN_DEFER_CUS", "0")) if not os.environ.get("IPLAN_NO_CU_MASK") else 0
         gen = torch.Generator().manual_seed(seed + 1)
         T1, nA, N = args.episode_limit + 1, args.n_agents, args.max_vehicle_num
@@ -196,18 +196,21 @@ class SyntheticLoop:
             # CU-masked streams are BLOCKING streams (the extension takes no flags): they synchronise implicitly with the
             # legacy default stream.  The cycle therefore runs on a non-blocking stream of its own, so that the masked decoder
             # stream really runs beside it.
-            if getattr(self, "_work", None) is None:
-                self._work = torch.cuda.Stream(dev)
             outer = torch.cuda.current_stream(dev)
             if outer.cuda_stream == 0:
-                self._work.wait_stream(outer)
+                # The default stream is joined ONCE, when the work stream is created, and never again: every operation put
+                # on the legacy default stream -- even an event wait -- waits for all earlier work of the blocking (masked)
+                # streams and holds back their later work, which would chain each cycle's rollout behind the previous
+                # cycle's decoder update.  Callers read results after a device synchronise (bench.py does).
+                if getattr(self, "_work", None) is None:
+                    self._work = torch.cuda.Stream(dev)
+                    self._work.wait_stream(outer)
                 self._in_work = True
                 try:
                     with torch.cuda.stream(self._work):
                         n = self.cycle()
                 finally:
                     self._in_work = False
-                outer.wait_stream(self._work)
                 return n
         # (the rollout itself is NOT masked to the complement: measured slower -- it can use the decoder update's CUs again
         # as soon as that is done; the update's long-lived 372-register waves keep other workgroups off its CUs meanwhile)
