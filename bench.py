@@ -42,15 +42,16 @@ def _kib(fetch, write):
     return int((2 * fetch + write) * 1024)
 
 
-# per launch at the config-3 shape (E = 32), profiles/r02d_pmc_{rollout,behaviour_learn,ppo_train}.txt (avg / dispatch)
+# per launch at the config-3 shape (E = 32), profiles/r02e_pmc_{rollout,behaviour_learn,ppo_train}.txt (avg / dispatch)
 PMC_TRAFFIC_BYTES = {
     ("gat_fwd_kernel", 32): _kib(5170.9, 1100.0),
-    ("beh_dec_bwd_kernel", 32): _kib(1009023.9, 1591471.0),       # per window-range launch (6 per BPTT)
-    ("beh_dec_fwd_kernel", 32): _kib(59320.4, 3293253.1),         # per window-range launch (4 per forward)
-    ("beh_enc_bwd_kernel", 32): _kib(470541.9, 17301.0),          # per window-range launch (6 per BPTT)
-    # one iplan_wgrad call on a decoder BPTT piece = wide + two thin partial kernels + the reduction
-    ("iplan_wgrad:beh_dec", 32): _kib(1341424.0 + 254499.5 + 254747.9 + 39447.8, 49726.1 + 18393.5 + 19241.9 + 542.7),
-    ("ac_fwd_kernel:train", 32): _kib(1287791.2, 960691.1),       # actor + critic forward of a PPO epoch (one launch)
+    ("beh_dec_bwd_kernel", 32): _kib(1008997.0, 1590885.6),       # per window-range launch (6 per BPTT)
+    ("beh_dec_fwd_kernel", 32): _kib(59286.7, 3295126.4),         # per window-range launch (4 per forward)
+    ("beh_enc_bwd_kernel", 32): _kib(470546.6, 17301.1),          # per window-range launch (6 per BPTT)
+    # iplan_wgrad over ONE WHOLE decoder BPTT (wide + two thin partial kernels + the reduction; the PMC pass ran it as 6
+    # window-range calls of 1/6 each): divided by the number of calls per learn() the bench run uses (1 when deferred)
+    ("iplan_wgrad:beh_dec", 32): 6 * _kib(1341424.3 + 254500.0 + 254748.0 + 39456.7, 49726.3 + 18393.6 + 19241.9 + 542.7),
+    ("ac_fwd_kernel:train", 32): _kib(1246046.2, 945376.6),       # actor + critic forward of a PPO epoch (one launch)
 }
 
 
@@ -146,9 +147,11 @@ def main():
         one_step()
     barrier()
     # roofline timing, live in the timed region: HIP events on the launch stream right around the launches of the kernels that
-    # make up > 5 % of a cycle (ops.KernelTimers; the two per-vector-step kernels are sampled every 8th launch)
+    # make up > 5 % of a cycle (ops.KernelTimers).  EVERY gat_fwd launch is bracketed: a rollout's first launches queue behind
+    # the decoder update the previous learn() deferred (2.8 ms for the unlucky one), and a 1-in-8 sample whose phase drifts
+    # against the 91 launches of a rollout over-weights them (275 us sampled vs 183 us in the rocprofv3 statistics)
     from iplan_amd import ops
-    ops.TIMERS = ops.KernelTimers(every={"gat_fwd_kernel": 8, "ac_fwd_kernel:rollout": 8})
+    ops.TIMERS = ops.KernelTimers(every={"ac_fwd_kernel:rollout": 8})
     t0 = time.perf_counter()
     for _ in range(opt.steps):
         one_step()
@@ -214,9 +217,15 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
             work = w
         ach = work / sec / unit_scale if n else nan
         return {"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                "traffic": PMC_TRAFFIC_BYTES.get((traffic_key or kernel, E)), "us_per_launch": sec * 1e6 if n else nan,
+                "traffic": traffic_of(traffic_key or kernel), "us_per_launch": sec * 1e6 if n else nan,
                 "launches_timed": n, ("algorithmic_gbyte_per_launch" if bound == "hbm" else "algorithmic_gflop_per_launch"): work / 1e9,
                 "note": note}
+
+    def traffic_of(key):
+        t = PMC_TRAFFIC_BYTES.get((key, E))
+        if t is not None and key == "iplan_wgrad:beh_dec":
+            t = t // pieces(key)
+        return t
 
     def pieces(key):
         n = timed.get(key, (0, nan, 0.0))[0]
