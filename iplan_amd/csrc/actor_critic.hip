@@ -313,7 +313,10 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
 #ifndef AC_PF
 #define AC_PF 3
 #endif
-    constexpr int PF = AC_PF;
+#ifndef AC_PF1                          // ring depth of the rollout form (one row tile per wave: 28 registers per slot)
+#define AC_PF1 3
+#endif
+    constexpr int PF = RT == 1 ? AC_PF1 : AC_PF;
     for (int s = 0; s < 4; ++s) {
         // this wave's tiles of block s: T in [b_lo, b_hi) with T % T_st == part; the fast ones are below f_hi
         // (km's arrays are indexed by the loop counter and live in scratch: what comes back is a VGPR, and loop bounds in
