@@ -222,7 +222,7 @@ class SyntheticLoop:
         # each behind the event of the stream that produced its gradients.)
         if dev.type != "cuda":
             if self.behavior is not None:
-                self.behavior.learn(batch, self.t_env)
+                self.behavior.learn(batch, self.t_env, **({"defer_decoder": True} if self.defer_decoder else {}))
             if self.prediction is not None:
                 self.prediction.learn(batch, self.t_env)
             self.learner.train(self.t_env)

@@ -130,6 +130,18 @@ for a in arenas_of(loop):
     g = gathered(a.data)
     assert torch.equal(g[0], g[1]), "replicas diverged"
     assert torch.isfinite(a.data).all()
+# ---------------------------------------------------------------- the deferred decoder update (what the GPU loop runs): encoder
+# and decoder arenas are all-reduced in two calls, the decoder's behind the encoder's optimiser step
+calls.clear()
+loop.defer_decoder = True
+with contextlib.redirect_stdout(io.StringIO()):
+    loop.cycle()
+loop.behavior.join_decoder()
+assert calls == [1, 1, 2] + [2] * args_r.ppo_epoch, calls     # behaviour: encoder, then decoder; prediction; one per PPO epoch
+for a in arenas_of(loop):
+    g = gathered(a.data)
+    assert torch.equal(g[0], g[1]), "replicas diverged (deferred decoder update)"
+    assert torch.isfinite(a.data).all()
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
