@@ -56,6 +56,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace iplan {
 
+// Rendezvous of the `n_waves` waves that share ONE chain tile (the decoder's four quarter-waves), through a counter in LDS
+// instead of s_barrier: a workgroup barrier would also tie the workgroup's OTHER tiles to this tile's pace although they
+// exchange nothing (three tiles per workgroup share one copy of the weights, and gfx950 has no named barriers).  Each wave
+// adds 1 after its own LDS writes have been issued (a wave's LDS operations execute in order) and spins until the count
+// reaches `target` (callers advance it by n_waves per rendezvous; the counter only grows, so no reset race).
+#ifdef IPLAN_HOST_EMULATION
+#define IPLAN_TILE_SYNC(cnt, target) __syncthreads()            /* (every wave of the block calls it the same number of times) */
+#else
+__device__ __forceinline__ void iplan_tile_sync(int* cnt, int target) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63u) == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+#define IPLAN_TILE_SYNC(cnt, target) iplan_tile_sync((cnt), (target))
+#endif
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 
