@@ -781,10 +781,11 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
     stage_matrix_t(s_outT, 24, EHd, PE + a.enc_off[IPLAN_ENC_OUT_W], a.Z, EHd);
     __syncthreads();
     BehChain c;
-    const bool live = beh_chain(a, c);                      // dead waves still take part in the block barriers below
+    const bool live = beh_chain(a, c);
     const bool valid = c.valid;
     const int l = lane_id(), n = c.n, g = c.g, J = c.J;
-    float (*turn)[256] = s_turn[wave_id()];
+    float (*turn)[256] = s_turn[wave_id()];                  // private to the wave: the turns below need no cross-wave barrier --
+                                                             // a wave's LDS accesses execute in order (IPLAN_WAVE_SYNC: emulator rendezvous)
     const float cn = a.hard ? 1.0f : a.coef, ck = a.hard ? 0.0f : 1.0f - a.coef;
 
     f32x4 aWih[6][2], aWhh[6][2], aLin[2], aOut[2];
@@ -873,13 +874,13 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
             }
             // dW_out += dlogit^T h_L
             park(0, dlog[0]); park(1, hL[0]); park(2, hL[1]);
-            IPLAN_LDS_BARRIER();
+            IPLAN_WAVE_SYNC();
             for (int s4 = 0; s4 < 4; ++s4) {
                 const float av = pick(0, s4);
                 aOut[0] = mfma4(av, pick(1, s4), aOut[0]);
                 aOut[1] = mfma4(av, pick(2, s4), aOut[1]);
             }
-            IPLAN_LDS_BARRIER();
+            IPLAN_WAVE_SYNC();
         }
         for (int t = a.L - 1; t >= 0; --t) {
             f32x4 dg[4 * ET], dd[ET], u[ET], hp[ET];
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
                 const bool wrap = t == 0, more = j > j_lo;
                 load_step(wrap && more ? j - 1 : j, wrap ? (more ? a.L - 1 : 0) : t - 1, cur);
             }
-            IPLAN_LDS_BARRIER();
+            IPLAN_WAVE_SYNC();
             for (int s4 = 0; s4 < 4; ++s4) {
                 const float u0 = pick(10, s4), u1 = pick(11, s4), h0 = pick(12, s4), h1 = pick(13, s4), xv = pick(14, s4);
                 for (int o = 0; o < 6; ++o) {
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
                 aLin[0] = mfma4(pick(8, s4), xv, aLin[0]);
                 aLin[1] = mfma4(pick(9, s4), xv, aLin[1]);
             }
-            IPLAN_LDS_BARRIER();
+            IPLAN_WAVE_SYNC();
         }
     }
     if (!live) return;
