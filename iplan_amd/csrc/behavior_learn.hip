@@ -850,26 +850,37 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
         }
         for (int q = 0; q < 4; ++q) o.x[q] = keep_if(ok && o.has_x && 4 * g + q < a.d, o.x[q]);
     };
+    // what a window's head backward reads (new latent, d loss / d latent from the decoder, h after the window's last step):
+    // fetched while the PREVIOUS window's last step runs, like the step records
+    struct WinIn {
+        f32x4 nl, dl, hL[ET];
+    };
+    auto load_win = [&](int j, WinIn& o) {
+        o.nl = *reinterpret_cast<const f32x4*>(a.saved_lat + (c.grow * J + j) * SVL + 4 * g);
+        o.dl = *reinterpret_cast<const f32x4*>(a.dsave_lat + (c.grow * J + j) * DSL + 4 * g);
+        for (int T = 0; T < ET; ++T) o.hL[T] = *reinterpret_cast<const f32x4*>(rec0 + ((int64_t)j * a.L + (a.L - 1)) * SVE + SE_H + 16 * T);
+    };
     EncIn cur;
+    WinIn win;
     load_step(j_hi - 1, a.L - 1, cur);
+    load_win(j_hi - 1, win);
     for (int j = j_hi - 1; j >= j_lo; --j) {
         // ---- latent update + head backward (dlat = d(loss)/d(latent_{j+1}) on entry)
         f32x4 dlog[1], hL[ET];
         {
-            const f32x4 nl = vload_a(a.saved_lat + (c.grow * J + j) * SVL, valid && live, 0);
+            const f32x4 nl = zero_unless(ok, win.nl);
             float s = 0.f;
             f32x4 dnew;
             for (int q = 0; q < 4; ++q) { dnew[q] = cn * dlat[q]; s = fmaf(nl[q], dnew[q], s); }
             s = group_sum(s);
-            const f32x4 dl_dec = vload_a(a.dsave_lat + (c.grow * J + j) * DSL, valid && live, 0);
+            const f32x4 dl_dec = zero_unless(ok, win.dl);
             for (int q = 0; q < 4; ++q) {
                 dlog[0][q] = nl[q] * (dnew[q] - s);
                 dlat[q] = ck * dlat[q] + dl_dec[q];          // now d(loss)/d(latent_j)
                 bO[q] += dlog[0][q];
             }
-            const float* seL = a.saved_enc + ((c.grow * J + j) * a.L + (a.L - 1)) * SVE;
             for (int T = 0; T < ET; ++T) {
-                hL[T] = vload_a(seL + SE_H, valid && live, T);
+                hL[T] = zero_unless(ok, win.hL[T]);
                 dhe[T] = dense_tile<1>(s_outT, 24, 16 * T, dlog, dhe[T]);
             }
             // dW_out += dlogit^T h_L
@@ -910,6 +921,7 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
             {   // the next step's record is fetched under this step's 104 weight-gradient MFMAs (the last step re-reads its own)
                 const bool wrap = t == 0, more = j > j_lo;
                 load_step(wrap && more ? j - 1 : j, wrap ? (more ? a.L - 1 : 0) : t - 1, cur);
+                if (wrap) load_win(more ? j - 1 : j, win);
             }
             IPLAN_WAVE_SYNC();
             for (int s4 = 0; s4 < 4; ++s4) {
