@@ -374,7 +374,8 @@ int iplan_ac_pack_fc1(const IplanAcPackArgs* args, iplan_stream_t stream);
 
 int iplan_ac_kpad(const IplanAcFeatures* feat);   /* padded length of the kernels' source-major feature order */
 int iplan_ac_fc1_groups(const IplanAcFeatures* feat); /* wave jobs along the feature axis of iplan_ac_bwd_fc1 (the caller
-                                                          sizes fc1_chunks so that groups x chunks x nets fill the chip) */
+                                                          sizes fc1_chunks so that groups x chunks x nets fill the chip:
+                                                          2048 waves, two per SIMD) */
 int iplan_ac_bwd_tail(const IplanAcBwdArgs* args, iplan_stream_t stream);
 int iplan_ac_bwd_fc1(const IplanAcBwdArgs* args, iplan_stream_t stream);
 int iplan_ac_bwd_fc1_finalize(const IplanAcBwdArgs* args, iplan_stream_t stream);

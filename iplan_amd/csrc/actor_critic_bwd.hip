@@ -213,15 +213,21 @@ __global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // G[m][kb] = sum_r dz1[r][m] * xhat[r][kb]   (xhat = (x - mu_r) * rstd_r, LN(F) without its affine part), with the
 // feature axis in the SOURCE-MAJOR K order of ac_kmap.h.  Same data path as wgrad.hip's wide jobs: a wave owns all
-// 4 o-tiles x up to FC1_KG k-tiles (192 accumulator registers, one wave per SIMD), both operands are loaded from
+// 4 o-tiles x up to FC1_KG k-tiles (128 accumulator registers, two waves per SIMD), both operands are loaded from
 // global memory directly in MFMA operand order (sub-step s: lane (i, g) reads dz1[row 4s+g][16t+i] and feature
 // 16u+i of row 4s+g from its source field), addressing is one uniform base per field + 32-bit byte offsets advanced
 // incrementally, and the registers of a sub-step are reloaded for the next block as soon as its MFMAs are issued.
-// dz1 is re-read once per k-group (14 groups at F = 2485), the feature fields exactly once.
+// dz1 is re-read once per k-group (21 groups at F = 2485), the feature fields exactly once.
 // A wave job never straddles two source blocks of the K order (each block's k-tiles are cut into groups of at most
 // FC1_KG), so a job reads ONE field: one base, one row offset per sub-step, no per-tile selection.
 // grid: (k-group, row chunk, which * n_agents + net); one wave per workgroup.
-constexpr int FC1_KG = 12;
+// FC1_KG = 8 (128 accumulator registers, 244 in all: TWO waves per SIMD) against 12 (one wave per SIMD), same box: ac_backward
+// 2.31 -> 1.99 ms, PPO train() 61.8 -> 57.5 ms; 10 / 6 / 5 / 4 k-tiles: 2.44 / 2.04 / 2.15 / 2.07 ms (profiles/r02g_notes.md).
+// The caller sizes the row chunks so that k-groups x chunks x nets = 2048 waves.
+#ifndef AC_FC1_KG
+#define AC_FC1_KG 8
+#endif
+constexpr int FC1_KG = AC_FC1_KG;
 
 struct Fc1Group { int blk, T0, nkt; };
 // k-group `gid` of the launch -> (source block, first k-tile, tiles); returns the number of groups when gid < 0

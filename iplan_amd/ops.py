@@ -476,9 +476,9 @@ def ac_backward(fwd, actor_arena, critic_arena, g_logp=None, g_entropy=0.0, g_va
     a.dsave, a.ln_part = dsave.data_ptr(), ln_part.data_ptr()
     Fpad = int(lib.c.iplan_ac_kpad(C.byref(fa.feat)))
     n_which = 2 if which == 2 else 1
-    # the fc1 contraction runs one wave per SIMD (12 k-tiles x 4 o-tiles per wave): as many row chunks as fill the chip once
+    # the fc1 contraction runs two waves per SIMD (8 k-tiles x 4 o-tiles per wave): as many row chunks as fill the chip once
     k_groups = int(lib.c.iplan_ac_fc1_groups(C.byref(fa.feat)))
-    want = max(1, 1024 // (k_groups * n_which * n_agents))
+    want = max(1, 2048 // (k_groups * n_which * n_agents))
     chunk_rows = max(256, ((rows + want - 1) // want + 15) // 16 * 16)
     chunks = (rows + chunk_rows - 1) // chunk_rows
     g_part = workspace(dev, n_which * n_agents * chunks * L.AC_HIDDEN * Fpad, "fc1")
