@@ -28,6 +28,9 @@ constexpr int GH = IPLAN_GAT_HIDDEN;   // H == A == 32
 constexpr int NP = IPLAN_MAX_ENTITIES; // 64
 constexpr int BST = 100;               // padded row stride (floats) of the W_b h_j table
 constexpr int QST = 33;                // padded row stride of q/k/v/x tables
+#ifndef IPLAN_GAT_BF3
+#define IPLAN_GAT_BF3 1                // recurrence on the bf16 matrix cores (fp32-exact split); 0 = fp32 MFMA (A/B builds)
+#endif
 
 __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float s_B[2][NP][BST];
@@ -137,17 +140,27 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
     // ---------------------------------------------------------------- phase 2: hard-attention bi-GRU
     if (tile_live) {
         const float* Whh = P + a.off[dir ? IPLAN_GAT_R_WHH : IPLAN_GAT_F_WHH];   // [3H][H]
-        f32x4 whh[6][2];
-        for (int t = 0; t < 6; ++t)
-            for (int T = 0; T < 2; ++T) whh[t][T] = wfrag_a(Whh, GH, 3 * GH, 16 * t, 16 * T);
-        const f32x4 bhn0 = bfrag(bhh, 3 * GH, 4), bhn1 = bfrag(bhh, 3 * GH, 5);
         const float* Wh = P + a.off[IPLAN_GAT_HARD_W];                           // [2][2H]
+        const f32x4 bhn0 = bfrag(bhh, 3 * GH, 4), bhn1 = bfrag(bhh, 3 * GH, 5);
         // hard-attention logits as a 7th MFMA chain: A = hard_encoding.weight[:, dir*H:(dir+1)*H] (2 real rows),
         // B = the hidden state -> class c of chain n lands in lane (n, g = 0), register c.  The chain runs one
         // step behind (it contracts the SAME h operand the recurrent chains use), so it rides along in the
         // round-robin issue order instead of costing cross-lane reductions on the critical path.
+#if IPLAN_GAT_BF3
+        // W_hh h on the bf16 matrix cores, fp32-exact (wave_tile.h, split-bf16): the three pieces of every weight
+        // fragment are loop invariants in registers, the hidden state is split once per step.  42 K=32 MFMAs per step
+        // (7 chains x 6 piece products) that run BESIDE the gate arithmetic of the SIMD's other wave, instead of 56
+        // fp32 MFMAs that take the VALU's issue time (1 792 of a step's 2 700 cycles).
+        Bf3 whh[6], wl;
+        for (int t = 0; t < 6; ++t) whh[t] = wfrag_bf3(Whh, GH, 3 * GH, 16 * t, 0);
+        wl = wfrag_bf3(Wh + dir * GH, 2 * GH, 2, 0, 0);
+#else
+        f32x4 whh[6][2];
+        for (int t = 0; t < 6; ++t)
+            for (int T = 0; T < 2; ++T) whh[t][T] = wfrag_a(Whh, GH, 3 * GH, 16 * t, 16 * T);
         f32x4 wl[2];
         for (int T = 0; T < 2; ++T) wl[T] = wfrag(Wh, 2 * GH, 2, 2 * GH, 0, dir * GH + 16 * T);
+#endif
         f32x4 h0 = splat4(0.f), h1 = splat4(0.f);
         auto brow = [&](int it) -> const float* {
             const int s = dir ? (N - 2 - it) : it;
@@ -171,6 +184,18 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
             acc[0] = areg[0]; acc[1] = areg[1]; acc[2] = areg[2]; acc[3] = areg[3];
             acc[4] = bhn0; acc[5] = bhn1; acc[6] = splat4(0.f);
             // 7 independent accumulator chains issued round-robin: consecutive MFMAs never depend on each other
+#if IPLAN_GAT_BF3
+            {
+                const Bf3 hs = split_bf3(h0, h1);
+                // smallest piece products first (the accumulator is fp32)
+#define GAT_BF3_ROUND(WP, HP)                                                  \
+    for (int c = 0; c < 6; ++c) acc[c] = mfma_bf16(whh[c].WP, hs.HP, acc[c]);  \
+    acc[6] = mfma_bf16(wl.WP, hs.HP, acc[6]);
+                GAT_BF3_ROUND(p2, p0) GAT_BF3_ROUND(p0, p2) GAT_BF3_ROUND(p1, p1)
+                GAT_BF3_ROUND(p1, p0) GAT_BF3_ROUND(p0, p1) GAT_BF3_ROUND(p0, p0)
+#undef GAT_BF3_ROUND
+            }
+#else
             for (int T = 0; T < 2; ++T) {
                 const f32x4 hb = T ? h1 : h0;
                 for (int q = 0; q < 4; ++q) {
@@ -178,6 +203,7 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
                     acc[6] = mfma4(wl[T][q], hb[q], acc[6]);
                 }
             }
+#endif
             if (it > 0 && g == 0 && valid) {                        // logits of the previous step
                 s_pl[dir][node][s_prev][0] = acc[6][0];
                 s_pl[dir][node][s_prev][1] = acc[6][1];
@@ -201,8 +227,14 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
         }
         {   // logits of the last step
             f32x4 la = splat4(0.f);
+#if IPLAN_GAT_BF3
+            const Bf3 hs = split_bf3(h0, h1);
+            la = mfma_bf16(wl.p2, hs.p0, la); la = mfma_bf16(wl.p0, hs.p2, la); la = mfma_bf16(wl.p1, hs.p1, la);
+            la = mfma_bf16(wl.p1, hs.p0, la); la = mfma_bf16(wl.p0, hs.p1, la); la = mfma_bf16(wl.p0, hs.p0, la);
+#else
             la = mma_block(wl[0], h0, la);
             la = mma_block(wl[1], h1, la);
+#endif
             if (g == 0 && valid) {
                 s_pl[dir][node][s_prev][0] = la[0];
                 s_pl[dir][node][s_prev][1] = la[1];

@@ -83,6 +83,51 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- split-bf16 contraction: an fp32 product out of the bf16 matrix cores ----------------------------------------
+// v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate on gfx950 (64 FLOP/clk/SIMD, MI355X_MICROARCH.md "Matrix cores")
+// and shares the VALU's issue time; v_mfma_f32_16x16x32_bf16 is 16x as fast and runs beside the VALU.  An fp32 value is
+// EXACTLY the sum of three bf16 pieces (3 x 8 significand bits, round-to-nearest residuals: x = p0 + p1 + p2), a
+// bf16 x bf16 product is exact in fp32, and the accumulator is fp32 -- so
+//      a . b  =  a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0)  +  O(2^-26 |a||b|)
+// six bf16 MFMAs (K = 32 each) reproduce the fp32 contraction to below fp32 round-off (the dropped terms are a quarter
+// of an fp32 half-ulp of the product).  Used in the recurrences, where the weights' pieces are loop invariants in
+// registers and the hidden state is split once per step (5.5 VALU operations per value).
+// K slots: a lane group g of the K = 32 instruction holds 8 k-values; slot j < 4 = element 4g + j of the first 16-tile,
+// slot j >= 4 = element 4g + j - 4 of the second one, i.e. exactly the 8 D-layout values a lane holds of a 32-vector --
+// A and B agree by construction, no data movement between steps.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Bf3 {
+    bf16x8 p0, p1, p2;
+};
+__device__ __forceinline__ Bf3 split_bf3(f32x4 lo, f32x4 hi) {
+    Bf3 s;
+    for (int j = 0; j < 8; ++j) {
+        const float v = j < 4 ? lo[j] : hi[j - 4];
+        const __bf16 b0 = (__bf16)v;                    // v_cvt_pk_bf16_f32: round to nearest even
+        const float r1 = v - (float)b0;                 // exact
+        const __bf16 b1 = (__bf16)r1;
+        const float r2 = r1 - (float)b1;                // exact, fits 8 bits
+        s.p0[j] = b0;
+        s.p1[j] = b1;
+        s.p2[j] = (__bf16)r2;
+    }
+    return s;
+}
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// A fragment (three pieces) of rows o0..o0+15, columns k0..k0+31 of a row-major matrix in the slot order above; rows
+// past `rows` read as zero.  16-byte aligned base, ld % 4 == 0.
+__device__ __forceinline__ Bf3 wfrag_bf3(const float* __restrict__ W, int ld, int rows, int o0, int k0) {
+    const int l = lane_id();
+    const int r = o0 + (l & 15);
+    const int rc = r < rows ? r : rows - 1;
+    const float* p = W + (size_t)rc * ld + k0 + 4 * (l >> 4);
+    f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 16);
+    if (r >= rows) lo = hi = f32x4{0.f, 0.f, 0.f, 0.f};
+    return split_bf3(lo, hi);
+}
+
 __device__ __forceinline__ f32x4 splat4(float v) {
     f32x4 r = {v, v, v, v};
     return r;

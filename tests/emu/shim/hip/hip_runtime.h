@@ -51,6 +51,7 @@ struct Wave {
     int nlanes = 0, arrived = 0, gen = 0;
     float fa[64], fb[64];
     int ia[64];
+    float fa8[64][8], fb8[64][8];   // operands of the K = 32 bf16 MFMA (8 k-slots per lane)
 };
 
 // Context switch.  glibc's swapcontext saves / restores the signal mask with a system call on every switch (half of the
@@ -153,6 +154,28 @@ inline __emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, __emu_
         float acc = c[reg];
         for (int k = 0; k < 4; ++k) acc = fmaf(w.fa[row + 16 * k], w.fb[col + 16 * k], acc);
         d[reg] = acc;
+    }
+    iplan_emu::wave_sync();
+    return d;
+}
+
+// v_mfma_f32_16x16x32_bf16: lane (i = l & 15, g = l >> 4) holds A[i][8g .. 8g+7] / B[8g .. 8g+7][i]; C/D as above.  The 32
+// products of an output element are exact in fp32; they are summed here in double and rounded once with C (the hardware's
+// internal summation order is not documented -- the GPU parity tests measure the real thing).
+typedef __bf16 __emu_bf16x8 __attribute__((ext_vector_type(8)));
+inline __emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(__emu_bf16x8 a, __emu_bf16x8 b, __emu_f32x4 c, int, int, int) {
+    auto& w = iplan_emu::g_block->waves[iplan_emu::g_cur->wave];
+    int l = iplan_emu::g_cur->lane;
+    for (int j = 0; j < 8; ++j) { w.fa8[l][j] = (float)a[j]; w.fb8[l][j] = (float)b[j]; }
+    iplan_emu::wave_sync();
+    __emu_f32x4 d = c;
+    int col = l & 15;
+    for (int reg = 0; reg < 4; ++reg) {
+        int row = 4 * (l >> 4) + reg;
+        double acc = (double)c[reg];
+        for (int g = 0; g < 4; ++g)
+            for (int j = 0; j < 8; ++j) acc += (double)w.fa8[row + 16 * g][j] * (double)w.fb8[col + 16 * g][j];
+        d[reg] = (float)acc;
     }
     iplan_emu::wave_sync();
     return d;
