@@ -240,21 +240,7 @@ __global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
 // ADDRESSING.  Everything a lane touches is a wave-uniform 64-bit base (SGPRs) plus a 32-bit lane byte offset: the records
 // of a tile are [16 chains][J*L steps][cols], so the per-step advance is one scalar add and the column is an immediate.
 // FULL = all 16 chains of the tile exist (every tile when rows % 16 == 0): no predication on any load / store.
-#ifndef IPLAN_DEC_BF3
-#define IPLAN_DEC_BF3 1                  // decoder GRU contractions on the bf16 matrix cores (split-bf16, wave_tile.h); 0 = fp32 MFMA (A/B builds)
-#endif
-// SPLIT-BF16 FORM (IPLAN_DEC_BF3).  fp32 MFMA issues at the VALU's rate and takes its issue time; as three bf16 pieces per
-// value the same contraction costs 6/8 as many (K = 32) instructions at half the issue interval, beside the gate arithmetic.
-// The pieces of the recurrent matrix (W_hh in the forward, W_hh^T in the BPTT) are loop invariants in registers (72 VGPRs
-// per quarter-wave), those of the input matrix live in LDS in fragment order (one contiguous 1 KiB read per fragment), and
-// the vectors the four quarters exchange (h, u; the gate gradients) are split ONCE by the quarter that produces them and
-// parked in LDS as ready B operands.  256 registers per wave = two waves per SIMD, so a workgroup holds 2 tiles
-// (512 threads); the exchange is double buffered, which also halves the rendezvous per step.
-#if IPLAN_DEC_BF3
-constexpr int DEC_TILES = 2;
-#else
 constexpr int DEC_TILES = 3;
-#endif
 constexpr int DEC_THREADS = 256 * DEC_TILES;
 
 
@@ -515,271 +501,6 @@ __device__ __forceinline__ void dec_fwd_body(const IplanBehArgs& a, const DecTil
     }
 }
 
-
-#if IPLAN_DEC_BF3
-// ---- split-bf16 decoder: LDS images -------------------------------------------------------------------------
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-struct Bf3h {                            // three pieces of a lane's 4 values of one 16-tile (half a K = 32 operand)
-    bf16x4 p0, p1, p2;
-};
-__device__ __forceinline__ Bf3h split_bf3h(f32x4 v) {
-    Bf3h s;
-    for (int j = 0; j < 4; ++j) {
-        const __bf16 b0 = (__bf16)v[j];
-        const float r1 = v[j] - (float)b0;
-        const __bf16 b1 = (__bf16)r1;
-        s.p0[j] = b0;
-        s.p1[j] = b1;
-        s.p2[j] = (__bf16)(r1 - (float)b1);
-    }
-    return s;
-}
-// Weight image: [piece 3][chunk KC][row tile RT][lane 64][8 bf16] -- the A fragment (piece, chunk, row tile) of a wave is
-// the 1 KiB block behind it, lane l reading its 16 bytes at l * 16 (conflict-free ds_read_b128).  Element j of lane
-// (m, g): W[16 rt + m][32 c + (j < 4 ? 4 g + j : 16 + 4 g + j - 4)]  (the K-slot order of wave_tile.h).  `tr`: the image
-// of W^T (row of the image = column of W), for the BPTT.  All threads of the block call it.
-__device__ __forceinline__ void stage_bf3(__bf16* __restrict__ dst, const float* __restrict__ W, int rows, int cols, bool tr) {
-    const int R = tr ? cols : rows, K = tr ? rows : cols;                // image is [R x K]
-    const int RT = R / 16, KC = K / 32, total = R * K;
-    for (int idx = (int)threadIdx.x; idx < total; idx += (int)blockDim.x) {
-        const int j = idx & 7, l = (idx >> 3) & 63, blk = idx >> 9;      // blk = c * RT + rt
-        const int rt = blk % RT, c = blk / RT, m = l & 15, g = l >> 4;
-        const int r = 16 * rt + m, k = 32 * c + (j < 4 ? 4 * g + j : 16 + 4 * g + j - 4);
-        const float v = tr ? W[(size_t)k * cols + r] : W[(size_t)r * cols + k];
-        const __bf16 b0 = (__bf16)v;
-        const float r1 = v - (float)b0;
-        const __bf16 b1 = (__bf16)r1;
-        dst[idx] = b0;
-        dst[total + idx] = b1;
-        dst[2 * total + idx] = (__bf16)(r1 - (float)b1);
-    }
-}
-__device__ __forceinline__ bf16x8 afrag_bf3(const __bf16* __restrict__ img, int total, int RT, int piece, int c, int rt) {
-    return *reinterpret_cast<const bf16x8*>(img + (size_t)piece * total + ((size_t)(c * RT + rt) * 64 + lane_id()) * 8);
-}
-// Exchange image of a 64-vector (4 tiles, one per quarter): [piece 3][chunk 2][lane 64][half 2][4 bf16]; quarter T writes
-// half T & 1 of chunk T >> 1, every quarter reads whole 16-byte B operands.
-constexpr int XV_BYTES = 3 * 2 * 64 * 16;                    // 6 KiB
-__device__ __forceinline__ void xv_put(char* __restrict__ img, int T, const Bf3h& s) {
-    char* p = img + ((T >> 1) * 64 + lane_id()) * 16 + (T & 1) * 8;
-    *reinterpret_cast<bf16x4*>(p) = s.p0;
-    *reinterpret_cast<bf16x4*>(p + 2 * 64 * 16) = s.p1;
-    *reinterpret_cast<bf16x4*>(p + 4 * 64 * 16) = s.p2;
-}
-__device__ __forceinline__ Bf3 xv_get(const char* __restrict__ img, int c) {
-    const char* p = img + (c * 64 + lane_id()) * 16;
-    Bf3 s;
-    s.p0 = *reinterpret_cast<const bf16x8*>(p);
-    s.p1 = *reinterpret_cast<const bf16x8*>(p + 2 * 64 * 16);
-    s.p2 = *reinterpret_cast<const bf16x8*>(p + 4 * 64 * 16);
-    return s;
-}
-// six piece products of one K = 32 chunk into one accumulator, smallest first
-#define IPLAN_BF3_PRODUCTS(X) X(p2, p0) X(p0, p2) X(p1, p1) X(p1, p0) X(p0, p1) X(p0, p0)
-
-constexpr int FX_H = 0, FX_U = XV_BYTES, FX_Y = 2 * XV_BYTES, FX_BYTES = 2 * XV_BYTES + 3 * 1024;   // one buffer of a tile's exchange
-
-template <bool FULL, int Q>
-__device__ __forceinline__ void dec_fwd_body_bf3(const IplanBehArgs& a, const DecTile& c, const __bf16* __restrict__ s_wih3,
-                                                 const float* __restrict__ s_lin, const float* __restrict__ s_out,
-                                                 const float* __restrict__ s_b, char* __restrict__ xch) {
-    constexpr int q = Q;
-    constexpr int WTOT = 3 * DHd * DHd;                       // elements of one piece image of W_ih
-    const bool valid = c.valid;
-    const int l = lane_id(), g = c.g, J = c.J, net = c.net;
-    const float inv_keep = 1.0f / (1.0f - a.drop_p);
-    const bool dec_only = a.win != nullptr;
-    const int Lw = a.L;
-    const int j_lo = dec_only ? 0 : imax(a.fwd_j_lo, 0), j_hi = (!dec_only && a.fwd_j_hi > 0) ? imin(a.fwd_j_hi, J) : J;
-    const int64_t steps_per_chain = (int64_t)J * Lw;
-    char* sd_base = reinterpret_cast<char*>(a.saved_dec + c.grow0 * steps_per_chain * SVD);
-    const uint32_t sd_lane = (uint32_t)((int64_t)c.n * steps_per_chain * SVD * 4) + 16u * (uint32_t)g;
-    const char* sl_base = reinterpret_cast<const char*>(a.saved_lat ? a.saved_lat + c.grow0 * J * SVL : nullptr);
-    const uint32_t sl_lane = (uint32_t)((int64_t)c.n * J * SVL * 4);
-    float* carry = (a.dec_carry && c.live) ? a.dec_carry + ((int64_t)net * c.tiles + c.tile) * 1024 : nullptr;
-    const int64_t grow = c.grow0 + c.n;
-
-    auto latent_shifted = [&](int j) {
-        f32x4 v = splat4(0.f);
-        if (FULL || valid) {
-            const float* lp = dec_only ? a.lat_in + grow * a.Z
-                                       : reinterpret_cast<const float*>(sl_base + sl_lane + (uint32_t)j * (uint32_t)(SVL * 4)) + 16;
-            for (int k = 0; k < 4; ++k) {
-                const int z = 4 * g + k - a.d;
-                if (z >= 0 && z < a.Z) v[k] = lp[z];
-            }
-        }
-        return v;
-    };
-    auto x_of = [&](int j, int t) {
-        if (dec_only) return ld_row_br<FULL>(reinterpret_cast<const char*>(a.win), (uint32_t)((grow * Lw + t) * a.d * 4), valid, a.d, g);
-        const int st = beh_x_step(a, j, t);
-        if (st < 0) return splat4(0.f);
-        return ld_row_br<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)st * a.h_s_t * 4), valid, a.d, g);
-    };
-    auto u_own = [&](f32x4 xin) {
-        f32x4 x1[1];
-        x1[0] = xin;
-        return relu4(dense_tile<1>(s_lin, 24, 16 * q, x1, bfrag_lds(s_b, q)));
-    };
-
-    // recurrent matrix: the three pieces of this quarter's r, z, n row tiles, both K chunks -- 72 registers for the whole launch
-    Bf3 whh[3][2];
-    {
-        const float* Whh = a.dec_params + (int64_t)net * a.dec_s_net + a.dec_off[IPLAN_DEC_WHH];
-        for (int i = 0; i < 3; ++i)
-            for (int kc = 0; kc < 2; ++kc) whh[i][kc] = wfrag_bf3(Whh, DHd, 3 * DHd, i * DHd + 16 * q, 32 * kc);
-    }
-    const int rt3[3] = {q, DT + q, 2 * DT + q};               // row tiles of W_ih's image: r, z, n gates of hidden tile q
-
-    f32x4 hq = dec_only ? ld4<FULL>(reinterpret_cast<const char*>(a.hd_in), (uint32_t)(grow * DHd * 4) + 64u * q + 16u * g, valid) : splat4(0.f);
-    if (j_lo > 0 && carry) hq = *reinterpret_cast<const f32x4*>(carry + 256 * q + 4 * l);
-    f32x4 latsh = latent_shifted(j_lo);
-    f32x4 xin = x_of(j_lo, 0) + latsh;
-    f32x4 uq = u_own(xin);
-    int buf = 0;
-    xv_put(xch + FX_H, q, split_bf3h(hq));
-    xv_put(xch + FX_U, q, split_bf3h(uq));
-    IPLAN_LDS_BARRIER();
-
-    float beh = 0.f, stab = 0.f;
-    for (int j = j_lo; j < j_hi; ++j) {
-        const float scale = (dec_only || q) ? 0.f : (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS);
-        float err = 0.f;
-        f32x4 latsh_next = latsh;
-        if (j + 1 < j_hi) latsh_next = latent_shifted(j + 1);
-        for (int t = 0; t < Lw; ++t) {
-            const uint32_t so = sd_lane + (uint32_t)(((int64_t)j * Lw + t) * SVD * 4);
-            const bool last_t = t + 1 == Lw;
-            const bool has_next = !last_t || j + 1 < j_hi;
-            f32x4 xin_next = splat4(0.f);
-            if (has_next) xin_next = x_of(last_t ? j + 1 : j, last_t ? 0 : t + 1) + (last_t ? latsh_next : latsh);
-            f32x4 nx = splat4(0.f);
-            float m = 0.f;
-            if (q == 0 && !dec_only) {
-                nx = ld_row_br<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)beh_y_step(a, j, t) * a.h_s_t * 4), valid, a.d, g);
-                if (FULL || valid) m = *reinterpret_cast<const float*>(c.mask + c.mask_lane + 4u * (uint32_t)beh_m_step(a, j, t));
-            }
-            if (q == 0) st4<FULL>(sd_base, so + 4u * SD_X, valid, xin);
-            st4<FULL>(sd_base, so + 4u * (SD_U + 16 * q), valid, uq);
-            // gates of hidden tile q: pre_r and pre_z collect W_ih u and W_hh h in one accumulator each, gi_n / gh_n apart
-            const char* xb = xch + buf * FX_BYTES;
-            f32x4 ar = bfrag_lds(s_b + 64, q) + bfrag_lds(s_b + 256, q);
-            f32x4 az = bfrag_lds(s_b + 64, DT + q) + bfrag_lds(s_b + 256, DT + q);
-            f32x4 gin = bfrag_lds(s_b + 64, 2 * DT + q);
-            f32x4 ghn = bfrag_lds(s_b + 256, 2 * DT + q);
-            for (int kc = 0; kc < 2; ++kc) {
-                const Bf3 ub = xv_get(xb + FX_U, kc), hb = xv_get(xb + FX_H, kc);
-                Bf3 wi[3];
-                for (int i = 0; i < 3; ++i) {
-                    wi[i].p0 = afrag_bf3(s_wih3, WTOT, 3 * DT, 0, kc, rt3[i]);
-                    wi[i].p1 = afrag_bf3(s_wih3, WTOT, 3 * DT, 1, kc, rt3[i]);
-                    wi[i].p2 = afrag_bf3(s_wih3, WTOT, 3 * DT, 2, kc, rt3[i]);
-                }
-                // four accumulator chains round-robin (six consecutive MFMAs never touch the same accumulator twice in a row)
-#define DEC_F_ROUND(WP, VP)                                  \
-    ar = mfma_bf16(wi[0].WP, ub.VP, ar);                     \
-    az = mfma_bf16(wi[1].WP, ub.VP, az);                     \
-    gin = mfma_bf16(wi[2].WP, ub.VP, gin);                   \
-    ghn = mfma_bf16(whh[2][kc].WP, hb.VP, ghn);              \
-    ar = mfma_bf16(whh[0][kc].WP, hb.VP, ar);                \
-    az = mfma_bf16(whh[1][kc].WP, hb.VP, az);
-                IPLAN_BF3_PRODUCTS(DEC_F_ROUND)
-#undef DEC_F_ROUND
-            }
-            const GruGates o = gru_gates(ar, az, gin, ghn, hq);
-            st4<FULL>(sd_base, so + 4u * (SD_R + 16 * q), valid, o.r);
-            st4<FULL>(sd_base, so + 4u * (SD_Z + 16 * q), valid, o.z);
-            st4<FULL>(sd_base, so + 4u * (SD_N + 16 * q), valid, o.n);
-            st4<FULL>(sd_base, so + 4u * (SD_HN + 16 * q), valid, o.hn);
-            st4<FULL>(sd_base, so + 4u * (SD_H + 16 * q), valid, o.h);
-            const f32x4 km = keep_tile(a, net, j, c.row, t, q, FULL || valid, c.rows);
-            f32x4 act[1];
-            for (int k = 0; k < 4; ++k) act[0][k] = tanh_f(o.h[k]) * (km[k] * inv_keep);
-            st4<FULL>(sd_base, so + 4u * (SD_A + 16 * q), valid, act[0]);
-            const f32x4 yp = dense_tile_k<1>(s_out, DLD, 0, 16 * q, act, q ? splat4(0.f) : bfrag_lds(s_b + 448, 0));
-            // hand-over through the OTHER buffer: nobody reads it before the rendezvous below, nobody writes this step's
-            // buffer before the next one -- one rendezvous per step
-            char* xn = xch + (buf ^ 1) * FX_BYTES;
-            hq = o.h;
-            xv_put(xn + FX_H, q, split_bf3h(hq));
-            if (q) *reinterpret_cast<f32x4*>(xn + FX_Y + (q - 1) * 1024 + 16 * l) = yp;
-            if (has_next) {
-                uq = u_own(xin_next);
-                xv_put(xn + FX_U, q, split_bf3h(uq));
-            }
-            IPLAN_LDS_BARRIER();
-            buf ^= 1;
-            const f32x4 xt = xin;
-            xin = xin_next;
-            if (q) continue;
-            const f32x4 y = (yp + *reinterpret_cast<const f32x4*>(xn + FX_Y + 16 * l)) +
-                            (*reinterpret_cast<const f32x4*>(xn + FX_Y + 1024 + 16 * l) + *reinterpret_cast<const f32x4*>(xn + FX_Y + 2048 + 16 * l));
-            st4<FULL>(sd_base, so + 4u * SD_Y, valid, y);
-            if (dec_only) {
-                if (FULL || valid) {
-                    float* po = a.pred_out + (grow * Lw + t) * a.d + 4 * g;
-                    for (int k = 0; k < 4; ++k)
-                        if (4 * g + k < a.d) po[k] = y[k];
-                }
-                continue;
-            }
-            float d2 = 0.f;
-            for (int k = 0; k < 4; ++k) {
-                if (4 * g + k < a.d) {
-                    err += fabsf(nx[k] - y[k]) * m;
-                    const float df = xt[k] - y[k];
-                    d2 = fmaf(df, df, d2);
-                }
-            }
-            d2 = group_sum(d2);
-            if ((FULL || valid) && g == 0) stab += fmaxf(sqrtf(d2) - a.thres, 0.f);
-        }
-        latsh = latsh_next;
-        if (dec_only) {
-            st4<FULL>(reinterpret_cast<char*>(a.hd_out), (uint32_t)(grow * DHd * 4) + 64u * q + 16u * g, valid, hq);
-            return;
-        }
-        beh = fmaf(err, scale, beh);
-    }
-    if (j_hi < J && carry) *reinterpret_cast<f32x4*>(carry + 256 * q + 4 * l) = hq;
-    beh = chain_sum_b(group_sum(beh)) / (a.hard ? 1.0f : (float)J);
-    stab = chain_sum_b(group_sum(stab)) / (float)a.E / (float)a.L / (float)J;
-    if (l == 0 && q == 0 && c.live) {
-        float* lp = a.loss_part + ((int64_t)net * c.tiles + c.tile) * 2;
-        lp[0] = j_lo > 0 ? lp[0] + beh : beh;
-        lp[1] = j_lo > 0 ? lp[1] + stab : stab;
-    }
-}
-
-constexpr size_t DEC_FWD_LDS_BF3 = (size_t)3 * 3 * DHd * DHd * 2 + sizeof(float) * (DHd * 24 + 16 * DLD + DEC_FWD_BIAS) + (size_t)DEC_TILES * 2 * FX_BYTES;
-
-__global__ __launch_bounds__(DEC_THREADS) void beh_dec_fwd_kernel(IplanBehArgs a) {
-    IPLAN_DYN_LDS(smem);
-    __bf16* s_wih3 = reinterpret_cast<__bf16*>(smem);        // [3 pieces][2 chunks][12 row tiles][64 lanes][8]   72 KiB
-    float* s_lin = smem + (3 * 3 * DHd * DHd) / 2;          // [64][24]   W_lin, columns [0, d + Z)
-    float* s_out = s_lin + DHd * 24;                        // [16][DLD]
-    float* s_b = s_out + 16 * DLD;                          // lin 64 | ih 192 | hh 192 | out 16
-    char* s_xch = reinterpret_cast<char*>(s_b + DEC_FWD_BIAS);      // [DEC_TILES][2 buffers][FX_BYTES]
-    const float* __restrict__ PD = a.dec_params + (int64_t)blockIdx.y * a.dec_s_net;
-    stage_bf3(s_wih3, PD + a.dec_off[IPLAN_DEC_WIH], 3 * DHd, DHd, false);
-    stage_matrix(s_lin, 24, DHd, PD + a.dec_off[IPLAN_DEC_LIN_W], DHd, a.d + a.Z);
-    stage_matrix(s_out, DLD, 16, PD + a.dec_off[IPLAN_DEC_OUT_W], a.d, DHd);
-    stage_vector(s_b, 64, PD + a.dec_off[IPLAN_DEC_LIN_B], 64);
-    stage_vector(s_b + 64, 192, PD + a.dec_off[IPLAN_DEC_BIH], 192);
-    stage_vector(s_b + 256, 192, PD + a.dec_off[IPLAN_DEC_BHH], 192);
-    stage_vector(s_b + 448, 16, PD + a.dec_off[IPLAN_DEC_OUT_B], a.d);
-    __syncthreads();
-    const int w = uniform_i(wave_id()), q = w & 3, ts = w >> 2;
-    DecTile c;
-    dec_tile(a, c, (int)blockIdx.x * DEC_TILES + ts);       // waves without a tile still take part in the block barriers
-    char* xch = s_xch + ts * (2 * FX_BYTES);
-#define IPLAN_DEC_FWD(F, QQ) dec_fwd_body_bf3<F, QQ>(a, c, s_wih3, s_lin, s_out, s_b, xch)
-    if (c.full) { if (q == 0) IPLAN_DEC_FWD(true, 0); else if (q == 1) IPLAN_DEC_FWD(true, 1); else if (q == 2) IPLAN_DEC_FWD(true, 2); else IPLAN_DEC_FWD(true, 3); }
-    else { if (q == 0) IPLAN_DEC_FWD(false, 0); else if (q == 1) IPLAN_DEC_FWD(false, 1); else if (q == 2) IPLAN_DEC_FWD(false, 2); else IPLAN_DEC_FWD(false, 3); }
-#undef IPLAN_DEC_FWD
-}
-#else
 __global__ __launch_bounds__(DEC_THREADS) void beh_dec_fwd_kernel(IplanBehArgs a) {
     IPLAN_DYN_LDS(smem);
     float* s_wih = smem;                                    // [192][DLD]
@@ -810,8 +531,6 @@ __global__ __launch_bounds__(DEC_THREADS) void beh_dec_fwd_kernel(IplanBehArgs a
     else { if (q == 0) IPLAN_DEC_FWD(false, 0); else if (q == 1) IPLAN_DEC_FWD(false, 1); else if (q == 2) IPLAN_DEC_FWD(false, 2); else IPLAN_DEC_FWD(false, 3); }
 #undef IPLAN_DEC_FWD
 }
-
-#endif  // IPLAN_DEC_BF3 (forward)
 
 __global__ __launch_bounds__(64) void beh_loss_kernel(IplanBehArgs a) {
     const int net = (int)blockIdx.x;
@@ -1007,210 +726,6 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
     if (j_lo > 0 && carry) *reinterpret_cast<f32x4*>(carry + 4 * l) = dhd;
 }
 
-
-#if IPLAN_DEC_BF3
-// Split-bf16 form of the BPTT (see IPLAN_DEC_BF3 above): W_hh^T pieces of output tile Q in registers (6 K chunks x 3 pieces),
-// W_ih^T pieces in LDS, the four gate-gradient vectors split by the quarter that produced them and parked as B operands.
-constexpr int BX_BYTES = 4 * XV_BYTES;                       // dr | dz | dn_i | dn_h images of one tile (24 KiB)
-
-template <bool FULL, int Q>
-__device__ __forceinline__ void dec_bwd_body_bf3(const IplanBehArgs& a, const DecTile& c, const __bf16* __restrict__ s_wihT3,
-                                                 const float* __restrict__ s_outT, const float* __restrict__ s_latT,
-                                                 char* __restrict__ xch, int* __restrict__ tcnt) {
-    constexpr int WTOT = 3 * DHd * DHd;
-    int sync_n = 0;
-    auto tile_sync = [&]() {
-        if (DEC_BWD_TILE_SYNC) { sync_n += 4; IPLAN_TILE_SYNC(tcnt, sync_n); }
-        else IPLAN_LDS_BARRIER();
-    };
-    const bool valid = c.valid;
-    const int l = lane_id(), g = c.g, J = c.J, net = c.net, Lw = a.L;
-    const float inv_keep = 1.0f / (1.0f - a.drop_p);
-    const int64_t steps_per_chain = (int64_t)J * Lw;
-    const char* sd_base = reinterpret_cast<const char*>(a.saved_dec + c.grow0 * steps_per_chain * SVD);
-    const uint32_t sd_lane = (uint32_t)((int64_t)c.n * steps_per_chain * SVD * 4) + 16u * (uint32_t)g;
-    char* dd_base = reinterpret_cast<char*>(a.dsave_dec + c.grow0 * steps_per_chain * DSD);
-    const uint32_t dd_lane = (uint32_t)((int64_t)c.n * steps_per_chain * DSD * 4) + 16u * (uint32_t)g;
-    char* dl_base = reinterpret_cast<char*>(a.dsave_lat + c.grow0 * J * DSL);
-    const uint32_t dl_lane = (uint32_t)((int64_t)c.n * J * DSL * 4) + 16u * (uint32_t)g;
-
-    struct StepIn {
-        f32x4 r, z, n, hn, hp, u, y, nx, xc;
-        float m;
-        bool first, has_xc;
-    };
-    auto load_step = [&](int j, int t, StepIn& o) {
-        const uint32_t so = sd_lane + (uint32_t)(((int64_t)j * Lw + t) * SVD * 4);
-        o.first = (j == 0 && t == 0);
-        o.r = ld4_raw<FULL>(sd_base, so + 4u * (SD_R + 16 * Q), valid);
-        o.z = ld4_raw<FULL>(sd_base, so + 4u * (SD_Z + 16 * Q), valid);
-        o.n = ld4_raw<FULL>(sd_base, so + 4u * (SD_N + 16 * Q), valid);
-        o.hn = ld4_raw<FULL>(sd_base, so + 4u * (SD_HN + 16 * Q), valid);
-        o.u = ld4_raw<FULL>(sd_base, so + 4u * (SD_U + 16 * Q), valid);
-        o.hp = ld4_raw<FULL>(sd_base, (o.first ? so : so - 4u * SVD) + 4u * (SD_H + 16 * Q), valid);
-        o.y = ld4_raw<FULL>(sd_base, so + 4u * SD_Y, valid);
-        o.nx = ld_row_raw<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)beh_y_step(a, j, t) * a.h_s_t * 4), valid, a.d, g);
-        o.m = *reinterpret_cast<const float*>(c.mask + c.mask_lane + 4u * (uint32_t)beh_m_step(a, j, t));
-        o.has_xc = false;
-        o.xc = splat4(0.f);
-        if (a.penalty != 0.f) {
-            const int st = beh_x_step(a, j, t);
-            o.has_xc = st >= 0;
-            o.xc = ld_row_raw<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)(st < 0 ? 0 : st) * a.h_s_t * 4), valid, a.d, g);
-        }
-    };
-    auto mask_step = [&](StepIn& o) {
-        o.hp = zero_unless(!o.first, o.hp);
-        for (int k = 0; k < 4; ++k) o.xc[k] = keep_if(o.has_xc && 4 * g + k < a.d, o.xc[k]);
-        if (!FULL) {
-            o.r = zero_unless(valid, o.r); o.z = zero_unless(valid, o.z); o.n = zero_unless(valid, o.n);
-            o.hn = zero_unless(valid, o.hn); o.u = zero_unless(valid, o.u); o.hp = zero_unless(valid, o.hp);
-            o.y = zero_unless(valid, o.y); o.nx = zero_unless(valid, o.nx); o.xc = zero_unless(valid, o.xc);
-            o.m = keep_if(valid, o.m);
-        }
-    };
-    const float pen = a.penalty / (float)J / (float)(a.E_norm > 0 ? a.E_norm : a.E) / (float)Lw;
-    const int j_hi = a.bwd_j_hi > 0 ? imin(a.bwd_j_hi, J) : J, j_lo = imax(a.bwd_j_lo, 0);
-    float* carry = (a.dec_carry && c.live) ? a.dec_carry + ((int64_t)net * c.tiles + c.tile) * 1024 + 256 * Q : nullptr;
-    f32x4 dhd = (j_hi < J && carry) ? *reinterpret_cast<const f32x4*>(carry + 4 * l) : splat4(0.f);
-
-    // W_hh^T, output tile Q: three pieces of all six K chunks ([dr | dz | dn_h] rows of W_hh), registers for the whole launch
-    Bf3 whhT[6];
-    {
-        const float* Whh = a.dec_params + (int64_t)net * a.dec_s_net + a.dec_off[IPLAN_DEC_WHH];
-        for (int kc = 0; kc < 6; ++kc) whhT[kc] = wfrag_t_bf3(Whh, DHd, 16 * Q, 32 * kc);
-    }
-    char* img_dr = xch, *img_dz = xch + XV_BYTES, *img_dni = xch + 2 * XV_BYTES, *img_dnh = xch + 3 * XV_BYTES;
-
-    StepIn cur;
-    load_step(j_hi - 1, Lw - 1, cur);
-    f32x4 hcur = ld4<FULL>(sd_base, sd_lane + (uint32_t)((((int64_t)(j_hi - 1)) * Lw + (Lw - 1)) * SVD * 4) + 4u * (SD_H + 16 * Q), valid);
-    for (int j = j_hi - 1; j >= j_lo; --j) {
-        const float scale = (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS) / (a.hard ? 1.0f : (float)J);
-        f32x4 dlat = splat4(0.f);
-        for (int t = Lw - 1; t >= 0; --t) {
-            const uint32_t dof = dd_lane + (uint32_t)(((int64_t)j * Lw + t) * DSD * 4);
-            // ---- part A: lane-local, consumes the step's record
-            mask_step(cur);
-            f32x4 dy[1];
-            for (int k = 0; k < 4; ++k) {
-                float v = 0.f;
-                if ((FULL || valid) && 4 * g + k < a.d) {
-                    const float er = cur.nx[k] - cur.y[k];
-                    v = -((er > 0.f) ? 1.0f : (er < 0.f ? -1.0f : 0.0f)) * cur.m * scale;
-                }
-                dy[0][k] = v;
-            }
-            if (a.penalty != 0.f) {
-                float d2 = 0.f;
-                f32x4 df;
-                for (int k = 0; k < 4; ++k) {
-                    df[k] = (4 * g + k < a.d) ? cur.xc[k] - cur.y[k] : 0.f;
-                    d2 = fmaf(df[k], df[k], d2);
-                }
-                const float nrm = sqrtf(group_sum(d2));
-                if ((FULL || valid) && nrm > a.thres)
-                    for (int k = 0; k < 4; ++k) dy[0][k] -= pen * df[k] / nrm;
-            }
-            if (Q == 0) st4<FULL>(dd_base, dof + 4u * DD_DY, valid, dy[0]);
-            const f32x4 da = dense_tile<1>(s_outT, 24, 16 * Q, dy, splat4(0.f));
-            const f32x4 km = keep_tile(a, net, j, c.row, t, Q, FULL || valid, c.rows);
-            f32x4 dht;
-            for (int k = 0; k < 4; ++k) {
-                const float th = tanh_f(hcur[k]);
-                dht[k] = fmaf(da[k] * km[k] * inv_keep, 1.0f - th * th, dhd[k]);
-            }
-            const GruGrads o = gru_gates_bwd(dht, cur.r, cur.z, cur.n, cur.hn, cur.hp);
-            st4<FULL>(dd_base, dof + 4u * (DD_DR + 16 * Q), valid, o.dr);
-            st4<FULL>(dd_base, dof + 4u * (DD_DZ + 16 * Q), valid, o.dz);
-            st4<FULL>(dd_base, dof + 4u * (DD_DNI + 16 * Q), valid, o.dni);
-            st4<FULL>(dd_base, dof + 4u * (DD_DNH + 16 * Q), valid, o.dnh);
-            xv_put(img_dr, Q, split_bf3h(o.dr));
-            xv_put(img_dz, Q, split_bf3h(o.dz));
-            xv_put(img_dni, Q, split_bf3h(o.dni));
-            xv_put(img_dnh, Q, split_bf3h(o.dnh));
-            const f32x4 u_own = cur.u;
-            hcur = cur.hp;
-            IPLAN_SCHED_FENCE();
-            {
-                const bool wrap = t == 0, more = j > j_lo;
-                load_step(wrap && more ? j - 1 : j, wrap ? (more ? Lw - 1 : 0) : t - 1, cur);
-            }
-            tile_sync();
-            // ---- part B: output tile Q of du = W_ih^T [dr dz dn_i] and dh_prev = W_hh^T [dr dz dn_h], K = 192 = 6 chunks;
-            // two accumulators per product (alternating piece products), so consecutive MFMAs on one accumulator are four
-            // instructions apart; one chunk's operands live at a time (register budget: 256 with W_hh^T's 72)
-            f32x4 du0 = splat4(0.f), du1 = splat4(0.f), pd0 = splat4(0.f), pd1 = splat4(0.f);
-#pragma unroll
-            for (int kc = 0; kc < 6; ++kc) {
-                const int gate = kc >> 1, cc = kc & 1;
-                const char* gi = gate == 0 ? img_dr : (gate == 1 ? img_dz : img_dni);
-                const Bf3 bi = xv_get(gi, cc);
-                Bf3 bh = bi;
-                if (gate == 2) bh = xv_get(img_dnh, cc);
-                Bf3 wa;
-                wa.p0 = afrag_bf3(s_wihT3, WTOT, DT, 0, kc, Q);
-                wa.p1 = afrag_bf3(s_wihT3, WTOT, DT, 1, kc, Q);
-                wa.p2 = afrag_bf3(s_wihT3, WTOT, DT, 2, kc, Q);
-                du0 = mfma_bf16(wa.p2, bi.p0, du0); pd0 = mfma_bf16(whhT[kc].p2, bh.p0, pd0);
-                du1 = mfma_bf16(wa.p0, bi.p2, du1); pd1 = mfma_bf16(whhT[kc].p0, bh.p2, pd1);
-                du0 = mfma_bf16(wa.p1, bi.p1, du0); pd0 = mfma_bf16(whhT[kc].p1, bh.p1, pd0);
-                du1 = mfma_bf16(wa.p1, bi.p0, du1); pd1 = mfma_bf16(whhT[kc].p1, bh.p0, pd1);
-                du0 = mfma_bf16(wa.p0, bi.p1, du0); pd0 = mfma_bf16(whhT[kc].p0, bh.p1, pd0);
-                du1 = mfma_bf16(wa.p0, bi.p0, du1); pd1 = mfma_bf16(whhT[kc].p0, bh.p0, pd1);
-            }
-            const f32x4 du = du0 + du1, pd = pd0 + pd1;
-            f32x4 dup[1];
-            for (int k = 0; k < 4; ++k) dup[0][k] = u_own[k] > 0.f ? du[k] : 0.f;
-            st4<FULL>(dd_base, dof + 4u * (DD_DU + 16 * Q), valid, dup[0]);
-            dhd = o.dh_direct + pd;
-            dlat = dense_tile_k<1>(s_latT, DLD, 0, 16 * Q, dup, dlat);
-            tile_sync();
-        }
-        // d(loss)/d(latent_j): sum of the four quarters' shares (through the head of the exchange area)
-        if (Q) *reinterpret_cast<f32x4*>(xch + (Q - 1) * 1024 + 16 * l) = dlat;
-        tile_sync();
-        if (Q == 0)
-            st4<FULL>(dl_base, dl_lane + (uint32_t)j * (uint32_t)(DSL * 4), valid,
-                      (dlat + *reinterpret_cast<const f32x4*>(xch + 16 * l)) +
-                          (*reinterpret_cast<const f32x4*>(xch + 1024 + 16 * l) + *reinterpret_cast<const f32x4*>(xch + 2048 + 16 * l)));
-        tile_sync();
-    }
-    if (j_lo > 0 && carry) *reinterpret_cast<f32x4*>(carry + 4 * l) = dhd;
-}
-
-constexpr size_t DEC_BWD_LDS_BF3 = (size_t)3 * 3 * DHd * DHd * 2 + sizeof(float) * (DHd * 24 + 16 * DLD + 16) + (size_t)DEC_TILES * BX_BYTES;
-
-__global__ __launch_bounds__(DEC_THREADS) void beh_dec_bwd_kernel(IplanBehArgs a) {
-    IPLAN_DYN_LDS(smem);
-    __bf16* s_wihT3 = reinterpret_cast<__bf16*>(smem);      // image of W_ih^T: [3 pieces][6 chunks][4 row tiles][64 lanes][8]   72 KiB
-    float* s_outT = smem + (3 * 3 * DHd * DHd) / 2;         // [64][24]    W_out^T (cols = d)
-    float* s_latT = s_outT + DHd * 24;                      // [16][DLD]   W_lin[:, d:d+Z]^T
-    int* s_tcnt = reinterpret_cast<int*>(s_latT + 16 * DLD);            // [DEC_TILES] rendezvous counters (+ pad to 16)
-    char* s_xch = reinterpret_cast<char*>(s_tcnt + 16);     // [DEC_TILES][BX_BYTES]
-    if (threadIdx.x < 16) s_tcnt[threadIdx.x] = 0;
-    const float* __restrict__ PD = a.dec_params + (int64_t)blockIdx.y * a.dec_s_net;
-    const int din = a.d + a.Z;
-    stage_bf3(s_wihT3, PD + a.dec_off[IPLAN_DEC_WIH], 3 * DHd, DHd, true);
-    stage_matrix_t(s_outT, 24, DHd, PD + a.dec_off[IPLAN_DEC_OUT_W], a.d, DHd);
-    {
-        const float* Wl = PD + a.dec_off[IPLAN_DEC_LIN_W];
-        for (int idx = (int)threadIdx.x; idx < 16 * DLD; idx += (int)blockDim.x) {
-            const int z = idx / DLD, m = idx - z * DLD;
-            s_latT[idx] = (z < a.Z && m < DHd) ? Wl[(int64_t)m * din + a.d + z] : 0.f;
-        }
-    }
-    __syncthreads();
-    const int w = uniform_i(wave_id()), q = w & 3, ts = w >> 2;
-    DecTile c;
-    dec_tile(a, c, (int)blockIdx.x * DEC_TILES + ts);
-    char* xch = s_xch + ts * BX_BYTES;
-#define IPLAN_DEC_BWD(F, QQ) dec_bwd_body_bf3<F, QQ>(a, c, s_wihT3, s_outT, s_latT, xch, s_tcnt + ts)
-    if (c.full) { if (q == 0) IPLAN_DEC_BWD(true, 0); else if (q == 1) IPLAN_DEC_BWD(true, 1); else if (q == 2) IPLAN_DEC_BWD(true, 2); else IPLAN_DEC_BWD(true, 3); }
-    else { if (q == 0) IPLAN_DEC_BWD(false, 0); else if (q == 1) IPLAN_DEC_BWD(false, 1); else if (q == 2) IPLAN_DEC_BWD(false, 2); else IPLAN_DEC_BWD(false, 3); }
-#undef IPLAN_DEC_BWD
-}
-#else
 __global__ __launch_bounds__(DEC_THREADS) void beh_dec_bwd_kernel(IplanBehArgs a) {
     IPLAN_DYN_LDS(smem);
     constexpr int TLD = 3 * DHd + 8;                        // 200: ld % 16 == 8 -> conflict-free ds_read_b128 fragments
@@ -1244,8 +759,6 @@ __global__ __launch_bounds__(DEC_THREADS) void beh_dec_bwd_kernel(IplanBehArgs a
     else { if (q == 0) IPLAN_DEC_BWD(false, 0); else if (q == 1) IPLAN_DEC_BWD(false, 1); else if (q == 2) IPLAN_DEC_BWD(false, 2); else IPLAN_DEC_BWD(false, 3); }
 #undef IPLAN_DEC_BWD
 }
-
-#endif  // IPLAN_DEC_BF3 (BPTT)
 
 // ------------------------------------------------------------------------------------------------------------
 // encoder BPTT with in-kernel weight gradients.  Per step the wave turns its 16-chain tiles of
@@ -1533,11 +1046,7 @@ extern "C" int iplan_beh_fwd(const IplanBehArgs* a, iplan_stream_t stream) {
     const int ph = a->win ? 2 : a->fwd_phase;
     if (ph == 0 || ph == 1) hipLaunchKernelGGL(beh_enc_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
     if (ph == 0 || ph == 2) {
-#if IPLAN_DEC_BF3
-        const size_t lds = DEC_FWD_LDS_BF3;
-#else
         const size_t lds = sizeof(float) * (2 * 3 * DHd * DLD + DHd * 24 + 16 * DLD + DEC_FWD_BIAS + DEC_TILES * XF_SLOTS * 256 + 16);
-#endif
 #ifndef IPLAN_HOST_EMULATION
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_dec_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
@@ -1560,11 +1069,7 @@ extern "C" int iplan_beh_bwd(const IplanBehArgs* a, iplan_stream_t stream) {
     const int tiles = (a->E * a->N + 15) / 16;
     const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets);
     const dim3 dgrid((unsigned)((tiles + DEC_TILES - 1) / DEC_TILES), (unsigned)a->n_nets);
-#if IPLAN_DEC_BF3
-    const size_t lds = DEC_BWD_LDS_BF3;
-#else
     const size_t lds = sizeof(float) * (2 * DHd * (3 * DHd + 8) + DHd * 24 + 16 * DLD + DEC_TILES * XB_SLOTS * 256 + 16);
-#endif
 #ifndef IPLAN_HOST_EMULATION
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_dec_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
