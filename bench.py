@@ -241,7 +241,9 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
     b_ac = nA * (4.0 * rows * F + 2 * 4.0 * rows * 648)                                  # features once + the saved activations
     out = [
         entry("gat_fwd_kernel", "gat_fwd_kernel", "mfma", gat_algorithmic_flops(nA, E, N, d + Z), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
-              f"rollout GAT_latent_update (5 nets x {E} envs x 55 entities), {rollouts_per_step * (T + 1)} launches per step"),
+              f"rollout GAT_latent_update (5 nets x {E} envs x 55 entities), {rollouts_per_step * (T + 1)} launches per step; fp32 results: "
+              "the 54-step bi-GRU recurrence (84 % of the algorithmic FLOPs) is issued as 6 bf16 piece products per fp32 product "
+              "on the bf16 matrix cores (fp32-exact split, DESIGN.md section 4), the rest as fp32 MFMA; peak = the fp32 MFMA / vector peak"),
         entry("beh_dec_bwd_kernel", "beh_dec_bwd_kernel", "mfma", f_dec / pieces("beh_dec_bwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
               f"decoder BPTT of Behavior_policy.learn (backward-data pass = 1x the forward FLOPs) in {pieces('beh_dec_bwd_kernel')} "
               "window-range launches per learn(), beside the weight-gradient contraction and the encoder BPTT of the previous range"),

@@ -28,20 +28,6 @@ constexpr int GH = IPLAN_GAT_HIDDEN;   // H == A == 32
 constexpr int NP = IPLAN_MAX_ENTITIES; // 64
 constexpr int BST = 100;               // padded row stride (floats) of the W_b h_j table
 constexpr int QST = 33;                // padded row stride of q/k/v/x tables
-#ifdef GAT_VAR          // A/B builds (scripts/build_variants.sh): hundreds = stagger in s_sleep units, tens = setprio, units = half order
-#define GAT_STAGGER (GAT_VAR / 100)
-#define GAT_PRIO ((GAT_VAR / 10) % 10)
-#define GAT_HALF (GAT_VAR % 10)
-#endif
-#ifndef GAT_STAGGER
-#define GAT_STAGGER 0
-#endif
-#ifndef GAT_PRIO
-#define GAT_PRIO 0
-#endif
-#ifndef GAT_HALF
-#define GAT_HALF 0
-#endif
 #ifndef IPLAN_GAT_BF3
 #define IPLAN_GAT_BF3 1                // recurrence on the bf16 matrix cores (fp32-exact split); 0 = fp32 MFMA (A/B builds)
 #endif
@@ -188,9 +174,6 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
             for (int t = 0; t < 6; ++t) bc[t] = *reinterpret_cast<const f32x4*>(Bj + 16 * t);
         }
         int s_prev = 0;
-#if GAT_STAGGER
-        if (dir) __builtin_amdgcn_s_sleep(GAT_STAGGER);
-#endif
         for (int it = 0; it < N - 1; ++it) {
             const int s = dir ? (N - 2 - it) : it;
             if (it + 1 < N - 1) {                                   // next step's W_b h_j rows: issued now, consumed next iteration
@@ -203,34 +186,16 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
             // 7 independent accumulator chains issued round-robin: consecutive MFMAs never depend on each other
 #if IPLAN_GAT_BF3
             {
+                // smallest piece products first (the accumulator is fp32).  MFMA time and VALU / transcendental time ADD on a
+                // SIMD -- across its two waves as well as inside one (ablations and a software-pipelined variant that issued
+                // tile 0's gates between tile 1's MFMAs: profiles/r02g_notes.md) -- so the plain order is kept.
                 const Bf3 hs = split_bf3(h0, h1);
-                // smallest piece products first (the accumulator is fp32)
-#if GAT_PRIO
-                __builtin_amdgcn_s_setprio(1);
-#endif
-#if GAT_HALF
-                // chains of hidden tile 0 (r0 z0 n0) first: their gate arithmetic can issue under the MFMAs of tile 1's chains
-#define GAT_BF3_ROUND(WP, HP) for (int c = 0; c < 6; c += 2) acc[c] = mfma_bf16(whh[c].WP, hs.HP, acc[c]);
-                GAT_BF3_ROUND(p2, p0) GAT_BF3_ROUND(p0, p2) GAT_BF3_ROUND(p1, p1)
-                GAT_BF3_ROUND(p1, p0) GAT_BF3_ROUND(p0, p1) GAT_BF3_ROUND(p0, p0)
-#undef GAT_BF3_ROUND
-#define GAT_BF3_ROUND(WP, HP)                                                      \
-    for (int c = 1; c < 6; c += 2) acc[c] = mfma_bf16(whh[c].WP, hs.HP, acc[c]);   \
-    acc[6] = mfma_bf16(wl.WP, hs.HP, acc[6]);
-                GAT_BF3_ROUND(p2, p0) GAT_BF3_ROUND(p0, p2) GAT_BF3_ROUND(p1, p1)
-                GAT_BF3_ROUND(p1, p0) GAT_BF3_ROUND(p0, p1) GAT_BF3_ROUND(p0, p0)
-#undef GAT_BF3_ROUND
-#else
 #define GAT_BF3_ROUND(WP, HP)                                                  \
     for (int c = 0; c < 6; ++c) acc[c] = mfma_bf16(whh[c].WP, hs.HP, acc[c]);  \
     acc[6] = mfma_bf16(wl.WP, hs.HP, acc[6]);
                 GAT_BF3_ROUND(p2, p0) GAT_BF3_ROUND(p0, p2) GAT_BF3_ROUND(p1, p1)
                 GAT_BF3_ROUND(p1, p0) GAT_BF3_ROUND(p0, p1) GAT_BF3_ROUND(p0, p0)
 #undef GAT_BF3_ROUND
-#endif
-#if GAT_PRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
             }
 #else
             for (int T = 0; T < 2; ++T) {
@@ -248,13 +213,6 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
             const f32x4 pr0 = acc[0] + bc[0], pr1 = acc[1] + bc[1], pz0 = acc[2] + bc[2], pz1 = acc[3] + bc[3];
             const f32x4 gn0 = areg[4] + bc[4], gn1 = areg[5] + bc[5];
             const GruGates o0 = gru_gates(pr0, pz0, gn0, acc[4], h0);
-#if GAT_HALF == 2
-            // 21 tile-1 MFMAs + 3 logit MFMAs against tile 0's ~130 gate instructions: one MFMA, then 5 VALU, 24 times
-            for (int i = 0; i < 24; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-            }
-#endif
             const GruGates o1 = gru_gates(pr1, pz1, gn1, acc[5], h1);
             h0 = o0.h;
             h1 = o1.h;
