@@ -14,8 +14,9 @@
 // all lane-local: no transposes, no LDS round trip between layers or between time steps.
 // The A fragment of a row-major weight matrix is 4 consecutive floats -> one 16-byte load.
 //
-// All arithmetic is fp32; v_mfma_f32_16x16x4_f32 is an exact fp32 fma chain (guide §3), which is
-// what the 1e-5 parity contract with the reference's fp32 CPU path needs.
+// All results are fp32: v_mfma_f32_16x16x4_f32 is an exact fp32 fma chain (guide §3), which is what the 1e-5 parity contract
+// with the reference's fp32 CPU path needs; contractions whose weights are loop invariants in registers may run in the
+// fp32-exact split-bf16 form on the bf16 matrix cores instead (split_bf3 / mfma_bf16 below).
 #pragma once
 #include <hip/hip_runtime.h>
 
