@@ -10,8 +10,8 @@
  *   - plain C, no C++/torch types; every pointer is a DEVICE pointer to contiguous fp32 unless
  *     stated; int64 strides are in ELEMENTS.
  *   - the caller owns all memory (PyTorch caching allocator in the shipped host code); the
- *     library allocates nothing, keeps no global mutable state, and enqueues every kernel on the
- *     stream handed in (no implicit synchronisation) -> thread-safe and stream-ordered.
+ *     library allocates nothing (one documented exception: iplan_p2p_alloc), keeps no global mutable state, and
+ *     enqueues every kernel on the stream handed in (no implicit synchronisation) -> thread-safe and stream-ordered.
  *   - return value: 0 on success, a negative IPLAN_E* code otherwise; iplan_last_error() returns
  *     a thread-local human-readable description of the last failure on the calling thread.
  *   - "nets": the reference keeps one private network set per learning agent and loops over
@@ -659,6 +659,43 @@ typedef struct {
 } IplanSeq2SeqArgs;
 
 int iplan_seq2seq_fwd(const IplanSeq2SeqArgs* args, iplan_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One-shot peer-to-peer sum all-reduce of a gradient arena over xGMI (the reference has no
+ * multi-GPU path -- this replaces the torch.distributed all-reduce behind parallel.DataParallel.all_reduce_grads when
+ * IPLAN_P2P_ALLREDUCE=1).  Arenas are 0.3-4 MB: a ring's 2 (n - 1) latency-bound steps cost more than every rank reading
+ * its peers' buffers directly.  Protocol, per collective `seq` (same on all ranks, +1 per call, >= 1):
+ *   publish: copy `data` into this rank's staging half (seq & 1), then store `seq` into flags[peer][rank] of EVERY rank
+ *            (system-scope release);
+ *   reduce : wait until flags[rank][p] >= seq for all p (system-scope acquire), then data[i] = sum over p = 0 .. world-1, in
+ *            that order on every rank (bit-identical replicas), of stage[p][half][i].
+ * Double-buffered staging needs no second barrier: a rank can only publish seq + 2 (the same half) after it finished
+ * seq + 1, which needed every peer's seq + 1, published only after that peer finished reading seq.
+ * The ONLY entry points that allocate: staging / flag buffers must be shareable between processes, so they come from
+ * hipMalloc directly (a caching allocator's sub-allocations cannot be exported); iplan_p2p_free releases them.
+ */
+#define IPLAN_P2P_MAX_RANKS 8
+typedef struct {
+    unsigned char bytes[64];                    /* hipIpcMemHandle_t */
+} IplanIpcHandle;
+int iplan_p2p_alloc(size_t bytes, void** dev_ptr);               /* zero-filled device memory of the current device */
+int iplan_p2p_free(void* dev_ptr);
+int iplan_p2p_export(void* dev_ptr, IplanIpcHandle* out);        /* hipIpcGetMemHandle */
+int iplan_p2p_open(const IplanIpcHandle* handle, void** dev_ptr); /* hipIpcOpenMemHandle (another process' allocation) */
+int iplan_p2p_close(void* dev_ptr);
+typedef struct {
+    int32_t world, rank;
+    int64_t count;                              /* floats to reduce, <= capacity, multiple of 4                         */
+    float* data;                                /* in / out, 16-byte aligned                                            */
+    float* stage[IPLAN_P2P_MAX_RANKS];          /* staging buffers of all ranks (own: local, peers: opened), 2 * capacity floats each */
+    uint32_t* flags[IPLAN_P2P_MAX_RANKS];       /* flag arrays of all ranks, IPLAN_P2P_MAX_RANKS words each              */
+    int64_t capacity;                           /* floats per staging half, multiple of 4                               */
+    uint32_t seq;
+    int32_t* error;                             /* device int, set to 1 when the wait gives up after spin_limit polls    */
+    int64_t spin_limit;                         /* 0 = wait for ever                                                     */
+} IplanP2pArgs;
+int iplan_p2p_publish(const IplanP2pArgs* args, iplan_stream_t stream);
+int iplan_p2p_reduce(const IplanP2pArgs* args, iplan_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -50,8 +50,10 @@ class IplanError(RuntimeError):
 # every entry point include/iplan_hip.h declares
 ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step", "iplan_wgrad",
                 "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_adv_norm", "iplan_ppo_loss", "iplan_gat_bwd",
-                "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd", "iplan_mlp3_fwd", "iplan_mlp3_bwd", "iplan_seq2seq_fwd", "iplan_ac_pack_fc1"]
-RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups", "iplan_sizeof", "iplan_ac_packed_floats"]      # non (args*, stream) signatures
+                "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd", "iplan_mlp3_fwd", "iplan_mlp3_bwd", "iplan_seq2seq_fwd", "iplan_ac_pack_fc1",
+                "iplan_p2p_publish", "iplan_p2p_reduce"]
+RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups", "iplan_sizeof", "iplan_ac_packed_floats",
+                    "iplan_p2p_alloc", "iplan_p2p_free", "iplan_p2p_export", "iplan_p2p_open", "iplan_p2p_close"]      # non (args*, stream) signatures
 
 
 class Lib:
@@ -77,6 +79,11 @@ class Lib:
         cdll.iplan_ac_packed_floats.argtypes = [C.c_void_p]
         cdll.iplan_wgrad_workspace_floats.restype = C.c_size_t
         cdll.iplan_wgrad_workspace_floats.argtypes = [C.c_void_p]
+        cdll.iplan_p2p_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+        cdll.iplan_p2p_free.argtypes = [C.c_void_p]
+        cdll.iplan_p2p_export.argtypes = [C.c_void_p, C.POINTER(IpcHandle)]
+        cdll.iplan_p2p_open.argtypes = [C.POINTER(IpcHandle), C.POINTER(C.c_void_p)]
+        cdll.iplan_p2p_close.argtypes = [C.c_void_p]
 
     def call(self, name, args, stream=None):
         rc = getattr(self.c, name)(C.byref(args), C.c_void_p(stream or 0))
@@ -188,6 +195,19 @@ class AcFwdArgs(C.Structure):
 class AcPackArgs(C.Structure):
     _fields_ = [("n_nets", i32), ("feat", AcFeatures), ("params", fp), ("params_s_net", i64), ("off_w1", i64), ("off_fn_w", i64),
                 ("off_fn_b", i64), ("packed", fp), ("packed_s_net", i64), ("parts", i32)]
+
+
+# ---- one-shot peer-to-peer all-reduce -----------------------------------------------------------------
+P2P_MAX_RANKS = 8
+
+
+class IpcHandle(C.Structure):
+    _fields_ = [("bytes", C.c_ubyte * 64)]
+
+
+class P2pArgs(C.Structure):
+    _fields_ = [("world", i32), ("rank", i32), ("count", i64), ("data", fp), ("stage", fp * P2P_MAX_RANKS), ("flags", fp * P2P_MAX_RANKS),
+                ("capacity", i64), ("seq", C.c_uint32), ("error", fp), ("spin_limit", i64)]
 
 
 # ---- optimiser -------------------------------------------------------------------------------------
@@ -340,4 +360,5 @@ STRUCT_MIRRORS = {"IplanGatSaved": GatSaved, "IplanGatFwdArgs": GatFwdArgs, "Ipl
                   "IplanEncFwdArgs": EncFwdArgs, "IplanAcNet": AcNet, "IplanAcFeatures": AcFeatures, "IplanAcFwdArgs": AcFwdArgs,
                   "IplanAcBwdArgs": AcBwdArgs, "IplanAdamArgs": AdamArgs, "IplanWgradProblem": WgradProblem,
                   "IplanWgradArgs": WgradArgs, "IplanPpoPrepareArgs": PpoPrepareArgs, "IplanPpoLossArgs": PpoLossArgs,
-                  "IplanPdecArgs": PdecArgs, "IplanBehArgs": BehArgs, "IplanMlp3Args": Mlp3Args, "IplanAdvNormArgs": AdvNormArgs, "IplanSeq2SeqArgs": Seq2SeqArgs, "IplanAcPackArgs": AcPackArgs}
+                  "IplanPdecArgs": PdecArgs, "IplanBehArgs": BehArgs, "IplanMlp3Args": Mlp3Args, "IplanAdvNormArgs": AdvNormArgs, "IplanSeq2SeqArgs": Seq2SeqArgs, "IplanAcPackArgs": AcPackArgs,
+                  "IplanIpcHandle": IpcHandle, "IplanP2pArgs": P2pArgs}

@@ -16,7 +16,105 @@ the PPO rows; advantage mean and std), so before its backward pass each learner 
 (``all_reduce_sum``) and scales its local loss by the GLOBAL denominators; the gradient arenas are then SUMMED, clipped
 and applied identically on every rank, which keeps the replicas bit-identical without parameter broadcasts.
 """
+import ctypes as C
+import os
+
+import torch
 import torch.distributed as dist
+
+
+class P2PAllReduce:
+    """One-shot peer-to-peer sum all-reduce over xGMI (include/iplan_hip.h, ``IplanP2pArgs``; opt-in: IPLAN_P2P_ALLREDUCE=1).
+
+    Every rank owns a double-buffered staging area and a flag array that its peers map through HIP IPC handles (exchanged
+    once through ``exchange``, normally ``dist.all_gather_object``).  ``all_reduce(tensor)`` = publish (copy into the staging
+    half, one flag store into every rank's flag array) + reduce (wait for all flags, sum all staging halves in rank order,
+    in place): two launches on the tensor's current stream, no host synchronisation, replicas bit-identical.  Tensors
+    larger than the staging capacity go through in slices.  ``exchange(obj) -> [obj of rank 0, ...]``."""
+
+    def __init__(self, world, rank, device, capacity_floats, exchange, lib=None, spin_limit=0):
+        from . import _lib as L
+        assert 1 <= world <= L.P2P_MAX_RANKS and capacity_floats % 4 == 0
+        self.L, self.lib = L, (lib or L.get_lib())
+        self.world, self.rank, self.device, self.capacity = world, rank, torch.device(device), int(capacity_floats)
+        self.spin_limit, self.seq = int(spin_limit), 0
+        self._own, self._opened = [], []
+        with self._dev():
+            self._stage, self._flags = self._alloc(2 * self.capacity * 4), self._alloc(L.P2P_MAX_RANKS * 4)
+        self.handles = (bytes(self._export(self._stage).bytes), bytes(self._export(self._flags).bytes))
+        self.error = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.stage = self.flags = None
+        if exchange is not None:
+            self.connect(exchange(self.handles))
+
+    def connect(self, handles):
+        """``handles[p]`` = rank p's ``.handles``: map every peer's staging area and flag array"""
+        self.stage, self.flags = [None] * self.world, [None] * self.world
+        with self._dev():
+            for p, (hs, hf) in enumerate(handles):
+                self.stage[p], self.flags[p] = (self._stage, self._flags) if p == self.rank else (self._open(hs), self._open(hf))
+
+    def _dev(self):
+        import contextlib
+        return torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise self.L.IplanError(f"{what} failed ({rc}): {self.lib.c.iplan_last_error().decode()}")
+
+    def _alloc(self, nbytes):
+        p = C.c_void_p()
+        self._check(self.lib.c.iplan_p2p_alloc(nbytes, C.byref(p)), "iplan_p2p_alloc")
+        self._own.append(p.value)
+        return p.value
+
+    def _export(self, ptr):
+        h = self.L.IpcHandle()
+        self._check(self.lib.c.iplan_p2p_export(ptr, C.byref(h)), "iplan_p2p_export")
+        return h
+
+    def _open(self, raw):
+        h = self.L.IpcHandle()
+        C.memmove(h.bytes, raw, 64)
+        p = C.c_void_p()
+        self._check(self.lib.c.iplan_p2p_open(C.byref(h), C.byref(p)), "iplan_p2p_open")
+        self._opened.append(p.value)
+        return p.value
+
+    def _args(self, ptr, count):
+        a = self.L.P2pArgs()
+        a.world, a.rank, a.count, a.data, a.capacity = self.world, self.rank, count, ptr, self.capacity
+        for p in range(self.world):
+            a.stage[p], a.flags[p] = self.stage[p], self.flags[p]
+        a.seq, a.error, a.spin_limit = self.seq, self.error.data_ptr(), self.spin_limit
+        return a
+
+    def publish(self, tensor):
+        """first half of ``all_reduce`` for one slice (<= capacity floats): returns the argument block for ``reduce``"""
+        assert tensor.dtype == torch.float32 and tensor.is_contiguous() and tensor.numel() <= self.capacity
+        n = tensor.numel()
+        assert n % 4 == 0, "pad gradient arenas to a multiple of 4 floats"
+        self.seq += 1
+        a = self._args(tensor.data_ptr(), n)
+        self.lib.call("iplan_p2p_publish", a, self.L.current_stream(tensor.device))
+        return a
+
+    def reduce(self, a, device):
+        self.lib.call("iplan_p2p_reduce", a, self.L.current_stream(device))
+
+    def all_reduce(self, tensor):
+        flat = tensor.view(-1)
+        for lo in range(0, flat.numel(), self.capacity):
+            part = flat[lo:lo + self.capacity]
+            self.reduce(self.publish(part), part.device)
+        return tensor
+
+    def close(self):
+        for p in self._opened:
+            self.lib.c.iplan_p2p_close(p)
+        for p in self._own:
+            self.lib.c.iplan_p2p_free(p)
+        self._opened, self._own = [], []
 
 
 class DataParallel:
@@ -25,6 +123,7 @@ class DataParallel:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.backend = dist.get_backend(group)
+        self.p2p = None                                      # P2PAllReduce, built on first use when IPLAN_P2P_ALLREDUCE=1
 
     def broadcast_arena(self, arena, src=0):
         dist.broadcast(arena.data, src=src, group=self.group)
@@ -53,6 +152,21 @@ class DataParallel:
     def all_reduce_grads(self, *arenas):
         """Sum the gradient arenas over the ranks (the local losses are already scaled by the global normalisers): one
         collective per arena, in place."""
+        if os.environ.get("IPLAN_P2P_ALLREDUCE") and self.world > 1 and arenas and arenas[0].grad.is_cuda:
+            if self.p2p is None:
+                def exchange(obj):
+                    out = [None] * self.world
+                    dist.all_gather_object(out, obj, group=self.group)
+                    return out
+                cap = int(os.environ.get("IPLAN_P2P_CAPACITY_FLOATS", str(2 << 20)))       # 8 MB halves: the largest arena is 4 MB
+                self.p2p = P2PAllReduce(self.world, self.rank, arenas[0].grad.device, cap, exchange,
+                                        spin_limit=int(os.environ.get("IPLAN_P2P_SPIN_LIMIT", "0")))
+            for a in arenas:
+                if a.grad.numel() % 4 == 0 and a.grad.data_ptr() % 16 == 0:
+                    self.p2p.all_reduce(a.grad)
+                else:
+                    dist.all_reduce(a.grad, op=dist.ReduceOp.SUM, group=self.group)
+            return
         works = [dist.all_reduce(a.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for a in arenas]
         for w in works:
             w.wait()
