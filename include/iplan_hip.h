@@ -401,6 +401,7 @@ typedef struct {
     float* value_preds;          /* [n_agents, bs, T] = values[:, :, :T]                             */
     int32_t skip_norm;           /* 1 = leave adv un-normalised (data-parallel callers normalise with the
                                     mean / std over ALL ranks' rows between this call and iplan_ppo_loss)      */
+    int32_t no_gae;              /* 1 = use_gae False (:360-362): ret_T = V_T, ret_t = ret_{t+1} gamma mask_{t+1} + r_t */
 } IplanPpoPrepareArgs;
 
 int iplan_ppo_prepare(const IplanPpoPrepareArgs* args, iplan_stream_t stream);
@@ -443,7 +444,13 @@ typedef struct {
     float* stats;                /* [n_agents, 8]                                                    */
     const float* mask_sum;       /* optional [n_agents]: sum(mask) over the rows of ALL data-parallel ranks -- the
                                     losses' denominator (NULL = this launch's own rows)                        */
+    int32_t flags;               /* IPLAN_PPO_* bits below; 0 = config/algs/ippo.yaml as shipped                 */
+    float row_count;             /* rows of ALL data-parallel ranks, the denominator of the *_MEAN forms (0 = rows) */
 } IplanPpoLossArgs;
+#define IPLAN_PPO_MSE 1          /* use_huber_loss False: e^2 / 2 (:145-147)                                     */
+#define IPLAN_PPO_NO_VCLIP 2     /* use_clipped_value_loss False: the unclipped value loss alone (:149-152)      */
+#define IPLAN_PPO_VALUE_MEAN 4   /* use_value_active_masks False: plain mean over the rows (:154-157)            */
+#define IPLAN_PPO_POLICY_MEAN 8  /* use_policy_active_masks False: plain mean over the rows (:190-196)           */
 
 int iplan_ppo_loss(const IplanPpoLossArgs* args, iplan_stream_t stream);
 

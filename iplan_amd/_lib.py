@@ -268,7 +268,7 @@ class PpoPrepareArgs(C.Structure):
         ("reward", fp), ("rw_s_net", i64), ("rw_s_ep", i64), ("rw_s_t", i64),
         ("terminated", fp), ("tm_s_net", i64), ("tm_s_ep", i64), ("tm_s_t", i64),
         ("values", fp), ("gamma", C.c_float), ("lam", C.c_float),
-        ("returns", fp), ("adv", fp), ("mask", fp), ("value_preds", fp), ("skip_norm", i32),
+        ("returns", fp), ("adv", fp), ("mask", fp), ("value_preds", fp), ("skip_norm", i32), ("no_gae", i32),
     ]
 
 
@@ -283,8 +283,11 @@ class PpoLossArgs(C.Structure):
         ("logp", fp), ("entropy", fp), ("values", fp), ("old_logp", fp), ("adv", fp),
         ("value_preds", fp), ("returns", fp), ("mask", fp),
         ("clip", C.c_float), ("huber_delta", C.c_float), ("value_loss_coef", C.c_float),
-        ("g_logp", fp), ("g_values", fp), ("stats", fp), ("mask_sum", fp),
+        ("g_logp", fp), ("g_values", fp), ("stats", fp), ("mask_sum", fp), ("flags", i32), ("row_count", C.c_float),
     ]
+
+
+PPO_MSE, PPO_NO_VCLIP, PPO_VALUE_MEAN, PPO_POLICY_MEAN = 1, 2, 4, 8
 
 
 # ---- GAT backward --------------------------------------------------------------------------------------

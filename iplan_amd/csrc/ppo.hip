@@ -30,13 +30,14 @@ __global__ __launch_bounds__(1024) void ppo_prepare_kernel(IplanPpoPrepareArgs a
     for (int b = (int)threadIdx.x; b < bs; b += (int)blockDim.x) {
         const float* rw = a.reward + (int64_t)net * a.rw_s_net + (int64_t)b * a.rw_s_ep;
         const uint8_t* tm = a.terminated + (int64_t)net * a.tm_s_net + (int64_t)b * a.tm_s_ep;
-        float gae = 0.f;
+        float gae = 0.f, disc = val[(int64_t)b * T1 + T];     // (no_gae: bootstrapped discounted return, :360-362)
         for (int t = T - 1; t >= 0; --t) {
             const float m1 = 1.0f - (float)tm[(int64_t)(t + 1) * a.tm_s_t];
             const float v0 = val[(int64_t)b * T1 + t], v1 = val[(int64_t)b * T1 + t + 1];
             const float delta = rw[(int64_t)t * a.rw_s_t] + a.gamma * v1 * m1 - v0;
             gae = delta + a.gamma * a.lam * m1 * gae;
-            const float r = gae + v0;
+            disc = disc * a.gamma * m1 + rw[(int64_t)t * a.rw_s_t];
+            const float r = a.no_gae ? disc : gae + v0;
             const float m0 = 1.0f - (float)tm[(int64_t)t * a.tm_s_t];
             ret[(int64_t)b * T + t] = r;
             msk[(int64_t)b * T + t] = m0;
@@ -105,6 +106,9 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(IplanPpoLossArgs a) {
     for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) sm += a.mask[o + i];
     const float msum_own = block_sum_1024(sm, s_part);
     const float msum = a.mask_sum ? a.mask_sum[net] : msum_own;
+    const float nrow = a.row_count > 0.f ? a.row_count : (float)n;
+    const bool mse = a.flags & IPLAN_PPO_MSE, no_vclip = a.flags & IPLAN_PPO_NO_VCLIP;
+    const bool v_mean = a.flags & IPLAN_PPO_VALUE_MEAN, p_mean = a.flags & IPLAN_PPO_POLICY_MEAN;
     float pol = 0.f, vls = 0.f, rat = 0.f, en = 0.f;
     for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
         const float m = a.mask[o + i], ad = a.adv[o + i];
@@ -112,25 +116,26 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(IplanPpoLossArgs a) {
         const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
         const float rc = fminf(fmaxf(ratio, lo), hi);
         const float s1 = ratio * ad, s2 = rc * ad;
-        pol -= fminf(s1, s2) * m;
+        const float wp = p_mean ? 1.0f / nrow : m / msum, wv = v_mean ? 1.0f / nrow : m / msum;   // row weights of the two losses
+        pol -= fminf(s1, s2) * wp;
         const bool inside = ratio >= lo && ratio <= hi;
         // th.min ties split evenly; inside the clip range both branches carry d/dratio = adv
         float dr = 0.f;
         if (s1 < s2) dr = ad;
         else if (s1 == s2) dr = inside ? ad : 0.5f * ad;
-        g_lp[i] = -(m / msum) * dr * ratio;
+        g_lp[i] = -wp * dr * ratio;
         rat += ratio;
         en += ent[i];
         const float v = val[i], vp = a.value_preds[o + i], rt = a.returns[o + i];
         const float dv = v - vp;
         const float vc = vp + fminf(fmaxf(dv, -a.clip), a.clip);
         const float e1 = rt - v, e2 = rt - vc;
-        const float h1 = huber_q(e1, a.huber_delta), h2 = huber_q(e2, a.huber_delta);
-        vls += fmaxf(h1, h2) * m;
-        const float d1 = -huber_dq(e1, a.huber_delta);
-        const float d2 = (dv >= -a.clip && dv <= a.clip) ? -huber_dq(e2, a.huber_delta) : 0.f;
-        const float dvl = h1 > h2 ? d1 : (h2 > h1 ? d2 : 0.5f * (d1 + d2));
-        g_v[i] = a.value_loss_coef * (m / msum) * dvl;
+        const float h1 = mse ? 0.5f * e1 * e1 : huber_q(e1, a.huber_delta), h2 = mse ? 0.5f * e2 * e2 : huber_q(e2, a.huber_delta);
+        const float d1 = -(mse ? e1 : huber_dq(e1, a.huber_delta));
+        const float d2 = (dv >= -a.clip && dv <= a.clip) ? -(mse ? e2 : huber_dq(e2, a.huber_delta)) : 0.f;
+        vls += (no_vclip ? h1 : fmaxf(h1, h2)) * wv;
+        const float dvl = (no_vclip || h1 > h2) ? d1 : (h2 > h1 ? d2 : 0.5f * (d1 + d2));
+        g_v[i] = a.value_loss_coef * wv * dvl;
     }
     pol = block_sum_1024(pol, s_part);
     vls = block_sum_1024(vls, s_part);
@@ -138,8 +143,8 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(IplanPpoLossArgs a) {
     en = block_sum_1024(en, s_part);
     if (threadIdx.x == 0) {
         float* st = a.stats + (int64_t)net * 8;
-        st[0] = pol / msum;            // policy_loss
-        st[1] = vls / msum;            // value_loss
+        st[0] = pol;                   // policy_loss (row weights applied above)
+        st[1] = vls;                   // value_loss
         st[2] = rat / (float)n;        // imp_weights.mean()
         st[3] = en / (float)n;         // dist_entropy (unmasked mean, act.py:164)
         st[4] = msum;

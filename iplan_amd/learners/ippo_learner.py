@@ -140,10 +140,12 @@ class IPPOLearner:
         self._use_gae = args.use_gae
         self.gae_lambda = args.gae_lambda
         self._use_max_grad_norm = args.use_max_grad_norm
-        if (not args.use_gae or not args.use_huber_loss or not args.use_clipped_value_loss
-                or not args.use_value_active_masks or not args.use_policy_active_masks):
-            raise NotImplementedError("iplan_amd implements the reference's shipped PPO loss configuration "
-                                      "(config/algs/ippo.yaml: GAE, clipped Huber value loss, active masks)")
+        # the PPO loss switches of config/algs/ippo.yaml (learners/ippo_learner.py:142-157,190-196,353-362) as kernel flags
+        self._use_clipped_value_loss, self._use_huber_loss = args.use_clipped_value_loss, args.use_huber_loss
+        self._use_value_active_masks, self._use_policy_active_masks = args.use_value_active_masks, args.use_policy_active_masks
+        self._loss_flags = ((0 if args.use_huber_loss else L.PPO_MSE) | (0 if args.use_clipped_value_loss else L.PPO_NO_VCLIP)
+                            | (0 if args.use_value_active_masks else L.PPO_VALUE_MEAN)
+                            | (0 if args.use_policy_active_masks else L.PPO_POLICY_MEAN))
 
         self.actor_params = mac.parameters()
         self.critic_params = mac.critic_parameters()
@@ -237,6 +239,7 @@ class IPPOLearner:
         lib = L.get_lib()
         stream = L.current_stream(dev)
         pp.skip_norm = 0 if self.dp is None else 1
+        pp.no_gae = 0 if self._use_gae else 1
         lib.call("iplan_ppo_prepare", pp, stream)
         if self.dp is not None:
             # data-parallel: advantage mean / unbiased std over ALL ranks' rows -- three launches of iplan_ppo_adv_norm
@@ -276,6 +279,7 @@ class IPPOLearner:
         stats = th.zeros(self.ppo_epoch, nA, 8, **f32)
         norms = th.zeros(self.ppo_epoch, 2, nA, **f32)
         pl.g_logp, pl.g_values = g_logp.data_ptr(), g_v.data_ptr()
+        pl.flags = self._loss_flags
         max_norm = self.max_grad_norm if self._use_max_grad_norm else None
         n_rows = float(rows)
         if self.dp is not None:
@@ -283,6 +287,7 @@ class IPPOLearner:
             msum = self.dp.all_reduce_sum(mask[:, :rows].sum(dim=1).contiguous())
             pl.mask_sum = msum.data_ptr()
             n_rows = float(self.dp_global_rows if self.dp_global_rows is not None else rows * self.dp.world)
+            pl.row_count = n_rows                               # denominator of the unmasked (mean) loss forms
         for ep in range(self.ppo_epoch):
             out = ops.ac_forward(mac.actor_arena, mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True,
                                  packed=mac.fc1_pack.get(spec), **fwd_kw)         # repacked after every Adam step
@@ -366,6 +371,7 @@ class IPPOLearner:
                 pl.clip, pl.huber_delta, pl.value_loss_coef = self.clip_param, self.huber_delta, self.value_loss_coef
                 g_logp, g_v = th.empty(nA, mbs, **f32), th.empty(nA, mbs, **f32)
                 pl.g_logp, pl.g_values = g_logp.data_ptr(), g_v.data_ptr()
+                pl.flags = self._loss_flags
                 pl.logp, pl.entropy, pl.values = out["logp"].data_ptr(), out["entropy"].data_ptr(), out["values"].data_ptr()
                 k = ep * nmb + i
                 pl.stats = stats[k].data_ptr()
@@ -407,6 +413,7 @@ class IPPOLearner:
         pp.values, pp.gamma, pp.lam = v_all.data_ptr(), self.gamma, self.gae_lambda
         outs = [th.empty(1, bs * T, **self.tpdv) for _ in range(4)]
         pp.returns, pp.adv, pp.mask, pp.value_preds = (o.data_ptr() for o in outs)
+        pp.no_gae = 0 if self._use_gae else 1
         L.get_lib().call("iplan_ppo_prepare", pp, L.current_stream(self.device))
         return outs[0].reshape(bs, T, 1)
 
@@ -421,6 +428,7 @@ class IPPOLearner:
         pl.clip, pl.huber_delta, pl.value_loss_coef = self.clip_param, self.huber_delta, 1.0
         g_lp, g_v, stats = th.empty(1, R, **self.tpdv), th.empty(1, R, **self.tpdv), th.zeros(1, 8, **self.tpdv)
         pl.g_logp, pl.g_values, pl.stats = g_lp.data_ptr(), g_v.data_ptr(), stats.data_ptr()
+        pl.flags = self._loss_flags
         L.get_lib().call("iplan_ppo_loss", pl, L.current_stream(self.device))
         return stats[0], g_lp[0], g_v[0]
 

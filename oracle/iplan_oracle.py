@@ -350,10 +350,17 @@ def build_inputs_train(agent_id, history, att, beh_lat, actions_onehot, n_agents
 # ----------------------------------------------------------------------------------------------
 # a16-a18 PPO pieces (learners/ippo_learner.py, utils/mappo_utils/util.py)
 # ----------------------------------------------------------------------------------------------
-def gae_returns(rewards, values_all, masks_all, gamma, lam):
+def gae_returns(rewards, values_all, masks_all, gamma, lam, use_gae=True):
     """compute_returns (ippo_learner.py:344-365).  rewards [bs,T,1], values_all [bs,T+1,1],
-    masks_all [bs,T+1,1] (= 1 - terminated) -> returns [bs,T,1]."""
+    masks_all [bs,T+1,1] (= 1 - terminated) -> returns [bs,T,1].  use_gae False (:360-362): discounted returns bootstrapped
+    from the last value."""
     T = rewards.shape[1]
+    if not use_gae:
+        out, nxt = [None] * T, values_all[:, T]
+        for t in reversed(range(T)):
+            nxt = nxt * gamma * masks_all[:, t + 1] + rewards[:, t]
+            out[t] = nxt
+        return torch.stack(out, dim=1)
     gae = torch.zeros_like(rewards[:, 0])
     out = [None] * T
     for t in reversed(range(T)):
@@ -379,16 +386,21 @@ def huber_loss(e, d):
 
 
 def ppo_losses(logp, ent, values, old_logp, adv, value_preds, returns, masks,
-               clip=0.2, huber_delta=10.0, ent_coef=0.01, vcoef=0.5):
+               clip=0.2, huber_delta=10.0, ent_coef=0.01, vcoef=0.5,
+               use_huber_loss=True, use_clipped_value_loss=True, use_value_active_masks=True, use_policy_active_masks=True):
     """ippo_learner.py:185-197 (policy) and :128-159 (value).  All [R,1].
     -> (actor_objective, policy_loss, critic_objective, value_loss, ratio)."""
     ratio = torch.exp(logp - old_logp)
     s1 = ratio * adv
     s2 = torch.clamp(ratio, 1.0 - clip, 1.0 + clip) * adv
-    pol = (-torch.min(s1, s2).sum(-1, keepdim=True) * masks).sum() / masks.sum()
+    surr = -torch.min(s1, s2).sum(-1, keepdim=True)
+    pol = (surr * masks).sum() / masks.sum() if use_policy_active_masks else surr.mean()
     vclip = value_preds + (values - value_preds).clamp(-clip, clip)
-    vl = torch.max(huber_loss(returns - values, huber_delta), huber_loss(returns - vclip, huber_delta))
-    vloss = (vl * masks).sum() / masks.sum()
+    loss = (lambda e: huber_loss(e, huber_delta)) if use_huber_loss else (lambda e: e ** 2 / 2)      # envs/util.py:28-29
+    vl = loss(returns - values)
+    if use_clipped_value_loss:
+        vl = torch.max(vl, loss(returns - vclip))
+    vloss = (vl * masks).sum() / masks.sum() if use_value_active_masks else vl.mean()
     return pol - ent * ent_coef, pol, vloss * vcoef, vloss, ratio
 
 
@@ -501,7 +513,7 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
     with torch.no_grad():
         v_all, _ = critic_value(critic_p, x_all.reshape(-1, F_), f["rnn_states_critics"][:, :, i].reshape(-1, M))
         v_all = v_all.reshape(E, T + 1, 1)
-        rets = gae_returns(f["reward"][:, :-1, i].to(dt), v_all, masks_all, args.gamma, args.gae_lambda)
+        rets = gae_returns(f["reward"][:, :-1, i].to(dt), v_all, masks_all, args.gamma, args.gae_lambda, getattr(args, "use_gae", True))
         adv = normalise_advantages(rets, v_all[:, :-1], masks_all[:, :-1])
         x = x_all[:, :-1].reshape(-1, F_)
         ha = f["rnn_states_actors"][:, :-1, i].reshape(-1, M)
@@ -524,7 +536,8 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
             a_obj, pol, c_obj, vl, ratio = ppo_losses(
                 logp, ent, val, old_logp[sl], adv.reshape(-1, 1)[sl], v_all[:, :-1].reshape(-1, 1)[sl],
                 rets.reshape(-1, 1)[sl], masks_all[:, :-1].reshape(-1, 1)[sl],
-                args.clip_param, args.huber_delta, args.entropy_coef, args.value_loss_coef)
+                args.clip_param, args.huber_delta, args.entropy_coef, args.value_loss_coef,
+                **{k: getattr(args, k, True) for k in ("use_huber_loss", "use_clipped_value_loss", "use_value_active_masks", "use_policy_active_masks")})
             a_obj.backward()
             c_obj.backward()
             norms = []

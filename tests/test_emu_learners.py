@@ -391,3 +391,14 @@ def test_ppo_minibatches_vs_oracle_emulated():
     reference draws them, post-train parameters and last-step gradients vs the oracle"""
     from tests.oracle_checks import check_ppo_train_vs_oracle
     check_ppo_train_vs_oracle(_small(num_mini_batch=3, ppo_epoch=2, episode_limit=10, batch_size=3), "cpu", seed=31)
+
+
+@pytest.mark.parametrize("flags", [
+    dict(use_huber_loss=False), dict(use_clipped_value_loss=False), dict(use_value_active_masks=False),
+    dict(use_policy_active_masks=False), dict(use_gae=False),
+    dict(use_huber_loss=False, use_clipped_value_loss=False, use_value_active_masks=False, use_policy_active_masks=False, use_gae=False)])
+def test_ppo_loss_switches_vs_oracle_emulated(flags):
+    """the PPO loss switches of config/algs/ippo.yaml away from their shipped values (learners/ippo_learner.py:142-157,
+    190-196, 353-362): MSE instead of Huber, no value clipping, plain means instead of active masks, no GAE"""
+    from tests.oracle_checks import check_ppo_train_vs_oracle
+    check_ppo_train_vs_oracle(_small(ppo_epoch=2, **flags), "cpu", seed=41)

@@ -120,3 +120,12 @@ def test_deferred_decoder_update_gpu():
     b = _args(max_vehicle_num=9, n_agents=2, episode_limit=20, batch_size_run=4)
     _log("behavior_learn_deferred_decoder", check_behavior_learn_vs_oracle(b, 4, "cuda", seed=43, learn_kwargs=dict(defer_decoder=True)))
     check_deferred_equals_inline(b, 4, "cuda")
+
+
+def test_ppo_loss_switches_vs_oracle():
+    """the PPO loss switches off their shipped values (MSE, no value clipping, plain means, no GAE) on the real kernels"""
+    from tests.oracle_checks import check_ppo_train_vs_oracle
+    from tests.test_emu_learners import _small
+    a = _small(ppo_epoch=2, use_huber_loss=False, use_clipped_value_loss=False, use_value_active_masks=False,
+               use_policy_active_masks=False, use_gae=False)
+    _log("ppo_loss_switches_all_off", check_ppo_train_vs_oracle(a, "cuda", seed=41))

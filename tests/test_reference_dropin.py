@@ -238,3 +238,36 @@ def test_device_resident_runner_all_terminated_break(emu):
     assert runner.t == 2 and float(batch["filled"].sum()) == 3 * args.batch_size_run
     assert batch["actions_onehot"][:, 3:].abs().sum() == 0 and batch["actions"][:, 3:].abs().sum() == 0
     assert torch.isfinite(batch["attention_latent"]).all() and batch["behavior_latent"][:, 2].abs().sum() > 0
+
+
+def test_oracle_ppo_loss_switches_match_the_reference(ref_path):
+    """oracle.ppo_losses / gae_returns with the loss switches off their shipped values == the reference's own
+    cal_value_loss / compute_returns (learners/ippo_learner.py:128-159, 344-365) on the same inputs"""
+    import itertools
+    from types import SimpleNamespace
+    import torch
+    from learners.ippo_learner import IPPOLearner as RefLearner            # the real reference (sys.path set up above)
+    from oracle import iplan_oracle as O
+    g = torch.Generator().manual_seed(5)
+    R = 257
+    values, vpred, rets = (torch.randn(R, 1, generator=g) * 3 for _ in range(3))
+    rets = rets * 8                                                        # beyond huber_delta on some rows
+    masks = (torch.rand(R, 1, generator=g) > 0.2).float()
+    zero = torch.zeros(R, 1)
+    for hub, clipv, act in itertools.product((True, False), repeat=3):
+        ref_self = SimpleNamespace(clip_param=0.2, huber_delta=10.0, _use_huber_loss=hub, _use_clipped_value_loss=clipv,
+                                   _use_value_active_masks=act)
+        want = RefLearner.cal_value_loss(ref_self, values, vpred, rets, masks)
+        got = O.ppo_losses(zero, zero.mean(), values, zero, zero, vpred, rets, masks, 0.2, 10.0, 0.01, 0.5,
+                           use_huber_loss=hub, use_clipped_value_loss=clipv, use_value_active_masks=act)[3]
+        assert torch.allclose(got, want, rtol=1e-6, atol=1e-7), (hub, clipv, act, float(got), float(want))
+    bs, T = 7, 11
+    rewards = torch.randn(bs, T, 1, generator=g)
+    v_all = torch.randn(bs, T + 1, generator=g)
+    terminated = (torch.rand(bs, T + 1, 1, generator=g) > 0.15).float()   # the reference's "terminated" IS the alive mask here
+    for use_gae in (True, False):
+        ref_self = SimpleNamespace(_use_gae=use_gae, gamma=0.99, gae_lambda=0.95,
+                                   mac=SimpleNamespace(get_value_ippo=lambda agent_id, obs, rnn: v_all.unsqueeze(-1)))
+        want = RefLearner.compute_returns(ref_self, 0, None, rewards, terminated, None)
+        got = O.gae_returns(rewards, v_all.unsqueeze(-1), terminated, 0.99, 0.95, use_gae=use_gae)
+        assert torch.allclose(got, want, rtol=1e-6, atol=1e-6), use_gae
