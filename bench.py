@@ -240,8 +240,11 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
     f_ac = nA * 2 * rows * (2 * F * M + 14 * M * M + 2 * M * 3)                          # actor + critic, n_out 5 / 1
     b_ac = nA * (4.0 * rows * F + 2 * 4.0 * rows * 648)                                  # features once + the saved activations
     out = [
-        entry("gat_fwd_kernel", "gat_fwd_kernel", "mfma", gat_algorithmic_flops(nA, E, N, d + Z), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
-              f"rollout GAT_latent_update (5 nets x {E} envs x 55 entities), {rollouts_per_step * (T + 1)} launches per step; fp32 results: "
+        entry("gat_enc_fwd_kernel", "gat_fwd_kernel", "mfma",
+              gat_algorithmic_flops(nA, E, N, d + Z) + nA * V * (Lw * (2 * d * R + 12 * R * R) + 2 * R * Z), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
+              f"the rollout's vector step as one launch: GAT_latent_update (5 nets x {E} envs x 55 entities = 160 scene workgroups, 6.41 GFLOP) "
+              f"+ the behaviour encoder's latent_update behind them (1.1 GFLOP), {rollouts_per_step * (T + 1)} launches per step (the episode-initial GAT "
+              "update of each rollout runs alone); fp32 results: "
               "the 54-step bi-GRU recurrence (84 % of the algorithmic FLOPs) is issued as 6 bf16 piece products per fp32 product "
               "on the bf16 matrix cores (fp32-exact split, DESIGN.md section 4), the rest as fp32 MFMA; peak = the fp32 MFMA / vector peak"),
         entry("beh_dec_bwd_kernel", "beh_dec_bwd_kernel", "mfma", f_dec / pieces("beh_dec_bwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",

@@ -150,6 +150,9 @@ typedef struct {
 } IplanEncFwdArgs;
 
 int iplan_enc_fwd(const IplanEncFwdArgs* args, iplan_stream_t stream);
+/* iplan_gat_fwd and iplan_enc_fwd of one rollout vector step (ippo_parallel_runner.py:223-230: both read the previous
+ * latents) as ONE launch: the GAT scenes' workgroups first, the encoder's behind them on the remaining CUs. */
+int iplan_gat_enc_fwd(const IplanGatFwdArgs* gat, const IplanEncFwdArgs* enc, iplan_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * R_Actor / R_Critic forward (modules/agents/ippo_actor.py:43-102, modules/critics/ippo_critic.py:47-65,

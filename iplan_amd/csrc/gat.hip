@@ -21,6 +21,7 @@
 // the activations the backward pass needs.
 #include "api_util.h"
 #include "wave_tile.h"
+#include "enc_body.h"
 
 namespace iplan {
 
@@ -32,16 +33,23 @@ constexpr int QST = 33;                // padded row stride of q/k/v/x tables
 #define IPLAN_GAT_BF3 1                // recurrence on the bf16 matrix cores (fp32-exact split); 0 = fp32 MFMA (A/B builds)
 #endif
 
-__global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_B[2][NP][BST];
-    __shared__ float s_q[NP][QST];
-    __shared__ float s_k[NP][QST];
-    __shared__ float s_v[NP][QST];
-    __shared__ float s_x[NP][QST];
-    __shared__ float s_pl[2][NP][NP][2];
+struct GatShared {                      // LDS of one scene (147 KB)
+    float B[2][NP][BST];
+    float q[NP][QST], k[NP][QST], v[NP][QST], x[NP][QST];
+    float pl[2][NP][NP][2];
+};
 
-    const int net = (int)blockIdx.x / a.B;
-    const int b = (int)blockIdx.x % a.B;
+// one scene = workgroup `block` of the launch (512 threads)
+__device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int block, GatShared& sh) {
+    auto& s_B = sh.B;
+    auto& s_q = sh.q;
+    auto& s_k = sh.k;
+    auto& s_v = sh.v;
+    auto& s_x = sh.x;
+    auto& s_pl = sh.pl;
+
+    const int net = block / a.B;
+    const int b = block % a.B;
     const int N = a.N;
     const int D = a.d0 + a.d1;
     const float* __restrict__ P = a.params + (int64_t)net * a.params_s_net;
@@ -60,7 +68,7 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
     constexpr int CLK_STRIDE = 5;
 #define GAT_SUBCLK(i) do {} while (0)
 #endif
-    int64_t* clk = a.phase_clocks ? a.phase_clocks + (int64_t)blockIdx.x * CLK_STRIDE : nullptr;
+    int64_t* clk = a.phase_clocks ? a.phase_clocks + (int64_t)block * CLK_STRIDE : nullptr;
     if (clk && threadIdx.x == 0) clk[0] = IPLAN_CLOCK();
 
     const float* bih = P + a.off[dir ? IPLAN_GAT_R_BIH : IPLAN_GAT_F_BIH];
@@ -384,20 +392,65 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
     }
 }
 
+__global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) GatShared sh;
+    gat_fwd_block(a, (int)blockIdx.x, sh);
+}
+
+// The rollout's vector step: GAT_latent_update and the behaviour encoder's latent_update read the PREVIOUS latents, are
+// independent of each other and were two launches on two streams -- whose workgroups the hardware dispatched in either order:
+// when the encoder's 140 small workgroups got onto the CUs first, GAT's 160 whole-CU workgroups waited for them (139 us
+// instead of 108 us in the kernel trace), and every step paid two cross-stream event round trips.  One launch instead: the
+// first n_nets * B workgroups are the GAT scenes (dispatched first, one CU each), the following ones run the encoder, eight
+// 16-row tiles each, on the CUs that are left (its LDS is the head of the same allocation).
+__global__ __launch_bounds__(512) void gat_enc_fwd_kernel(IplanGatFwdArgs a, IplanEncFwdArgs e, int n_gat, int enc_blocks_per_net) {
+    __shared__ __attribute__((aligned(16))) GatShared sh;
+    static_assert(sizeof(GatShared) >= sizeof(float) * ENC_LDS_FLOATS, "encoder LDS must fit into the scene's");
+    const int block = (int)blockIdx.x;
+    if (block < n_gat) {
+        gat_fwd_block(a, block, sh);
+    } else {
+        const int j = block - n_gat, net = j / enc_blocks_per_net, tb = j - net * enc_blocks_per_net;
+        enc_fwd_block(e, net, tb * 8 + wave_id(), reinterpret_cast<float*>(&sh));
+    }
+}
+
 }  // namespace iplan
+
+static int check_gat(const IplanGatFwdArgs* a, const char* what);
+
+extern "C" int iplan_gat_enc_fwd(const IplanGatFwdArgs* a, const IplanEncFwdArgs* e, iplan_stream_t stream) {
+    using namespace iplan;
+    if (int rc = check_gat(a, "iplan_gat_enc_fwd")) return rc;
+    if (!e) return fail(IPLAN_EINVAL, "iplan_gat_enc_fwd: null encoder args");
+    if (e->d < 1 || e->d > 16 || e->Z < 1 || e->Z > 16 || e->L < 1 || e->n_nets < 1 || e->B < 1 || e->N < 1)
+        return fail(IPLAN_EINVAL, "iplan_gat_enc_fwd: unsupported encoder dims d=%d Z=%d L=%d", e->d, e->Z, e->L);
+    if (!e->x || !e->h0 || !e->hL || !e->latent_out || !e->params)
+        return fail(IPLAN_EINVAL, "iplan_gat_enc_fwd: null encoder tensor pointer");
+    const int n_gat = a->n_nets * a->B, per_net = (e->B * e->N + 127) / 128;
+    hipLaunchKernelGGL(gat_enc_fwd_kernel, dim3((unsigned)(n_gat + per_net * e->n_nets)), dim3(512), 0, (hipStream_t)stream, *a, *e,
+                       n_gat, per_net);
+    return check_launch("iplan_gat_enc_fwd");
+}
+
+static int check_gat(const IplanGatFwdArgs* a, const char* what) {
+    using namespace iplan;
+    if (!a) return fail(IPLAN_EINVAL, "%s: null args", what);
+    if (a->N < 2 || a->N > IPLAN_MAX_ENTITIES)
+        return fail(IPLAN_EINVAL, "%s: N=%d outside [2,%d]", what, a->N, IPLAN_MAX_ENTITIES);
+    if (a->n_nets < 1 || a->B < 1 || a->d0 < 1 || a->d1 < 0)
+        return fail(IPLAN_EINVAL, "%s: bad dims n_nets=%d B=%d d0=%d d1=%d", what, a->n_nets, a->B, a->d0, a->d1);
+    if (!a->src0 || (a->d1 > 0 && !a->src1) || !a->h_prev || !a->out || !a->noise || !a->params)
+        return fail(IPLAN_EINVAL, "%s: null tensor pointer", what);
+    if (!aligned16(a->h_prev) || !aligned16(a->out) || (a->h_s_net & 3) || (a->h_s_b & 3) ||
+        (a->out_s_net & 3) || (a->out_s_b & 3))
+        return fail(IPLAN_EALIGN, "%s: h_prev/out must be 16-byte aligned with strides %% 4 == 0", what);
+    return IPLAN_OK;
+}
 
 extern "C" int iplan_gat_fwd(const IplanGatFwdArgs* a, iplan_stream_t stream) {
     using namespace iplan;
-    if (!a) return fail(IPLAN_EINVAL, "iplan_gat_fwd: null args");
-    if (a->N < 2 || a->N > IPLAN_MAX_ENTITIES)
-        return fail(IPLAN_EINVAL, "iplan_gat_fwd: N=%d outside [2,%d]", a->N, IPLAN_MAX_ENTITIES);
-    if (a->n_nets < 1 || a->B < 1 || a->d0 < 1 || a->d1 < 0)
-        return fail(IPLAN_EINVAL, "iplan_gat_fwd: bad dims n_nets=%d B=%d d0=%d d1=%d", a->n_nets, a->B, a->d0, a->d1);
-    if (!a->src0 || (a->d1 > 0 && !a->src1) || !a->h_prev || !a->out || !a->noise || !a->params)
-        return fail(IPLAN_EINVAL, "iplan_gat_fwd: null tensor pointer");
-    if (!aligned16(a->h_prev) || !aligned16(a->out) || (a->h_s_net & 3) || (a->h_s_b & 3) ||
-        (a->out_s_net & 3) || (a->out_s_b & 3))
-        return fail(IPLAN_EALIGN, "iplan_gat_fwd: h_prev/out must be 16-byte aligned with strides %% 4 == 0");
+    if (int rc = check_gat(a, "iplan_gat_fwd")) return rc;
     hipLaunchKernelGGL(gat_fwd_kernel, dim3((unsigned)(a->n_nets * a->B)), dim3(512), 0, (hipStream_t)stream, *a);
     return check_launch("iplan_gat_fwd");
 }

@@ -166,9 +166,19 @@ class SyntheticLoop:
             if getattr(self, "_side", None) is None:
                 self._side = torch.cuda.Stream(dev)
             side = self._side
+        # One launch per step for both latent updates (iplan_gat_enc_fwd: GAT's whole-CU workgroups are dispatched ahead of the
+        # encoder's, and the two cross-stream joins of a step disappear); IPLAN_NO_FUSE_ENC=1: two launches on two streams
+        fuse = self.prediction is not None and self.behavior is not None and not os.environ.get("IPLAN_NO_FUSE_ENC")
         for t in range(T):
             self.mac.select_actions_ippo(batch, t, test_mode=False, q_noise=q_all[t], as_numpy=False, write_back=True)
             # env.step would run here; its outputs are the pre-generated tensors
+            if fuse:
+                window = hist_all[t + 1:t + 1 + L].permute(1, 2, 3, 0, 4)
+                enc = self.behavior.latent_update(window, eh[t & 1], D["behavior_latent"][:, t], out_latent=D["behavior_latent"][:, t + 1],
+                                                  out_hidden=eh[(t + 1) & 1][:, 0], launch=False)
+                self.prediction.GAT_latent_update(D["history"][:, t + 1], D["attention_latent"][:, t], D["behavior_latent"][:, t],
+                                                  noise=noise[t], out=D["attention_latent"][:, t + 1], fuse_enc=enc)
+                continue
             if two_streams:
                 side.wait_stream(main)
             if self.prediction is not None:

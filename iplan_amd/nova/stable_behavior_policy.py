@@ -59,7 +59,7 @@ class Behavior_policy:
                       weight_decay=self.weight_decay) for i in range(self.n_agents)]
 
     # ---------------------------------------------------------------------------- rollout
-    def latent_update(self, history, encoder_hidden, prev_latent, out_latent=None, out_hidden=None):
+    def latent_update(self, history, encoder_hidden, prev_latent, out_latent=None, out_hidden=None, launch=True):
         """history [E,nA,N,L,d], encoder_hidden [E,layers,nA,N,R], prev_latent [E,nA,N,Z] ->
         (new_latent [E,nA,N,Z], new_hidden [E,layers,nA,N,R])  (stable_behavior_policy.py:83-123).
         numpy history -> numpy latent + torch hidden (as the reference returns); device tensors in
@@ -71,10 +71,13 @@ class Behavior_policy:
         hid = _as_dev(encoder_hidden, self.device)
         prev = _as_dev(prev_latent, self.device)
         E, nA, N, L, d = hist.shape
-        lat, hL = ops.enc_forward(self.enc_arena, hist.permute(1, 0, 2, 3, 4), hid[:, 0].permute(1, 0, 2, 3),
-                                  prev.permute(1, 0, 2, 3), self.soft_update_coef, self.latent_dim,
-                                  out_lat=None if out_latent is None else out_latent.permute(1, 0, 2, 3),
-                                  out_h=None if out_hidden is None else out_hidden.permute(1, 0, 2, 3))
+        res = ops.enc_forward(self.enc_arena, hist.permute(1, 0, 2, 3, 4), hid[:, 0].permute(1, 0, 2, 3),
+                              prev.permute(1, 0, 2, 3), self.soft_update_coef, self.latent_dim,
+                              out_lat=None if out_latent is None else out_latent.permute(1, 0, 2, 3),
+                              out_h=None if out_hidden is None else out_hidden.permute(1, 0, 2, 3), launch=launch)
+        if not launch:                                    # device-resident rollout: the launch is fused into the GAT's
+            return res[2]                                 # (``Prediction_policy.GAT_latent_update(fuse_enc=...)``)
+        lat, hL = res
         lat = lat.permute(1, 0, 2, 3)                     # [E, nA, N, Z]
         hL = hL.permute(1, 0, 2, 3).unsqueeze(1)          # [E, 1, nA, N, R]
         if as_np:

@@ -29,10 +29,12 @@ def _nb_strides(t, inner):
     return t.stride(0), t.stride(1)
 
 
-def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None, phase_clocks=None, lib=None):
+def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None, phase_clocks=None, lib=None, fuse_enc=None):
     """GAT_Net.forward for all nets.  src0 [n_nets,B,N,d0], src1 [n_nets,B,N,d1] or None,
     h_prev [n_nets,B,N,A] (first two dims may be arbitrarily strided views), noise
-    [n_nets,B,N,N-1,2] contiguous.  Returns (out [n_nets,B,N,A], saved dict or None)."""
+    [n_nets,B,N,N-1,2] contiguous.  Returns (out [n_nets,B,N,A], saved dict or None).
+    ``fuse_enc``: what ``enc_forward(..., launch=False)`` returned -- the encoder's latent update of the same rollout step rides
+    in this launch (iplan_gat_enc_fwd: the GAT scenes' workgroups first, the encoder's behind them)."""
     lib = _lib(lib)
     n_nets, B, N, d0 = src0.shape
     d1 = 0 if src1 is None else src1.shape[-1]
@@ -75,14 +77,21 @@ def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None
         )
         for k, v in saved.items():
             setattr(a.saved, k, v.data_ptr())
-    _launch("gat_fwd_kernel", lambda: lib.call("iplan_gat_fwd", a, L.current_stream(dev)))
+    if fuse_enc is not None:
+        def fused():
+            rc = lib.c.iplan_gat_enc_fwd(C.byref(a), C.byref(fuse_enc["args"]), C.c_void_p(L.current_stream(dev) or 0))
+            if rc != 0:
+                raise L.IplanError(f"iplan_gat_enc_fwd failed ({rc}): {lib.c.iplan_last_error().decode()}")
+        _launch("gat_fwd_kernel", fused)
+    else:
+        _launch("gat_fwd_kernel", lambda: lib.call("iplan_gat_fwd", a, L.current_stream(dev)))
     if saved is not None:
         saved["_args"] = a
         saved["_keep"] = (src0, src1, h_prev, noise, out)
     return out, saved
 
 
-def enc_forward(arena, x, h0, prev_latent, coef, Z, out_lat=None, out_h=None, lib=None):
+def enc_forward(arena, x, h0, prev_latent, coef, Z, out_lat=None, out_h=None, lib=None, launch=True):
     """EncoderRNN + soft update for all nets.  x [n_nets,B,N,L,d] (any strides as long as the last dim is
     contiguous: a sliding window over a time-major observation log is read in place), h0 [n_nets,B,N,R],
     prev_latent [n_nets,B,N,Z] or None (first two dims may be strided views).  ``out_lat`` / ``out_h``:
@@ -114,6 +123,8 @@ def enc_forward(arena, x, h0, prev_latent, coef, Z, out_lat=None, out_h=None, li
     a.params_s_net = arena.net_stride
     for i, k in enumerate(L.ENC_PARAM_ORDER):
         a.off[i] = arena.off(k)
+    if not launch:                                           # the caller hands ``args`` to gat_forward(fuse_enc=...)
+        return lat, hL, dict(args=a, keep=(x, h0, prev_latent, lat, hL))
     lib.call("iplan_enc_fwd", a, L.current_stream(dev))
     return lat, hL
 

@@ -172,6 +172,29 @@ def test_harness_rollout_emulated():
     assert batch["actions"].max() < args.n_actions
 
 
+def test_fused_gat_encoder_launch_equals_two_launches_emulated(monkeypatch):
+    """iplan_gat_enc_fwd (one launch per rollout step for GAT_latent_update + the encoder's latent_update) writes bit for bit what
+    the two separate launches write"""
+    from iplan_amd.config import default_args
+    from iplan_amd.harness import SyntheticLoop
+    args = default_args("highway", use_cuda=False, max_vehicle_num=19, n_agents=2, episode_limit=3, batch_size_run=9)   # 171 rows: ragged encoder tiles
+
+    def run(no_fuse):
+        if no_fuse:
+            monkeypatch.setenv("IPLAN_NO_FUSE_ENC", "1")
+        else:
+            monkeypatch.delenv("IPLAN_NO_FUSE_ENC", raising=False)
+        loop = SyntheticLoop(args, 9, seed=3, device="cpu")
+        torch.manual_seed(11)
+        b = loop.rollout()
+        return {k: b[k].clone() for k in ("attention_latent", "behavior_latent", "actions", "rnn_states_actors")}
+
+    fused, plain = run(False), run(True)
+    for k in fused:
+        assert torch.equal(fused[k], plain[k]), k
+    assert fused["behavior_latent"][:, 1:].abs().sum() > 0 and fused["attention_latent"][:, 1:].abs().sum() > 0
+
+
 def test_harness_full_cycle_emulated(capsys):
     """rollout -> insert -> behaviour learn -> prediction learn -> PPO train, end to end (tiny dims)."""
     from iplan_amd.config import default_args
