@@ -42,9 +42,10 @@ def _kib(fetch, write):
     return int((2 * fetch + write) * 1024)
 
 
-# per launch at the config-3 shape (E = 32), profiles/r02f_pmc_*{behaviour_learn,ppo_train}.txt and r02g_pmc_rollout.txt (avg / dispatch; equal within 0.2 % across series)
+# per launch at the config-3 shape (E = 32), profiles/r02f_pmc_*{behaviour_learn,ppo_train}.txt and r02h_pmc_rollout.txt (avg / dispatch; equal within 0.2 % across series)
 PMC_TRAFFIC_BYTES = {
     ("gat_fwd_kernel", 32): _kib(5172.7, 1100.0),
+    ("gat_enc_fwd_kernel", 32): _kib(7454.8, 2475.0),            # GAT scenes + encoder tiles of one rollout step (r02h_pmc_rollout.txt)
     ("beh_dec_bwd_kernel", 32): _kib(1008997.0, 1590885.6),       # per window-range launch (6 per BPTT)
     ("beh_dec_fwd_kernel", 32): _kib(59286.7, 3295126.4),         # per window-range launch (4 per forward)
     ("beh_enc_bwd_kernel", 32): _kib(470546.6, 17301.1),          # per window-range launch (6 per BPTT)

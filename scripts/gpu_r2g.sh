@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round-2 series g evidence (one gpurun call, after the split-bf16 GAT recurrence): GPU tests + smoke, bench lines (weak default incl.
 # cpu_baseline, strong N=1), rocprofv3 kernel statistics of the bench command, microbench, PMC passes of the rollout pieces, config 5.
-# Outputs -> gpurun_out/g/ (copied to profiles/r02g_*).  The behaviour / PPO kernels are those of series f (profiles/r02f_*).
+# Outputs -> gpurun_out/$SERIES/ (copied to profiles/r02<series>_*).  The behaviour / PPO kernels are those of series f (profiles/r02f_*).
 set -u
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"; O=gpurun_out/g; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"; O=gpurun_out/${SERIES:-g}; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
 timeout 600 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log < /dev/null
 cp gpurun_out/parity_errors.json $O/parity_errors.json 2>/dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1 < /dev/null

@@ -7,7 +7,7 @@ python - "$f" <<'PY' | tee $O/seq.txt
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = sorted(((r["Kernel_Name"].split("(")[0].replace("iplan::",""), int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Stream_Id", ""), r.get("Queue_Id","")) for r in rows), key=lambda r: r[1])
-gat = [i for i, k in enumerate(ks) if "gat_fwd" in k[0]]
+gat = [i for i, k in enumerate(ks) if "gat_enc_fwd" in k[0]]
 i0 = gat[len(gat) // 2 + 40]            # mid-rollout somewhere
 t0 = ks[i0][1]
 for k in ks[i0:i0 + 16]:

@@ -8,7 +8,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = sorted(((r["Kernel_Name"].split("(")[0], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows), key=lambda r: r[1])
 # rollouts: runs of gat_fwd launches; a new rollout starts when the gap since the previous gat_fwd exceeds 2 ms
-gat = [k for k in ks if "gat_fwd" in k[0]]
+gat = [k for k in ks if "gat_enc_fwd" in k[0] or "gat_fwd" in k[0]]
 starts = [gat[0][1]]
 for a, b in zip(gat, gat[1:]):
     if b[1] - a[2] > 2_000_000:
