@@ -179,10 +179,15 @@ class ParallelRunner:
             self.host_seconds += time.perf_counter() - t0
             # what the simulator produced: one batch of pinned host -> device copies
             D("history")[:, t + 1] = self._to_dev("single", single, torch.float32)
-            if a.GAT_enable:
+            if a.GAT_enable and a.Behavior_enable:           # both latent updates of the step in one launch (iplan_gat_enc_fwd)
+                enc = self.behavior_learner.latent_update(self._to_dev("window", window, torch.float32), eh[t & 1], D("behavior_latent")[:, t],
+                                                          out_latent=D("behavior_latent")[:, t + 1], out_hidden=eh[(t + 1) & 1][:, 0], launch=False)
+                self.prediction_learner.GAT_latent_update(D("history")[:, t + 1], D("attention_latent")[:, t], D("behavior_latent")[:, t],
+                                                          out=D("attention_latent")[:, t + 1], fuse_enc=enc)
+            elif a.GAT_enable:
                 self.prediction_learner.GAT_latent_update(D("history")[:, t + 1], D("attention_latent")[:, t], D("behavior_latent")[:, t],
                                                           out=D("attention_latent")[:, t + 1])
-            if a.Behavior_enable:
+            elif a.Behavior_enable:
                 self.behavior_learner.latent_update(self._to_dev("window", window, torch.float32), eh[t & 1], D("behavior_latent")[:, t],
                                                     out_latent=D("behavior_latent")[:, t + 1], out_hidden=eh[(t + 1) & 1][:, 0])
             D("reward")[:, t] = self._to_dev("reward", self._masked(reward, (E, nA), alive), torch.float32).unsqueeze(-1)
