@@ -78,11 +78,11 @@ class SyntheticLoop:
     @torch.no_grad()
     def rollout(self):
         """One vectorised episode of E envs x T steps (ippo_parallel_runner.py:105-281 order of calls).
-        Device resident: the three fused launches of a vector step read their inputs from, and write their
+        Device resident: the launches of a vector step (actor / critic, then GAT + encoder as one) read their inputs from, and write their
         outputs into, the episode-buffer tensors in place; the per-step random draws (gumbel noise of the hard
         attention, the exponential race of the action sampling) are drawn for the whole rollout in two launches.
 
-        IPLAN_ROLLOUT_GRAPH=1 (opt-in): the whole episode -- 3 x 90 launches on two streams plus the draws -- is captured
+        IPLAN_ROLLOUT_GRAPH=1 (opt-in): the whole episode -- 2 x 90 launches plus the draws -- is captured
         ONCE per observation set in a HIP graph and replayed into one static episode batch.  Measured on MI355X
         (profiles/r01g_notes.md): an isolated rollout gains 2 % (22.5 vs 23.1 ms: the gaps between the three dependent
         kernels of a vector step shrink), but inside the full training cycle graph replays cost 5-15 % (the learners'
@@ -159,7 +159,8 @@ class SyntheticLoop:
             q_all = torch.empty(T, nA, E, a.n_actions, device=dev).exponential_()
         # The instant-incentive (GAT) and behavioural-incentive (encoder) updates of a step are independent of each
         # other (both read the PREVIOUS latents), and the GAT launch leaves 96 of the 256 CUs idle (one scene per
-        # workgroup): the encoder runs beside it on a second HIP stream, joined before the next action selection.
+        # workgroup): the encoder runs beside it -- as trailing workgroups of the same launch (below), or, with
+        # IPLAN_NO_FUSE_ENC=1, on a second HIP stream joined before the next action selection.
         two_streams = torch.device(dev).type == "cuda" and self.prediction is not None and self.behavior is not None
         if two_streams:
             main = torch.cuda.current_stream(dev)
