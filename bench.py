@@ -156,6 +156,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(opt.steps):
         one_step()
+    if hasattr(loop, "finish"):
+        loop.finish()                                       # the last cycle's staged loss read-backs (host run-ahead, harness.cycle)
     barrier()
     dt = time.perf_counter() - t0
     timed = ops.TIMERS.summary()

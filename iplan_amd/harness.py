@@ -259,11 +259,30 @@ class SyntheticLoop:
                 done = torch.cuda.Event()
                 done.record(strm)
             fins.append((f, done))
+        # IPLAN_RUN_AHEAD=1 (opt-in; measured 362-364 vs 358 ms per cycle with it off, profiles/r02h_notes.md)
+        run_ahead = self.behavior is not None and self.defer_decoder and bool(os.environ.get("IPLAN_RUN_AHEAD"))
+        late = []                                            # host read-backs of this cycle, delivered during the next one
         if self.behavior is not None:
             # the decoder's weight-gradient contraction + optimiser step run on beside the next rollout (see learn())
-            self.behavior.learn(batch, self.t_env, **({"defer_decoder": True} if self.defer_decoder else {}))
+            kw = {"defer_decoder": True} if self.defer_decoder else {}
+            if run_ahead:
+                # ... and the HOST does not wait for the device either: losses / norms are staged to pinned memory behind
+                # the enqueued work (streams.AsyncHost) and read one cycle later, so the next rollout's launches are
+                # already queued when the last kernel of this learn() retires
+                late.append(self.behavior.learn(batch, self.t_env, defer_readback=True, **kw))
+            else:
+                self.behavior.learn(batch, self.t_env, **kw)
         for f, done in fins:
             main.wait_event(done)
             if f is not None:
-                f()
+                late.append(f) if run_ahead else f()
+        for f in getattr(self, "_late", ()):                 # the previous cycle's read-backs: long complete, no waiting
+            f()
+        self._late = late
         return self.E * self.args.episode_limit
+
+    def finish(self):
+        """deliver the read-backs the last cycle() left staged (logging only; no effect on any device value)"""
+        for f in getattr(self, "_late", ()):
+            f()
+        self._late = []

@@ -22,6 +22,7 @@ import torch as th
 from .. import _lib as L
 from .. import ops
 from ..optim import FusedAdam, step_all
+from ..streams import AsyncHost
 from ..utils.mappo_utils.util import update_linear_schedule
 
 _STORE_KEYS = ("history", "attention_latent", "behavior_latent", "actions", "avail_actions", "reward",
@@ -308,8 +309,14 @@ class IPPOLearner:
         st_d = stats.mean(dim=(0, 1))
         nr_d = norms.sqrt().mean(dim=(0, 2)) if max_norm is not None else th.zeros(2, device=dev)
 
+        staged = AsyncHost(th.cat([st_d.reshape(-1), nr_d.reshape(-1)])) if defer else None     # read back whenever the caller likes
+
         def finish():
-            st, nr = st_d.cpu(), nr_d.cpu()
+            if staged is not None:
+                both = staged.get()
+                st, nr = both[:st_d.numel()], both[st_d.numel():]
+            else:
+                st, nr = st_d.cpu(), nr_d.cpu()
             train_info = {"value_loss": float(st[1]), "policy_loss": float(st[0]), "dist_entropy": float(st[3]),
                           "actor_grad_norm": float(nr[0]), "critic_grad_norm": float(nr[1]), "ratio": float(st[2])}
             self.last_train_info = train_info
@@ -383,8 +390,11 @@ class IPPOLearner:
         st_d = stats.mean(dim=(0, 1))
         nr_d = norms.sqrt().mean(dim=(0, 2)) if max_norm is not None else th.zeros(2, device=dev)
 
+        staged = AsyncHost(th.cat([st_d.reshape(-1), nr_d.reshape(-1)]))
+
         def finish():
-            st, nr = st_d.cpu(), nr_d.cpu()
+            both = staged.get()
+            st, nr = both[:st_d.numel()], both[st_d.numel():]
             train_info = {"value_loss": float(st[1]), "policy_loss": float(st[0]), "dist_entropy": float(st[3]),
                           "actor_grad_norm": float(nr[0]), "critic_grad_norm": float(nr[1]), "ratio": float(st[2])}
             self.last_train_info = train_info

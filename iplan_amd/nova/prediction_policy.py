@@ -13,6 +13,7 @@ import torch
 from .. import ops
 from ..arena import ParamArena
 from ..optim import FusedAdam, step_all
+from ..streams import AsyncHost
 from .GAT_Net import GAT_Net, gumbel_noise
 from .prediction_net import Prediction_Decoder
 
@@ -171,9 +172,10 @@ class Prediction_policy:
             self.dp.all_reduce_grads(self.gat_arena, self.dec_arena)
         sq = step_all(self.pred_optimizer, self.max_grad_norm if self._use_max_grad_norm else None)
         stats = torch.cat([fwd["loss"], sq.sqrt().reshape(-1)])
+        staged = AsyncHost(stats) if defer else None             # deferred: staged behind THIS stream's work, read whenever
 
         def finish():
-            host = stats.cpu()                                                      # ONE host read-back
+            host = staged.get() if staged is not None else stats.cpu()              # ONE host read-back
             losses = host[:nA].numpy()
             norms = host[nA:].reshape(nA, 2)
             train_info = {"prediction_loss": float(losses.sum()), "pred_encoder_grad_norm": float(norms[:, 0].sum()),

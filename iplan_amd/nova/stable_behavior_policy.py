@@ -10,7 +10,7 @@ import torch
 from .. import ops
 from ..arena import ParamArena
 from ..optim import FusedAdam, step_all
-from ..streams import masked_stream
+from ..streams import AsyncHost, masked_stream
 from .behavior_net import Behavior_Latent_Decoder, EncoderRNN
 from .prediction_policy import _as_dev
 
@@ -132,7 +132,7 @@ class Behavior_policy:
             torch.cuda.current_stream(self.device).wait_event(ev)
             self._dec_done = None
 
-    def learn(self, batch, t_env, keep=None, defer_decoder=False):
+    def learn(self, batch, t_env, keep=None, defer_decoder=False, defer_readback=False):
         """nova/stable_behavior_policy.py:161-279 for all agents at once: ONE persistent forward launch
         walks every (env, entity) chain through the T-1-L windows (decoder + encoder GRUs, soft latent
         update, masked L1), ONE backward launch does the BPTT, then weight-gradient contractions,
@@ -145,7 +145,11 @@ class Behavior_policy:
         Nothing outside behaviour learning reads the decoder (the rollout uses the encoder only), so that work -- the largest
         bandwidth-bound item of a ``learn`` -- runs beside the next rollout, whose kernels leave 96 of the 256 CUs idle; the
         next ``learn`` (and save / load) waits for it.  Same arithmetic, same order of optimiser steps; the logged decoder
-        gradient norm is the previous call's."""
+        gradient norm is the previous call's.
+
+        ``defer_readback=True``: the call does not wait for the device at all -- the losses / gradient norms are staged to
+        pinned host memory behind the enqueued work and the call returns a function that delivers the three lists (and logs)
+        when called; the host can then enqueue the next rollout while this call's kernels still run."""
         a = self.args
         dev = self.device
         self.join_decoder()
@@ -210,27 +214,30 @@ class Behavior_policy:
                     self._dec_done.record(ds)
             del bwd
             dec_col = prev_dec if prev_dec is not None else torch.zeros(nA, device=dev)
-            host = torch.cat([loss_dev.reshape(-1), sq[:, 0].sqrt(), dec_col.sqrt()]).cpu()      # ONE host read-back
-            loss = host[:2 * nA].reshape(nA, 2).numpy()
-            norms = host[2 * nA:].reshape(2, nA).t()
+            host_dev, split = torch.cat([loss_dev.reshape(-1), sq[:, 0].sqrt(), dec_col.sqrt()]), True
         else:
             if getattr(self, "dp", None) is not None:
                 self.dp.all_reduce_grads(self.enc_arena, self.dec_arena)
             sq = step_all(self.behavior_optimizer, max_norm)
-            host = torch.cat([loss_dev.reshape(-1), sq.sqrt().reshape(-1)]).cpu()       # ONE host read-back
+            host_dev, split = torch.cat([loss_dev.reshape(-1), sq.sqrt().reshape(-1)]), False
+        staged = AsyncHost(host_dev) if defer_readback else None
+
+        def finish():
+            host = staged.get() if staged is not None else host_dev.cpu()              # ONE host read-back
             loss = host[:2 * nA].reshape(nA, 2).numpy()
-            norms = host[2 * nA:].reshape(nA, 2)
-        beh = [np.asarray(loss[i, 0]) for i in range(nA)]
-        stab = [np.asarray(loss[i, 1]) for i in range(nA)]
-        total = [np.asarray(loss[i, 0] + self.behavior_variation_penalty * loss[i, 1]) for i in range(nA)]
-        train_info = {"behavior_loss": float(loss[:, 0].sum()), "stability_loss": float(loss[:, 1].sum()),
-                      "behavior_total": float(sum(float(t) for t in total)),
-                      "behavior_encoder_grad_norm": float(norms[:, 0].sum()),
-                      "behavior_decoder_grad_norm": float(norms[:, 1].sum())}
-        if t_env - self.log_stats_t >= self.args.learner_log_interval:
-            for k, v in train_info.items():
-                self.logger.log_stat(self.log_prefix + k, v, t_env)
-        return beh, stab, total
+            norms = host[2 * nA:].reshape(2, nA).t() if split else host[2 * nA:].reshape(nA, 2)
+            beh = [np.asarray(loss[i, 0]) for i in range(nA)]
+            stab = [np.asarray(loss[i, 1]) for i in range(nA)]
+            total = [np.asarray(loss[i, 0] + self.behavior_variation_penalty * loss[i, 1]) for i in range(nA)]
+            train_info = {"behavior_loss": float(loss[:, 0].sum()), "stability_loss": float(loss[:, 1].sum()),
+                          "behavior_total": float(sum(float(t) for t in total)),
+                          "behavior_encoder_grad_norm": float(norms[:, 0].sum()),
+                          "behavior_decoder_grad_norm": float(norms[:, 1].sum())}
+            if t_env - self.log_stats_t >= self.args.learner_log_interval:
+                for k, v in train_info.items():
+                    self.logger.log_stat(self.log_prefix + k, v, t_env)
+            return beh, stab, total
+        return finish if defer_readback else finish()
 
     # ---------------------------------------------------------------------------- checkpoints
     def save_models(self, path):

@@ -49,3 +49,35 @@ def masked_stream(device, n_cus, first=0):
         return torch.cuda.ExternalStream(handle.value, device=device)
     except Exception:                                          # noqa: BLE001  (no extension: the plain stream is always correct)
         return torch.cuda.Stream(device)
+
+
+class AsyncHost:
+    """Device tensor -> pinned host copy on a dedicated copy stream, ordered behind everything enqueued so far on the CURRENT
+    stream (where the tensor was produced); ``get()`` waits for that copy alone.  A plain ``tensor.cpu()`` is ordered on the
+    current stream: called later it would also wait for whatever the caller has enqueued there since (the next rollout)."""
+    _copy_streams = {}
+
+    def __init__(self, t):
+        self.ev = None
+        if t.device.type != "cuda":
+            self.host = t
+            return
+        dev = t.device
+        cs = AsyncHost._copy_streams.get(str(dev))
+        if cs is None:
+            cs = AsyncHost._copy_streams[str(dev)] = torch.cuda.Stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        self.host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        with torch.cuda.stream(cs):
+            cs.wait_event(ready)
+            self.host.copy_(t, non_blocking=True)
+            self.ev = torch.cuda.Event()
+            self.ev.record(cs)
+        t.record_stream(cs)
+
+    def get(self):
+        if self.ev is not None:
+            self.ev.synchronize()
+            self.ev = None
+        return self.host

@@ -115,20 +115,24 @@ def check_deferred_equals_inline(args, E, device, seed=23):
     _, batch = _fields(args, E, seed + 1, 0.8, device)
     nA, N, Lw, T = args.n_agents, args.max_vehicle_num, args.max_history_len, args.episode_limit
     keep = (torch.rand(2, nA, T - 1 - Lw, E * N, Lw, args.decoder_rnn_dim, generator=torch.Generator().manual_seed(seed)) < 0.9).to(torch.uint8)
-    arenas = []
-    for kw in ({}, dict(defer_decoder=True)):
+    arenas, losses = [], []
+    for kw in ({}, dict(defer_decoder=True), dict(defer_decoder=True, defer_readback=True)):
         torch.manual_seed(seed)
         pol = Behavior_policy(args, _Log())
-        for it in range(2):
-            pol.learn(batch, it, keep=keep[it].to(device), **kw)
+        outs = [pol.learn(batch, it, keep=keep[it].to(device), **kw) for it in range(2)]
+        if kw.get("defer_readback"):                        # staged read-backs, delivered after both calls were enqueued
+            outs = [f() for f in outs]
+        losses.append([[float(x) for x in lst] for o in outs for lst in o])
         pol.join_decoder()
         if torch.device(device).type == "cuda":
             torch.cuda.synchronize()
         arenas.append((pol.enc_arena.data.clone().cpu(), pol.dec_arena.data.clone().cpu(),
                        [o._steps for o in pol.behavior_optimizer]))
-    (e0, d0, s0), (e1, d1, s1) = arenas
-    assert s0 == s1 == [2] * nA
+    (e0, d0, s0), (e1, d1, s1), (e2, d2, s2) = arenas
+    assert s0 == s1 == s2 == [2] * nA
     assert _rel(e1, e0) < 1e-6 and _rel(d1, d0) < 1e-6, (_rel(e1, e0), _rel(d1, d0))
+    assert torch.equal(e2, e1) and torch.equal(d2, d1)              # the read-back's timing changes no device value
+    assert losses[2] == losses[1]
 
 
 
