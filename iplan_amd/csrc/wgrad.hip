@@ -21,8 +21,6 @@
 //          the latency of the next block's loads, so one wave per SIMD is enough
 //   narrow  4 x 4 tiles, three waves per SIMD: the small heads (a few MFMAs per block) are latency
 //          bound and get their parallelism from loads in flight and several waves per SIMD instead
-#include <cstdlib>
-
 #include "api_util.h"
 #include "wave_tile.h"
 
@@ -312,15 +310,19 @@ extern "C" int iplan_wgrad(IplanWgradArgs* a, iplan_stream_t stream) {
     if (off > a->workspace_floats)
         return fail(IPLAN_EINVAL, "iplan_wgrad: workspace too small (%lld floats needed, %lld given)", (long long)off,
                     (long long)a->workspace_floats);
-    // thin / square (latency-bound) jobs first: they finish in the shadow of the wide ones' start
+    // The wide jobs first (one long-lived 372-register wave per SIMD: nothing else gets onto the chip while they run), the
+    // thin / square ones -- many short waves -- behind them.  In the training loop this call is the decoder update that
+    // Behavior_policy.learn defers beside the next rollout: with the thin kernels in front (1.6 ms) the wide one was still
+    // running when the rollout's first GAT launches arrived and they queued behind it (in-situ gat_enc_fwd mean 143-145 us);
+    // with the wide one in front it has retired by then (116 us).  Cycle time unchanged (356.2-358.2 ms either way, same box).
 #define IPLAN_WGRAD_LAUNCH(KIND, TO_, TK_, RB_)                                                                              \
     if (jl[KIND].n)                                                                                                          \
         hipLaunchKernelGGL((wgrad_partial_kernel<TO_, TK_, RB_>), dim3((unsigned)jl[KIND].n, (unsigned)vcs[KIND], (unsigned)a->n_nets), \
                            dim3(64), 0, (hipStream_t)stream, *a, jl[KIND], chunks_wide);
+    IPLAN_WGRAD_LAUNCH(J_WIDE, WG_TO_WIDE, WG_TK, 1)
     IPLAN_WGRAD_LAUNCH(J_THIN_K, WG_TO_NARROW, 1, 2)
     IPLAN_WGRAD_LAUNCH(J_THIN_O, 1, WG_TK, 2)
     IPLAN_WGRAD_LAUNCH(J_SQUARE, WG_TO_NARROW, WG_TK, 1)
-    IPLAN_WGRAD_LAUNCH(J_WIDE, WG_TO_WIDE, WG_TK, 1)
 #undef IPLAN_WGRAD_LAUNCH
     const unsigned z = (unsigned)(a->n_problems * a->n_nets);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((max_elems + 255) / 256), z), dim3(256), 0,
