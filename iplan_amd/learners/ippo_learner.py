@@ -128,6 +128,11 @@ class IPPOLearner:
 
         self.store = EpisodeStore(args, self.device)
         self.buffers = [_AgentBuffer(self.store, i, self.n_agents) for i in range(self.n_agents)]
+        # diagnostics / parity tests: keep a copy of both parameter arenas as they were BEFORE train()'s last optimiser
+        # step (``last_step_params``), so that the last step's gradients can be checked at that exact parameter point
+        self.probe_last_step = False
+        self.last_step_params = None
+        self.last_step_relu = None                           # ([2, nA, rows, M] bool, same): which side of the fc1 / fc2 ReLU kink each unit took
 
         self.clip_param = args.clip_param
         self.ppo_epoch = args.ppo_epoch
@@ -299,6 +304,9 @@ class IPPOLearner:
                             g_entropy=-self.entropy_coef / n_rows, g_values=g_v)
             if self.dp is not None:
                 self.dp.all_reduce_grads(mac.actor_arena, mac.critic_arena)
+            if self.probe_last_step and ep == self.ppo_epoch - 1:
+                self.last_step_params = (mac.actor_arena.data.clone(), mac.critic_arena.data.clone())
+                self.last_step_relu = (out["saved"][..., 0:64] > 0, out["saved"][..., 128:192] > 0)       # fc1 / fc2 ReLU branches taken
             sq_a = step_all(self.actor_optimizers, max_norm)
             norms[ep, 0] = sq_a[:, 0]
             sq_c = step_all(self.critic_optimizers, max_norm)
@@ -384,6 +392,9 @@ class IPPOLearner:
                 pl.stats = stats[k].data_ptr()
                 lib.call("iplan_ppo_loss", pl, stream)
                 ops.ac_backward(out, mac.actor_arena, mac.critic_arena, g_logp=g_logp, g_entropy=-self.entropy_coef / float(mbs), g_values=g_v)
+                if self.probe_last_step and k == self.ppo_epoch * nmb - 1:
+                    self.last_step_params = (mac.actor_arena.data.clone(), mac.critic_arena.data.clone())
+                    self.last_step_relu = (out["saved"][..., 0:64] > 0, out["saved"][..., 128:192] > 0)
                 norms[k, 0] = step_all(self.actor_optimizers, max_norm)[:, 0]
                 norms[k, 1] = step_all(self.critic_optimizers, max_norm)[:, 0]
         self.store.clear()

@@ -29,8 +29,15 @@ class P2PAllReduce:
     Every rank owns a double-buffered staging area and a flag array that its peers map through HIP IPC handles (exchanged
     once through ``exchange``, normally ``dist.all_gather_object``).  ``all_reduce(tensor)`` = publish (copy into the staging
     half, one flag store into every rank's flag array) + reduce (wait for all flags, sum all staging halves in rank order,
-    in place): two launches on the tensor's current stream, no host synchronisation, replicas bit-identical.  Tensors
-    larger than the staging capacity go through in slices.  ``exchange(obj) -> [obj of rank 0, ...]``."""
+    in place): two launches, no host synchronisation, replicas bit-identical.  Tensors larger than the staging capacity go
+    through in slices.  ``exchange(obj) -> [obj of rank 0, ...]``.
+
+    STREAMS.  The double-buffer argument (a rank can publish ``seq + 2`` only after it finished ``seq + 1``) holds only if a
+    rank's collectives execute in the order their sequence numbers were handed out.  The training loop issues them from
+    several producer streams (prediction / PPO learner streams, main, the deferred decoder update's side stream), so on CUDA
+    every collective runs on ONE dedicated per-rank communication stream, the way RCCL does it: the comm stream waits for an
+    event of the producer stream, publish and reduce are enqueued there in host order (= ``seq`` order, the same on every
+    rank), and the producer stream then waits for the collective's completion event.  No host synchronisation either way."""
 
     def __init__(self, world, rank, device, capacity_floats, exchange, lib=None, spin_limit=0):
         from . import _lib as L
@@ -44,6 +51,7 @@ class P2PAllReduce:
         self.handles = (bytes(self._export(self._stage).bytes), bytes(self._export(self._flags).bytes))
         self.error = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.stage = self.flags = None
+        self.comm = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         if exchange is not None:
             self.connect(exchange(self.handles))
 
@@ -104,17 +112,42 @@ class P2PAllReduce:
 
     def all_reduce(self, tensor):
         flat = tensor.view(-1)
-        for lo in range(0, flat.numel(), self.capacity):
-            part = flat[lo:lo + self.capacity]
-            self.reduce(self.publish(part), part.device)
+        if self.comm is None:                                 # host emulation: one implicit stream
+            for lo in range(0, flat.numel(), self.capacity):
+                part = flat[lo:lo + self.capacity]
+                self.reduce(self.publish(part), part.device)
+            return tensor
+        producer = torch.cuda.current_stream(self.device)
+        self.comm.wait_stream(producer)                       # (an event of the producer: the gradients are complete)
+        with torch.cuda.stream(self.comm):
+            for lo in range(0, flat.numel(), self.capacity):
+                part = flat[lo:lo + self.capacity]
+                self.reduce(self.publish(part), part.device)
+        tensor.record_stream(self.comm)
+        producer.wait_stream(self.comm)
         return tensor
 
+    def check_error(self):
+        """Raise if a reduce gave up waiting for a peer (``spin_limit`` > 0): the tensor it was called on is then NOT reduced
+        (or only partly), and carrying on would let the replicas diverge silently.  Synchronises the device."""
+        if int(self.error.item()) != 0:
+            raise self.L.IplanError(f"P2P all-reduce: rank {self.rank} timed out waiting for a peer's flag (seq <= {self.seq}); "
+                                    "gradients were not reduced")
+
     def close(self):
+        if self.device.type == "cuda" and (self._opened or self._own):
+            torch.cuda.synchronize(self.device)
         for p in self._opened:
             self.lib.c.iplan_p2p_close(p)
         for p in self._own:
             self.lib.c.iplan_p2p_free(p)
         self._opened, self._own = [], []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DataParallel:
@@ -125,9 +158,24 @@ class DataParallel:
         self.backend = dist.get_backend(group)
         self.p2p = None                                      # P2PAllReduce, built on first use when IPLAN_P2P_ALLREDUCE=1
 
+    def _via_host(self, tensor):
+        """gloo process groups (CPU tests; the two-processes-on-one-GPU test, where RCCL refuses the duplicate device) move
+        CUDA tensors through the host"""
+        return self.backend == "gloo" and tensor.is_cuda
+
     def broadcast_arena(self, arena, src=0):
-        dist.broadcast(arena.data, src=src, group=self.group)
+        if self._via_host(arena.data):
+            h = arena.data.cpu()
+            dist.broadcast(h, src=src, group=self.group)
+            arena.data.copy_(h)
+        else:
+            dist.broadcast(arena.data, src=src, group=self.group)
         arena.version += 1
+
+    def close(self):
+        if self.p2p is not None:
+            self.p2p.close()
+            self.p2p = None
 
     def attach(self, loop):
         """Hook a SyntheticLoop-like object (``.mac``, ``.learner``, ``.behavior``, ``.prediction``): replicas
@@ -146,6 +194,11 @@ class DataParallel:
 
     def all_reduce_sum(self, tensor):
         """Sum a (small) tensor of loss normalisers over the ranks, in place; returns it."""
+        if self._via_host(tensor):
+            h = tensor.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            tensor.copy_(h)
+            return tensor
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
         return tensor
 
@@ -165,7 +218,13 @@ class DataParallel:
                 if a.grad.numel() % 4 == 0 and a.grad.data_ptr() % 16 == 0:
                     self.p2p.all_reduce(a.grad)
                 else:
-                    dist.all_reduce(a.grad, op=dist.ReduceOp.SUM, group=self.group)
+                    self.all_reduce_sum(a.grad)
+            if self.p2p.spin_limit > 0:                          # the time-out mode: never carry on with unreduced gradients
+                self.p2p.check_error()
+            return
+        if arenas and self._via_host(arenas[0].grad):
+            for a in arenas:
+                self.all_reduce_sum(a.grad)
             return
         works = [dist.all_reduce(a.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for a in arenas]
         for w in works:

@@ -115,7 +115,11 @@ class ParallelRunner:
 
     # ------------------------------------------------------------------------------------------ one vectorised episode
     @torch.no_grad()
-    def run(self, test_mode=False):
+    def run(self, test_mode=False, noise=None, q_all=None):
+        """``noise`` [T+1, nA, E, N, N-1, 2] / ``q_all`` [T, nA, E, n_actions]: pre-drawn gumbel samples (step t's update uses
+        ``noise[t]``, the episode-initial one ``noise[T]``) and Exp(1) samples of the action race -- the parity tests inject
+        them into this loop and into the oracle (same convention as harness.SyntheticLoop._rollout_body); default: drawn on
+        the device per step, like the reference draws them inside F.gumbel_softmax / Categorical.sample."""
         import time
         a, E, nA = self.args, self.args.batch_size_run, self.n_agents
         state, obs = self.reset()
@@ -138,14 +142,14 @@ class ParallelRunner:
         eh = torch.zeros(2, E, a.num_encoder_layer, nA, self.max_vehicle_num, a.encoder_rnn_dim, device=dev)    # ping-pong
         if a.GAT_enable:
             self.prediction_learner.GAT_latent_update(D("history")[:, 0], D("attention_latent")[:, 0], D("behavior_latent")[:, 0],
-                                                      out=D("attention_latent")[:, 0])
+                                                      out=D("attention_latent")[:, 0], noise=None if noise is None else noise[a.episode_limit])
         D("filled")[:, 0] = 1
         act_host = torch.empty(E, nA, dtype=torch.long, pin_memory=dev.type == "cuda")
         for _ in range(a.episode_limit):
             t = self.t
             # actions, their one-hot and the new GRU states go straight into the episode container
             # (the reference never forwards test_mode to the controller -- it samples in test runs too, :172-173)
-            self.mac.select_actions_ippo(self.batch, t_ep=t, as_numpy=False, write_back=True)
+            self.mac.select_actions_ippo(self.batch, t_ep=t, as_numpy=False, write_back=True, q_noise=None if q_all is None else q_all[t])
             if terminated.any():                 # envs that terminated earlier store action 0 (action2env_tuple, :81-83, 177-180)
                 dead = torch.as_tensor(np.flatnonzero(terminated), device=dev)
                 D("actions")[dead, t] = 0
@@ -171,6 +175,10 @@ class ParallelRunner:
                 self.env_steps_this_run += int((1 - terminated).sum())
             if terminated.all():
                 self.host_seconds += time.perf_counter() - t0
+                # the reference breaks before it stores the step's new GRU states (:212-214 vs :253-266); the fused launch
+                # above has already written them at t + 1
+                D("rnn_states_actors")[:, t + 1].zero_()
+                D("rnn_states_critics")[:, t + 1].zero_()
                 break
             hw.obs_history_create(obs)
             single = hw.obs_single_history_output()
@@ -183,10 +191,10 @@ class ParallelRunner:
                 enc = self.behavior_learner.latent_update(self._to_dev("window", window, torch.float32), eh[t & 1], D("behavior_latent")[:, t],
                                                           out_latent=D("behavior_latent")[:, t + 1], out_hidden=eh[(t + 1) & 1][:, 0], launch=False)
                 self.prediction_learner.GAT_latent_update(D("history")[:, t + 1], D("attention_latent")[:, t], D("behavior_latent")[:, t],
-                                                          out=D("attention_latent")[:, t + 1], fuse_enc=enc)
+                                                          out=D("attention_latent")[:, t + 1], fuse_enc=enc, noise=None if noise is None else noise[t])
             elif a.GAT_enable:
                 self.prediction_learner.GAT_latent_update(D("history")[:, t + 1], D("attention_latent")[:, t], D("behavior_latent")[:, t],
-                                                          out=D("attention_latent")[:, t + 1])
+                                                          out=D("attention_latent")[:, t + 1], noise=None if noise is None else noise[t])
             elif a.Behavior_enable:
                 self.behavior_learner.latent_update(self._to_dev("window", window, torch.float32), eh[t & 1], D("behavior_latent")[:, t],
                                                     out_latent=D("behavior_latent")[:, t + 1], out_hidden=eh[(t + 1) & 1][:, 0])
@@ -199,6 +207,10 @@ class ParallelRunner:
             self.t += 1
             D("filled")[:, self.t] = 1
             alive = np.flatnonzero(~terminated)
+        if dev.type == "cuda":
+            # the last step's host -> device copies read the pinned staging buffers asynchronously and nothing after them
+            # synchronises: the next run()'s reset() would overwrite 'single' / 'state' / 'obs' while they are in flight
+            torch.cuda.current_stream(dev).synchronize()
         avg_win_rates, avg_rwd, avg_len = np.mean(episode_wins, axis=0), np.mean(episode_returns, axis=0), np.mean(episode_lengths, axis=0)
         if not test_mode:
             self.t_env += self.env_steps_this_run

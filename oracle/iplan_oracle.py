@@ -279,31 +279,48 @@ def layer_norm(x, w, b, eps=1e-5):
     return (x - mu) / torch.sqrt(var + eps) * w + b
 
 
-def ac_trunk(p, x, h):
+RELU_HINT_LOG = []      # one entry per hinted ReLU evaluation: (units within delta of the kink, of those: branch taken from the hint differs)
+
+
+def _relu_hinted(z, hint, delta):
+    """ReLU whose branch at units within ``delta * max|z|`` of the kink is taken from ``hint`` (bool, same shape): at z = 0 both
+    one-sided derivatives are valid, and an fp32 forward pass whose pre-activation differs from this one by a rounding error
+    may sit on the other side.  The parity tests hand in the branch the implementation under test took (its saved
+    activation > 0) so that a gradient is compared on the SAME branch; everywhere else the hint is ignored."""
+    if hint is None:
+        return torch.relu(z)
+    own = z.detach() > 0
+    amb = z.detach().abs() <= delta * z.detach().abs().max()
+    RELU_HINT_LOG.append((int(amb.sum()), int((amb & (hint != own)).sum())))
+    return z * torch.where(amb, hint, own).to(z.dtype)
+
+
+def ac_trunk(p, x, h, relu_hint=None, hint_delta=1e-5):
     """MLPBase (mlp.py:44-52, 24-28; layer_N = 1) + RNNLayer (rnn.py:24-27,77).
-    x [R,F], h [R,M] -> (features [R,M], h' [R,M])."""
+    x [R,F], h [R,M] -> (features [R,M], h' [R,M]).  ``relu_hint`` = (fc1 branch, fc2 branch): see _relu_hinted."""
+    h1, h2 = relu_hint if relu_hint is not None else (None, None)
     f = layer_norm(x, p["base.feature_norm.weight"], p["base.feature_norm.bias"])
-    f = torch.relu(f @ p["base.mlp.fc1.0.weight"].t() + p["base.mlp.fc1.0.bias"])
+    f = _relu_hinted(f @ p["base.mlp.fc1.0.weight"].t() + p["base.mlp.fc1.0.bias"], h1, hint_delta)
     f = layer_norm(f, p["base.mlp.fc1.2.weight"], p["base.mlp.fc1.2.bias"])
-    f = torch.relu(f @ p["base.mlp.fc2.0.0.weight"].t() + p["base.mlp.fc2.0.0.bias"])
+    f = _relu_hinted(f @ p["base.mlp.fc2.0.0.weight"].t() + p["base.mlp.fc2.0.0.bias"], h2, hint_delta)
     f = layer_norm(f, p["base.mlp.fc2.0.2.weight"], p["base.mlp.fc2.0.2.bias"])
     hn = gru_cell(f, h, p["rnn.rnn.weight_ih_l0"], p["rnn.rnn.weight_hh_l0"],
                   p["rnn.rnn.bias_ih_l0"], p["rnn.rnn.bias_hh_l0"])
     return layer_norm(hn, p["rnn.norm.weight"], p["rnn.norm.bias"]), hn
 
 
-def actor_logits(p, x, h, avail=None):
-    f, hn = ac_trunk(p, x, h)
+def actor_logits(p, x, h, avail=None, relu_hint=None):
+    f, hn = ac_trunk(p, x, h, relu_hint)
     logits = f @ p["act.action_out.linear.weight"].t() + p["act.action_out.linear.bias"]
     if avail is not None:
         logits = torch.where(avail == 0, torch.full_like(logits, -1e10), logits)   # distributions.py:66-67
     return logits, hn
 
 
-def actor_evaluate(p, x, h, actions, avail=None):
+def actor_evaluate(p, x, h, actions, avail=None, relu_hint=None):
     """R_Actor.evaluate_actions (ippo_actor.py:74-102, act.py:159-164):
     -> (logp [R,1], entropy scalar = unmasked mean over rows)."""
-    logits, _ = actor_logits(p, x, h, avail)
+    logits, _ = actor_logits(p, x, h, avail, relu_hint)
     logp_all = torch.log_softmax(logits, dim=-1)
     logp = logp_all.gather(-1, actions.long().reshape(-1, 1))
     pr = logp_all.exp()
@@ -311,9 +328,9 @@ def actor_evaluate(p, x, h, actions, avail=None):
     return logp, ent
 
 
-def critic_value(p, x, h):
+def critic_value(p, x, h, relu_hint=None):
     """R_Critic.forward (ippo_critic.py:47-65); PopArt.forward is a plain Linear (popart.py:41-46)."""
-    f, hn = ac_trunk(p, x, h)
+    f, hn = ac_trunk(p, x, h, relu_hint)
     return f @ p["v_out.weight"].t() + p["v_out.bias"], hn
 
 
@@ -492,11 +509,20 @@ def behavior_fc_learn_loss(enc_p, dec_p, history, L):
 #     normalisation -> ppo_epoch x (evaluate, losses, clip, Adam) on the first batch_size * T rows.
 #     num_mini_batch == 1: every epoch is a full-batch step, so the randperm order does not matter.
 # ----------------------------------------------------------------------------------------------
-def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_index_lists=None):
+def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_index_lists=None, probe_last_step=None,
+                    probe_relu_hint=None):
     """fields: dict of [E, T+1, nA, ...] episode tensors (the buffer content).  actor_p / critic_p: dicts of leaf
     tensors with requires_grad (updated IN PLACE by Adam).  ``row_index_lists``: optional list (per epoch) of lists of
     row-index tensors (minibatches, generate_data :368-424); default = one minibatch with the first ``rows`` rows.
-    Returns dict(returns, adv, old_logp, values_all, stats per epoch)."""
+    ``probe_last_step`` = (actor params, critic params) dicts: BEFORE the last optimiser step the clipped gradients of that
+    step's minibatch are also evaluated AT these parameters (old log-probs / advantages / returns still those of the
+    pre-train parameters, as in the reference) and returned as ``probe_grads`` -- the parity tests hand in the parameters
+    the implementation under test actually held before its last step, so that a multi-step gradient is compared at ONE
+    parameter point instead of across two trajectories that Adam's sign-like first steps have already separated.
+    ``probe_relu_hint`` = ((actor fc1, fc2 branches), (critic fc1, fc2 branches)), bool [rows of the last minibatch, M]: the
+    ReLU branches the implementation took in that step's forward pass, used by the probe evaluation at units within fp32
+    rounding of the kink only (_relu_hinted).
+    Returns dict(returns, adv, old_logp, values_all, stats per epoch[, probe_grads])."""
     f, i = fields, agent_id
     gat, behv = args.GAT_enable, args.Behavior_enable
     E, T1 = f["history"].shape[:2]
@@ -525,19 +551,35 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
     vs = [{k: torch.zeros_like(v) for k, v in prm.items()} for prm in (actor_p, critic_p)]
     steps = [0, 0]
     stats = []
+    loss_kw = {k: getattr(args, k, True) for k in ("use_huber_loss", "use_clipped_value_loss", "use_value_active_masks", "use_policy_active_masks")}
+
+    def objectives(ap, cp, sl, hints=(None, None)):
+        logp, ent = actor_evaluate(ap, x[sl], ha[sl], acts[sl], avail[sl], relu_hint=hints[0])
+        val, _ = critic_value(cp, x[sl], hc[sl], relu_hint=hints[1])
+        return ppo_losses(logp, ent, val, old_logp[sl], adv.reshape(-1, 1)[sl], v_all[:, :-1].reshape(-1, 1)[sl],
+                          rets.reshape(-1, 1)[sl], masks_all[:, :-1].reshape(-1, 1)[sl],
+                          args.clip_param, args.huber_delta, args.entropy_coef, args.value_loss_coef, **loss_kw) + (ent,)
+
+    probe_grads = None
+    n_steps = sum(len([slice(0, rows)] if row_index_lists is None else row_index_lists[ep]) for ep in range(args.ppo_epoch))
     for ep in range(args.ppo_epoch):
         batches = [slice(0, rows)] if row_index_lists is None else row_index_lists[ep]
         for sl in batches:
+            if probe_last_step is not None and steps[0] == n_steps - 1:
+                pa, pc = ({k: (v.detach().to(dt) if v.is_floating_point() else v.detach()).clone().requires_grad_(v.is_floating_point())
+                           for k, v in src.items()} for src in probe_last_step)
+                a_obj, _, c_obj, _, _, _ = objectives(pa, pc, sl, probe_relu_hint if probe_relu_hint is not None else (None, None))
+                a_obj.backward()
+                c_obj.backward()
+                probe_grads = []
+                for prm in (pa, pc):
+                    trainable = [k for k in prm if prm[k].grad is not None]
+                    clip_grad_norm([prm[k].grad for k in trainable], args.max_grad_norm)
+                    probe_grads.append({k: prm[k].grad for k in trainable})
             for prm in (actor_p, critic_p):
                 for v in prm.values():
                     v.grad = None
-            logp, ent = actor_evaluate(actor_p, x[sl], ha[sl], acts[sl], avail[sl])
-            val, _ = critic_value(critic_p, x[sl], hc[sl])
-            a_obj, pol, c_obj, vl, ratio = ppo_losses(
-                logp, ent, val, old_logp[sl], adv.reshape(-1, 1)[sl], v_all[:, :-1].reshape(-1, 1)[sl],
-                rets.reshape(-1, 1)[sl], masks_all[:, :-1].reshape(-1, 1)[sl],
-                args.clip_param, args.huber_delta, args.entropy_coef, args.value_loss_coef,
-                **{k: getattr(args, k, True) for k in ("use_huber_loss", "use_clipped_value_loss", "use_value_active_masks", "use_policy_active_masks")})
+            a_obj, pol, c_obj, vl, ratio, ent = objectives(actor_p, critic_p, sl)
             a_obj.backward()
             c_obj.backward()
             norms = []
@@ -551,7 +593,7 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
                                   args.lr if gi == 0 else args.critic_lr, args.optim_eps)
             stats.append(dict(policy_loss=float(pol.detach()), value_loss=float(vl.detach()), entropy=float(ent.detach()), ratio=float(ratio.detach().mean()),
                               actor_grad_norm=norms[0], critic_grad_norm=norms[1]))
-    return dict(returns=rets, adv=adv, old_logp=old_logp, values_all=v_all, stats=stats)
+    return dict(returns=rets, adv=adv, old_logp=old_logp, values_all=v_all, stats=stats, probe_grads=probe_grads)
 
 
 # ----------------------------------------------------------------------------------------------

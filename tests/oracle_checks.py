@@ -201,16 +201,48 @@ def check_prediction_learn_vs_oracle(args, E, device, seed=0, tol=1e-5, post_tol
 
 
 # ------------------------------------------------------------------------------------------------ IPPOLearner.train
+def probe_dicts(learner, mac, pre, i):
+    """(actor, critic) state dicts of agent i as the learner held them before its last optimiser step"""
+    if not learner.probe_last_step:
+        return None
+    out = []
+    for snap, arena, sd in ((learner.last_step_params[0], mac.actor_arena, pre["actors"][i]),
+                            (learner.last_step_params[1], mac.critic_arena, pre["critics"][i])):
+        d = {k: v.clone() for k, v in sd.items()}
+        for k in arena.names:
+            n = int(torch.Size(arena.shapes[k]).numel())
+            d[k] = snap[i, arena.offsets[k]:arena.offsets[k] + n].view(arena.shapes[k]).detach().cpu().clone()
+        out.append(d)
+    return tuple(out)
+
+
 def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, terminated_p=0.15, also_fp32=True, agents=None,
-                              assert_grads=True):
-    """insert buffer_size episodes -> train() (ppo_epoch fused epochs) vs oracle.ppo_train_agent, every agent: clipped
-    gradients of the LAST epoch and the post-train parameters.
-    ``assert_grads=False`` (multi-epoch runs at full size): Adam's first steps are sign-like -- lr * g / (|g| + eps) per
-    ENTRY -- so an absolute gradient error of 1e-7 * max|g| on an entry 1000x smaller than the tensor's max moves that
-    weight's update by 1e-4 of lr, and the NEXT epoch's gradient (dominated by curvature x update when the zero-mean
-    advantages cancel the first-order term) inherits it: the fp32 reference itself sits 2e-4 from the fp64 result there
-    (logged as fp32_oracle_grad_vs_fp64).  The per-epoch arithmetic is pinned by the single-epoch run; multi-epoch runs
-    assert the post-train parameters and log the last epoch's gradient distance."""
+                              e32_factor=1.5, table=None, assert_grads=True):
+    """insert buffer_size episodes -> train() (ppo_epoch fused epochs x num_mini_batch steps) vs oracle.ppo_train_agent, every
+    agent: clipped gradients of the LAST optimiser step and the post-train parameters.
+
+    Gradients are compared AT ONE PARAMETER POINT.  With more than one optimiser step the last step's gradient is a function
+    of the parameters the earlier steps produced, and Adam's first steps are sign-like -- lr * g / (|g| + eps) per ENTRY with
+    eps = 1e-5 -- so two fp32 implementations whose first-step gradients agree to 1e-6 of the tensor's max already sit
+    ~1e-3 of a step apart on the entries with |g| <~ eps, and their SECOND gradients differ by that much whatever their
+    arithmetic (the fp32 reference itself sits 2.4e-4 from the fp64 trajectory at config 3, two epochs).  That distance
+    measures the conditioning of the trajectory, not the kernels.  So the learner keeps the parameters it held before its
+    last step (``probe_last_step``) and the oracle evaluates that step's gradient AT THEM, in fp64 (ground truth) and in
+    fp32 (= the reference's arithmetic, whose error e32 at the same point is logged): asserted
+    kernel <= max(tol, e32_factor * e32) per agent.  The trajectory distances are still logged (``*_trajectory``), and the
+    post-train parameters are asserted against the fp64 oracle's own trajectory as before.
+
+    And ON ONE BRANCH of every ReLU.  The two ReLUs of the trunk are kinks: a unit whose pre-activation lies within fp32
+    rounding of zero (|z| <= 1e-5 max|z|; the K = 2485 fc1 contraction carries ~2.6e-6 max|z| of fp32 error in any
+    implementation) may come out on either side, and both one-sided derivatives are valid.  At config 3 there are ~1.5 M
+    units per layer and net, a few dozen of them that close to zero in every forward pass; ONE flipped unit moves the
+    gradient of its layer and of everything below it by 4e-4 ... 1.6e-3 of the tensor's max where the row sum cancels
+    (profiles/r03a_ppo_grad_notes.md: found by bisection, the same build passes or fails with the last bit of the inputs).
+    The learner therefore also keeps the branches its forward pass took (``last_step_relu``) and the oracle's probe
+    evaluation takes the branch from there for the units inside that band -- nowhere else; how many units were in the band and
+    how many branches actually came from the hint is logged (``relu_units_near_kink`` / ``relu_branches_from_hint``).
+    ``table``: optional list that receives one row per (agent, net, tensor) for scripts/ppo_grad_error_table.py (which also
+    passes ``assert_grads=False`` to see every row of a failing case; the tests never do)."""
     from iplan_amd.controllers.dcntrl_controller import DcntrlMAC
     from iplan_amd.learners.ippo_learner import IPPOLearner
     args = SimpleNamespace(**dict(vars(args), use_cuda=(torch.device(device).type == "cuda")))
@@ -226,6 +258,8 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
     learner.insert_episode_batch(batch)
     assert learner.buffers[0].can_sample()
     torch.manual_seed(seed + 77)                               # generate_data's randperm draws (num_mini_batch > 1)
+    n_steps = args.ppo_epoch * max(1, args.num_mini_batch)
+    learner.probe_last_step = True                             # (a single step: the probe point is the pre-train parameters)
     learner.train(0)
     index_lists = None
     if args.num_mini_batch > 1:
@@ -234,33 +268,66 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
         mbs = rows // nmb
         perms = [[torch.randperm(rows) for _ in range(args.ppo_epoch)] for _ in range(args.n_agents)]   # the reference's order
         index_lists = [[[p[i * mbs:(i + 1) * mbs] for i in range(nmb)] for p in pa] for pa in perms]
-    worst = dict(grad=0.0, post=0.0, fp32_oracle_grad_vs_fp64=0.0, fp32_oracle_post_vs_fp64=0.0)
+    worst = dict(grad=0.0, post=0.0, fp32_oracle_grad_vs_fp64=0.0, fp32_oracle_post_vs_fp64=0.0,
+                 grad_vs_fp64_trajectory=0.0, fp32_oracle_grad_vs_fp64_trajectory=0.0)
     f64 = {k: (v.double() if v.is_floating_point() else v) for k, v in fields.items()}
+
+    def probe_of(i):
+        return probe_dicts(learner, mac, pre, i)
+
     for i in (range(args.n_agents) if agents is None else agents):
         # ground truth = the oracle in fp64; the fp32 oracle (= the reference's arithmetic) is run beside it (when
         # ``also_fp32``) to record how far the reference's own fp32 rounding sits from it
+        probe = probe_of(i)
+        hint = None
+        if probe is not None:                                    # [which][fc1 | fc2] -> bool [rows of the last step, M]
+            r1, r2 = learner.last_step_relu
+            hint = tuple((r1[w, i].cpu(), r2[w, i].cpu()) for w in range(2))
+        il = None if index_lists is None else index_lists[i]
         ap, cp = _req(pre["actors"][i], torch.float64), _req(pre["critics"][i], torch.float64)
-        O.ppo_train_agent(i, ap, cp, f64, args, row_index_lists=None if index_lists is None else index_lists[i])
+        O.RELU_HINT_LOG.clear()
+        r64 = O.ppo_train_agent(i, ap, cp, f64, args, row_index_lists=il, probe_last_step=probe, probe_relu_hint=hint)
+        worst["relu_units_near_kink"] = worst.get("relu_units_near_kink", 0) + sum(n for n, _ in O.RELU_HINT_LOG)
+        worst["relu_branches_from_hint"] = worst.get("relu_branches_from_hint", 0) + sum(n for _, n in O.RELU_HINT_LOG)
+        g64 = r64["probe_grads"] if probe is not None else [{k: p[k].grad for k in p if p[k].grad is not None} for p in (ap, cp)]
+        g32 = None
+        e32 = 0.0
         if also_fp32:
             a32, c32 = _req(pre["actors"][i]), _req(pre["critics"][i])
-            O.ppo_train_agent(i, a32, c32, fields, args, row_index_lists=None if index_lists is None else index_lists[i])
-            for p32, p64 in ((a32, ap), (c32, cp)):
+            r32 = O.ppo_train_agent(i, a32, c32, fields, args, row_index_lists=il, probe_last_step=probe, probe_relu_hint=hint)
+            g32 = r32["probe_grads"] if probe is not None else [{k: p[k].grad for k in p if p[k].grad is not None} for p in (a32, c32)]
+            for gi, (p32, p64) in enumerate(((a32, ap), (c32, cp))):
                 for k in p64:
                     if p64[k].grad is not None:
-                        worst["fp32_oracle_grad_vs_fp64"] = max(worst["fp32_oracle_grad_vs_fp64"], _grad_err(p32[k].grad, p64[k].grad))
+                        worst["fp32_oracle_grad_vs_fp64_trajectory"] = max(worst["fp32_oracle_grad_vs_fp64_trajectory"],
+                                                                           _grad_err(p32[k].grad, p64[k].grad))
+                        e32 = max(e32, _grad_err(g32[gi][k], g64[gi][k]))
                     worst["fp32_oracle_post_vs_fp64"] = max(worst["fp32_oracle_post_vs_fp64"], _rel(p32[k].detach(), p64[k].detach()))
-        gtol = max(tol, 4.0 * worst["fp32_oracle_grad_vs_fp64"])       # see the module docstring
+            worst["fp32_oracle_grad_vs_fp64"] = max(worst["fp32_oracle_grad_vs_fp64"], e32)
+        gtol = max(tol, e32_factor * e32)
         ptol = max(post_tol, 4.0 * worst["fp32_oracle_post_vs_fp64"])
-        for name, prm, arena, mods in (("actor", ap, mac.actor_arena, mac.agents), ("critic", cp, mac.critic_arena, mac.critics)):
+        import os as _os
+        if _os.environ.get("IPLAN_DUMP"):
+            torch.save(dict(probe=probe, g64=[{k: v.clone() for k, v in g.items()} for g in g64],
+                            kernel={k: mac.actor_arena.grad_of(i, k).detach().cpu().clone() for k in mac.actor_arena.names},
+                            old_logp=r64["old_logp"], adv=r64["adv"]), _os.environ["IPLAN_DUMP"])
+        for gi, (name, prm, arena, mods) in enumerate((("actor", ap, mac.actor_arena, mac.agents), ("critic", cp, mac.critic_arena, mac.critics))):
             sd = mods[i].state_dict()
             for k in prm:
-                if prm[k].grad is not None:
-                    e = _grad_err(arena.grad_of(i, k), prm[k].grad)
-                    worst["grad"] = max(worst["grad"], e)
-                    assert e <= gtol or not assert_grads, ("clipped grad (last epoch) vs fp64 oracle", name, i, k, e, gtol)
                 pe = _rel(sd[k], prm[k].detach())
+                if prm[k].grad is not None:
+                    got = arena.grad_of(i, k)
+                    e = _grad_err(got, g64[gi][k])
+                    et = _grad_err(got, prm[k].grad)
+                    worst["grad"] = max(worst["grad"], e)
+                    worst["grad_vs_fp64_trajectory"] = max(worst["grad_vs_fp64_trajectory"], et)
+                    if table is not None:
+                        table.append(dict(agent=i, net=name, tensor=k, gmax=float(g64[gi][k].abs().max()), kernel=e,
+                                          fp32_oracle=None if g32 is None else _grad_err(g32[gi][k], g64[gi][k]),
+                                          kernel_vs_trajectory=et, post=pe))
+                    assert e <= gtol or not assert_grads, ("clipped grad (last step, at the learner's own parameters) vs fp64 oracle", name, i, k, e, gtol)
                 worst["post"] = max(worst["post"], pe)
-                assert pe <= ptol, ("post", name, i, k, pe, ptol)
+                assert pe <= ptol or not assert_grads, ("post", name, i, k, pe, ptol)
     return worst
 
 
