@@ -26,7 +26,10 @@ class ParamArena:
             off += (v.numel() + 3) // 4 * 4           # keep every tensor 16-byte aligned
         self.size = off
         self.trainable = {k: v.requires_grad for k, v in named}
-        self.version = 0          # bumped by every KERNEL-side write to ``data`` (Adam, collectives); torch-side writes bump data._version
+        # bumped by every KERNEL-side write to ``data`` (Adam, collectives), by load_state_dict and by touch().  Torch-side
+        # in-place writes through a Parameter bump THAT Parameter's ``_version`` (``p.data = view`` below gives it its own
+        # counter, not the arena tensor's): derived caches (ops.Fc1Pack) watch both
+        self.version = 0
         self.data = torch.zeros(self.n_nets, self.size, dtype=torch.float32, device=device)
         self.grad = torch.zeros_like(self.data)
         for i, m in enumerate(self.modules):
@@ -40,6 +43,10 @@ class ParamArena:
             m.register_load_state_dict_post_hook(lambda module, incompatible_keys: self._bump())
 
     def _bump(self):
+        self.version += 1
+
+    def touch(self):
+        """Tell derived caches that ``data`` was written through a path they cannot see (``p.data.mul_()``, a raw pointer)."""
         self.version += 1
 
     @property

@@ -275,14 +275,24 @@ class _Packed(tuple):
 
 class Fc1Pack:
     """fc1.weight + feature_norm.{weight, bias} of the actor and critic arenas in the forward kernels' own K order and MFMA
-    fragment order (iplan_ac_pack_fc1).  ``get(spec)`` repacks only when an arena changed since the last pack (torch-side
-    writes bump ``arena.data._version``, kernel-side writes -- Adam -- bump ``arena.version``) or the feature layout differs.
+    fragment order (iplan_ac_pack_fc1).  ``get(spec)`` repacks only when an arena changed since the last pack or the feature
+    layout differs.  What counts as "changed" (the staleness key):
+      * ``arena.version`` -- bumped by every kernel-side write (FusedAdam, DataParallel.broadcast_arena), by the modules'
+        ``load_state_dict`` hook and by ``arena.touch()``;
+      * the sum of ``p._version`` over the packed Parameters of all nets -- in-place writes THROUGH a Parameter (``p.add_()``,
+        ``p.copy_()``, ``nn.init.*`` under no_grad, a torch.optim optimiser on ``mac.parameters()``) bump it.  The Parameters are
+        bound to the arena with ``p.data = view``, which does NOT share the arena tensor's version counter, so
+        ``arena.data._version`` says nothing about them;
+      * ``arena.data._version`` -- writes on the arena tensor itself.
+    A write through a detached alias (``p.data.mul_()``, a raw pointer) is invisible to all three: call ``arena.touch()``.
     ``fold=True`` also brings W gamma / W beta up to date (the rollout's folded LayerNorm(F) reads them; the streaming
     forward of a PPO epoch does not, and a repack after each of its 30 Adam steps would spend more on them than on the
     fragments)."""
 
     def __init__(self, actor_arena, critic_arena):
         self.arenas = (actor_arena, critic_arena)
+        names = ("base.mlp.fc1.0.weight", "base.feature_norm.weight", "base.feature_norm.bias")
+        self.watched = [[dict(m.named_parameters())[n] for m in arena.modules for n in names] for arena in self.arenas]
         self.buf = [None, None]
         self.key = [[None, None], [None, None]]             # per arena: key of the fragment part, of the W gamma / W beta part
 
@@ -295,7 +305,7 @@ class Fc1Pack:
         floats = int(lib.c.iplan_ac_packed_floats(C.byref(a.feat)))
         sig = (spec.N, tuple(s[1] for s in spec.sources), spec.n_actions, spec.n_id)
         for k, (arena, order) in enumerate(zip(self.arenas, (L.ACTOR_PARAM_ORDER, L.CRITIC_PARAM_ORDER))):
-            key = (arena.data._version, arena.version, sig)
+            key = (arena.data._version, arena.version, sum(p._version for p in self.watched[k]), sig)
             if self.buf[k] is None or self.buf[k].shape[1] != floats:
                 self.buf[k] = torch.empty(arena.n_nets, floats, dtype=torch.float32, device=arena.data.device)
                 self.key[k] = [None, None]

@@ -156,7 +156,8 @@ class DataParallel:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.backend = dist.get_backend(group)
-        self.p2p = None                                      # P2PAllReduce, built on first use when IPLAN_P2P_ALLREDUCE=1
+        self.p2p = None                                      # P2PAllReduce, built on first use
+        self.use_p2p = bool(os.environ.get("IPLAN_P2P_ALLREDUCE"))   # opt-in: one-shot peer-to-peer all-reduce for the gradient arenas
 
     def _via_host(self, tensor):
         """gloo process groups (CPU tests; the two-processes-on-one-GPU test, where RCCL refuses the duplicate device) move
@@ -205,7 +206,7 @@ class DataParallel:
     def all_reduce_grads(self, *arenas):
         """Sum the gradient arenas over the ranks (the local losses are already scaled by the global normalisers): one
         collective per arena, in place."""
-        if os.environ.get("IPLAN_P2P_ALLREDUCE") and self.world > 1 and arenas and arenas[0].grad.is_cuda:
+        if self.use_p2p and self.world > 1 and arenas and arenas[0].grad.is_cuda:
             if self.p2p is None:
                 def exchange(obj):
                     out = [None] * self.world
