@@ -18,6 +18,8 @@
 //   beh_enc_bwd  BPTT of the encoder with its weight gradients accumulated IN the kernel (H = 32: the
 //                24 accumulator tiles fit in registers; operands are turned through LDS each step)
 // hidden states and the latent are carried from window to window in registers (D layout of wave_tile.h).
+#include <cstdlib>
+
 #include "api_util.h"
 #include "gru_tile.h"
 
@@ -1014,6 +1016,479 @@ __global__ __launch_bounds__(256) void beh_enc_grad_kernel(IplanBehArgs a) {
     *dst = a.enc_grad_beta != 0.f ? fmaf(a.enc_grad_beta, *dst, s) : s;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Decoder forward, SECOND FORM (round 3; opt-in, IPLAN_DEC_FWD_V2=1: see iplan_beh_fwd for why the first form stays the default).
+//
+// The first form is bound by fp32-MFMA + VALU issue (v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate and takes the VALU's
+// slots: 416 of them per tile-step) and by LDS operand delivery (a weight fragment read from LDS serves 16 chains).  Here
+//  * every contraction of the GRU runs in the fp32-exact split-bf16 form (wave_tile.h) on the bf16 matrix cores, and EVERY weight
+//    piece is a loop invariant in registers -- possible because the work of a chain tile is split over EIGHT waves by
+//    (hidden quarter q) x (matrix): wave B_q owns the rows (r_q, z_q, n_q) of W_hh (72 piece registers), wave A_q the same rows
+//    of W_ih; a 512-thread workgroup = 4 B-waves + 4 A-waves, B_q and A_q on the same SIMD, and carries D2_TILES = 3 chain tiles
+//    that every wave walks one after the other (three independent chains of work per wave);
+//  * the input projection  gi_t = W_ih u_t + b  does not depend on the hidden state: the A-waves run AHEAD of the recurrence
+//    (a 2-slot ring per (tile, quarter) in LDS, the result lands as the initial accumulator of B_q's chain), so the recurrent
+//    critical path of a step is 36 bf16 MFMAs + the gate arithmetic + one exchange of the new hidden quarter's bf16 pieces;
+//  * nothing is lock-stepped: every hand-off (u pieces among the A-waves, h pieces among the B-waves, gi from A_q to B_q, output
+//    partials from the B-waves to the A-wave that owns the tile's output / loss work) is a monotonic counter in LDS, double
+//    buffered so that no second rendezvous is needed.  While B_q waits it sleeps and A_q has the SIMD.
+// Same arithmetic results as the first form up to fp32 round-off of the split products (< 2^-26 per product); same records.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int D2_TILES = 3, D2_THREADS = 512, D2_LAG = 2;
+constexpr int D2_GI = D2_TILES * 4 * 2 * 3 * 256;          // floats: [tile][q][slot][gate][64 lanes x f32x4]
+constexpr int D2_HX = D2_TILES * 2 * 2 * 3 * 256;          //         [tile][parity][k-chunk][piece][64 lanes x bf16x8]
+constexpr int D2_UX = D2_HX;
+constexpr int D2_YX = D2_TILES * 2 * 4 * 128;              //         [tile][parity][q][32 lanes x f32x4]  (outputs 0..7: d <= 8)
+constexpr int D2_CNT_INTS = 16;                            // hcnt | ucnt | ycnt | rcnt | gcnt[4] | bcnt[4] | pad
+constexpr int D2_MAX_WINDOWS = 512;                        // per-window loss normalisers of a launch (floats)
+constexpr int D2_LDS_FLOATS = D2_GI + D2_HX + D2_UX + D2_YX + D2_CNT_INTS + D2_MAX_WINDOWS;
+
+#ifdef IPLAN_HOST_EMULATION
+__device__ inline void d2_signal(int* c) { IPLAN_WAVE_SYNC(); if (lane_id() == 0) *c += 1; }
+__device__ inline void d2_wait(const int* c, int target) { while (*reinterpret_cast<const volatile int*>(c) < target) iplan_emu::yield_(); }
+#else
+__device__ __forceinline__ void d2_signal(int* c) {        // (a wave's LDS operations execute in order: the data is there before the count)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63u) == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void d2_wait(const int* c, int target) {
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+#endif
+
+// the three bf16 pieces of a lane's 4 values of ONE 16-tile (half of a K = 32 operand): x = p0 + p1 + p2 exactly
+__device__ __forceinline__ void split_bf3_half(f32x4 v, bf16x4& p0, bf16x4& p1, bf16x4& p2) {
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 b0 = (__bf16)v[j];
+        const float r1 = v[j] - (float)b0;
+        const __bf16 b1 = (__bf16)r1;
+        p0[j] = b0; p1[j] = b1; p2[j] = (__bf16)(r1 - (float)b1);
+    }
+}
+// 36 MFMAs: acc[gate] += W[gate][chunk] . x[chunk] for 3 gate tiles x 2 k-chunks x 6 piece products, smallest products first,
+// the three accumulator chains issued round-robin
+__device__ __forceinline__ void d2_contract(const Bf3 (&W)[3][2], const Bf3 (&x)[2], f32x4 (&acc)[3]) {
+#define D2_ROUND(WP, XP)                     \
+    for (int cc = 0; cc < 2; ++cc)           \
+        for (int gt = 0; gt < 3; ++gt) acc[gt] = mfma_bf16(W[gt][cc].WP, x[cc].XP, acc[gt]);
+    D2_ROUND(p2, p0) D2_ROUND(p0, p2) D2_ROUND(p1, p1) D2_ROUND(p1, p0) D2_ROUND(p0, p1) D2_ROUND(p0, p0)
+#undef D2_ROUND
+}
+
+#ifndef D2_ABL
+#define D2_ABL 0                        // timing ablations (results WRONG): 1 no B-wave record stores, 2 no A-wave record stores
+#endif
+// -DD2_CLOCKS: cycle accounting of wave B_0 / A_0 of workgroup (0, 0) per step segment (diagnostic builds only; read back with
+// iplan_debug_d2_clocks).  s_memtime waits for the wave's LDS operations, so the instrumented kernel is slower than the plain one.
+#if defined(D2_CLOCKS) && !defined(IPLAN_HOST_EMULATION)
+__device__ long long g_d2_clk[32];
+#define D2_CLK_DECL(n) long long clk_acc[n]; for (int ci = 0; ci < n; ++ci) clk_acc[ci] = 0; long long clk_last = __builtin_amdgcn_s_memtime(); const bool clk_on = blockIdx.x == 0 && blockIdx.y == 0 && q == 0
+#define D2_CLK(i) do { if (clk_on) { const long long now = __builtin_amdgcn_s_memtime(); clk_acc[i] += now - clk_last; clk_last = now; } } while (0)
+#define D2_CLK_OUT(base, n) do { if (clk_on && l == 0) for (int ci = 0; ci < n; ++ci) g_d2_clk[base + ci] = clk_acc[ci]; } while (0)
+#else
+#define D2_CLK_DECL(n) do {} while (0)
+#define D2_CLK(i) do {} while (0)
+#define D2_CLK_OUT(base, n) do {} while (0)
+#endif
+
+// Global loads of the A-waves.  vmcnt counts loads AND stores, in order, and the compiler's wait-count pass gives up on exact
+// counts as soon as control flow lies between a load and its use (here: the spin loops of the LDS counters and the owner's
+// conditional output work): the loop-carried prefetch of the next step's inputs came back as `s_waitcnt vmcnt(0)` at the top of
+// every step -- a full drain, the wave's own record stores of the previous step included (5.3 of the kernel's 5.5 ms were
+// spent like that).  So these loads are issued from inline asm (the compiler then inserts no wait for them), and the code
+// waits by hand: D2_VM_WINDOW is smaller than the number of vector-memory operations any A-wave issues between a prefetch and
+// its use WHEN ALL THREE TILES EXIST (>= 19: the wave that owns no tile's output; owners 29-32), so `vmcnt(D2_VM_WINDOW)` leaves
+// the latest stores and prefetches in flight and still covers the loads about to be consumed; workgroups with fewer tiles
+// (the last one of a net) drain completely.  NO compiler-visible load may be issued while such
+// loads are in flight (its computed wait count would not include them): the A-waves' step loop has none.
+constexpr int D2_VM_WINDOW = 16;
+#ifdef IPLAN_HOST_EMULATION
+__device__ inline void d2_gload(float& dst, const char* sbase, uint32_t voff) { dst = *reinterpret_cast<const float*>(sbase + voff); }
+__device__ inline const char* d2_ubase(const char* p) { return p; }
+template <int WINDOW> __device__ inline void d2_landed(float (&)[4], float (&)[4]) {}
+template <int WINDOW> __device__ inline void d2_landed(float (&)[4], float (&)[4], float&) {}
+__device__ inline void d2_drain_vm() {}
+#else
+__device__ __forceinline__ void d2_gload(float& dst, const char* sbase, uint32_t voff) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+// a wave-uniform base address the compiler keeps in VGPRs (it cannot prove it uniform) -> SGPR pair.  v_readfirstlane is a VALU
+// write of an SGPR; a vector-memory instruction that reads it as its address needs 5 wait states behind it, and nothing pads
+// inside or around inline asm (guide 5.7): the s_nop stands between the pair and the loads that use it.
+__device__ __forceinline__ const char* d2_ubase(const char* p) {
+    const uint64_t b = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    const char* u = reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+    asm volatile("s_nop 4" : "+s"(u));
+    return u;
+}
+template <int WINDOW> __device__ __forceinline__ void d2_landed(float (&a)[4], float (&b)[4]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(WINDOW) : "memory");
+}
+template <int WINDOW> __device__ __forceinline__ void d2_landed(float (&a)[4], float (&b)[4], float& m) {
+    asm volatile("s_waitcnt vmcnt(%9)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(m) : "n"(WINDOW) : "memory");
+}
+__device__ __forceinline__ void d2_drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+
+// what every wave of the workgroup knows (uniform unless noted)
+struct D2Ctx {
+    float *s_gi, *s_hx, *s_ux, *s_yx, *s_scale;
+    int *hcnt, *ucnt, *ycnt, *rcnt, *gcnt, *bcnt;            // gcnt / bcnt: this wave's quarter
+    int q, l, n, g, net, J, Lw, j_lo, j_hi, steps, YL, n_live;
+    int64_t steps_per_chain;
+    const float* PD;
+};
+// piece exchange slots: writer = the quarter that owns 16-tile q of the vector (half of k-chunk q >> 1), reader = everyone
+__device__ __forceinline__ void d2_px_write(const D2Ctx& x, float* base, int k, int par, f32x4 v) {
+    bf16x4 p0, p1, p2;
+    split_bf3_half(v, p0, p1, p2);
+    char* slot = reinterpret_cast<char*>(base + ((k * 2 + par) * 2 + (x.q >> 1)) * 3 * 256) + 16 * x.l + 8 * (x.q & 1);
+    *reinterpret_cast<bf16x4*>(slot) = p0;
+    *reinterpret_cast<bf16x4*>(slot + 1024) = p1;
+    *reinterpret_cast<bf16x4*>(slot + 2048) = p2;
+}
+__device__ __forceinline__ void d2_px_read(const D2Ctx& x, const float* base, int k, int par, Bf3 (&v)[2]) {
+    for (int cc = 0; cc < 2; ++cc) {
+        const char* slot = reinterpret_cast<const char*>(base + ((k * 2 + par) * 2 + cc) * 3 * 256) + 16 * x.l;
+        v[cc].p0 = *reinterpret_cast<const bf16x8*>(slot);
+        v[cc].p1 = *reinterpret_cast<const bf16x8*>(slot + 1024);
+        v[cc].p2 = *reinterpret_cast<const bf16x8*>(slot + 2048);
+    }
+}
+__device__ __forceinline__ f32x4* d2_gi_slot(const D2Ctx& x, int k, int slot, int gate) {
+    return reinterpret_cast<f32x4*>(x.s_gi + (((k * 4 + x.q) * 2 + slot) * 3 + gate) * 256) + x.l;
+}
+__device__ __forceinline__ char* d2_sd_base(const IplanBehArgs& a, const D2Ctx& x, const DecTile& ct) {
+    return reinterpret_cast<char*>(a.saved_dec + ct.grow0 * x.steps_per_chain * SVD);
+}
+__device__ __forceinline__ uint32_t d2_sd_off(const D2Ctx& x, int step) {
+    return (uint32_t)((int64_t)x.n * x.steps_per_chain * SVD * 4) + 16u * (uint32_t)x.g + (uint32_t)((int64_t)step * SVD * 4);
+}
+
+// ---- B_q: the recurrence.  FAST = all three tiles exist and are full: no predication, no branch around any memory operation
+// (a branch around a load or a store makes the compiler drain the wait counters at its join).
+template <bool FAST>
+__device__ __forceinline__ void d2_recurrent(const IplanBehArgs& a, const D2Ctx& x, const DecTile (&c)[D2_TILES]) {
+    const int q = x.q, l = x.l, g = x.g, net = x.net, Lw = x.Lw;
+    (void)g;
+    const float* Whh = x.PD + a.dec_off[IPLAN_DEC_WHH];
+    Bf3 W[3][2];
+    for (int gt = 0; gt < 3; ++gt)
+        for (int cc = 0; cc < 2; ++cc) W[gt][cc] = wfrag_bf3(Whh, DHd, 3 * DHd, gt * DHd + 16 * q, 32 * cc);
+    const f32x4 bhn = bfrag_a(x.PD + a.dec_off[IPLAN_DEC_BHH], 2 * DT + q);
+    const f32x4 wout = wfrag(x.PD + a.dec_off[IPLAN_DEC_OUT_W], DHd, a.d, DHd, 0, 16 * q);        // W_out[m][16 q + 4 g ..]: rows = outputs
+    const f32x4 bout = q ? splat4(0.f) : bfrag(x.PD + a.dec_off[IPLAN_DEC_OUT_B], a.d, 0);
+    const float inv_keep = 1.0f / (1.0f - a.drop_p);
+    f32x4 hq[D2_TILES];
+#pragma unroll
+    for (int k = 0; k < D2_TILES; ++k) {
+        hq[k] = splat4(0.f);
+        if (!FAST && !c[k].live) continue;
+        if (x.j_lo > 0 && a.dec_carry)
+            hq[k] = *reinterpret_cast<const f32x4*>(a.dec_carry + ((int64_t)net * c[k].tiles + c[k].tile) * 1024 + 256 * q + 4 * l);
+        d2_px_write(x, x.s_hx, k, 1, hq[k]);                                         // h_{-1}: parity of step -1
+    }
+    d2_signal(x.hcnt);
+    D2_CLK_DECL(8);
+    int j = x.j_lo, t = 0;
+    for (int s = 0; s < x.steps; ++s) {
+        const uint32_t so = d2_sd_off(x, j * Lw + t);
+        D2_CLK(7);
+        d2_wait(x.hcnt, 4 * (s + 1));
+        d2_wait(x.gcnt, s + 1);
+        D2_CLK(0);
+        f32x4 acc[D2_TILES][3], gin[D2_TILES];
+#pragma unroll
+        for (int k = 0; k < D2_TILES; ++k) {
+            if (!FAST && !c[k].live) continue;
+            Bf3 H[2];
+            d2_px_read(x, x.s_hx, k, (s + 1) & 1, H);
+            acc[k][0] = *d2_gi_slot(x, k, s & 1, 0);
+            acc[k][1] = *d2_gi_slot(x, k, s & 1, 1);
+            gin[k] = *d2_gi_slot(x, k, s & 1, 2);
+            acc[k][2] = bhn;
+            d2_contract(W, H, acc[k]);
+        }
+        D2_CLK(1);
+        d2_signal(x.bcnt);                                                           // the ring slots may be refilled
+        GruGates o[D2_TILES];
+#pragma unroll
+        for (int k = 0; k < D2_TILES; ++k) {
+            if (!FAST && !c[k].live) continue;
+            o[k] = gru_gates(acc[k][0], acc[k][1], gin[k], acc[k][2], hq[k]);
+            hq[k] = o[k].h;
+            d2_px_write(x, x.s_hx, k, s & 1, o[k].h);
+        }
+        d2_signal(x.hcnt);
+        D2_CLK(2);
+        f32x4 yp[D2_TILES];
+#pragma unroll
+        for (int k = 0; k < D2_TILES; ++k) {
+            if (!FAST && !c[k].live) continue;
+            const bool valid = FAST || c[k].valid;
+            char* sdb = d2_sd_base(a, x, c[k]);
+            if (!(D2_ABL & 1)) {
+                st4<FAST>(sdb, so + 4u * (SD_R + 16 * q), valid, o[k].r);
+                st4<FAST>(sdb, so + 4u * (SD_Z + 16 * q), valid, o[k].z);
+                st4<FAST>(sdb, so + 4u * (SD_N + 16 * q), valid, o[k].n);
+                st4<FAST>(sdb, so + 4u * (SD_HN + 16 * q), valid, o[k].hn);
+                st4<FAST>(sdb, so + 4u * (SD_H + 16 * q), valid, o[k].h);
+            }
+            const f32x4 km = keep_tile(a, net, j, c[k].row, t, q, valid, c[k].rows);
+            f32x4 act;
+            for (int i = 0; i < 4; ++i) act[i] = tanh_f(o[k].h[i]) * (km[i] * inv_keep);
+            if (!(D2_ABL & 1)) st4<FAST>(sdb, so + 4u * (SD_A + 16 * q), valid, act);
+            yp[k] = mma_block(wout, act, bout);                                      // own share of y = W_out act + b
+        }
+        D2_CLK(3);
+        if (s >= 2) d2_wait(x.rcnt, x.n_live * (s - 1));                              // the output slots of step s - 2 were consumed
+        D2_CLK(4);
+#pragma unroll
+        for (int k = 0; k < D2_TILES; ++k)
+            if ((FAST || c[k].live) && l < x.YL) *(reinterpret_cast<f32x4*>(x.s_yx + ((k * 2 + (s & 1)) * 4 + q) * 128) + l) = yp[k];
+        d2_signal(x.ycnt);
+        D2_CLK(5);
+        if (++t == Lw) { t = 0; ++j; }
+    }
+    D2_CLK_OUT(0, 8);
+#pragma unroll
+    for (int k = 0; k < D2_TILES; ++k)
+        if ((FAST || c[k].live) && x.j_hi < x.J && a.dec_carry)
+            *reinterpret_cast<f32x4*>(a.dec_carry + ((int64_t)net * c[k].tiles + c[k].tile) * 1024 + 256 * q + 4 * l) = hq[k];
+}
+
+// ---- A_q: input projection, running ahead of the recurrence; A_k (k < D2_TILES) also owns tile k's output / loss work.
+// Q0 = the wave that stores the Linear's input row of the record (compile-time: no branch around that store).
+template <bool FAST, bool Q0>
+__device__ __forceinline__ void d2_input(const IplanBehArgs& a, const D2Ctx& x, const DecTile (&c)[D2_TILES]) {
+    const int q = x.q, l = x.l, n = x.n, g = x.g, Lw = x.Lw, J = x.J, din = a.d + a.Z;
+    const float* Wih = x.PD + a.dec_off[IPLAN_DEC_WIH];
+    Bf3 W[3][2];
+    for (int gt = 0; gt < 3; ++gt)
+        for (int cc = 0; cc < 2; ++cc) W[gt][cc] = wfrag_bf3(Wih, DHd, 3 * DHd, gt * DHd + 16 * q, 32 * cc);
+    const float* bih = x.PD + a.dec_off[IPLAN_DEC_BIH];
+    const float* bhh = x.PD + a.dec_off[IPLAN_DEC_BHH];
+    const f32x4 b_r = bfrag_a(bih, q) + bfrag_a(bhh, q), b_z = bfrag_a(bih, DT + q) + bfrag_a(bhh, DT + q), b_n = bfrag_a(bih, 2 * DT + q);
+    const f32x4 wlin = wfrag(x.PD + a.dec_off[IPLAN_DEC_LIN_W], din, DHd, din, 16 * q, 0);        // W_lin[16 q + m][4 g ..] (cols < d + Z)
+    const f32x4 blin = bfrag_a(x.PD + a.dec_off[IPLAN_DEC_LIN_B], q);
+    // Everything read from global memory is fetched ONE STEP AHEAD and branch-free (consumed where it is loaded, every tile of
+    // every step would sit out an L2 / HBM round trip and the recurrence would starve on gi: first measurement of this kernel,
+    // 6.1 ms; with a uniform branch around the latent's fetch the compiler drained vmcnt at every join and the "prefetch"
+    // was waited for on the spot: 5.3 ms).  A lane's four entries of the Linear's input tile [x_t (d) | latent_j (Z) | 0] come
+    // from two rows; every address is a UNIFORM base that moves with the step / the window (scalar arithmetic only) plus a
+    // per-lane byte offset that never changes (clamped into the row), and what a lane has no use for is removed by
+    // loop-invariant bit masks where the value is consumed.
+    uint32_t hl[D2_TILES], lv[D2_TILES], vm[D2_TILES], cx[4], cz[4], mx[4], ml[4];
+    const char* latb[D2_TILES];
+    for (int i = 0; i < 4; ++i) {
+        const int col = 4 * g + i, zc = col - a.d;
+        mx[i] = col < a.d ? 0xFFFFFFFFu : 0u;
+        ml[i] = (zc >= 0 && zc < a.Z) ? 0xFFFFFFFFu : 0u;
+        cx[i] = 4u * (uint32_t)(col < a.d ? col : a.d - 1);
+        cz[i] = 4u * (uint32_t)(16 + (zc < 0 ? 0 : (zc < a.Z ? zc : a.Z - 1)));
+    }
+#pragma unroll
+    for (int k = 0; k < D2_TILES; ++k) {
+        const bool valid = FAST || c[k].valid;
+        vm[k] = valid ? 0xFFFFFFFFu : 0u;
+        latb[k] = reinterpret_cast<const char*>(a.saved_lat + c[k].grow0 * J * SVL);
+        hl[k] = valid ? c[k].hist_lane : 0u;
+        lv[k] = (uint32_t)(((int64_t)(valid ? n : 0) * J) * SVL * 4);
+    }
+    auto bits = [](float v) { return __builtin_bit_cast(uint32_t, v); };
+    auto x_fetch4 = [&](float (&v)[4], uint32_t lane_off, int st) {   // raw entries of history step max(st, 0) at the lane's offsets
+        const char* hb = d2_ubase(c[0].hist + (int64_t)(st < 0 ? 0 : st) * a.h_s_t * 4);
+        for (int i = 0; i < 4; ++i) d2_gload(v[i], hb, lane_off + cx[i]);
+    };
+    auto lat_fetch4 = [&](float (&v)[4], int k, int jj) {
+        const char* lb = d2_ubase(latb[k] + (int64_t)jj * (SVL * 4));
+        for (int i = 0; i < 4; ++i) d2_gload(v[i], lb, lv[k] + cz[i]);
+    };
+    auto x_keep = [&](const float (&v)[4], int st, uint32_t vmask) {     // zero what is not a real x entry of a real chain at a real step
+        const uint32_t sm = st >= 0 ? vmask : 0u;
+        f32x4 r;
+        for (int i = 0; i < 4; ++i) r[i] = __builtin_bit_cast(float, bits(v[i]) & mx[i] & sm);
+        return r;
+    };
+    // output / loss bookkeeping of the tile this wave owns (A_k <-> tile k)
+    const int ko = q < D2_TILES ? q : 0;
+    DecTile co = c[0];                                       // (selected, not indexed: a run-time index would put c[] into scratch)
+    if (q == 1) co = c[1];
+    if (q == 2) co = c[D2_TILES - 1];
+    const bool owner = q < D2_TILES && (FAST || co.live);
+    const bool ovalid = FAST || co.valid;
+    const uint32_t xoo = q == 1 ? hl[1] : (q == 2 ? hl[D2_TILES - 1] : hl[0]);
+    const uint32_t vmo = ovalid ? 0xFFFFFFFFu : 0u;
+    float beh = 0.f, stab = 0.f, err = 0.f;
+    struct YIn { float nx[4], xt[4], m, scale; };
+    auto y_fetch = [&](YIn& o, int jj, int tt) {             // targets / mask / window normaliser of step (jj, tt)
+        x_fetch4(o.nx, xoo, beh_y_step(a, jj, tt));
+        x_fetch4(o.xt, xoo, beh_x_step(a, jj, tt));
+        d2_gload(o.m, d2_ubase(co.mask), (ovalid ? co.mask_lane : 0u) + 4u * (uint32_t)beh_m_step(a, jj, tt));
+        o.scale = x.s_scale[jj - x.j_lo];
+    };
+    auto finish_y = [&](int s, int jj, int tt, YIn& in) {
+        d2_landed<FAST ? D2_VM_WINDOW : 0>(in.nx, in.xt, in.m);
+        d2_wait(x.ycnt, 4 * (s + 1));
+        f32x4 yq[4];
+        for (int i = 0; i < 4; ++i) {
+            yq[i] = splat4(0.f);
+            if (l < x.YL) yq[i] = *(reinterpret_cast<const f32x4*>(x.s_yx + ((ko * 2 + (s & 1)) * 4 + i) * 128) + l);
+        }
+        d2_signal(x.rcnt);
+        const f32x4 y = (yq[0] + yq[1]) + (yq[2] + yq[3]);
+        st4<FAST>(d2_sd_base(a, x, co), d2_sd_off(x, jj * Lw + tt) + 4u * SD_Y, ovalid, y);
+        const f32x4 nx = x_keep(in.nx, beh_y_step(a, jj, tt), vmo), xt = x_keep(in.xt, beh_x_step(a, jj, tt), vmo);
+        const float m = __builtin_bit_cast(float, bits(in.m) & vmo);
+        float d2 = 0.f;
+        for (int i = 0; i < 4; ++i) {                        // (nx, xt and the mask are zero beyond the d real columns: y is not)
+            const float yi = __builtin_bit_cast(float, bits(y[i]) & mx[i]);
+            err += fabsf(nx[i] - yi) * m;
+            const float df = xt[i] - yi;
+            d2 = fmaf(df, df, d2);
+        }
+        d2 = group_sum(d2);
+        stab += (ovalid && g == 0) ? fmaxf(sqrtf(d2) - a.thres, 0.f) : 0.f;
+        if (tt == Lw - 1) { beh = fmaf(err, in.scale, beh); err = 0.f; }
+    };
+    float xr[D2_TILES][4], lr[D2_TILES][4];
+    d2_drain_vm();                                           // every compiler-visible load (the weights) has landed: see d2_gload
+#pragma unroll
+    for (int k = 0; k < D2_TILES; ++k) {
+        x_fetch4(xr[k], hl[k], beh_x_step(a, x.j_lo, 0));
+        lat_fetch4(lr[k], k, x.j_lo);
+    }
+    YIn yin;
+    y_fetch(yin, x.j_lo, 0);
+    int j = x.j_lo, t = 0, jy = x.j_lo, ty = 0;               // (j, t) of step s; (jy, ty) of the next step whose output gets finished
+    D2_CLK_DECL(8);
+    for (int s = 0; s < x.steps; ++s) {
+        int jn = j, tn = t + 1;                              // the step fetched now (clamped to the launch's last step)
+        if (tn == Lw) { tn = 0; ++jn; }
+        if (s + 1 >= x.steps) { jn = j; tn = t; }
+        const uint32_t so = d2_sd_off(x, j * Lw + t);
+        f32x4 uk[D2_TILES], xk[D2_TILES];                    // record entries: stored BEHIND the step's gi hand-off (a store that
+        D2_CLK(7);                                           // waits for room in the memory pipeline must not hold up the recurrence)
+#pragma unroll
+        for (int k = 0; k < D2_TILES; ++k) {
+            if (!FAST && !c[k].live) continue;
+            f32x4 xin;                                       // [x_t | latent_j | 0]: the two sources occupy disjoint columns
+            d2_landed<FAST ? D2_VM_WINDOW : 0>(xr[k], lr[k]);
+            {
+                const uint32_t sm = beh_x_step(a, j, t) >= 0 ? vm[k] : 0u;
+                for (int i = 0; i < 4; ++i) xin[i] = __builtin_bit_cast(float, (bits(xr[k][i]) & mx[i] & sm) | (bits(lr[k][i]) & ml[i] & vm[k]));
+            }
+            x_fetch4(xr[k], hl[k], beh_x_step(a, jn, tn));
+            lat_fetch4(lr[k], k, jn);                        // (every step, not only at a window's end: no branch around a load)
+            const f32x4 u = relu4(mma_block(wlin, xin, blin));
+            uk[k] = u;
+            if (Q0) xk[k] = xin;
+            d2_px_write(x, x.s_ux, k, s & 1, u);
+        }
+        d2_signal(x.ucnt);
+        D2_CLK(0);
+        d2_wait(x.ucnt, 4 * (s + 1));
+        D2_CLK(1);
+        if (s >= 2) d2_wait(x.bcnt, s - 1);                                          // B_q has taken gi(s - 2) out of this ring slot
+        D2_CLK(3);                                                                   // (long ago: checked before the products so that
+#pragma unroll                                                                       //  each tile's result leaves the registers at once)
+        for (int k = 0; k < D2_TILES; ++k) {
+            if (!FAST && !c[k].live) continue;
+            Bf3 U[2];
+            d2_px_read(x, x.s_ux, k, s & 1, U);
+            f32x4 acc[3] = {b_r, b_z, b_n};
+            d2_contract(W, U, acc);
+            *d2_gi_slot(x, k, s & 1, 0) = acc[0];
+            *d2_gi_slot(x, k, s & 1, 1) = acc[1];
+            *d2_gi_slot(x, k, s & 1, 2) = acc[2];
+        }
+        D2_CLK(2);
+        d2_signal(x.gcnt);
+        D2_CLK(4);
+        if (!(D2_ABL & 2)) {
+#pragma unroll
+            for (int k = 0; k < D2_TILES; ++k) {
+                if (!FAST && !c[k].live) continue;
+                char* sdb = d2_sd_base(a, x, c[k]);
+                if (Q0) st4<FAST>(sdb, so + 4u * SD_X, FAST || c[k].valid, xk[k]);
+                st4<FAST>(sdb, so + 4u * (SD_U + 16 * q), FAST || c[k].valid, uk[k]);
+            }
+        }
+        if (owner && s >= D2_LAG) {
+            finish_y(s - D2_LAG, jy, ty, yin);
+            if (++ty == Lw) { ty = 0; ++jy; }
+            y_fetch(yin, jy, ty);                            // (s - D2_LAG + 1 < steps: always a step of this launch)
+        }
+        D2_CLK(5);
+        if (++t == Lw) { t = 0; ++j; }
+    }
+    D2_CLK_OUT(8, 8);
+    if (!owner) return;
+    for (int s = imax(x.steps - D2_LAG, 0); s < x.steps; ++s) {
+        d2_drain_vm();                                       // (the tail: fewer operations behind the fetch than D2_VM_WINDOW)
+        finish_y(s, jy, ty, yin);
+        if (s + 1 < x.steps) {
+            if (++ty == Lw) { ty = 0; ++jy; }
+            y_fetch(yin, jy, ty);
+        }
+    }
+    d2_drain_vm();
+    beh = chain_sum_b(group_sum(beh)) / (a.hard ? 1.0f : (float)J);
+    stab = chain_sum_b(group_sum(stab)) / (float)a.E / (float)a.L / (float)J;
+    if (l == 0) {
+        float* lp = a.loss_part + ((int64_t)x.net * co.tiles + co.tile) * 2;
+        lp[0] = x.j_lo > 0 ? lp[0] + beh : beh;             // pieces accumulate
+        lp[1] = x.j_lo > 0 ? lp[1] + stab : stab;
+    }
+}
+
+__global__ __launch_bounds__(D2_THREADS, 2) void beh_dec_fwd2_kernel(IplanBehArgs a) {
+    IPLAN_DYN_LDS(smem);
+    D2Ctx x;
+    x.s_gi = smem;
+    x.s_hx = x.s_gi + D2_GI;
+    x.s_ux = x.s_hx + D2_HX;
+    x.s_yx = x.s_ux + D2_UX;
+    int* s_cnt = reinterpret_cast<int*>(x.s_yx + D2_YX);
+    x.s_scale = reinterpret_cast<float*>(s_cnt + D2_CNT_INTS);
+    if (threadIdx.x < D2_CNT_INTS) s_cnt[threadIdx.x] = 0;
+    const int w = uniform_i(wave_id()), role = w >> 2;                                // role 0: recurrent wave B_q, 1: input wave A_q
+    x.q = w & 3;
+    x.l = lane_id(); x.n = x.l & 15; x.g = x.l >> 4; x.net = (int)blockIdx.y;
+    x.PD = a.dec_params + (int64_t)x.net * a.dec_s_net;
+    x.Lw = a.L;
+    DecTile c[D2_TILES];
+#pragma unroll
+    for (int k = 0; k < D2_TILES; ++k) dec_tile(a, c[k], (int)blockIdx.x * D2_TILES + k);
+    x.J = c[0].J;
+    x.j_lo = imax(a.fwd_j_lo, 0);
+    x.j_hi = a.fwd_j_hi > 0 ? imin(a.fwd_j_hi, x.J) : x.J;
+    x.steps = (x.j_hi - x.j_lo) * x.Lw;
+    x.steps_per_chain = (int64_t)x.J * x.Lw;
+    x.YL = 16 * ((a.d + 3) / 4);                                                      // lanes that hold real outputs
+    x.hcnt = s_cnt + 0; x.ucnt = s_cnt + 1; x.ycnt = s_cnt + 2; x.rcnt = s_cnt + 3; x.gcnt = s_cnt + 4 + x.q; x.bcnt = s_cnt + 8 + x.q;
+    x.n_live = 0;
+    bool fast = true;
+#pragma unroll
+    for (int k = 0; k < D2_TILES; ++k) { x.n_live += c[k].live ? 1 : 0; fast = fast && c[k].full; }
+    // the loss normaliser of every window of this launch (the mask alone decides it): wave w takes windows w, w + 8, ...
+    for (int jj = x.j_lo + w; jj < x.j_hi; jj += D2_THREADS / 64) {
+        const float sc = (float)(a.d * a.N) / (window_mask_sum(a, x.net, jj) + BEPS);
+        if (x.l == 0) x.s_scale[jj - x.j_lo] = sc;
+    }
+    __syncthreads();
+    const bool fastu = uniform_i(fast ? 1 : 0) != 0;
+    if (role == 0) {
+        if (fastu) d2_recurrent<true>(a, x, c); else d2_recurrent<false>(a, x, c);
+    } else if (x.q == 0) {
+        if (fastu) d2_input<true, true>(a, x, c); else d2_input<false, true>(a, x, c);
+    } else {
+        if (fastu) d2_input<true, false>(a, x, c); else d2_input<false, false>(a, x, c);
+    }
+}
+
 static int check_beh(const IplanBehArgs* a, const char* what) {
     if (!a) return fail(IPLAN_EINVAL, "%s: null args", what);
     if (a->n_nets < 1 || a->E < 1 || a->N < 1 || a->L < 1 || (a->hard ? a->T / a->L - 1 : a->T - 1 - a->L) < 1 || a->d < 1 || a->Z < 1 ||
@@ -1045,7 +1520,21 @@ extern "C" int iplan_beh_fwd(const IplanBehArgs* a, iplan_stream_t stream) {
     const dim3 dgrid((unsigned)((tiles + DEC_TILES - 1) / DEC_TILES), (unsigned)a->n_nets);  // decoder: 3 tiles x 4 quarter-waves
     const int ph = a->win ? 2 : a->fwd_phase;
     if (ph == 0 || ph == 1) hipLaunchKernelGGL(beh_enc_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
-    if (ph == 0 || ph == 2) {
+    // The second form (split-bf16, register-resident weights, input projection ahead of the recurrence) is OPT-IN
+    // (IPLAN_DEC_FWD_V2=1; not in single-window mode, d <= 8): same results, and on MI355X the same time as the first form --
+    // 6.0 vs 5.9 ms per pass alone, 22.2 vs 22.5 ms per learn() -- because both end up behind the record stores: without them
+    // the second form takes 3.5 ms, the 13.8 GB of records alone 3.1 ms in this layout (scripts/ubench/record_store.hip:
+    // 4.4 TB/s; 6.8 TB/s as contiguous 1 KiB blocks), and a wave that waits for room in the store path issues nothing else,
+    // so the two add instead of overlapping (profiles/r03b_notes.md).
+    const bool v2 = !a->win && a->d <= 8 && (a->hard ? a->T / a->L - 1 : a->T - 1 - a->L) <= D2_MAX_WINDOWS && getenv("IPLAN_DEC_FWD_V2") != nullptr;
+    if ((ph == 0 || ph == 2) && v2) {
+        const dim3 grid2((unsigned)((tiles + D2_TILES - 1) / D2_TILES), (unsigned)a->n_nets);
+        const size_t lds = sizeof(float) * D2_LDS_FLOATS;
+#ifndef IPLAN_HOST_EMULATION
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_dec_fwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#endif
+        hipLaunchKernelGGL(beh_dec_fwd2_kernel, grid2, dim3(D2_THREADS), lds, (hipStream_t)stream, *a);
+    } else if (ph == 0 || ph == 2) {
         const size_t lds = sizeof(float) * (2 * 3 * DHd * DLD + DHd * 24 + 16 * DLD + DEC_FWD_BIAS + DEC_TILES * XF_SLOTS * 256 + 16);
 #ifndef IPLAN_HOST_EMULATION
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_dec_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1055,6 +1544,12 @@ extern "C" int iplan_beh_fwd(const IplanBehArgs* a, iplan_stream_t stream) {
     if (!a->win && (ph == 0 || ph == 3)) hipLaunchKernelGGL(beh_loss_kernel, dim3((unsigned)a->n_nets), dim3(64), 0, (hipStream_t)stream, *a);
     return check_launch("iplan_beh_fwd");
 }
+
+#if defined(D2_CLOCKS) && !defined(IPLAN_HOST_EMULATION)
+extern "C" int iplan_debug_d2_clocks(long long* out) {     // diagnostic builds only: 16 accumulated segment clocks of the last launch
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(iplan::g_d2_clk), 16 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int iplan_beh_bwd(const IplanBehArgs* a, iplan_stream_t stream) {
     using namespace iplan;

@@ -135,3 +135,14 @@ def test_ppo_loss_switches_vs_oracle():
     # contraction is one sequential fp32 chain, the oracle's a blocked one) -- while every other tensor of the case sits at
     # <= 2.6e-6.  Bound for this case: 6 x e32.
     _log("ppo_loss_switches_all_off", check_ppo_train_vs_oracle(a, "cuda", seed=41, e32_factor=6.0))
+
+
+def test_behavior_learn_decoder_forward_second_form_gpu(monkeypatch):
+    """IPLAN_DEC_FWD_V2=1 at config-3 size (one agent, 32 envs, the whole episode) and at a ragged size (partial / missing
+    tiles in the last workgroup of a net) vs the fp64 oracle"""
+    from tests.oracle_checks import check_behavior_learn_vs_oracle
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    monkeypatch.setenv("IPLAN_DEC_FWD_V2", "1")
+    _log("behavior_learn_cfg3_E32_agent0_dec_fwd_v2", check_behavior_learn_vs_oracle(_args(batch_size_run=32), 32, "cuda", seed=23, agents=(0,)))
+    b = _args(max_vehicle_num=9, n_agents=2, episode_limit=20, batch_size_run=4)
+    _log("behavior_learn_ragged_dec_fwd_v2", check_behavior_learn_vs_oracle(b, 4, "cuda", seed=43))
