@@ -34,26 +34,42 @@ from iplan_amd.config import default_args  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32, dense)
 HBM_PEAK_GBS = 8000.0                # HBM3E spec (same guide; ~6.3 TB/s is what a float4 copy achieves)
-# HBM bytes per launch from the committed PMC passes (profiles/r01*_pmc_*.txt), keyed by (kernel, envs per GPU):
-# (2 * FETCH_SIZE + WRITE_SIZE) KiB -> bytes.  Counters cannot be collected from inside bench.py; None = not profiled.
-def _kib(fetch, write):
-    """HBM bytes of one launch from rocprofv3's FETCH_SIZE / WRITE_SIZE (KiB per dispatch, separate --pmc passes): on gfx950
-    FETCH_SIZE counts 128-byte requests as 64 bytes (MI355X_MICROARCH.md, HBM section) -> 2 x FETCH_SIZE + WRITE_SIZE."""
-    return int((2 * fetch + write) * 1024)
+def csrc_sha16():
+    """Hash of the kernel sources this checkout builds libiplan_hip.so from (every file of iplan_amd/csrc + the C header)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "iplan_amd", "csrc", "*"))) + [os.path.join(ROOT, "include", "iplan_hip.h")]
+    for f in files:
+        if os.path.isfile(f) and not f.endswith((".o", ".so")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
-# per launch at the config-3 shape (E = 32), profiles/r02f_pmc_*{behaviour_learn,ppo_train}.txt and r02h_pmc_rollout.txt (avg / dispatch; equal within 0.2 % across series)
-PMC_TRAFFIC_BYTES = {
-    ("gat_fwd_kernel", 32): _kib(5172.7, 1100.0),
-    ("gat_enc_fwd_kernel", 32): _kib(7454.8, 2475.0),            # GAT scenes + encoder tiles of one rollout step (r02h_pmc_rollout.txt)
-    ("beh_dec_bwd_kernel", 32): _kib(1008997.0, 1590885.6),       # per window-range launch (6 per BPTT)
-    ("beh_dec_fwd_kernel", 32): _kib(59286.7, 3295126.4),         # per window-range launch (4 per forward)
-    ("beh_enc_bwd_kernel", 32): _kib(470546.6, 17301.1),          # per window-range launch (6 per BPTT)
-    # iplan_wgrad over ONE WHOLE decoder BPTT (wide + two thin partial kernels + the reduction; the PMC pass ran it as 6
-    # window-range calls of 1/6 each): divided by the number of calls per learn() the bench run uses (1 when deferred)
-    ("iplan_wgrad:beh_dec", 32): 6 * _kib(1341424.3 + 254500.0 + 254748.0 + 39456.7, 49726.3 + 18393.6 + 19241.9 + 542.7),
-    ("ac_fwd_kernel:train", 32): _kib(1246046.2, 945376.6),       # actor + critic forward of a PPO epoch (one launch)
-}
+def load_pmc_traffic(envs_per_gpu):
+    """``roofline.traffic`` comes from ONE place: the newest profiles/*_pmc_summary.json (scripts/gpu_pmc_all.sh +
+    scripts/pmc_to_bench_json.py: rocprofv3 --pmc passes of the bench's own pieces, FETCH_SIZE and WRITE_SIZE in separate
+    passes, HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be
+    collected from inside bench.py, so the file is a committed measurement -- of a particular build: it records the hash of
+    the kernel sources it was taken on, and a file whose hash is not this checkout's is REFUSED (traffic = null) rather than
+    quoted for kernels it never saw.  -> ({bench key: bytes per launch}, source note)"""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        best = (f, d)
+    if best is None:
+        return {}, "no profiles/*_pmc_summary.json"
+    f, d = best
+    if d.get("csrc_sha16") != csrc_sha16():
+        return {}, f"{os.path.basename(f)} was measured on kernel sources {d.get('csrc_sha16')}, this build is {csrc_sha16()}: refused"
+    if d.get("envs_per_gpu") != envs_per_gpu:
+        return {}, f"{os.path.basename(f)} was measured at {d.get('envs_per_gpu')} envs per GPU"
+    return {k: v["bytes"] for k, v in d["per_launch"].items()}, f"{os.path.basename(f)} (series {d.get('series')}, kernel sources {d.get('csrc_sha16')})"
 
 
 def gat_algorithmic_flops(n_nets, B, N, D, H=32, A=32):
@@ -66,7 +82,7 @@ def cpu_baseline(args, E):
     """The oracle (CPU port of the reference arithmetic, kind "port") timed on this host's cores on a BOUNDED sample of the
     same workload (oracle/cpu_baseline.py: a rollout vector step at full width plus one Behaviour / Prediction / PPO learner
     pass on a reduced number of envs / rows; warm-up + best of 3; scaled to seconds per env-step and summed).  Reported beside
-    the GPU number, never mixed into it.  profiles/r02_cpu_baseline_anchor.json ties the oracle's speed to the REAL reference
+    the GPU number, never mixed into it.  profiles/r03_cpu_baseline_anchor.json ties the oracle's speed to the REAL reference
     classes timed on identical inputs in the build container (the reference cannot travel to the GPU box)."""
     from oracle.cpu_baseline import measure
     # intra-op threads: the path is thousands of small ATen ops; beyond ~16 threads fork/join overhead dominates (with all
@@ -74,9 +90,9 @@ def cpu_baseline(args, E):
     cores = min(os.cpu_count() or 1, 16)
     # Behaviour learn (the dominant CPU leg) at the FULL env count of one rollout: its per-env cost keeps falling with the
     # batch (anchor file: behaviour_leg_linearity), so a small-batch sample would understate the CPU path
-    m = measure("oracle", E, cores, Eb=min(E, 32), reps=2)
+    m = measure("oracle", E, cores, Eb=min(E, 32), reps=2)       # (the behaviour leg: all agents, timed once)
     return dict(value=m["value"], unit="env-steps/s", cores=cores, kind="port",
-                sample=m["sample"] + "; oracle-vs-reference speed on identical inputs: profiles/r02_cpu_baseline_anchor.json")
+                sample=m["sample"] + "; oracle-vs-reference speed on identical inputs: profiles/r03_cpu_baseline_anchor.json")
 
 
 def main():
@@ -91,6 +107,10 @@ def main():
                          "rollout, the first 255 episodes trained on), all gradients all-reduced")
     ap.add_argument("--total-envs", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="W",
+                    help="diagnostic, 1 GPU, with --scaling strong: run ONE rank's share of config 4 on W GPUs (total-envs / W envs, its "
+                         "slice of the global buffer, the union's normalisers, every collective launched on a 1-rank RCCL group) and "
+                         "report the PROJECTED W-GPU strong-scaling figure next to this GPU's own number")
     ap.add_argument("--rollout-only", action="store_true", help="diagnostic: time rollout inference without the learners")
     opt = ap.parse_args()
     if os.environ.get("IPLAN_BENCH_WATCHDOG"):
@@ -103,31 +123,36 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    emu_world = opt.emulate_rank_of if (opt.emulate_rank_of > 1 and world == 1 and opt.scaling == "strong") else 0
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+    elif emu_world:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29800 + os.getpid() % 100}", rank=0, world_size=1, device_id=dev)
 
     strong = opt.scaling == "strong"
+    shard_world = emu_world or world                             # how many ranks the global run is split over
     if strong:
         # config 4: the env rows of ONE 256-env run are sharded over the ranks; rank r stores its own episodes of the global
         # buffer, the reference's "first batch_size = buffer_size - 1 episodes" drops the last episode of the last rank
-        assert opt.total_envs % world == 0, "--total-envs must be divisible by the number of GPUs"
-        E = opt.total_envs // world
+        assert opt.total_envs % shard_world == 0, "--total-envs must be divisible by the number of GPUs"
+        E = opt.total_envs // shard_world
         base = default_args("highway")
         drop = base.buffer_size - base.batch_size               # 1: train() uses the first buffer_size - 1 episodes
         args = default_args("highway", use_cuda=True, batch_size_run=E, buffer_size=E,
-                            batch_size=E - (drop if rank == world - 1 else 0))
+                            batch_size=E - (drop if (rank == world - 1 and not emu_world) else 0))
     else:
         E = opt.envs
         args = default_args("highway", use_cuda=True, batch_size_run=E)
     from iplan_amd.harness import SyntheticLoop
     loop = SyntheticLoop(args, E, seed=1234 + rank, device=dev)
-    if world > 1:
+    if world > 1 or emu_world:
         from iplan_amd.parallel import DataParallel
         DataParallel(dist.group.WORLD).attach(loop)
         if strong:
-            loop.learner.dp_global_rows = (args.buffer_size * world - drop) * args.episode_limit
-            loop.learner.dp_global_count = args.buffer_size * world * args.episode_limit
+            loop.learner.dp_global_rows = (args.buffer_size * shard_world - drop) * args.episode_limit
+            loop.learner.dp_global_count = args.buffer_size * shard_world * args.episode_limit
     rollouts_per_step = max(1, args.buffer_size // E)
 
     def one_step():
@@ -187,6 +212,15 @@ def main():
                        "env_steps_per_step": rollouts_per_step * E * args.episode_limit * world},
             "roofline": rl[0], "roofline_others": rl[1:],
         }
+        if emu_world:
+            per_rank = env_steps / dt
+            line["projection"] = {
+                "what": f"PROJECTED {emu_world}-GPU strong-scaling figure of config 4, not a measurement: this GPU ran rank 0's share "
+                        f"({E} of {opt.total_envs} envs, its {args.buffer_size} episodes of the global buffer, loss normalisers of the union, "
+                        "every gradient / normaliser collective launched on a 1-rank RCCL group, i.e. at its launch cost without any "
+                        "xGMI transfer or straggler wait); projected value = total envs x 90 / this rank's step time",
+                "emulated_world": emu_world, "projected_value": per_rank * emu_world, "unit": "env-steps/s",
+                "not_included": "xGMI transfer and rank skew of the 2 + 2 + 30 small all-reduces per step (0.3-4 MB each)"}
         if not opt.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, E)
 
@@ -199,14 +233,14 @@ def main():
                 return [clean(v) for v in o]
             return o
         print(json.dumps(clean(line)))
-    if world > 1:
+    if world > 1 or emu_world:
         dist.destroy_process_group()
 
 
 def rooflines(args, E, timed, opt, rollouts_per_step):
     """Roofline entries of every kernel above 5 % of a cycle's kernel time (profiles/r02*_full_cycle_kernel_stats.csv):
     ALGORITHMIC work per launch (SURVEY.md §8d convention) / the in-situ mean launch duration.  ``traffic`` =
-    HBM bytes per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE KiB), at the config-3 shape only."""
+    HBM bytes per launch from profiles/<series>_pmc_summary.json (load_pmc_traffic: null when that file is not of this build)."""
     nA, N, d, Z = args.n_agents, args.max_vehicle_num, args.obs_shape_single, args.latent_dim
     Hd, R, Lw, M, T = args.decoder_rnn_dim, args.encoder_rnn_dim, args.max_history_len, args.rnn_hidden_dim, args.episode_limit
     J = T - 1 - Lw
@@ -221,11 +255,14 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
         ach = work / sec / unit_scale if n else nan
         return {"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                 "traffic": traffic_of(traffic_key or kernel), "us_per_launch": sec * 1e6 if n else nan,
+                "traffic_source": pmc_src,
                 "launches_timed": n, ("algorithmic_gbyte_per_launch" if bound == "hbm" else "algorithmic_gflop_per_launch"): work / 1e9,
                 "note": note}
 
+    pmc, pmc_src = load_pmc_traffic(E)
+
     def traffic_of(key):
-        t = PMC_TRAFFIC_BYTES.get((key, E))
+        t = pmc.get(key)
         if t is not None and key == "iplan_wgrad:beh_dec":
             t = t // pieces(key)
         return t

@@ -343,7 +343,7 @@ class IPPOLearner:
         (agent-major, one per epoch) from torch's global CPU generator."""
         a, d, nA, mac = self.args, self.store.data, self.n_agents, self.mac
         if self.dp is not None:
-            raise NotImplementedError("num_mini_batch > 1 is not wired into the data-parallel path")
+            return self._train_minibatches_dp(t_env, rows, last, ln_stats, old_logp, adv, returns, vpred, mask)
         dev = self.device
         f32 = dict(dtype=th.float32, device=dev)
         T, T1, nmb = self.episode_limit, self.episode_limit + 1, self.num_mini_batch
@@ -406,6 +406,115 @@ class IPPOLearner:
         def finish():
             both = staged.get()
             st, nr = both[:st_d.numel()], both[st_d.numel():]
+            train_info = {"value_loss": float(st[1]), "policy_loss": float(st[0]), "dist_entropy": float(st[3]),
+                          "actor_grad_norm": float(nr[0]), "critic_grad_norm": float(nr[1]), "ratio": float(st[2])}
+            self.last_train_info = train_info
+            if t_env - self.log_stats_t >= self.args.learner_log_interval:
+                for kk, v in train_info.items():
+                    self.logger.log_stat(self.log_prefix + kk, v, t_env)
+            return train_info
+        return finish
+
+    def _train_minibatches_dp(self, t_env, rows, last, ln_stats, old_logp, adv, returns, vpred, mask):
+        """num_mini_batch > 1 under data parallelism: the minibatches are those of ONE process holding the
+        union of the ranks' rows.  Rank 0 draws the reference's permutations of the GLOBAL row range (agent-major, one per
+        epoch, torch's global CPU generator -- exactly what the single process would draw) and broadcasts them; minibatch i of
+        an epoch is the global rows ``perm[i * mbs : (i + 1) * mbs]``, and every rank trains on the ones that fall into its own
+        row range.  Their number differs per agent and rank, while one fused launch covers all agents with one row count: each
+        agent's selection is padded to the launch's row count with rows of ZERO weight (mask 0 -> no policy / value term,
+        per-row entropy weight 0), the masked-mean denominators and the entropy count are the global minibatch's (one
+        all-reduce of all mask sums up front), and the gradient arenas are summed over the ranks before every step -- so an
+        N-rank step equals the union's step.  The unmasked-mean loss forms (use_*_active_masks off) weight every row of a
+        launch alike and cannot ignore padding: not available in this combination."""
+        a, d, nA, mac, dp = self.args, self.store.data, self.n_agents, self.mac, self.dp
+        if not (self._use_value_active_masks and self._use_policy_active_masks):
+            raise NotImplementedError("data-parallel num_mini_batch > 1 needs use_value_active_masks and use_policy_active_masks")
+        dev = self.device
+        f32 = dict(dtype=th.float32, device=dev)
+        T, T1, nmb = self.episode_limit, self.episode_limit + 1, self.num_mini_batch
+        # this rank's place in the union's row order: ranks in order, each with its own rows
+        counts = th.zeros(dp.world, dtype=th.int64, device=dev)
+        counts[dp.rank] = rows
+        counts = dp.all_reduce_sum(counts.to(th.float32)).to(th.int64).cpu()
+        G = int(counts.sum())
+        if self.dp_global_rows is not None:
+            assert G == int(self.dp_global_rows), (G, self.dp_global_rows)
+        off = int(counts[:dp.rank].sum())
+        mbs = G // nmb
+        perms = th.empty(nA, self.ppo_epoch, G, dtype=th.int64)
+        if dp.rank == 0:
+            perms = th.stack([th.stack([th.randperm(G) for _ in range(self.ppo_epoch)]) for _ in range(nA)])
+        perms = dp.broadcast_tensor(perms.to(dev))
+        steps = self.ppo_epoch * nmb
+        mb = perms[:, :, :mbs * nmb].reshape(nA, steps, mbs)                  # global rows of every (agent, step)
+        mine = (mb >= off) & (mb < off + rows)
+        n_loc = mine.sum(-1)                                                  # [nA, steps]
+        n_pad = n_loc.max(0).values.clamp_min(1).cpu().tolist()               # launch row count per step
+        # local selections, own rows first (stable), padded with this rank's row 0 at weight 0
+        order = th.argsort((~mine).to(th.int8), dim=-1, stable=True)
+        loc = (th.gather(mb, -1, order) - off).clamp_(0, rows - 1)            # [nA, steps, mbs]; beyond n_loc: padding
+        w_all = (th.arange(mbs, device=dev)[None, None, :] < n_loc[..., None]).to(th.float32)
+        ag = th.arange(nA, device=dev)[:, None]
+        # the masked-mean denominators of every global minibatch in ONE all-reduce
+        msk_loc = th.gather(mask[:, None, :].expand(nA, steps, mask.shape[1]), -1, loc) * w_all
+        msum_all = dp.all_reduce_sum(msk_loc.sum(-1).t().contiguous())       # [steps, nA]
+        lib = L.get_lib()
+        stream = L.current_stream(dev)
+        max_norm = self.max_grad_norm if self._use_max_grad_norm else None
+        stats = th.zeros(steps, nA, 8, **f32)
+        norms = th.zeros(steps, 2, nA, **f32)
+        widths = mac._widths()
+        avail_all = d["avail_actions"] if d["avail_actions"].dtype == th.int32 else d["avail_actions"].to(th.int32)
+        for k in range(steps):
+            n = int(n_pad[k])
+            idx, w = loc[:, k, :n], w_all[:, k, :n].contiguous()              # [nA, n]
+            e_i, t_i = idx // T, idx % T
+            src = [(d[key][e_i, t_i, ag].reshape(nA, n, -1).contiguous(), wd) for key, wd in widths]
+            la = last[e_i, t_i, ag].contiguous()
+            ha, hc = d["rnn_states_actors"][e_i, t_i, ag].contiguous(), d["rnn_states_critics"][e_i, t_i, ag].contiguous()
+            av = avail_all[e_i, t_i, ag].contiguous()
+            ac = d["actions"][e_i, t_i, ag].contiguous()
+            lns = ln_stats.reshape(nA, -1, 2)[ag, e_i * T1 + t_i].contiguous()
+            g = lambda x: x[ag, idx].contiguous()                             # noqa: E731
+            olp, adv_g, ret_g, vp_g = g(old_logp), g(adv), g(returns), g(vpred)
+            msk_g = (g(mask) * w).contiguous()
+            spec = ops.AcFeatureSpec(a.max_vehicle_num, [(t, wd, t.stride(0), t.stride(1)) for t, wd in src],
+                                     n_actions=a.n_actions if a.obs_last_action else 0, last_action=la,
+                                     la_strides=(la.stride(0), 1), n_id=nA if a.obs_agent_id else 0, T=1, T_phys=1)
+            out = ops.ac_forward(mac.actor_arena, mac.critic_arena, 2, spec, n, nA, h_actor=ha, h_critic=hc,
+                                 h_strides=(ha.stride(0), ha.stride(1)), avail=av, avail_strides=(av.stride(0), av.stride(1)),
+                                 mode=2, actions_in=ac, act_strides=(ac.stride(0), ac.stride(1)), n_actions=a.n_actions,
+                                 ksplit=1, want_h=False, ln_stats=lns, ln_stats_mode=2, save=True, want_entropy=True,
+                                 packed=mac.fc1_pack.get(spec))
+            pl = L.PpoLossArgs()
+            pl.n_agents, pl.rows, pl.row_stride = nA, n, n
+            pl.old_logp, pl.adv, pl.value_preds = olp.data_ptr(), adv_g.data_ptr(), vp_g.data_ptr()
+            pl.returns, pl.mask = ret_g.data_ptr(), msk_g.data_ptr()
+            pl.clip, pl.huber_delta, pl.value_loss_coef = self.clip_param, self.huber_delta, self.value_loss_coef
+            g_logp, g_v = th.empty(nA, n, **f32), th.empty(nA, n, **f32)
+            pl.g_logp, pl.g_values = g_logp.data_ptr(), g_v.data_ptr()
+            pl.flags = self._loss_flags
+            pl.logp, pl.entropy, pl.values = out["logp"].data_ptr(), out["entropy"].data_ptr(), out["values"].data_ptr()
+            pl.mask_sum, pl.row_count = msum_all[k].data_ptr(), float(mbs)
+            pl.stats = stats[k].data_ptr()
+            lib.call("iplan_ppo_loss", pl, stream)
+            ops.ac_backward(out, mac.actor_arena, mac.critic_arena, g_logp=g_logp, g_entropy=(w * (-self.entropy_coef / float(mbs))).contiguous(),
+                            g_values=g_v)
+            dp.all_reduce_grads(mac.actor_arena, mac.critic_arena)
+            if self.probe_last_step and k == steps - 1:
+                self.last_step_params = (mac.actor_arena.data.clone(), mac.critic_arena.data.clone())
+                self.last_step_relu = (out["saved"][..., 0:64] > 0, out["saved"][..., 128:192] > 0)
+            norms[k, 0] = step_all(self.actor_optimizers, max_norm)[:, 0]
+            norms[k, 1] = step_all(self.critic_optimizers, max_norm)[:, 0]
+        self.store.clear()
+        st_d = stats.mean(dim=(0, 1))
+        nr_d = norms.sqrt().mean(dim=(0, 2)) if max_norm is not None else th.zeros(2, device=dev)
+        staged = AsyncHost(th.cat([st_d.reshape(-1), nr_d.reshape(-1)]))
+
+        def finish():
+            both = staged.get()
+            st, nr = both[:st_d.numel()], both[st_d.numel():]
+            # (policy / value losses are this rank's share of the global masked means; ratio and entropy include the padding rows)
             train_info = {"value_loss": float(st[1]), "policy_loss": float(st[0]), "dist_entropy": float(st[3]),
                           "actor_grad_norm": float(nr[0]), "critic_grad_norm": float(nr[1]), "ratio": float(st[2])}
             self.last_train_info = train_info

@@ -193,6 +193,16 @@ class DataParallel:
             self.broadcast_arena(a)
         return self
 
+    def broadcast_tensor(self, tensor, src=0):
+        """rank ``src``'s values into every rank's ``tensor`` (same shape / dtype everywhere), in place; returns it."""
+        if self._via_host(tensor):
+            h = tensor.cpu()
+            dist.broadcast(h, src=src, group=self.group)
+            tensor.copy_(h)
+        else:
+            dist.broadcast(tensor, src=src, group=self.group)
+        return tensor
+
     def all_reduce_sum(self, tensor):
         """Sum a (small) tensor of loss normalisers over the ranks, in place; returns it."""
         if self._via_host(tensor):

@@ -6,7 +6,8 @@ which ties the oracle's speed to the reference's.
 
 Pieces (each: one warm-up call, then the best of ``reps`` timed calls), scaled to seconds per env-step and summed:
   rollout   vector step at full width E: GAT_latent_update + latent_update + select_actions_ippo (5 agents)
-  behaviour Behavior_policy.learn forward + backward, ONE agent, Eb envs, full 90-step episode
+  behaviour Behavior_policy.learn forward + backward, ALL n_agents agents one after the other (the reference's loop), Eb envs,
+            full 90-step episode -- the dominant CPU leg: timed in full at the width the GPU run uses, not extrapolated from one agent
   predict   Prediction_policy.learn forward + backward, ONE agent, 64 samples
   ppo       one PPO epoch (actor evaluate + critic, forward + backward), ONE agent, Rp rows
 """
@@ -65,11 +66,14 @@ def _oracle_pieces(ca, E, Eb, Rp):
                 O.critic_value(cri[i], x[:, i], ha[:, i])
     f = synth.make_episode_fields(ca, Eb, seed=1, terminated_p=0.5)
 
-    def behaviour():
-        ep, dp = req(enc[0]), req(bdec)
-        _, _, loss = O.behavior_learn_loss(ep, dp, f["history"][:, :-1, 0], f["terminated"][:, :-1, 0, 0].float(), L,
-                                           ca.soft_update_coef, None, 0.0)
-        loss.backward()
+    bdecs = [bdec] + [sd(Behavior_Latent_Decoder(d + Z, 64, 1, d, 0.1)) for _ in range(nA - 1)]
+
+    def behaviour(agents=range(nA)):
+        for i in agents:
+            ep, dp = req(enc[i]), req(bdecs[i])
+            _, _, loss = O.behavior_learn_loss(ep, dp, f["history"][:, :-1, i], f["terminated"][:, :-1, i, 0].float(), L,
+                                               ca.soft_update_coef, None, 0.0)
+            loss.backward()
     S = ca.pred_batch_size
     gen = torch.Generator().manual_seed(2)
     obs = synth.make_history(gen, (S,), N, d)
@@ -140,12 +144,17 @@ def _reference_pieces(ca, E, Eb, Rp, ref_root):
     one = copy.copy(ca)
     one.n_agents = 1
     one.batch_size_run = Eb
-    beh1, pred1 = Behavior_policy(one, Log()), Prediction_policy(one, Log())
-    b1 = episode_batch(one, Eb, 1)
+    pred1 = Prediction_policy(one, Log())
     b64 = episode_batch(one, max(Eb, 2), 2)
+    allb = copy.copy(ca)
+    allb.batch_size_run = Eb
+    beh_all = Behavior_policy(allb, Log())                   # learn() loops over all n_agents agents itself
+    b_all = episode_batch(allb, Eb, 1)
+    beh1 = Behavior_policy(one, Log())
+    b1 = episode_batch(one, Eb, 1)
 
-    def behaviour():
-        beh1.learn(b1, 0)
+    def behaviour(agents=None):
+        (beh_all.learn(b_all, 0) if agents is None else beh1.learn(b1, 0))
 
     def predict():
         pred1.learn(b64, 0)
@@ -171,14 +180,19 @@ def measure(backend, E, cores, Eb=2, Rp=2048, reps=3, ref_root="/root/reference"
     torch.manual_seed(0)
     ca = default_args("highway", use_cuda=False)
     pieces = _oracle_pieces(ca, E, Eb, Rp) if backend == "oracle" else _reference_pieces(ca, E, Eb, Rp, ref_root)
-    t = {k: _best(fn, reps if k != "rollout" else max(reps, 5)) for k, fn in pieces.items()}
+    t = {k: _best(fn, reps if k != "rollout" else max(reps, 5)) for k, fn in pieces.items() if k != "behaviour"}
+    # the behaviour leg is the long one (all agents, full width): warm up on ONE agent, then time the whole pass once
+    pieces["behaviour"]([0] if backend == "oracle" else 1)
+    t0 = time.perf_counter()
+    pieces["behaviour"]()
+    t["behaviour"] = time.perf_counter() - t0
     nA, T = ca.n_agents, ca.episode_limit
     per = dict(rollout=t["rollout"] / E,                                             # one vector step serves E env-steps
-               behaviour=nA * t["behaviour"] / (Eb * T),                             # Behavior_policy.learn once per rollout
+               behaviour=t["behaviour"] / (Eb * T),                                  # Behavior_policy.learn (all agents) once per rollout
                predict=nA * t["predict"] / (E * T),                                  # Prediction_policy.learn once per rollout
                ppo=nA * ca.ppo_epoch * t["ppo"] / Rp * (ca.batch_size / ca.buffer_size))     # 15 epochs over 255/256 of the rows
     return dict(value=1.0 / sum(per.values()), seconds=t, per_env_step=per, backend=backend, cores=cores,
                 sample=f"{backend} on {cores} threads, best of {reps} after a warm-up call: rollout vector step at E={E} ({t['rollout']:.3f}s); "
-                       f"Behaviour learn fwd+bwd 1 agent x {Eb} envs x full episode ({t['behaviour']:.2f}s); Prediction learn fwd+bwd 1 agent x "
+                       f"Behaviour learn fwd+bwd ALL {nA} agents x {Eb} envs x full episode, timed once after a one-agent warm-up ({t['behaviour']:.2f}s); Prediction learn fwd+bwd 1 agent x "
                        f"{ca.pred_batch_size} samples ({t['predict']:.2f}s); one PPO epoch 1 agent x {Rp} rows ({t['ppo']:.3f}s); each scaled "
-                       "linearly to s/env-step and summed")
+                       "linearly to s/env-step (the one-agent legs x n_agents) and summed")

@@ -12,5 +12,5 @@ SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLIC
 FETCH_SIZE GRBM_GUI_ACTIVE
 WRITE_SIZE
 PASSES
-python scripts/pmc_summary.py gpurun_out/pmc_$tag > gpurun_out/pmc_$tag.txt 2>&1
+python scripts/pmc_summary.py gpurun_out/pmc_$tag --json gpurun_out/pmc_$tag.json > gpurun_out/pmc_$tag.txt 2>&1
 rm -rf gpurun_out/pmc_$tag

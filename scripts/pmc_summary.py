@@ -1,6 +1,11 @@
-"""Average PMC counter values per kernel from rocprofv3 --pmc csv outputs (one sub-directory per pass)."""
+"""Average PMC counter values per kernel from rocprofv3 --pmc csv outputs (one sub-directory per pass).
+
+    python scripts/pmc_summary.py <dir with p1/ p2/ ...>                       -> text table on stdout
+    python scripts/pmc_summary.py <dir> --json out.json                        -> also {kernel: {counter: [avg per dispatch, dispatches]}}
+"""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
@@ -20,3 +25,7 @@ for k in sorted(agg):
     for c in sorted(agg[k]):
         s, n = agg[k][c]
         print(f"    {c:32s} avg/dispatch {s / n:16.1f}   (n={n})")
+if "--json" in sys.argv:
+    out = {k: {c: [v[0] / v[1], v[1]] for c, v in cs.items()} for k, cs in agg.items()}
+    with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)

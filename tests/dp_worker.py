@@ -118,6 +118,29 @@ for a in (loop.mac.actor_arena, loop.mac.critic_arena):
     g = gathered(a.data)
     assert torch.equal(g[0], g[1]), "replicas diverged (strong-mode trigger)"
 
+# ---------------------------------------------------------------- num_mini_batch = 2 under data parallelism: the minibatches are the
+# UNION's (rank 0 draws the reference's permutations of the global row range and broadcasts them; every rank trains on the rows
+# that fall into its own range, padded to a common launch size at weight 0)
+for a, b in zip(arenas_of(loop), arenas_of(full)):
+    a.data.copy_(b.data)
+args_fm = default_args("highway", batch_size_run=EF, buffer_size=EF, batch_size=EF, num_mini_batch=2, **kw)
+args_rm = default_args("highway", batch_size_run=ER, buffer_size=ER, batch_size=ER, num_mini_batch=2, **kw)
+lf_m = IPPOLearner(full.mac, full.scheme, full.logger, args_fm)
+lr_m = IPPOLearner(loop.mac, loop.scheme, loop.logger, args_rm)
+lr_m.dp = dp
+with contextlib.redirect_stdout(io.StringIO()):
+    torch.manual_seed(77)
+    lf_m.insert_episode_batch(b_full)
+    lf_m.train(0)
+    torch.manual_seed(77)
+    lr_m.insert_episode_batch(b_rank)
+    lr_m.train(0)
+close(loop.mac.actor_arena.data, full.mac.actor_arena.data, "PPO actors (2 minibatches)")
+close(loop.mac.critic_arena.data, full.mac.critic_arena.data, "PPO critics (2 minibatches)")
+for a in (loop.mac.actor_arena, loop.mac.critic_arena):
+    g = gathered(a.data)
+    assert torch.equal(g[0], g[1]), "replicas diverged (2 minibatches)"
+
 # ---------------------------------------------------------------- a full synthetic cycle keeps the replicas identical
 calls = []
 orig = dp.all_reduce_grads
