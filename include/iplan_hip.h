@@ -262,6 +262,14 @@ typedef struct {
 int iplan_ac_fwd(const IplanAcFwdArgs* args, iplan_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Gumbel(0, 1) samples  g = -log(-log(u)),  u uniform on (0, 1): the noise F.gumbel_softmax draws inside
+ * GAT_Net.forward (nova/GAT_Net.py:93, `-empty_like(logits).exponential_().log()`), for a whole rollout in one launch
+ * (one pass over `out` instead of the three of the torch expression).  Counter based: out[i] depends on (seed, i) only, so
+ * any partition of the range gives the same samples.  n % 4 == 0, out 16-byte aligned.
+ */
+int iplan_gumbel_noise(float* out, int64_t n, uint64_t seed, iplan_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * clip_grad_norm_ + torch.optim.Adam on flat arenas (learners/ippo_learner.py:204-221,
  * nova/prediction_policy.py:231-241, nova/stable_behavior_policy.py:252-262), all nets per launch.
  */

@@ -53,7 +53,7 @@ ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_st
                 "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd", "iplan_mlp3_fwd", "iplan_mlp3_bwd", "iplan_seq2seq_fwd", "iplan_ac_pack_fc1",
                 "iplan_p2p_publish", "iplan_p2p_reduce"]
 RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups", "iplan_sizeof", "iplan_ac_packed_floats",
-                    "iplan_p2p_alloc", "iplan_p2p_free", "iplan_p2p_export", "iplan_p2p_open", "iplan_p2p_close", "iplan_gat_enc_fwd"]      # non (args*, stream) signatures
+                    "iplan_p2p_alloc", "iplan_p2p_free", "iplan_p2p_export", "iplan_p2p_open", "iplan_p2p_close", "iplan_gat_enc_fwd", "iplan_gumbel_noise"]      # non (args*, stream) signatures
 
 
 class Lib:
@@ -80,6 +80,7 @@ class Lib:
         cdll.iplan_wgrad_workspace_floats.restype = C.c_size_t
         cdll.iplan_wgrad_workspace_floats.argtypes = [C.c_void_p]
         cdll.iplan_gat_enc_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        cdll.iplan_gumbel_noise.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]
         cdll.iplan_p2p_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
         cdll.iplan_p2p_free.argtypes = [C.c_void_p]
         cdll.iplan_p2p_export.argtypes = [C.c_void_p, C.POINTER(IpcHandle)]

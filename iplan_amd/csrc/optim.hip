@@ -48,7 +48,38 @@ __global__ __launch_bounds__(256) void adam_kernel(IplanAdamArgs a) {
     }
 }
 
+// Gumbel noise: two uniforms per 64-bit mix of (seed, counter) -- splitmix64's finaliser on a Weyl sequence, the generator
+// behind java.util.SplittableRandom (passes BigCrush) --, 23 random bits each, centred so that u is never 0 or 1.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float gumbel_of(uint32_t bits) {
+    const float u = ((float)(bits >> 9) + 0.5f) * (1.0f / 8388608.0f);      // 23 bits: k + 0.5 is exact, u in [2^-24, 1 - 2^-24]
+    return -logf(-logf(u));
+}
+__global__ __launch_bounds__(256) void gumbel_kernel(float* __restrict__ out, int64_t n4, uint64_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t a = mix64(seed + 0x9E3779B97F4A7C15ull * (uint64_t)(2 * i + 1)), b = mix64(seed + 0x9E3779B97F4A7C15ull * (uint64_t)(2 * i + 2));
+        f32x4 v;
+        v[0] = gumbel_of((uint32_t)a); v[1] = gumbel_of((uint32_t)(a >> 32));
+        v[2] = gumbel_of((uint32_t)b); v[3] = gumbel_of((uint32_t)(b >> 32));
+        *reinterpret_cast<f32x4*>(out + 4 * i) = v;
+    }
+}
+
 }  // namespace iplan
+
+extern "C" int iplan_gumbel_noise(float* out, int64_t n, uint64_t seed, iplan_stream_t stream) {
+    using namespace iplan;
+    if (!out || n < 0 || (n & 3) || !aligned16(out)) return fail(IPLAN_EINVAL, "iplan_gumbel_noise: out must be 16-byte aligned and n a multiple of 4");
+    const int64_t n4 = n / 4;
+    if (n4 == 0) return IPLAN_OK;
+    const unsigned blocks = (unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(gumbel_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, n4, seed);
+    return check_launch("iplan_gumbel_noise");
+}
 
 extern "C" int iplan_grad_sqnorm(const float* grad, int64_t stride, int64_t off, int64_t n, int32_t n_nets,
                                  float* out, int32_t out_stride, int32_t slot, iplan_stream_t stream) {

@@ -664,6 +664,19 @@ def _beh_pieces(which, default):
     return int(os.environ.get("IPLAN_BEH_PIECES_" + which, os.environ.get("IPLAN_BEH_PIECES", str(default))))
 
 
+def _piece_bounds(J, pieces):
+    """Window ranges of the pipelined behaviour forward / BPTT: ``pieces`` equal ranges behind ONE short range at the low end
+    (windows [0, J // 16)).  The forward walks the ranges bottom up and its decoder can only start once the encoder has
+    finished the first range; the BPTT walks them top down and the encoder's BPTT of the last range -- plus the gradient
+    reduction and the optimiser step the next rollout waits for -- trails the decoder's.  With equal ranges both waits were a
+    whole range of encoder work (0.65 ms in front of the decoder forward, 1.3 ms behind the decoder BPTT: rocprofv3 trace of
+    a training cycle, profiles/r02h_cycle_trace_learn_phase.txt); the short range makes them a sixteenth of the episode."""
+    if pieces <= 1 or J < 4 * pieces or os.environ.get("IPLAN_BEH_EQUAL_PIECES"):
+        return [round(J * k / pieces) for k in range(pieces + 1)]
+    s0 = max(1, J // 16)
+    return [0] + [s0 + round((J - s0) * k / pieces) for k in range(pieces + 1)]
+
+
 def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p, keep=None, seed=0, hard=False, win_norm=None,
                 lib=None):
     """Forward of Behavior_policy.learn for all nets.  hist [n_nets, E, T, N, d] (first three dims may be
@@ -713,7 +726,8 @@ def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p,
     if pieces == 1:
         lib.call("iplan_beh_fwd", a, stream)
     else:
-        bounds = [round(J * k / pieces) for k in range(pieces + 1)]
+        bounds = _piece_bounds(J, pieces)
+        pieces = len(bounds) - 1
         out["enc_carry"] = torch.empty(n_nets, tiles, 768, **f32)
         out["dec_carry"] = torch.empty(n_nets, tiles, 2, 512, **f32)
         a.enc_carry, a.dec_carry = out["enc_carry"].data_ptr(), out["dec_carry"].data_ptr()
@@ -817,7 +831,8 @@ def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_nor
     if defer_dec_wgrad and side is None and dev.type == "cuda":
         main = torch.cuda.current_stream(dev)
     pieces = max(1, min(_beh_pieces("BWD", 6 if side is not None else 1), J))
-    bounds = [round(J * k / pieces) for k in range(pieces + 1)]
+    bounds = _piece_bounds(J, pieces)
+    pieces = len(bounds) - 1
     carry = torch.empty(n_nets, tiles, 2, 512, **f32)
     ecarry = torch.empty(n_nets, tiles, 768, **f32)
     a.dec_carry, a.enc_carry = carry.data_ptr(), ecarry.data_ptr()
@@ -854,6 +869,13 @@ def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_nor
                 dec_wgrad(0, J * Lw, 1.0 if accumulate else 0.0)
                 return
             strm.wait_event(ev_bptt)
+            # ... and behind whatever the caller has enqueued on the main stream by now (Behavior_policy.learn: the encoder's
+            # BPTT tail, gradient reduction and optimiser step -- what the next rollout waits for).  The wide contraction's
+            # 372-register waves take whole CUs: started right behind the last decoder range it ran beside the encoder's last
+            # range and stretched it from 0.6 to 3.9 ms (rocprofv3 trace, profiles/r03c_notes.md).
+            ev_now = torch.cuda.Event()
+            ev_now.record(torch.cuda.current_stream(dev))
+            strm.wait_event(ev_now)
             with torch.cuda.stream(strm):
                 dec_wgrad(0, J * Lw, 1.0 if accumulate else 0.0)
             for t in (dd, fwd["saved_dec"]):

@@ -16,7 +16,8 @@ print(f"learn phase: {(ks[j1][1] - t0) / 1e6:.2f} ms")
 agg = {}
 for k in ks[i0 + 1:j1]:
     if k[2] - k[1] > 150_000 or "beh_" in k[0]:
-        print(f"{k[0][:46]:46s} start {(k[1] - t0) / 1e6:7.3f}  end {(k[2] - t0) / 1e6:7.3f}  dur {(k[2] - k[1]) / 1e6:6.3f} ms  q{k[4]}")
+        print(f"{k[0][:46]:46s} start {(k[1] - t0) / 1e6:7.3f}  end {(k[2] - t0) / 1e6:7.3f}  dur {(k[2] - k[1]) / 1e6:6.3f} ms  q{k[4]}"
+              + (("   " + k[0][:220]) if k[0].startswith("at::") else ""))
     a = agg.setdefault(k[0][:46], [0, 0])
     a[0] += 1; a[1] += k[2] - k[1]
 print("-- totals in the phase")

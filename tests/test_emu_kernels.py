@@ -371,3 +371,28 @@ def test_fc1_pack_follows_parameter_writes_emulated(monkeypatch):
     mac.critic_arena.touch()                                        # ... until the arena is told
     v2 = values()
     assert (v2[:, 1] - v1[:, 1]).abs().max() > 1e-4 and same(v2, values(no_pack=True))
+
+
+def check_gumbel_noise(lib, device, n):
+    """iplan_gumbel_noise: Gumbel(0, 1) moments (mean = Euler's gamma, variance = pi^2 / 6), no non-finite value, the same
+    samples for the same seed whatever the launch covers (counter based), different ones for another seed"""
+    import ctypes as C
+    stream = L.current_stream(device)
+    a, b, c = (torch.empty(n, dtype=torch.float32, device=device) for _ in range(3))
+    for out, seed in ((a, 7), (b, 7), (c, 8)):
+        assert lib.c.iplan_gumbel_noise(C.c_void_p(out.data_ptr()), C.c_int64(n), C.c_uint64(seed), C.c_void_p(stream)) == 0
+    half = torch.empty(n // 2, dtype=torch.float32, device=device)
+    assert lib.c.iplan_gumbel_noise(C.c_void_p(half.data_ptr()), C.c_int64(n // 2), C.c_uint64(7), C.c_void_p(stream)) == 0
+    a, b, c, half = a.cpu().double(), b.cpu().double(), c.cpu().double(), half.cpu().double()
+    assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a[:n // 2], half) and (a != c).float().mean() > 0.99
+    tol = 6.0 * (1.6449 / n) ** 0.5
+    assert abs(a.mean().item() - 0.5772157) < tol and abs(a.var().item() - 1.6449341) < 12 * tol, (a.mean().item(), a.var().item())
+    # P(g <= x) = exp(-exp(-x))
+    for x in (-1.0, 0.0, 1.0, 3.0):
+        p = float(torch.exp(-torch.exp(torch.tensor(-x))))
+        assert abs((a <= x).double().mean().item() - p) < 5.0 * (p * (1 - p) / n) ** 0.5 + 1e-9, x
+    assert lib.c.iplan_gumbel_noise(C.c_void_p(a.data_ptr()), C.c_int64(3), C.c_uint64(1), C.c_void_p(stream)) != 0   # n % 4
+
+
+def test_gumbel_noise_emulated():
+    check_gumbel_noise(get_emu_lib(), "cpu", 1 << 15)

@@ -41,3 +41,17 @@ def test_reference_checkpoint_matches(golden, tmp_path):
 def test_seq2seq_forward_matches_reference(golden):
     from tests.test_emu_kernels import check_seq2seq
     check_seq2seq(golden, "cuda")
+
+
+def test_gumbel_noise_gpu():
+    """the rollout's noise draw (iplan_gumbel_noise, one launch per rollout) on the real kernel"""
+    from iplan_amd import _lib as L
+    from tests.test_emu_kernels import check_gumbel_noise
+    L.use_library_for_tests(None)
+    check_gumbel_noise(L.get_lib(), "cuda", 1 << 22)
+    from iplan_amd.nova.GAT_Net import gumbel_noise
+    torch.manual_seed(5)
+    a = gumbel_noise((3, 5, 8), "cuda")
+    torch.manual_seed(5)
+    b = gumbel_noise((3, 5, 8), "cuda")
+    assert torch.equal(a, b) and a.shape == (3, 5, 8)
