@@ -257,6 +257,10 @@ typedef struct {
     const float* packed_actor;
     const float* packed_critic;
     int64_t packed_s_net;
+    /* optional (which = 2, ksplit = 1, ln_stats_mode = 2): fc1's pre-activation  W LN_F(x)  (WITHOUT fc1.bias) of every row, as
+     * iplan_ac_fc1_split_fwd leaves it, [2, n_agents, rows, 64]; the launch then skips the F-wide contraction and runs the
+     * 64-wide tail only.  NULL = contract here.                                                                            */
+    const float* fc1_pre;
 } IplanAcFwdArgs;
 
 int iplan_ac_fwd(const IplanAcFwdArgs* args, iplan_stream_t stream);
@@ -365,6 +369,7 @@ typedef struct {
     float* actor_grad;          /* gradient arenas (fc1.weight, feature_norm.* are written by finalize)  */
     float* critic_grad;
     int64_t actor_grad_s_net, critic_grad_s_net;
+    const float* xb;            /* iplan_ac_bwd_fc1_split only: the row-major-K fragments of iplan_ac_xhat_pack  */
 } IplanAcBwdArgs;
 
 /* iplan_ac_pack_fc1: packed[net] = { Wp [KT][4 o-tiles][64 lanes][4] | gamma_p [KT][16] | beta_p [KT][16] | W gamma [64] | W beta [64] },
@@ -382,6 +387,47 @@ typedef struct {
 } IplanAcPackArgs;
 int64_t iplan_ac_packed_floats(const IplanAcFeatures* feat);
 int iplan_ac_pack_fc1(const IplanAcPackArgs* args, iplan_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * fc1 of the PPO epochs on the bf16 matrix cores (learners/ippo_learner.py:190-221: the 15 epochs evaluate the same stored
+ * rows, only the weights move).  The normalised feature rows  xhat = (x - mean) * rstd  (LayerNorm(F) without its affine
+ * part, which is folded into the weights:  fc1(LN(x)) = (W o gamma) xhat + W beta + b)  are gathered ONCE per train() into
+ * two fp32 fragment-major copies -- `xf` for the forward (K = features), `xb` for the weight gradient (K = rows) -- and every
+ * epoch runs
+ *    iplan_ac_fc1_split_fwd    z1 = (W o gamma) xhat + W beta     for the actor and the critic of every agent, one pass over xf
+ *    iplan_ac_fwd(fc1_pre=z1)  the 64-wide tail
+ *    iplan_ac_bwd_fc1_split    G = dz1^T xhat  for both nets, one pass over xb  (then iplan_ac_bwd_fc1_finalize as before)
+ * with every fp32 operand split into three bf16 pieces in registers (x = p0 + p1 + p2 exactly) and the six largest piece
+ * products accumulated in fp32 on v_mfma_f32_16x16x32_bf16: the result agrees with the fp32 contraction to fp32 round-off.
+ * Fragment layouts (KT = iplan_ac_kpad / 16 k-tiles of the source-major feature order, KS = ceil(KT / 2) k-steps of 32):
+ *    xf [n_agents, 2 * RB, KS, 64 lanes, 8]   lane (n, g) of row tile t, slot j: xhat[16 t + n][k-tile 2 ks + (j >> 2)][4 g + (j & 3)]
+ *    xb [n_agents, RB, KT, 64 lanes, 8]       lane (f, g) of 32-row block b, slot j: xhat[32 b + 8 g + j][k-tile T][f]
+ * RB = ceil(rows / 32); rows past `rows` and features past F are zeros.                                                    */
+typedef struct {
+    int32_t n_agents, rows;
+    IplanAcFeatures feat;
+    const float* ln_stats;      /* (mean, rstd) per (net, physical row), as iplan_ac_fwd(ln_stats_mode = 1) stored them */
+    int64_t ln_stats_s_net;
+    float* xf;
+    float* xb;
+} IplanAcXhatArgs;
+int64_t iplan_ac_xhat_floats(const IplanAcFeatures* feat, int32_t rows, int32_t which);   /* per agent: which 0 = xf, 1 = xb */
+int iplan_ac_xhat_pack(const IplanAcXhatArgs* args, iplan_stream_t stream);
+
+typedef struct {
+    int32_t n_agents, rows;
+    IplanAcFeatures feat;        /* only N, w[], n_actions, n_id are read                                               */
+    IplanAcNet actor, critic;
+    const float* xf;
+    void* wsplit;                /* workspace, n_agents * KS * 24576 bytes: the bf16 pieces of W o gamma in fragment order */
+    float* wbeta;                /* workspace [2, n_agents, 64]: W beta                                                  */
+    float* z1;                   /* out [2, n_agents, rows, 64]                                                           */
+} IplanAcFc1SplitArgs;
+int iplan_ac_fc1_split_fwd(const IplanAcFc1SplitArgs* args, iplan_stream_t stream);
+/* args->xb set, fwd.which = 2, fc1_chunk_rows a multiple of 32; g_part as for iplan_ac_bwd_fc1.  iplan_ac_fc1_split_chunks:
+ * the row chunking that fills the chip once (returns fc1_chunks, writes fc1_chunk_rows). */
+int iplan_ac_fc1_split_chunks(const IplanAcFeatures* feat, int32_t n_agents, int32_t rows, int32_t* chunk_rows);
+int iplan_ac_bwd_fc1_split(const IplanAcBwdArgs* args, iplan_stream_t stream);
 
 int iplan_ac_kpad(const IplanAcFeatures* feat);   /* padded length of the kernels' source-major feature order */
 int iplan_ac_fc1_groups(const IplanAcFeatures* feat); /* wave jobs along the feature axis of iplan_ac_bwd_fc1 (the caller

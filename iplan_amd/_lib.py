@@ -51,9 +51,10 @@ class IplanError(RuntimeError):
 ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_step", "iplan_wgrad",
                 "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_adv_norm", "iplan_ppo_loss", "iplan_gat_bwd",
                 "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd", "iplan_mlp3_fwd", "iplan_mlp3_bwd", "iplan_seq2seq_fwd", "iplan_ac_pack_fc1",
+                "iplan_ac_xhat_pack", "iplan_ac_fc1_split_fwd", "iplan_ac_bwd_fc1_split",
                 "iplan_p2p_publish", "iplan_p2p_reduce"]
 RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups", "iplan_sizeof", "iplan_ac_packed_floats",
-                    "iplan_p2p_alloc", "iplan_p2p_free", "iplan_p2p_export", "iplan_p2p_open", "iplan_p2p_close", "iplan_gat_enc_fwd", "iplan_gumbel_noise"]      # non (args*, stream) signatures
+                    "iplan_p2p_alloc", "iplan_p2p_free", "iplan_p2p_export", "iplan_p2p_open", "iplan_p2p_close", "iplan_gat_enc_fwd", "iplan_gumbel_noise", "iplan_ac_xhat_floats", "iplan_ac_fc1_split_chunks"]      # non (args*, stream) signatures
 
 
 class Lib:
@@ -77,6 +78,9 @@ class Lib:
         cdll.iplan_sizeof.argtypes = [C.c_char_p]
         cdll.iplan_ac_packed_floats.restype = C.c_int64
         cdll.iplan_ac_packed_floats.argtypes = [C.c_void_p]
+        cdll.iplan_ac_fc1_split_chunks.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+        cdll.iplan_ac_xhat_floats.restype = C.c_int64
+        cdll.iplan_ac_xhat_floats.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         cdll.iplan_wgrad_workspace_floats.restype = C.c_size_t
         cdll.iplan_wgrad_workspace_floats.argtypes = [C.c_void_p]
         cdll.iplan_gat_enc_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -190,8 +194,17 @@ class AcFwdArgs(C.Structure):
         ("ho_s_net", i64), ("ho_s_row", i64), ("ao_s_net", i64), ("ao_s_row", i64),
         ("onehot_out", fp), ("oh_s_net", i64), ("oh_s_row", i64),
         ("ln_stats", fp), ("ln_stats_s_net", i64), ("ln_stats_mode", i32), ("phase_clocks", fp),
-        ("packed_actor", fp), ("packed_critic", fp), ("packed_s_net", i64),
+        ("packed_actor", fp), ("packed_critic", fp), ("packed_s_net", i64), ("fc1_pre", fp),
     ]
+
+
+class AcXhatArgs(C.Structure):
+    _fields_ = [("n_agents", i32), ("rows", i32), ("feat", AcFeatures), ("ln_stats", fp), ("ln_stats_s_net", i64), ("xf", fp), ("xb", fp)]
+
+
+class AcFc1SplitArgs(C.Structure):
+    _fields_ = [("n_agents", i32), ("rows", i32), ("feat", AcFeatures), ("actor", AcNet), ("critic", AcNet), ("xf", fp),
+                ("wsplit", fp), ("wbeta", fp), ("z1", fp)]
 
 
 class AcPackArgs(C.Structure):
@@ -260,7 +273,7 @@ class AcBwdArgs(C.Structure):
         ("fwd", AcFwdArgs), ("g_logp", fp), ("g_entropy", fp), ("g_entropy_const", C.c_float),
         ("g_values", fp), ("dsave", fp), ("ln_part", fp), ("g_part", fp),
         ("fc1_chunk_rows", i32), ("fc1_chunks", i32), ("actor_grad", fp), ("critic_grad", fp),
-        ("actor_grad_s_net", i64), ("critic_grad_s_net", i64),
+        ("actor_grad_s_net", i64), ("critic_grad_s_net", i64), ("xb", fp),
     ]
 
 
@@ -366,4 +379,4 @@ STRUCT_MIRRORS = {"IplanGatSaved": GatSaved, "IplanGatFwdArgs": GatFwdArgs, "Ipl
                   "IplanAcBwdArgs": AcBwdArgs, "IplanAdamArgs": AdamArgs, "IplanWgradProblem": WgradProblem,
                   "IplanWgradArgs": WgradArgs, "IplanPpoPrepareArgs": PpoPrepareArgs, "IplanPpoLossArgs": PpoLossArgs,
                   "IplanPdecArgs": PdecArgs, "IplanBehArgs": BehArgs, "IplanMlp3Args": Mlp3Args, "IplanAdvNormArgs": AdvNormArgs, "IplanSeq2SeqArgs": Seq2SeqArgs, "IplanAcPackArgs": AcPackArgs,
-                  "IplanIpcHandle": IpcHandle, "IplanP2pArgs": P2pArgs}
+                  "IplanIpcHandle": IpcHandle, "IplanP2pArgs": P2pArgs, "IplanAcXhatArgs": AcXhatArgs, "IplanAcFc1SplitArgs": AcFc1SplitArgs}

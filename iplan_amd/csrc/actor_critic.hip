@@ -22,7 +22,8 @@ constexpr int AT = AM / 16;            // 4 tiles
 #define AC_RT 2                       // row tiles per wave in the streaming (PPO) variant
 #endif
 
-template <int RT>
+// PRE: fc1's pre-activation comes from iplan_ac_fc1_split_fwd (a.fc1_pre) -- the launch is the 64-wide tail alone.
+template <int RT, bool PRE>
 __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     __shared__ float s_red[8][16], s_red2[8][16], s_cc[8][2][AM];
     __shared__ __attribute__((aligned(16))) f32x4 s_acc[RT == 1 ? 8 : 1][AT][64];          // (cross-wave K reduction: rollout shape only)
@@ -159,14 +160,14 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     //   P1 = W (gamma o x) on MFMA,  W gamma and W beta (lane-local dot products with the same W fragments),  sum x,  sum x^2
     // and  fc1(LN(x)) = rstd (P1 - mu W gamma) + W beta  is finished after the cross-wave reduction (no statistics pre-pass
     // over the row: it cost a third of the launch, all of it load latency).
-    const bool fold = RT == 1 && ks > 1 && a.ln_stats_mode == 0;
+    const bool fold = !PRE && RT == 1 && ks > 1 && a.ln_stats_mode == 0;
     float mu[RT], rstd[RT];
     float fsx = 0.f, fsxx = 0.f;
     float c1a[AT], c2a[AT];                                   // lane-local partial (W gamma)[16 oo + n], (W beta)[16 oo + n]
     for (int o = 0; o < AT; ++o) { c1a[o] = 0.f; c2a[o] = 0.f; }
     if (fold) {
         for (int t = 0; t < RT; ++t) { mu[t] = 0.f; rstd[t] = 1.f; }
-    } else if (a.ln_stats_mode == 2) {
+    } else if (PRE || a.ln_stats_mode == 2) {
         for (int t = 0; t < RT; ++t) {
             mu[t] = 0.f; rstd[t] = 0.f;
             if (vld[t]) {
@@ -317,7 +318,13 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
 #define AC_PF1 3
 #endif
     constexpr int PF = RT == 1 ? AC_PF1 : AC_PF;
-    for (int s = 0; s < 4; ++s) {
+    if (PRE) {
+        for (int t = 0; t < RT; ++t) {
+            const float* zrow = a.fc1_pre + (((int64_t)which * a.n_agents + net) * a.rows + (vld[t] ? rr[t] : 0)) * AM;
+            for (int o = 0; o < AT; ++o) accs[t][o] = vload_a(zrow, vld[t], o);
+        }
+    }
+    for (int s = 0; s < (PRE ? 0 : 4); ++s) {
         // this wave's tiles of block s: T in [b_lo, b_hi) with T % T_st == part; the fast ones are below f_hi
         // (km's arrays are indexed by the loop counter and live in scratch: what comes back is a VGPR, and loop bounds in
         // VGPRs make every branch below a divergent one -- exec-masked loads, wait counters drained at each join.  Through
@@ -663,13 +670,16 @@ extern "C" int iplan_ac_fwd(const IplanAcFwdArgs* a, iplan_stream_t stream) {
         return fail(IPLAN_EINVAL, "iplan_ac_fwd: n_actions=%d outside [1,16]", a->actor.n_out);
     if (a->which != 1 && a->mode == 1 && !a->q_noise) return fail(IPLAN_EINVAL, "iplan_ac_fwd: mode 1 needs q_noise");
     if (a->which != 1 && a->mode == 2 && !a->actions_in) return fail(IPLAN_EINVAL, "iplan_ac_fwd: mode 2 needs actions_in");
+    if (a->fc1_pre && (a->ksplit != 1 || a->ln_stats_mode != 2 || !a->ln_stats || !iplan::aligned16(a->fc1_pre)))
+        return fail(IPLAN_EINVAL, "iplan_ac_fwd: fc1_pre needs ksplit 1 and stored LayerNorm statistics (ln_stats_mode 2)");
     const int tiles = (a->rows + 15) / 16;
     if (a->ksplit == 8) {
         dim3 grid((unsigned)tiles, (unsigned)a->n_agents, a->which == 2 ? 2u : 1u);
-        hipLaunchKernelGGL(ac_fwd_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL((ac_fwd_kernel<1, false>), grid, dim3(512), 0, (hipStream_t)stream, *a);
     } else {
         dim3 grid((unsigned)((tiles + 8 * AC_RT - 1) / (8 * AC_RT)), (unsigned)a->n_agents, a->which == 2 ? 2u : 1u);   // 8 waves x AC_RT row tiles
-        hipLaunchKernelGGL(ac_fwd_kernel<AC_RT>, grid, dim3(512), 0, (hipStream_t)stream, *a);
+        if (a->fc1_pre) hipLaunchKernelGGL((ac_fwd_kernel<AC_RT, true>), grid, dim3(512), 0, (hipStream_t)stream, *a);
+        else hipLaunchKernelGGL((ac_fwd_kernel<AC_RT, false>), grid, dim3(512), 0, (hipStream_t)stream, *a);
     }
     return check_launch("iplan_ac_fwd");
 }

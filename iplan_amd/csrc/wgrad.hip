@@ -27,7 +27,19 @@
 namespace iplan {
 
 constexpr int WG_TK = 4;            // k-tiles per wave job (both shapes)
-constexpr int WG_TO_WIDE = 12;      // o-tiles per wave job: wide shape (problems with more than 8 o-tiles) ...
+#ifndef IPLAN_WG_TO_WIDE
+#define IPLAN_WG_TO_WIDE 12
+#endif
+#ifndef IPLAN_WG_WIDE_RB
+#define IPLAN_WG_WIDE_RB 1
+#endif
+#ifndef IPLAN_WG_WIDE_ROUNDS_MAX
+#define IPLAN_WG_WIDE_ROUNDS_MAX 1024
+#endif
+#ifndef IPLAN_WG_WIDE_SLOTS
+#define IPLAN_WG_WIDE_SLOTS 1024    // wave slots one round of wide jobs fills (1024 SIMDs x resident wide waves per SIMD)
+#endif
+constexpr int WG_TO_WIDE = IPLAN_WG_TO_WIDE;      // o-tiles per wave job: wide shape (problems with more than 8 o-tiles) ...
 constexpr int WG_TO_NARROW = 4;     // ... and narrow shape
 
 struct WgradGeom {
@@ -277,8 +289,8 @@ extern "C" int iplan_wgrad(IplanWgradArgs* a, iplan_stream_t stream) {
     int chunks_wide = IPLAN_WGRAD_MAX_CHUNKS;
     if (wide_jobs > 0) {
         const int per_chunk = wide_jobs * a->n_nets;
-        const int rounds = imax(1, per_chunk * IPLAN_WGRAD_MAX_CHUNKS / 1024);
-        chunks_wide = imax(1, imin(IPLAN_WGRAD_MAX_CHUNKS, rounds * 1024 / per_chunk));
+        const int rounds = imin(IPLAN_WG_WIDE_ROUNDS_MAX, imax(1, per_chunk * IPLAN_WGRAD_MAX_CHUNKS / IPLAN_WG_WIDE_SLOTS));
+        chunks_wide = imax(1, imin(IPLAN_WGRAD_MAX_CHUNKS, rounds * IPLAN_WG_WIDE_SLOTS / per_chunk));
     }
     int64_t off = 0;
     int max_elems = 1;
@@ -319,7 +331,7 @@ extern "C" int iplan_wgrad(IplanWgradArgs* a, iplan_stream_t stream) {
     if (jl[KIND].n)                                                                                                          \
         hipLaunchKernelGGL((wgrad_partial_kernel<TO_, TK_, RB_>), dim3((unsigned)jl[KIND].n, (unsigned)vcs[KIND], (unsigned)a->n_nets), \
                            dim3(64), 0, (hipStream_t)stream, *a, jl[KIND], chunks_wide);
-    IPLAN_WGRAD_LAUNCH(J_WIDE, WG_TO_WIDE, WG_TK, 1)
+    IPLAN_WGRAD_LAUNCH(J_WIDE, WG_TO_WIDE, WG_TK, IPLAN_WG_WIDE_RB)
     IPLAN_WGRAD_LAUNCH(J_THIN_K, WG_TO_NARROW, 1, 2)
     IPLAN_WGRAD_LAUNCH(J_THIN_O, 1, WG_TK, 2)
     IPLAN_WGRAD_LAUNCH(J_SQUARE, WG_TO_NARROW, WG_TK, 1)

@@ -17,6 +17,8 @@ Host code here is bookkeeping only: every number is produced by kernels in libip
 """
 import copy
 
+import os
+
 import torch as th
 
 from .. import _lib as L
@@ -294,9 +296,12 @@ class IPPOLearner:
             pl.mask_sum = msum.data_ptr()
             n_rows = float(self.dp_global_rows if self.dp_global_rows is not None else rows * self.dp.world)
             pl.row_count = n_rows                               # denominator of the unmasked (mean) loss forms
+        # the epochs re-evaluate the SAME rows: their normalised features are gathered once into the fragment-major arrays the
+        # split-bf16 fc1 kernels stream (ops.ac_xhat_pack); IPLAN_PPO_FC1_FP32=1 keeps the fp32 contraction (A/B, diagnostics)
+        xhat = None if os.environ.get("IPLAN_PPO_FC1_FP32") else ops.ac_xhat_pack(spec, rows, nA, ln_stats)
         for ep in range(self.ppo_epoch):
-            out = ops.ac_forward(mac.actor_arena, mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True,
-                                 packed=mac.fc1_pack.get(spec), **fwd_kw)         # repacked after every Adam step
+            out = ops.ac_forward(mac.actor_arena, mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True, xhat=xhat,
+                                 packed=None if xhat is not None else mac.fc1_pack.get(spec), **fwd_kw)   # (repacked after every Adam step)
             pl.logp, pl.entropy, pl.values = out["logp"].data_ptr(), out["entropy"].data_ptr(), out["values"].data_ptr()
             pl.stats = stats[ep].data_ptr()
             lib.call("iplan_ppo_loss", pl, stream)

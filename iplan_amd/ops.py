@@ -177,13 +177,15 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
                h_strides=(0, 0), avail=None, avail_strides=(0, 0), mode=0, q_noise=None, actions_in=None,
                act_strides=(0, 0), n_actions=5, ksplit=None, save=False, want_probs=False, want_entropy=False,
                want_h=True, h_out=None, actions_out=None, onehot_out=None, ln_stats=None, ln_stats_mode=0, phase_clocks=None,
-               packed=None, lib=None):
+               packed=None, xhat=None, lib=None):
     """Fused actor (which=0) / critic (1) / both (2) forward for all agents.
     Returns a dict with the requested outputs, each laid out [n_agents, rows, ...].
     Optional in-place destinations (rollout: write straight into the episode buffer):
       h_out = (actor_tensor, critic_tensor, (s_net, s_row));  actions_out = (int64 tensor, (s_net, s_row));
       onehot_out = (float tensor, (s_net, s_row)).
-    ln_stats [n_agents, n_physical_rows, 2] with ln_stats_mode 1 (compute + store) / 2 (re-use)."""
+    ln_stats [n_agents, n_physical_rows, 2] with ln_stats_mode 1 (compute + store) / 2 (re-use).
+    xhat: ``ac_xhat_pack(...)`` of the same (spec, rows) -- which = 2 only: fc1 runs as the split-bf16 contraction over the
+    packed rows (iplan_ac_fc1_split_fwd) and this launch is the 64-wide tail; ``ac_backward`` then takes the matching path."""
     lib = _lib(lib)
     dev = (actor_arena if which != 1 else critic_arena).data.device
     a = L.AcFwdArgs()
@@ -261,11 +263,46 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
     if save:
         out["saved"] = torch.empty(2, n_agents, rows, L.AC_SAVE_FLOATS, **f32)
         a.saved = out["saved"].data_ptr()
+    z1 = None
+    if xhat is not None:
+        assert which == 2 and a.ksplit == 1 and ln_stats_mode == 2 and xhat["rows"] == rows and xhat["n_agents"] == n_agents
+        s = L.AcFc1SplitArgs()
+        s.n_agents, s.rows = n_agents, rows
+        spec.fill(s.feat)
+        s.actor, s.critic = a.actor, a.critic
+        KS = (xhat["KT"] + 1) // 2
+        ws = workspace(dev, n_agents * KS * 6144 + 2 * n_agents * L.AC_HIDDEN, "fc1_split")
+        z1 = torch.empty(2, n_agents, rows, L.AC_HIDDEN, **f32)
+        s.xf, s.wsplit, s.wbeta, s.z1 = xhat["xf"].data_ptr(), ws.data_ptr(), ws.data_ptr() + 4 * n_agents * KS * 6144, z1.data_ptr()
+        # algorithmic work of the launch: 2 FLOP per (row, feature, output) of both nets
+        _launch("ac_fc1_split_fwd", lambda: lib.call("iplan_ac_fc1_split_fwd", s, L.current_stream(dev)),
+                work=2.0 * n_agents * rows * spec.F * 2 * L.AC_HIDDEN)
+        a.fc1_pre = z1.data_ptr()
+        out["_xhat"] = xhat
     _launch("ac_fwd_kernel:train" if save else ("ac_fwd_kernel:rollout" if rows <= 512 else "ac_fwd_kernel:infer"),
             lambda: lib.call("iplan_ac_fwd", a, L.current_stream(dev)))
     out["_args"] = a
-    out["_keep"] = (spec, h_actor, h_critic, avail, q_noise, actions_in, h_out, actions_out, onehot_out, ln_stats, packed)
+    out["_keep"] = (spec, h_actor, h_critic, avail, q_noise, actions_in, h_out, actions_out, onehot_out, ln_stats, packed, z1, xhat)
     return out
+
+
+def ac_xhat_pack(spec, rows, n_agents, ln_stats, lib=None):
+    """The normalised feature rows of a PPO batch, gathered once per train() into the two fragment-major copies the
+    split-bf16 fc1 kernels stream (include/iplan_hip.h: IplanAcXhatArgs).  ``ln_stats``: the (mean, rstd) table a
+    ``ac_forward(..., ln_stats_mode=1)`` pass stored for the same physical rows."""
+    lib = _lib(lib)
+    dev = ln_stats.device
+    a = L.AcXhatArgs()
+    a.n_agents, a.rows = n_agents, rows
+    spec.fill(a.feat)
+    assert ln_stats.dtype == torch.float32 and ln_stats.shape[0] == n_agents and ln_stats.stride(2) == 1 and ln_stats.stride(1) == 2
+    a.ln_stats, a.ln_stats_s_net = ln_stats.data_ptr(), ln_stats.stride(0)
+    nf, nb = (int(lib.c.iplan_ac_xhat_floats(C.byref(a.feat), rows, k)) for k in (0, 1))
+    xf = torch.empty(n_agents, nf, dtype=torch.float32, device=dev)
+    xb = torch.empty(n_agents, nb, dtype=torch.float32, device=dev)
+    a.xf, a.xb = xf.data_ptr(), xb.data_ptr()
+    _launch("ac_xhat_pack", lambda: lib.call("iplan_ac_xhat_pack", a, L.current_stream(dev)))
+    return dict(xf=xf, xb=xb, rows=rows, n_agents=n_agents, KT=int(lib.c.iplan_ac_kpad(C.byref(a.feat))) // 16, _keep=(spec, ln_stats))
 
 
 class _Packed(tuple):
@@ -497,16 +534,27 @@ def ac_backward(fwd, actor_arena, critic_arena, g_logp=None, g_entropy=0.0, g_va
     a.dsave, a.ln_part = dsave.data_ptr(), ln_part.data_ptr()
     Fpad = int(lib.c.iplan_ac_kpad(C.byref(fa.feat)))
     n_which = 2 if which == 2 else 1
-    # the fc1 contraction runs two waves per SIMD (8 k-tiles x 4 o-tiles per wave): as many row chunks as fill the chip once
-    k_groups = int(lib.c.iplan_ac_fc1_groups(C.byref(fa.feat)))
-    want = max(1, 2048 // (k_groups * n_which * n_agents))
-    chunk_rows = max(256, ((rows + want - 1) // want + 15) // 16 * 16)
+    xhat = fwd.get("_xhat")
+    if xhat is not None:
+        # split-bf16 form: a workgroup owns a block of k-tiles x both nets over a row chunk; the library sizes the chunks
+        cr = C.c_int32(0)
+        lib.c.iplan_ac_fc1_split_chunks(C.byref(fa.feat), n_agents, rows, C.byref(cr))
+        chunk_rows = cr.value
+        a.xb = xhat["xb"].data_ptr()
+    else:
+        # the fc1 contraction runs two waves per SIMD (8 k-tiles x 4 o-tiles per wave): as many row chunks as fill the chip once
+        k_groups = int(lib.c.iplan_ac_fc1_groups(C.byref(fa.feat)))
+        want = max(1, 2048 // (k_groups * n_which * n_agents))
+        chunk_rows = max(256, ((rows + want - 1) // want + 15) // 16 * 16)
     chunks = (rows + chunk_rows - 1) // chunk_rows
     g_part = workspace(dev, n_which * n_agents * chunks * L.AC_HIDDEN * Fpad, "fc1")
     a.g_part, a.fc1_chunk_rows, a.fc1_chunks = g_part.data_ptr(), chunk_rows, chunks
     stream = L.current_stream(dev)
     lib.call("iplan_ac_bwd_tail", a, stream)
-    lib.call("iplan_ac_bwd_fc1", a, stream)
+    if xhat is not None:
+        _launch("ac_fc1_split_wgrad", lambda: lib.call("iplan_ac_bwd_fc1_split", a, stream), work=2.0 * n_agents * rows * spec.F * 2 * L.AC_HIDDEN)
+    else:
+        lib.call("iplan_ac_bwd_fc1", a, stream)
     T, T_phys = spec.T, spec.T_phys
     hs = (fa.hs_net, fa.hs_row)
     if which != 1:

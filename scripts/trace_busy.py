@@ -36,5 +36,5 @@ for lo, hi in ((0, 5e3), (5e3, 2e4), (2e4, 1e5), (1e5, 1e6), (1e6, 1e9)):
 # phases of the cycle's rollouts
 for i in range(8):
     a, b = starts[-16 + i], starts[-16 + i + 1]
-    last_ac = max(k[2] for k in ks if a <= k[1] < b and "ac_fwd_kernel<1>" in k[0])
+    last_ac = max(k[2] for k in ks if a <= k[1] < b and "ac_fwd_kernel<1" in k[0])
     print(f"  rollout {i}: {(last_ac - a) / 1e6:6.2f} ms, then until the next rollout {(b - last_ac) / 1e6:6.2f} ms")

@@ -396,3 +396,105 @@ def check_gumbel_noise(lib, device, n):
 
 def test_gumbel_noise_emulated():
     check_gumbel_noise(get_emu_lib(), "cpu", 1 << 15)
+
+
+def check_fc1_split_vs_fp32(device, rows_per_ep=7, n_eps=5, seed=3, N=5, log=None):
+    """The split-bf16 fc1 path of the PPO epochs (iplan_ac_xhat_pack / iplan_ac_fc1_split_fwd / iplan_ac_bwd_fc1_split)
+    against the fp32 MFMA path of the same launch and against an fp64 evaluation of fc1(LayerNorm(x)): the forward's
+    pre-activation and every fc1 / feature_norm gradient.  Ragged on purpose: rows not a multiple of 16 or 32, an odd number
+    of k-tiles."""
+    from iplan_amd import ops, synth
+    from iplan_amd import _lib as L
+    from iplan_amd.config import default_args
+    from iplan_amd.controllers.dcntrl_controller import DcntrlMAC
+    args = default_args("highway", use_cuda=(device != "cpu"), max_vehicle_num=N, n_agents=2, episode_limit=rows_per_ep)
+    torch.manual_seed(seed)
+    mac = DcntrlMAC(synth.make_scheme(args), {"agents": args.n_agents}, args)
+    with torch.no_grad():                                         # LayerNorm(F) affine away from its (1, 0) initialisation
+        for arena in (mac.actor_arena, mac.critic_arena):
+            for m in arena.modules:
+                p = dict(m.named_parameters())
+                p["base.feature_norm.weight"].add_(0.3 * torch.randn_like(p["base.feature_norm.weight"]))
+                p["base.feature_norm.bias"].add_(0.3 * torch.randn_like(p["base.feature_norm.bias"]))
+            arena.touch()
+    nA, T, T1, M = args.n_agents, rows_per_ep, rows_per_ep + 1, 64
+    f = {k: v.to(device) for k, v in synth.make_episode_fields(args, n_eps, seed, 0.2).items()}
+    srcs = []
+    for key, w in mac._widths():
+        t = f[key]
+        srcs.append((t, w, t.stride(2), t.stride(1)))
+    last = torch.randint(-1, args.n_actions, (n_eps, T1, nA), dtype=torch.int32, device=device)
+    spec_all = ops.AcFeatureSpec(args.max_vehicle_num, srcs, n_actions=args.n_actions, last_action=last, la_strides=(1, nA),
+                                 n_id=nA, T=T1, T_phys=T1)
+    spec = ops.AcFeatureSpec(args.max_vehicle_num, srcs, n_actions=args.n_actions, last_action=last, la_strides=(1, nA),
+                             n_id=nA, T=T, T_phys=T1)
+    rows = n_eps * T
+    h = torch.randn(2, n_eps, T1, nA, M, device=device) * 0.1
+    hs = (h[0].stride(2), h[0].stride(1))
+    ln_stats = torch.empty(nA, n_eps * T1, 2, device=device)
+    ops.ac_forward(None, mac.critic_arena, 1, spec_all, n_eps * T1, nA, h_critic=h[1], h_strides=hs, ksplit=1, want_h=False,
+                   ln_stats=ln_stats, ln_stats_mode=1)
+    actions = torch.randint(0, args.n_actions, (n_eps, T1, nA, 1), device=device)
+    kw = dict(h_actor=h[0], h_critic=h[1], h_strides=hs, mode=2, actions_in=actions, act_strides=(actions.stride(2), actions.stride(1)),
+              n_actions=args.n_actions, ksplit=1, want_h=False, ln_stats=ln_stats, ln_stats_mode=2, save=True, want_entropy=True)
+    xhat = ops.ac_xhat_pack(spec, rows, nA, ln_stats)
+    g1, g2 = torch.randn(nA, rows, device=device), torch.randn(nA, rows, device=device)
+    res = {}
+    for tag, xh in (("fp32", None), ("split", xhat)):
+        for arena in (mac.actor_arena, mac.critic_arena):
+            arena.grad.zero_()
+        out = ops.ac_forward(mac.actor_arena, mac.critic_arena, 2, spec, rows, nA, xhat=xh, **kw)
+        bw = ops.ac_backward(out, mac.actor_arena, mac.critic_arena, g_logp=g1, g_entropy=-0.01 / rows, g_values=g2)
+        res[tag] = dict(a1=out["saved"][..., 0:M].clone(), logp=out["logp"].clone(), values=out["values"].clone(),
+                        dz1=bw["dsave"][..., 0:M].clone(), ga=mac.actor_arena.grad.clone(), gc=mac.critic_arena.grad.clone(),
+                        z1=None if xh is None else out["_keep"][11].clone())
+    # fp64 evaluation from the raw fields
+    x = torch.cat([torch.cat([f[key][:, :T].double() for key, _ in mac._widths()], dim=-1).flatten(-2)], dim=-1)   # [eps, T, nA, N*W]
+    oh_last = torch.zeros(n_eps, T, nA, args.n_actions, dtype=torch.float64, device=device)
+    lidx = last[:, :T].long()
+    oh_last.scatter_(-1, lidx.clamp(min=0).unsqueeze(-1), (lidx >= 0).double().unsqueeze(-1))
+    ident = torch.eye(nA, dtype=torch.float64, device=device).expand(n_eps, T, nA, nA)
+    x = torch.cat([x, oh_last, ident], dim=-1)                     # [eps, T, nA, F]
+    xhat64 = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    worst = {}
+    for which, arena in enumerate((mac.actor_arena, mac.critic_arena)):
+        for i in range(nA):
+            W, gam, bet = (arena.param(i, n).double() for n in ("base.mlp.fc1.0.weight", "base.feature_norm.weight", "base.feature_norm.bias"))
+            xr = xhat64[:, :, i].reshape(rows, -1)
+            z64 = (xr * gam + bet) @ W.t()
+            z = res["split"]["z1"][which, i].double()
+            worst["z1"] = max(worst.get("z1", 0.0), rel_err(z, z64))
+            b = arena.param(i, "base.mlp.fc1.0.bias").double()
+            for tag in ("fp32", "split"):
+                worst["a1_" + tag] = max(worst.get("a1_" + tag, 0.0), rel_err(res[tag]["a1"][which, i].double(), torch.relu(z64 + b)))
+            # gradients of fc1.weight / feature_norm from each path's OWN dz1 (the tails differ by rounding), in fp64
+            for tag in ("fp32", "split"):
+                dz = res[tag]["dz1"][which, i].double()
+                G = dz.t() @ xr
+                S = dz.sum(0)
+                ref = {"base.mlp.fc1.0.weight": gam * G + bet * S[:, None], "base.feature_norm.weight": (W * G).sum(0),
+                       "base.feature_norm.bias": (W * S[:, None]).sum(0)}
+                garena = res[tag]["ga" if which == 0 else "gc"]
+                for name, r64 in ref.items():
+                    off, numel = arena.off(name), r64.numel()
+                    got = garena[i, off:off + numel].view(r64.shape).double()
+                    worst[f"{name}_{tag}"] = max(worst.get(f"{name}_{tag}", 0.0), rel_err(got, r64))
+    worst["logp_split_vs_fp32"] = rel_err(res["split"]["logp"], res["fp32"]["logp"])
+    worst["values_split_vs_fp32"] = rel_err(res["split"]["values"], res["fp32"]["values"])
+    if log is not None:
+        log(worst)
+    assert worst["logp_split_vs_fp32"] < 1e-5 and worst["values_split_vs_fp32"] < 1e-5, worst
+    # every quantity within the parity contract's 1e-5 of the fp64 value, and the split path as close to fp64 as the fp32
+    # MFMA path is (the K = F contraction is one fp32 chain there, 2.6e-6 of max|z| at F = 2485; six exact bf16 piece
+    # products per K = 32 step accumulated in fp32 here)
+    for k, v in worst.items():
+        assert v < 1e-5, (k, v, worst)
+    assert worst["z1"] <= max(2e-6, 1.5 * worst["a1_fp32"]), worst
+    for name in ("a1", "base.mlp.fc1.0.weight", "base.feature_norm.weight", "base.feature_norm.bias"):
+        assert worst[name + "_split"] <= max(2e-6, 1.5 * worst[name + "_fp32"]), (name, worst)
+    return worst
+
+
+def test_fc1_split_vs_fp32_emulated():
+    check_fc1_split_vs_fp32("cpu")
+    check_fc1_split_vs_fp32("cpu", rows_per_ep=13, n_eps=5, seed=4)     # 65 rows: three 32-row blocks, the last one ragged

@@ -401,7 +401,10 @@ def test_ppo_loss_switches_vs_oracle_emulated(flags):
     """the PPO loss switches of config/algs/ippo.yaml away from their shipped values (learners/ippo_learner.py:142-157,
     190-196, 353-362): MSE instead of Huber, no value clipping, plain means instead of active masks, no GAE"""
     from tests.oracle_checks import check_ppo_train_vs_oracle
-    check_ppo_train_vs_oracle(_small(ppo_epoch=2, **flags), "cpu", seed=41)
+    # all switches off: the NAMED EXCEPTION of tests/test_gpu_parity_fullsize.py::test_ppo_loss_switches_vs_oracle (DESIGN.md
+    # section 5) -- the critic's v_out.bias / rnn.norm.bias gradients are nearly cancelling means of v - return (condition
+    # number ~ 300), any fp32 value head lands 1e-5 ... 4e-5 of the tensor's max from the fp64 result: 6 x e32 for that case
+    check_ppo_train_vs_oracle(_small(ppo_epoch=2, **flags), "cpu", seed=41, e32_factor=6.0 if len(flags) > 1 else 1.5)
 
 
 def test_behavior_learn_decoder_forward_second_form_emulated(monkeypatch):

@@ -146,3 +146,10 @@ def test_behavior_learn_decoder_forward_second_form_gpu(monkeypatch):
     _log("behavior_learn_cfg3_E32_agent0_dec_fwd_v2", check_behavior_learn_vs_oracle(_args(batch_size_run=32), 32, "cuda", seed=23, agents=(0,)))
     b = _args(max_vehicle_num=9, n_agents=2, episode_limit=20, batch_size_run=4)
     _log("behavior_learn_ragged_dec_fwd_v2", check_behavior_learn_vs_oracle(b, 4, "cuda", seed=43))
+
+
+def test_fc1_split_vs_fp32_gpu():
+    """the split-bf16 fc1 kernels of the PPO epochs at the full feature width (55 entities, F = 2485: 157 k-tiles, an odd
+    count) against the fp32 MFMA kernels and an fp64 evaluation -- forward pre-activation and the fc1 / feature_norm gradients"""
+    from tests.test_emu_kernels import check_fc1_split_vs_fp32
+    check_fc1_split_vs_fp32("cuda", rows_per_ep=37, n_eps=29, seed=5, N=55, log=lambda w: _log("fc1_split_vs_fp32", w))
