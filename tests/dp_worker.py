@@ -194,6 +194,7 @@ if DEV != "cpu":
         for c in range(3):
             torch.manual_seed(1000 + c)
             torch.cuda.manual_seed(1000 + c)
+            np.random.seed(1000 + c)                                # (the prediction learner's sample draw: np.random.choice)
             with contextlib.redirect_stdout(io.StringIO()):
                 lp.cycle()
         lp.behavior.join_decoder()
