@@ -25,6 +25,6 @@ inline int check_launch(const char* what) {
     return IPLAN_OK;
 }
 
-inline bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
+__host__ __device__ inline bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
 
 }  // namespace iplan

@@ -9,12 +9,37 @@
 namespace iplan {
 
 // out[net*out_stride + slot] = sum(g[net*g_stride + off .. + n)^2); one block per net, fixed order.
+// Latency bound (one workgroup streams the whole slice): 16-byte loads, four of them in flight per thread -- with one dword
+// per thread and iteration the 190 000-float actor slice took 55 us, twice per PPO epoch.
 __global__ __launch_bounds__(1024) void sqnorm_kernel(const float* __restrict__ g, int64_t g_stride, int64_t off,
                                                       int64_t n, float* __restrict__ out, int out_stride, int slot) {
     __shared__ float s_part[16];
     const float* p = g + (int64_t)blockIdx.x * g_stride + off;
     float acc = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc = fmaf(p[i], p[i], acc);
+    int64_t done = 0;
+    if (aligned16(p)) {
+        const f32x4* __restrict__ p4 = reinterpret_cast<const f32x4*>(p);
+        const int64_t n4 = n >> 2, B = blockDim.x;
+        f32x4 a4[4];
+        for (int u = 0; u < 4; ++u) a4[u] = splat4(0.f);
+        int64_t i = threadIdx.x;
+        for (; i + 3 * B < n4; i += 4 * B) {
+            const f32x4 v0 = p4[i], v1 = p4[i + B], v2 = p4[i + 2 * B], v3 = p4[i + 3 * B];
+            for (int q = 0; q < 4; ++q) {
+                a4[0][q] = fmaf(v0[q], v0[q], a4[0][q]);
+                a4[1][q] = fmaf(v1[q], v1[q], a4[1][q]);
+                a4[2][q] = fmaf(v2[q], v2[q], a4[2][q]);
+                a4[3][q] = fmaf(v3[q], v3[q], a4[3][q]);
+            }
+        }
+        for (; i < n4; i += B) {
+            const f32x4 v = p4[i];
+            for (int q = 0; q < 4; ++q) a4[0][q] = fmaf(v[q], v[q], a4[0][q]);
+        }
+        for (int u = 0; u < 4; ++u) acc += (a4[u][0] + a4[u][1]) + (a4[u][2] + a4[u][3]);
+        done = n4 << 2;
+    }
+    for (int64_t i = done + threadIdx.x; i < n; i += blockDim.x) acc = fmaf(p[i], p[i], acc);
     acc = wave_sum(acc);
     if (lane_id() == 0) s_part[wave_id()] = acc;
     __syncthreads();

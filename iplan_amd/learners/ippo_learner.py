@@ -268,11 +268,18 @@ class IPPOLearner:
         fwd_kw = dict(h_actor=ha, h_critic=hc, h_strides=hs, avail=avail, avail_strides=av_s, mode=2,
                       actions_in=actions, act_strides=act_s, n_actions=n_act, ksplit=1, want_h=False,
                       ln_stats=ln_stats, ln_stats_mode=2)
-        old_logp = ops.ac_forward(mac.actor_arena, None, 0, spec, rows, nA, packed=mac.fc1_pack.get(spec), **fwd_kw)["logp"]
-        if bs * T != rows:                                   # pad to the [nA, bs*T] stride of adv / returns
-            tmp = th.zeros(nA, bs * T, **f32)
-            tmp[:, :rows] = old_logp
-            old_logp = tmp
+        # old_action_log_probs (:383): the actor's log-probs at the parameters train() starts from.  The full-batch split-bf16
+        # path takes them from its own first epoch (same parameters, same kernels: ratio == 1 there, as in the reference,
+        # which evaluates one network twice); the other paths need them up front.
+        split = self.num_mini_batch == 1 and not os.environ.get("IPLAN_PPO_FC1_FP32")
+        if split:
+            old_logp = th.zeros(nA, bs * T, **f32)
+        else:
+            old_logp = ops.ac_forward(mac.actor_arena, None, 0, spec, rows, nA, packed=mac.fc1_pack.get(spec), **fwd_kw)["logp"]
+            if bs * T != rows:                               # pad to the [nA, bs*T] stride of adv / returns
+                tmp = th.zeros(nA, bs * T, **f32)
+                tmp[:, :rows] = old_logp
+                old_logp = tmp
 
         if self.num_mini_batch > 1:
             fin = self._train_minibatches(t_env, rows, last, ln_stats, old_logp, adv, returns, vpred, mask)
@@ -298,10 +305,12 @@ class IPPOLearner:
             pl.row_count = n_rows                               # denominator of the unmasked (mean) loss forms
         # the epochs re-evaluate the SAME rows: their normalised features are gathered once into the fragment-major arrays the
         # split-bf16 fc1 kernels stream (ops.ac_xhat_pack); IPLAN_PPO_FC1_FP32=1 keeps the fp32 contraction (A/B, diagnostics)
-        xhat = None if os.environ.get("IPLAN_PPO_FC1_FP32") else ops.ac_xhat_pack(spec, rows, nA, ln_stats)
+        xhat = ops.ac_xhat_pack(spec, rows, nA, ln_stats) if split else None
         for ep in range(self.ppo_epoch):
             out = ops.ac_forward(mac.actor_arena, mac.critic_arena, 2, spec, rows, nA, save=True, want_entropy=True, xhat=xhat,
                                  packed=None if xhat is not None else mac.fc1_pack.get(spec), **fwd_kw)   # (repacked after every Adam step)
+            if split and ep == 0:
+                old_logp[:, :rows].copy_(out["logp"])
             pl.logp, pl.entropy, pl.values = out["logp"].data_ptr(), out["entropy"].data_ptr(), out["values"].data_ptr()
             pl.stats = stats[ep].data_ptr()
             lib.call("iplan_ppo_loss", pl, stream)

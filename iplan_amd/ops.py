@@ -5,6 +5,7 @@ pointers / strides, (c) calls the entry point on torch's current stream.  No ari
 here.  ``lib`` defaults to the gfx950 build; the CPU test-suite passes the host-emulated build of
 the same kernel sources instead.
 """
+import contextlib
 import ctypes as C
 
 import os
@@ -551,22 +552,40 @@ def ac_backward(fwd, actor_arena, critic_arena, g_logp=None, g_entropy=0.0, g_va
     a.g_part, a.fc1_chunk_rows, a.fc1_chunks = g_part.data_ptr(), chunk_rows, chunks
     stream = L.current_stream(dev)
     lib.call("iplan_ac_bwd_tail", a, stream)
+    ev_tail = None
+    if which == 2 and dev.type == "cuda":
+        ev_tail = torch.cuda.Event()
+        ev_tail.record(torch.cuda.current_stream(dev))
     if xhat is not None:
         _launch("ac_fc1_split_wgrad", lambda: lib.call("iplan_ac_bwd_fc1_split", a, stream), work=2.0 * n_agents * rows * spec.F * 2 * L.AC_HIDDEN)
     else:
         lib.call("iplan_ac_bwd_fc1", a, stream)
     T, T_phys = spec.T, spec.T_phys
     hs = (fa.hs_net, fa.hs_row)
+    # The weight-gradient contractions of the 64-wide layers are small, latency-bound launches (a wide one and three narrow
+    # ones per arena, 0.25 ms per arena at config 3) and the two arenas are independent: the critic's run on a side stream
+    # beside the actor's and the fc1 contraction, joined before the finalize (it reads both fc1.bias gradients).
+    side = None
+    if which == 2 and dev.type == "cuda" and not os.environ.get("IPLAN_AC_WGRAD_SERIAL"):
+        main = torch.cuda.current_stream(dev)
+        side = _SIDE_STREAMS.setdefault((str(dev), main.cuda_stream, "ac"), torch.cuda.Stream(dev))
+        side.wait_event(ev_tail)
     if which != 1:
         w = Wgrad(actor_arena.grad, n_agents)
         _ac_wgrad(w, actor_arena, ("act.action_out.linear.weight", "act.action_out.linear.bias"), saved, dsave, 0,
                   n_agents, rows, T, h_actor.data_ptr(), hs, T_phys, fa.actor.n_out, tiles, ln_part)
         w.run(lib)
     if which != 0:
-        w = Wgrad(critic_arena.grad, n_agents)
-        _ac_wgrad(w, critic_arena, ("v_out.weight", "v_out.bias"), saved, dsave, 1,
-                  n_agents, rows, T, h_critic.data_ptr(), hs, T_phys, 1, tiles, ln_part)
-        w.run(lib)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            w = Wgrad(critic_arena.grad, n_agents)
+            _ac_wgrad(w, critic_arena, ("v_out.weight", "v_out.bias"), saved, dsave, 1,
+                      n_agents, rows, T, h_critic.data_ptr(), hs, T_phys, 1, tiles, ln_part)
+            w.run(lib)
+            if side is not None:
+                ev_side = torch.cuda.Event()
+                ev_side.record(side)
+        if side is not None:
+            main.wait_event(ev_side)
     lib.call("iplan_ac_bwd_fc1_finalize", a, stream)
     return dict(dsave=dsave, ln_part=ln_part)
 
