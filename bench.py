@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 from iplan_amd.config import default_args  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32, dense)
+BF16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: v_mfma_f32_16x16x32_bf16, dense (the split-bf16 kernels issue 6 of them per fp32 product)
 HBM_PEAK_GBS = 8000.0                # HBM3E spec (same guide; ~6.3 TB/s is what a float4 copy achieves)
 def csrc_sha16():
     """Hash of the kernel sources this checkout builds libiplan_hip.so from (every file of iplan_amd/csrc + the C header)."""
@@ -277,8 +278,10 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
     if E > 128:                                                                         # env-chunked behaviour learning
         f_dec, f_enc = f_dec * 128 / E, f_enc * 128 / E
     rows = args.batch_size * T
-    f_ac = nA * 2 * rows * (2 * F * M + 14 * M * M + 2 * M * 3)                          # actor + critic, n_out 5 / 1
-    b_ac = nA * (4.0 * rows * F + 2 * 4.0 * rows * 648)                                  # features once + the saved activations
+    kpad32 = -(-(-(-N * d // 16) + -(-N * args.attention_dim // 16) + -(-N * Z // 16) + -(-(args.n_actions + nA) // 16)) // 2) * 32
+    f_fc1 = nA * 2.0 * rows * F * 2 * M                                                  # fc1 of actor + critic: 2 F M FLOP per row and net
+    b_fc1 = nA * (4.0 * rows * kpad32 + 2 * 4.0 * rows * M)                              # fragments once + z1 of both nets
+    b_tail = nA * 2 * 4.0 * rows * (M + M + 648)                                         # z1 + h in, the activation record out
     out = [
         entry("gat_enc_fwd_kernel", "gat_fwd_kernel", "mfma",
               gat_algorithmic_flops(nA, E, N, d + Z) + nA * V * (Lw * (2 * d * R + 12 * R * R) + 2 * R * Z), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
@@ -298,11 +301,18 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
               "the iplan_wgrad call on each decoder-BPTT window range of Behavior_policy.learn (4 problems: W_out, W_ih, W_hh, W_lin; 3 partial "
               "kernels + reduction, side stream): algorithmic bytes = each operand row read once, 4 (O + K) bytes per row and problem",
               traffic_key="iplan_wgrad:beh_dec", work_from_timer=True),
-        entry("ac_fwd_kernel<PPO>", "ac_fwd_kernel:train", "mfma", f_ac, 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
-              f"actor + critic forward of one PPO epoch ({rows} rows x F = {F}, 5 agents, activations saved); SURVEY.md §8d: AI ~ ridge, so "
-              "both roofs are reported", traffic_key="ac_fwd_kernel:train"),
-        entry("ac_fwd_kernel<PPO> (HBM roof)", "ac_fwd_kernel:train", "hbm", b_ac, 1e9, HBM_PEAK_GBS, "GB/s",
-              "same launches against the HBM roof: gathered features read once for both nets + saved activations written",
+        entry("ac_fc1_split_fwd_kernel", "ac_fc1_split_fwd", "mfma", f_fc1, 1e12, BF16_MFMA_PEAK_TFLOPS / 6.0, "TFLOP/s",
+              f"fc1 of the actor AND the critic of one PPO epoch ({rows} rows x F = {F} x 128 outputs, 5 agents) over the packed normalised "
+              "features, fp32-exact split-bf16: 6 bf16 piece products per fp32 product, so peak = the dense bf16 MFMA peak / 6 in "
+              "fp32-equivalent FLOPs (the timed span includes the two small weight-piece kernels in front of the contraction)"),
+        entry("ac_fc1_split_fwd_kernel (HBM roof)", "ac_fc1_split_fwd", "hbm", b_fc1, 1e9, HBM_PEAK_GBS, "GB/s",
+              "same launches against the HBM roof: the fp32 feature fragments read once for both nets + the pre-activations written",
+              traffic_key="ac_fc1_split_fwd"),
+        entry("ac_fc1_split_wgrad_kernel", "ac_fc1_split_wgrad", "mfma", f_fc1, 1e12, BF16_MFMA_PEAK_TFLOPS / 6.0, "TFLOP/s",
+              "fc1 weight gradient G = dz1^T xhat of both nets of one PPO epoch, same split-bf16 form (K = rows)"),
+        entry("ac_fwd_kernel<PPO tail>", "ac_fwd_kernel:train", "hbm", b_tail, 1e9, HBM_PEAK_GBS, "GB/s",
+              f"the 64-wide tail of the actor + critic forward of one PPO epoch from the stored fc1 pre-activations ({rows} rows, 5 agents): "
+              "reads z1 and the stored GRU state, writes the 648-float activation record per row and net",
               traffic_key="ac_fwd_kernel:train"),
     ]
     return out

@@ -230,6 +230,163 @@ __global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a, Wgr
     }
 }
 
+// The wide jobs on the bf16 matrix cores: same job shape, row chunks, addressing and partial-tile layout as the fp32 kernel
+// above, but a block is 32 rows (the K of v_mfma_f32_16x16x32_bf16: lane (i, g) holds rows 8 g + j, j < 8, of column i of
+// every operand tile), every loaded value is split into its three bf16 pieces in registers (x = p0 + p1 + p2 exactly) and the
+// six largest piece products are accumulated in fp32 -- the fp32 contraction to fp32 round-off at 6/16 of its matrix-pipe
+// time (a [192 x 64] GRU weight over 1.4 M rows per net is 2.2 ms of v_mfma_f32_16x16x4_f32 issue, the floor of the fp32 form).
+// Rolling prefetch per operand tile: as soon as a tile's raw values are split its registers are reloaded with the next block.
+// NO control flow around the loads (the compiler drains the memory counter at every join behind one: a branch per loaded row for
+// the recurrent operand's initial-state rows made this kernel 5x slower than the fp32 form): masks are bitwise ANDs, and
+// problems WITH an initial-state operand (x0) stay on the fp32 kernel (iplan_wgrad routes them; a second always-executed load
+// per X value for those rare rows cost more than the matrix time it saved: behaviour learn with in-line pieces 21.7 -> 28 ms).
+template <int TO, int TK>
+__global__ __launch_bounds__(64) void wgrad_partial_bf16_kernel(IplanWgradArgs a, WgradJobs jl, int chunks_wide) {
+    const int pj = jl.pj[blockIdx.x], pi = pj >> 8, job = pj & 255, net = (int)blockIdx.z;
+    const IplanWgradProblem& p = a.p[pi];
+    const WgradGeom gm = wgrad_geom(p, chunks_wide);
+    const int vc = (int)blockIdx.y;
+    if (vc >= gm.vchunks) return;
+    const int og = job / gm.n_kg, kg = job % gm.n_kg;
+    const int l = lane_id(), i = l & 15, g = l >> 4;
+    const int ot0 = og * TO, kt0 = kg * WG_TK;
+    const int not_ = imin(TO, gm.OT - ot0), nkt = gm.KT > 0 ? imin(TK, gm.KT - kt0) : 0;
+    const bool want_bias = (kg == 0);
+
+    f32x4 acc[TO][TK];
+    float bsum[TO];
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+        bsum[t] = 0.f;
+#pragma unroll
+        for (int u = 0; u < TK; ++u) acc[t][u] = splat4(0.f);
+    }
+    const int64_t r_lo = (int64_t)vc * gm.vrows;
+    const int64_t r_hi = gm.rows < r_lo + gm.vrows ? gm.rows : r_lo + gm.vrows;
+    const int o_lo = (int)(r_lo / p.n_inner);
+    const char* __restrict__ abase = reinterpret_cast<const char*>(p.dy + (int64_t)net * p.dy_s_net + (int64_t)o_lo * p.dy_s_outer);
+    // (a bias-only problem has no X: its B loads read dY's first row instead and are masked to zero)
+    const bool has_x = nkt > 0 && p.x != nullptr;
+    const char* __restrict__ xbase = has_x ? reinterpret_cast<const char*>(p.x + (int64_t)net * p.x_s_net + (int64_t)o_lo * p.x_s_outer) : abase;
+    uint32_t acolb[TO], bcolb[TK];
+#pragma unroll
+    for (int t = 0; t < TO; ++t) acolb[t] = 4u * (uint32_t)ocol(p, imin((ot0 + imin(t, not_ - 1)) * 16 + i, p.O - 1));
+#pragma unroll
+    for (int u = 0; u < TK; ++u) {
+        const int kc = has_x ? imin((kt0 + imin(u, nkt - 1)) * 16 + i, p.K - 1) : 0;
+        bcolb[u] = has_x ? 4u * (uint32_t)(p.x_col0 + kc) : 0u;
+    }
+    // cursors of this lane's 8 rows of the block being LOADED (rows 8 g + j), advanced by 32 rows per block
+    int ri[8];
+    uint32_t aoff[8], xoff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t r = r_lo + 8 * g + j;
+        const int ro = (int)(r / p.n_inner);
+        ri[j] = (int)(r - (int64_t)ro * p.n_inner);
+        aoff[j] = (uint32_t)(4 * ((int64_t)(ro - o_lo) * p.dy_s_outer + (int64_t)ri[j] * p.dy_s_inner));
+        xoff[j] = (uint32_t)(4 * ((int64_t)(ro - o_lo) * p.x_s_outer + (int64_t)(ri[j] + p.x_shift) * p.x_s_inner));
+    }
+    const int adv_o = 32 / p.n_inner, adv_i = 32 % p.n_inner;
+    const uint32_t a_adv = (uint32_t)(4 * ((int64_t)adv_o * p.dy_s_outer + (int64_t)adv_i * p.dy_s_inner));
+    const uint32_t x_adv = (uint32_t)(4 * ((int64_t)adv_o * p.x_s_outer + (int64_t)adv_i * p.x_s_inner));
+    const uint32_t a_wrap = (uint32_t)(4 * (p.dy_s_outer - (int64_t)p.n_inner * p.dy_s_inner));
+    const uint32_t x_wrap = (uint32_t)(4 * (p.x_s_outer - (int64_t)p.n_inner * p.x_s_inner));
+    const bool shifted = p.x_shift != 0;
+
+    float ar[TO][8], br[TK][8];
+    // offsets / masks of the block the raw registers are (re)loaded with, fixed by `advance` before the block's loads are issued
+    uint32_t ao[8], xo[8];
+    bool rvj[8], xvj[8];
+    auto advance = [&](int64_t rb, bool tail) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool rv = !tail || rb + 8 * g + j < r_hi;
+            const bool inr = !shifted || (unsigned)(ri[j] + p.x_shift) < (unsigned)p.n_inner;
+            ao[j] = rv ? aoff[j] : 0u;
+            xo[j] = (rv && inr) ? xoff[j] : 0u;
+            rvj[j] = rv;
+            xvj[j] = rv && inr && has_x;                     // (the step before a chain's first one reads zeros: no x0 here)
+            ri[j] += adv_i;
+            aoff[j] += a_adv;
+            xoff[j] += x_adv;
+            if (ri[j] >= p.n_inner) { ri[j] -= p.n_inner; aoff[j] += a_wrap; xoff[j] += x_wrap; }
+        }
+    };
+    auto load_b = [&](int u) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            br[u][j] = keep_if(xvj[j], *reinterpret_cast<const float*>(xbase + (xo[j] + bcolb[u])));
+        }
+    };
+    auto load_a = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ar[t][j] = keep_if(rvj[j], *reinterpret_cast<const float*>(abase + (ao[j] + acolb[t])));
+    };
+    auto split8 = [&](const float (&v)[8]) {
+        f32x4 lo, hi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lo[q] = v[q]; hi[q] = v[4 + q]; }
+        return split_bf3(lo, hi);
+    };
+    advance(r_lo, r_lo + 32 > r_hi);
+#pragma unroll
+    for (int u = 0; u < TK; ++u) load_b(u);
+#pragma unroll
+    for (int t = 0; t < TO; ++t) load_a(t);
+    for (int64_t rb = r_lo; rb < r_hi; rb += 32) {
+        const int64_t nb = rb + 32;                          // the block whose loads are issued during this one
+        Bf3 bp[TK];
+#pragma unroll
+        for (int u = 0; u < TK; ++u) bp[u] = split8(br[u]);
+        advance(nb, nb + 32 > r_hi);
+#pragma unroll
+        for (int u = 0; u < TK; ++u) load_b(u);
+#pragma unroll
+        for (int t = 0; t < TO; ++t) {
+            const Bf3 ap = split8(ar[t]);
+            float bs = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bs += ar[t][j];
+            bsum[t] += bs;
+            load_a(t);
+            // all TK products of the tile, smallest piece products first; tiles past the job's edge repeat the last valid one
+            // (clamped columns) and are never written out
+#pragma unroll
+            for (int u = 0; u < TK; ++u) acc[t][u] = mfma_bf16(ap.p2, bp[u].p0, acc[t][u]);
+#pragma unroll
+            for (int u = 0; u < TK; ++u) acc[t][u] = mfma_bf16(ap.p0, bp[u].p2, acc[t][u]);
+#pragma unroll
+            for (int u = 0; u < TK; ++u) acc[t][u] = mfma_bf16(ap.p1, bp[u].p1, acc[t][u]);
+#pragma unroll
+            for (int u = 0; u < TK; ++u) acc[t][u] = mfma_bf16(ap.p1, bp[u].p0, acc[t][u]);
+#pragma unroll
+            for (int u = 0; u < TK; ++u) acc[t][u] = mfma_bf16(ap.p0, bp[u].p1, acc[t][u]);
+#pragma unroll
+            for (int u = 0; u < TK; ++u) acc[t][u] = mfma_bf16(ap.p0, bp[u].p0, acc[t][u]);
+        }
+    }
+    float* __restrict__ part = a.workspace + p.ws_off + ((int64_t)net * gm.vchunks + vc) * gm.part_floats;
+    const int ldp = gm.KT * 16 + 1;
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+        if (t >= not_) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = (ot0 + t) * 16 + 4 * g + q;
+#pragma unroll
+            for (int u = 0; u < TK; ++u)
+                if (u < nkt) part[(int64_t)o * ldp + (kt0 + u) * 16 + i] = acc[t][u][q];
+        }
+        if (want_bias) {
+            float b = bsum[t];
+            b += __shfl_xor(b, 16);
+            b += __shfl_xor(b, 32);
+            if (g == 0) part[(int64_t)((ot0 + t) * 16 + i) * ldp + gm.KT * 16] = b;
+        }
+    }
+}
+
 // grid: (ceil(O*(K+1)/256), problem * n_nets + net)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(IplanWgradArgs a, int chunks_wide) {
     const int pi = (int)blockIdx.y / a.n_nets, net = (int)blockIdx.y % a.n_nets;
@@ -331,7 +488,18 @@ extern "C" int iplan_wgrad(IplanWgradArgs* a, iplan_stream_t stream) {
     if (jl[KIND].n)                                                                                                          \
         hipLaunchKernelGGL((wgrad_partial_kernel<TO_, TK_, RB_>), dim3((unsigned)jl[KIND].n, (unsigned)vcs[KIND], (unsigned)a->n_nets), \
                            dim3(64), 0, (hipStream_t)stream, *a, jl[KIND], chunks_wide);
+#ifdef IPLAN_WG_WIDE_FP32                                    // A/B builds: the fp32 MFMA form of the wide jobs
     IPLAN_WGRAD_LAUNCH(J_WIDE, WG_TO_WIDE, WG_TK, IPLAN_WG_WIDE_RB)
+#else
+    if (jl[J_WIDE].n) {
+        bool any_x0 = false;
+        for (int k = 0; k < jl[J_WIDE].n; ++k) any_x0 = any_x0 || a->p[jl[J_WIDE].pj[k] >> 8].x0 != nullptr;
+        if (any_x0) { IPLAN_WGRAD_LAUNCH(J_WIDE, WG_TO_WIDE, WG_TK, IPLAN_WG_WIDE_RB) }
+        else
+            hipLaunchKernelGGL((wgrad_partial_bf16_kernel<WG_TO_WIDE, WG_TK>), dim3((unsigned)jl[J_WIDE].n, (unsigned)vcs[J_WIDE], (unsigned)a->n_nets),
+                               dim3(64), 0, (hipStream_t)stream, *a, jl[J_WIDE], chunks_wide);
+    }
+#endif
     IPLAN_WGRAD_LAUNCH(J_THIN_K, WG_TO_NARROW, 1, 2)
     IPLAN_WGRAD_LAUNCH(J_THIN_O, 1, WG_TK, 2)
     IPLAN_WGRAD_LAUNCH(J_SQUARE, WG_TO_NARROW, WG_TK, 1)

@@ -172,6 +172,10 @@ class Behavior_policy:
             loss_dev = fwd["loss"]
         else:
             defer = False
+            if defer_decoder and not getattr(self, "_warned_chunked_defer", False):
+                self._warned_chunked_defer = True
+                print(f"Behavior_policy.learn: defer_decoder ignored -- {E} envs are learnt in chunks of {chunk} "
+                      "(one optimiser step behind the last chunk, decoder included)")
             # Large batches (config 4's 256 envs on one GPU: 230 GB of BPTT records at once): env chunks run one after the
             # other -- chains never interact; the loss normalisers are the window mask sums over ALL envs (and ranks), so
             # the chunk gradients simply add up in the arenas -- and one clip + Adam step follows.
@@ -207,7 +211,11 @@ class Behavior_policy:
             with (torch.cuda.stream(ds) if on_gpu else contextlib.nullcontext()):
                 if getattr(self, "dp", None) is not None:
                     self.dp.all_reduce_grads(self.dec_arena)
-                sq_d = step_all(self.behavior_optimizer, max_norm, slices=(1,), steps=steps)
+                # (its own norm buffer: the encoder half of the NEXT call fills the shared one on the main stream while this
+                # half may still be running here)
+                if getattr(self, "_dec_sq_buf", None) is None:
+                    self._dec_sq_buf = torch.zeros(nA, len(self.behavior_optimizer[0].slices), dtype=torch.float32, device=dev)
+                sq_d = step_all(self.behavior_optimizer, max_norm, slices=(1,), steps=steps, sq=self._dec_sq_buf)
                 self._dec_sq = sq_d[:, 1].clone()
                 if on_gpu:
                     self._dec_done = torch.cuda.Event()
@@ -232,7 +240,11 @@ class Behavior_policy:
             train_info = {"behavior_loss": float(loss[:, 0].sum()), "stability_loss": float(loss[:, 1].sum()),
                           "behavior_total": float(sum(float(t) for t in total)),
                           "behavior_encoder_grad_norm": float(norms[:, 0].sum()),
+                          # deferred decoder update: the norm of the PREVIOUS call's decoder step (this call's is still on its
+                          # way; 0 on the first call) -- flagged by the extra stat below
                           "behavior_decoder_grad_norm": float(norms[:, 1].sum())}
+            if split:
+                train_info["behavior_decoder_grad_norm_lag_calls"] = 1.0
             if t_env - self.log_stats_t >= self.args.learner_log_interval:
                 for k, v in train_info.items():
                     self.logger.log_stat(self.log_prefix + k, v, t_env)

@@ -141,11 +141,13 @@ class FusedAdam(torch.optim.Optimizer):
                 self.param_groups[0][k] = sd["param_groups"][0][k]
 
 
-def step_all(optimizers, max_norm, slices=None, steps=None):
+def step_all(optimizers, max_norm, slices=None, steps=None, sq=None):
     """Advance the per-agent optimisers of a learner together: one norm launch and one Adam launch
     per arena for ALL agents (they must own net i of the same arenas, i = position in the list).
     ``slices`` restricts the call to some of the optimisers' arenas (indices into ``FusedAdam.slices``); a later call for
-    the remaining arenas of the SAME optimiser step passes the ``steps`` this one returned through ``last_steps``."""
+    the remaining arenas of the SAME optimiser step passes the ``steps`` this one returned through ``last_steps``.
+    ``sq``: the [n_agents, n_slices] buffer the squared norms go to (default: one buffer owned by the first optimiser -- a
+    caller that runs two halves of a step on different streams gives the second half its own)."""
     first = optimizers[0]
     n = len(optimizers)
     if steps is None:
@@ -155,9 +157,11 @@ def step_all(optimizers, max_norm, slices=None, steps=None):
     first.last_steps = steps
     g = first.param_groups[0]
     dev = first.slices[0][0].data.device
-    if getattr(first, "_sq_all", None) is None or first._sq_all.shape[0] != n:
-        first._sq_all = torch.zeros(n, len(first.slices), dtype=torch.float32, device=dev)
-    sq = first._sq_all
+    if sq is None:
+        if getattr(first, "_sq_all", None) is None or first._sq_all.shape[0] != n:
+            first._sq_all = torch.zeros(n, len(first.slices), dtype=torch.float32, device=dev)
+        sq = first._sq_all
+    assert sq.shape == (n, len(first.slices)) and sq.dtype == torch.float32 and sq.is_contiguous()
     for k, (arena, _) in enumerate(first.slices):
         if slices is not None and k not in slices:
             continue
