@@ -186,6 +186,7 @@ enum {
 };
 #define IPLAN_AC_HIDDEN 64
 #define IPLAN_AC_SAVE_FLOATS (10 * IPLAN_AC_HIDDEN + 8)
+#define IPLAN_AC_KS_SLOT_FLOATS (16 * IPLAN_AC_HIDDEN + 32)   /* a workgroup's partial fc1 sums of one row tile + row sums, row sums of squares */
 
 typedef struct {
     const float* params;        /* arena of the actors (or critics) */
@@ -261,6 +262,14 @@ typedef struct {
      * iplan_ac_fc1_split_fwd leaves it, [2, n_agents, rows, 64]; the launch then skips the F-wide contraction and runs the
      * 64-wide tail only.  NULL = contract here.                                                                            */
     const float* fc1_pre;
+    /* optional, rollout shape only (ksplit = 8, ln_stats_mode = 0, packed operands, saved = NULL): the F-wide contraction of a
+     * (row tile, net) unit is split over ksplit_wg (2 .. 8) workgroups; their partial sums meet in ks_scratch
+     * [units, ksplit_wg, IPLAN_AC_KS_SLOT_FLOATS] and the last arrival (ticket in ks_count [units], zero before the first
+     * launch, left zero by every launch) adds them in workgroup order and runs the tail.  units = ceil(rows / 16) * n_agents *
+     * (which == 2 ? 2 : 1).  0 / 1 = off.                                                                                   */
+    int32_t ksplit_wg;
+    float* ks_scratch;
+    int32_t* ks_count;
 } IplanAcFwdArgs;
 
 int iplan_ac_fwd(const IplanAcFwdArgs* args, iplan_stream_t stream);

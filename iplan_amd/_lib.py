@@ -165,6 +165,7 @@ CRITIC_PARAM_ORDER = AC_TRUNK_ORDER + ["v_out.weight", "v_out.bias"]
 AC_NPARAM = 18
 AC_HIDDEN = 64
 AC_SAVE_FLOATS = 10 * AC_HIDDEN + 8
+AC_KS_SLOT_FLOATS = 16 * AC_HIDDEN + 32
 
 
 class AcNet(C.Structure):
@@ -195,6 +196,7 @@ class AcFwdArgs(C.Structure):
         ("onehot_out", fp), ("oh_s_net", i64), ("oh_s_row", i64),
         ("ln_stats", fp), ("ln_stats_s_net", i64), ("ln_stats_mode", i32), ("phase_clocks", fp),
         ("packed_actor", fp), ("packed_critic", fp), ("packed_s_net", i64), ("fc1_pre", fp),
+        ("ksplit_wg", i32), ("ks_scratch", fp), ("ks_count", fp),
     ]
 
 

@@ -76,6 +76,14 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     const int ks = RT == 1 ? a.ksplit : 1;
     const int groups = 8 / ks;
     const int part = w % ks;
+    // Rollout shape, K split over KW WORKGROUPS as well (a.ksplit_wg): 2 row tiles x 10 nets are 20 workgroups on 256 CUs and
+    // the F-wide contraction is a latency chain of ~20 k-tiles per wave; with KW = 4 every wave owns ~5 and the partial sums
+    // of a (tile, net) unit meet in global memory -- the LAST of its KW workgroups to arrive (atomic ticket) adds them in
+    // workgroup order and runs the tail.  Fixed summation order, so the result does not depend on who arrives last.
+    const int KW = (RT == 1 && !PRE && a.ksplit_wg > 1 && ks == 8) ? a.ksplit_wg : 1;
+    const int pw = bx % KW;
+    bx /= KW;
+    const int kpart = part * KW + pw;
     const bool clk = a.phase_clocks && bx == 0 && by == 0 && bz == 0 && threadIdx.x == 0;
     if (clk) a.phase_clocks[0] = IPLAN_CLOCK();
     const KMap km = make_kmap(ft);
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     const float* __restrict__ pkc = pkw ? pkb + (int64_t)KT * 16 : nullptr;      // (W gamma)[64] | (W beta)[64]
     // k-tiles are dealt round-robin to the ks cooperating waves (tile T belongs to wave T % ks): the slow tiles
     // (the gathered history block) are spread evenly instead of landing on one straggler wave
-    const int T_lo = part, T_hi = KT, T_st = ks;
+    const int T_lo = kpart, T_hi = KT, T_st = ks * KW;
 
     int rr[RT], last[RT];
     bool vld[RT];
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
         // SGPRs the ring keeps its PF k-tiles of loads in flight.)
         const int kt0s = uniform_i(km.kt0[s]);
         const int b_end = imin(T_hi, uniform_i(km.kt0[s + 1]));
-        const int b_lo = kt0s + ((part - kt0s) % T_st + T_st) % T_st;               // first owned tile of the block
+        const int b_lo = kt0s + ((kpart - kt0s) % T_st + T_st) % T_st;              // first owned tile of the block
         if (b_lo >= b_end) continue;
         int f_hi = b_lo;
         if (s < 3 && (uniform_i(km.w[s]) & 3) == 0 && uniform_i(ft.w[s]) > 0) f_hi = imin(b_end, kt0s + uniform_i(km.len[s]) / 16);
@@ -400,6 +408,38 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
             if (part == 0) {
                 float sx = 0.f, sxx = 0.f;
                 for (int p2 = 0; p2 < ks; ++p2) { sx += s_red[w + p2][n]; sxx += s_red2[w + p2][n]; }
+                if (KW > 1) {
+                    const int unit = (bz * (int)gridDim.y + by) * ((int)gridDim.x / KW) + bx;
+                    float* slot = a.ks_scratch + ((int64_t)unit * KW + pw) * IPLAN_AC_KS_SLOT_FLOATS;
+                    for (int t = 0; t < AT; ++t) *reinterpret_cast<f32x4*>(slot + (t * 64 + l) * 4) = accs[0][t];
+                    if (g == 0) { slot[AT * 256 + n] = sx; slot[AT * 256 + 16 + n] = sxx; }
+                    // release our partial, take a ticket, acquire the others' (agent scope: the workgroups of a unit may sit
+                    // on different XCDs, i.e. behind different L2s)
+                    int ticket = 0;
+#ifdef IPLAN_HOST_EMULATION
+                    IPLAN_WAVE_SYNC();
+                    if (l == 0) { ticket = a.ks_count[unit]; a.ks_count[unit] = ticket + 1 == KW ? 0 : ticket + 1; s_red[0][0] = (float)ticket; }
+                    IPLAN_WAVE_SYNC();
+                    ticket = (int)s_red[0][0];
+#else
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (l == 0) ticket = __hip_atomic_fetch_add(a.ks_count + unit, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    ticket = __builtin_amdgcn_readfirstlane(ticket);
+#endif
+                    if (ticket != KW - 1) return;                 // (the tail belongs to the last arrival)
+#ifndef IPLAN_HOST_EMULATION
+                    if (l == 0) __hip_atomic_store(a.ks_count + unit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+                    sx = 0.f; sxx = 0.f;
+                    for (int t = 0; t < AT; ++t) accs[0][t] = splat4(0.f);
+                    for (int q2 = 0; q2 < KW; ++q2) {
+                        const float* sl = a.ks_scratch + ((int64_t)unit * KW + q2) * IPLAN_AC_KS_SLOT_FLOATS;
+                        for (int t = 0; t < AT; ++t) accs[0][t] += *reinterpret_cast<const f32x4*>(sl + (t * 64 + l) * 4);
+                        sx += sl[AT * 256 + n];
+                        sxx += sl[AT * 256 + 16 + n];
+                    }
+                }
                 mu[0] = sx / (float)F;
                 rstd[0] = 1.0f / sqrtf(fmaxf(sxx / (float)F - mu[0] * mu[0], 0.f) + 1e-5f);
                 for (int t = 0; t < AT; ++t)
@@ -673,8 +713,12 @@ extern "C" int iplan_ac_fwd(const IplanAcFwdArgs* a, iplan_stream_t stream) {
     if (a->fc1_pre && (a->ksplit != 1 || a->ln_stats_mode != 2 || !a->ln_stats || !iplan::aligned16(a->fc1_pre)))
         return fail(IPLAN_EINVAL, "iplan_ac_fwd: fc1_pre needs ksplit 1 and stored LayerNorm statistics (ln_stats_mode 2)");
     const int tiles = (a->rows + 15) / 16;
+    if (a->ksplit_wg > 1 && (a->ksplit != 8 || a->ln_stats_mode != 0 || !a->ks_scratch || !a->ks_count || a->saved ||
+                             (a->which != 1 && !a->packed_actor) || (a->which != 0 && !a->packed_critic) || a->ksplit_wg > 8))
+        return fail(IPLAN_EINVAL, "iplan_ac_fwd: ksplit_wg needs the rollout shape (ksplit 8, folded LayerNorm statistics, packed fc1 operands incl. "
+                                  "W gamma / W beta, no saved activations), ks_scratch and ks_count");
     if (a->ksplit == 8) {
-        dim3 grid((unsigned)tiles, (unsigned)a->n_agents, a->which == 2 ? 2u : 1u);
+        dim3 grid((unsigned)(tiles * (a->ksplit_wg > 1 ? a->ksplit_wg : 1)), (unsigned)a->n_agents, a->which == 2 ? 2u : 1u);
         hipLaunchKernelGGL((ac_fwd_kernel<1, false>), grid, dim3(512), 0, (hipStream_t)stream, *a);
     } else {
         dim3 grid((unsigned)((tiles + 8 * AC_RT - 1) / (8 * AC_RT)), (unsigned)a->n_agents, a->which == 2 ? 2u : 1u);   // 8 waves x AC_RT row tiles

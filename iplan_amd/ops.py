@@ -264,6 +264,17 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
     if save:
         out["saved"] = torch.empty(2, n_agents, rows, L.AC_SAVE_FLOATS, **f32)
         a.saved = out["saved"].data_ptr()
+    ks_bufs = None
+    kw = int(os.environ.get("IPLAN_AC_KSPLIT_WG", "4"))
+    if (kw > 1 and a.ksplit == 8 and not save and a.ln_stats_mode == 0 and packed is not None and getattr(packed, "fold", False)):
+        # rollout shape: the F-wide contraction of every (row tile, net) unit over kw workgroups (include/iplan_hip.h: ksplit_wg)
+        units = ((rows + 15) // 16) * n_agents * (2 if which == 2 else 1)
+        key = (str(dev), L.current_stream(dev), units, kw)
+        ks_bufs = _KSPLIT_BUFS.get(key)
+        if ks_bufs is None:
+            ks_bufs = _KSPLIT_BUFS[key] = (torch.empty(units * kw * L.AC_KS_SLOT_FLOATS, **f32),
+                                           torch.zeros(units, dtype=torch.int32, device=dev))
+        a.ksplit_wg, a.ks_scratch, a.ks_count = kw, ks_bufs[0].data_ptr(), ks_bufs[1].data_ptr()
     z1 = None
     if xhat is not None:
         assert which == 2 and a.ksplit == 1 and ln_stats_mode == 2 and xhat["rows"] == rows and xhat["n_agents"] == n_agents
@@ -283,7 +294,7 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
     _launch("ac_fwd_kernel:train" if save else ("ac_fwd_kernel:rollout" if rows <= 512 else "ac_fwd_kernel:infer"),
             lambda: lib.call("iplan_ac_fwd", a, L.current_stream(dev)))
     out["_args"] = a
-    out["_keep"] = (spec, h_actor, h_critic, avail, q_noise, actions_in, h_out, actions_out, onehot_out, ln_stats, packed, z1, xhat)
+    out["_keep"] = (spec, h_actor, h_critic, avail, q_noise, actions_in, h_out, actions_out, onehot_out, ln_stats, packed, z1, xhat, ks_bufs)
     return out
 
 
@@ -366,6 +377,7 @@ class Fc1Pack:
 # ---- weight gradients ----------------------------------------------------------------------------------
 _WORKSPACES = {}
 _SIDE_STREAMS = {}
+_KSPLIT_BUFS = {}
 
 
 class KernelTimers:

@@ -498,3 +498,39 @@ def check_fc1_split_vs_fp32(device, rows_per_ep=7, n_eps=5, seed=3, N=5, log=Non
 def test_fc1_split_vs_fp32_emulated():
     check_fc1_split_vs_fp32("cpu")
     check_fc1_split_vs_fp32("cpu", rows_per_ep=13, n_eps=5, seed=4)     # 65 rows: three 32-row blocks, the last one ragged
+
+
+def check_ac_ksplit_wg(device, N=5, E=19, monkeypatch=None):
+    """The rollout-shaped actor / critic launch with its F-wide contraction split over 4 workgroups per (row tile, net) unit
+    (IplanAcFwdArgs.ksplit_wg: partial sums through global memory, the last arrival runs the tail) against the one-workgroup
+    form: same actions, values / log-probs to fp32 round-off; twice in a row (the ticket counters must be left at zero)."""
+    from iplan_amd import synth
+    from iplan_amd.config import default_args
+    from iplan_amd.controllers.dcntrl_controller import DcntrlMAC
+    args = default_args("highway", use_cuda=(device != "cpu"), max_vehicle_num=N, n_agents=3, episode_limit=4)
+    torch.manual_seed(11)
+    mac = DcntrlMAC(synth.make_scheme(args), {"agents": args.n_agents}, args)
+    batch = synth.make_batch(args, E, seed=5, device=device)
+    res = {}
+    for kw in ("1", "4", "4", "2"):
+        monkeypatch.setenv("IPLAN_AC_KSPLIT_WG", kw)
+        out = mac.select_actions_ippo(batch, 1, test_mode=True, as_numpy=False)
+        flat = []
+        for o in out:
+            flat += list(o) if isinstance(o, (list, tuple)) else [o]
+        res.setdefault(kw, []).append([torch.as_tensor(o).clone().cpu() for o in flat])
+    ref = res["1"][0]
+    for kw, runs in res.items():
+        for got in runs:
+            for a, b in zip(got, ref):
+                if a.dtype in (torch.int64, torch.int32):
+                    assert torch.equal(a, b), kw
+                else:
+                    assert (a.double() - b.double()).abs().max() <= 2e-6 * max(1.0, float(b.abs().max())), (kw, float((a - b).abs().max()))
+    for a, b in zip(res["4"][0], res["4"][1]):
+        assert torch.equal(a, b)                                   # same launch twice: bit-identical
+
+
+def test_ac_ksplit_wg_emulated(monkeypatch):
+    check_ac_ksplit_wg("cpu", monkeypatch=monkeypatch)
+    check_ac_ksplit_wg("cpu", N=9, E=35, monkeypatch=monkeypatch)     # three row tiles, the last one ragged

@@ -55,3 +55,12 @@ def test_gumbel_noise_gpu():
     torch.manual_seed(5)
     b = gumbel_noise((3, 5, 8), "cuda")
     assert torch.equal(a, b) and a.shape == (3, 5, 8)
+
+
+@pytest.mark.gpu
+def test_ac_ksplit_wg_gpu(monkeypatch):
+    """the rollout launch's contraction split over workgroups (partial sums through global memory, last arrival runs the tail)
+    against the one-workgroup form, at the full feature width"""
+    from tests.test_emu_kernels import check_ac_ksplit_wg
+    check_ac_ksplit_wg("cuda", N=55, E=32, monkeypatch=monkeypatch)
+    check_ac_ksplit_wg("cuda", N=55, E=70, monkeypatch=monkeypatch)
