@@ -265,10 +265,11 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
         out["saved"] = torch.empty(2, n_agents, rows, L.AC_SAVE_FLOATS, **f32)
         a.saved = out["saved"].data_ptr()
     ks_bufs = None
-    kw = int(os.environ.get("IPLAN_AC_KSPLIT_WG", "4"))
+    units = ((rows + 15) // 16) * n_agents * (2 if which == 2 else 1)
+    # rollout shape: the F-wide contraction of every (row tile, net) unit over kw workgroups (include/iplan_hip.h: ksplit_wg)
+    # while the launch is far from filling the 256 CUs: 4 up to 40 units (config 3: 20), 2 up to 96, off beyond
+    kw = int(os.environ.get("IPLAN_AC_KSPLIT_WG", "0")) or (4 if units <= 40 else (2 if units <= 96 else 1))
     if (kw > 1 and a.ksplit == 8 and not save and a.ln_stats_mode == 0 and packed is not None and getattr(packed, "fold", False)):
-        # rollout shape: the F-wide contraction of every (row tile, net) unit over kw workgroups (include/iplan_hip.h: ksplit_wg)
-        units = ((rows + 15) // 16) * n_agents * (2 if which == 2 else 1)
         key = (str(dev), L.current_stream(dev), units, kw)
         ks_bufs = _KSPLIT_BUFS.get(key)
         if ks_bufs is None:

@@ -1,8 +1,8 @@
 """TEST / MEASUREMENT INFRASTRUCTURE: the bounded CPU sample bench.py reports as ``cpu_baseline`` -- the same four pieces of
 one training cycle timed either on the oracle (``backend="oracle"``: the in-repo restatement, what the GPU box can run) or
 on the REAL reference classes imported from /root/reference (``backend="reference"``: build container only).
-``scripts/anchor_cpu_baseline.py`` runs both on identical inputs and commits the ratio (profiles/r02_cpu_baseline_anchor.json),
-which ties the oracle's speed to the reference's.
+``scripts/anchor_cpu_baseline.py`` runs both on identical inputs and commits the ratio (profiles/r0N_cpu_baseline_anchor.json),
+which ties the oracle's speed to the reference's (round 3: profiles/r03_cpu_baseline_anchor.json -- behaviour leg of all agents at Eb = 32).
 
 Pieces (each: one warm-up call, then the best of ``reps`` timed calls), scaled to seconds per env-step and summed:
   rollout   vector step at full width E: GAT_latent_update + latent_update + select_actions_ippo (5 agents)
