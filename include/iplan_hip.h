@@ -340,6 +340,14 @@ typedef struct {
     int32_t n_outer, n_inner;
     int32_t dw_ld, dw_col0;
     float beta, scale;
+    /* Column-grouped operands (0 = plain rows): column c of dY / X lives at element (c >> 4) * cg_stride + (c & 15) of its row
+     * -- the behaviour decoder's records are stored [chain tile][16-column group][step][chain][16] so that a row's 16-column
+     * group is contiguous over (step, chain) (rows = (tile, step * 16 + chain), row stride 16).  dY columns are then addressed
+     * through seg_c0 / seg_c1 and X columns through x_col0 (not by offsetting the pointers).                                */
+    int32_t dy_cg_stride, x_cg_stride;
+    /* x_shift < 0 only: the |x_shift| rows in front of every outer index's first row exist in memory (the previous steps of a
+     * window range that does not start at step 0) and are read in place instead of x0 / zeros.                              */
+    int32_t x_pre_valid;
 } IplanWgradProblem;
 
 typedef struct {
@@ -604,6 +612,11 @@ int iplan_pdec_bwd(const IplanPdecArgs* args, iplan_stream_t stream);
  *   saved_dec  [x_t || latent] 0 (d+Z <= 16 cols) | 16 (16, unused) | u 32 | r 96 | z 160 | n 224 | hn 288 | h 352 | a 416 (64 each) | y 480 (16)
  *   saved_enc  u 0 | r 32 | z 64 | n 96 | hn 128 | h 160 (32 each)
  *   dsave_dec  dy 0 (16) | du 16 | dr 80 | dz 144 | dn_i 208 | dn_h 272 (64 each)
+ * The two DECODER records are stored column-grouped: [n_nets, ceil(rows / 16) chain tiles, columns / 16 groups, J * L steps,
+ * 16 chains, 16 floats] -- column c of (chain, step) at group c >> 4, float c & 15.  A wave's access to one 16-column group of
+ * its 16 chains is then one contiguous 1 KiB block, and a group's rows are contiguous over (step, chain): the weight-gradient
+ * contraction reads them as rows (tile, step * 16 + chain) with IplanWgradProblem.dy_cg_stride / x_cg_stride = J * L * 256.
+ * The chain slots of a ragged last tile are never written: the caller zeroes them.  saved_enc stays [rows, J, L, 192].
  */
 #define IPLAN_BEH_SAVE_DEC 496
 #define IPLAN_BEH_SAVE_ENC 192
@@ -627,12 +640,12 @@ typedef struct {
     const float* dec_params;
     int64_t dec_s_net;
     int64_t dec_off[IPLAN_DEC_NPARAM];
-    float* saved_dec;           /* [n_nets, rows, J, L, IPLAN_BEH_SAVE_DEC]                             */
+    float* saved_dec;           /* column-grouped (above): n_nets * ceil(rows/16)*16 * J * L * IPLAN_BEH_SAVE_DEC floats */
     float* saved_enc;           /* [n_nets, rows, J, L, IPLAN_BEH_SAVE_ENC]                             */
     float* saved_lat;           /* [n_nets, rows, J, IPLAN_BEH_SAVE_LAT]  softmax output of window j    */
     float* loss_part;           /* [n_nets, ceil(rows/16), 2]                                           */
     float* loss;                /* [n_nets, 2]  behaviour error, stability error                        */
-    float* dsave_dec;           /* backward: [n_nets, rows, J, L, IPLAN_BEH_DSAVE_DEC]                  */
+    float* dsave_dec;           /* backward: column-grouped like saved_dec, IPLAN_BEH_DSAVE_DEC columns               */
     float* dsave_lat;           /* backward: [n_nets, rows, J, IPLAN_BEH_DSAVE_LAT] d(loss)/d(latent_j) through
                                    the decoder inputs of window j (decoder BPTT -> encoder BPTT hand-off) */
     /* single-window decoder mode = Behavior_Latent_Decoder.forward (nova/behavior_net.py:55-69): set T = L + 2 (one

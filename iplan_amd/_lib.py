@@ -255,6 +255,7 @@ class WgradProblem(C.Structure):
         ("O", i32), ("K", i32), ("seg_split", i32), ("seg_c0", i32), ("seg_c1", i32),
         ("x_col0", i32), ("x_shift", i32), ("n_outer", i32), ("n_inner", i32),
         ("dw_ld", i32), ("dw_col0", i32), ("beta", C.c_float), ("scale", C.c_float),
+        ("dy_cg_stride", i32), ("x_cg_stride", i32), ("x_pre_valid", i32),
     ]
 
 

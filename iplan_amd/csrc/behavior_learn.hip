@@ -257,6 +257,7 @@ struct DecTile {
     const char* mask;             // uniform: a.mask + net * E * T
     uint32_t mask_lane;           // e * T * 4
     int64_t grow0;                // net * rows + tile * 16  (first chain of the tile)
+    int64_t trow0;                // (net * tiles + tile) * 16: first chain slot of the tile in the column-grouped decoder records
 };
 __device__ __forceinline__ void dec_tile(const IplanBehArgs& a, DecTile& c, int tile) {
     const int l = lane_id();
@@ -279,7 +280,14 @@ __device__ __forceinline__ void dec_tile(const IplanBehArgs& a, DecTile& c, int 
     c.mask = reinterpret_cast<const char*>(a.mask ? a.mask + (int64_t)c.net * a.E * a.T : nullptr);
     c.mask_lane = (uint32_t)(c.e * a.T * 4);
     c.grow0 = (int64_t)c.net * c.rows + (int64_t)(c.live ? tile : 0) * 16;
+    c.trow0 = ((int64_t)c.net * c.tiles + (int64_t)(c.live ? tile : 0)) * 16;
 }
+
+// Decoder records are COLUMN-GROUPED (include/iplan_hip.h, IPLAN_BEH_SAVE_DEC): [net][chain tile][16-column group][step][chain][16].
+// A lane's 16-byte slice of column group cg of step s:  tile base (uniform)  +  cg * cgs  +  s * 1024  +  n * 64 + g * 16  bytes,
+// cgs = steps per chain * 1024: every store / load instruction of a wave is ONE contiguous 1 KiB block (the chain-major layout
+// of rounds 1-2 made it 16 segments of 64 bytes 1.5 MB apart: 3.3 instead of 5.6 TB/s of stores, scripts/ubench/record_store.hip).
+#define REC_CG(col) ((uint32_t)((col) >> 4))
 
 // Loads are BRANCH-FREE: a lane that has nothing to fetch reads a clamped (in-bounds) address and the result is replaced by
 // zeros with a select.  A load under `if (lane condition)` becomes an exec-masked block, and the compiler's wait-count
@@ -363,8 +371,8 @@ __device__ __forceinline__ void dec_fwd_body(const IplanBehArgs& a, const DecTil
     const int j_lo = dec_only ? 0 : imax(a.fwd_j_lo, 0), j_hi = (!dec_only && a.fwd_j_hi > 0) ? imin(a.fwd_j_hi, J) : J;
     // record bases of this tile (uniform) and lane offsets; a step's record starts at step * cols * 4 bytes
     const int64_t steps_per_chain = (int64_t)J * Lw;
-    char* sd_base = reinterpret_cast<char*>(a.saved_dec + c.grow0 * steps_per_chain * SVD);
-    const uint32_t sd_lane = (uint32_t)((int64_t)c.n * steps_per_chain * SVD * 4) + 16u * (uint32_t)g;
+    char* sd_base = reinterpret_cast<char*>(a.saved_dec + c.trow0 * steps_per_chain * SVD);
+    const uint32_t sd_lane = 64u * (uint32_t)c.n + 16u * (uint32_t)g, cgs = (uint32_t)(steps_per_chain * 1024);
     const char* sl_base = reinterpret_cast<const char*>(a.saved_lat ? a.saved_lat + c.grow0 * J * SVL : nullptr);
     const uint32_t sl_lane = (uint32_t)((int64_t)c.n * J * SVL * 4);
     float* carry = (a.dec_carry && c.live) ? a.dec_carry + ((int64_t)net * c.tiles + c.tile) * 1024 : nullptr;
@@ -416,7 +424,7 @@ __device__ __forceinline__ void dec_fwd_body(const IplanBehArgs& a, const DecTil
         f32x4 latsh_next = latsh;
         if (j + 1 < j_hi) latsh_next = latent_shifted(j + 1);
         for (int t = 0; t < Lw; ++t) {
-            const uint32_t so = sd_lane + (uint32_t)(((int64_t)j * Lw + t) * SVD * 4);           // this step's record
+            const uint32_t so = sd_lane + (uint32_t)(((int64_t)j * Lw + t) * 1024);           // this step's record
             // next step's Linear input (the first step of the next window uses that window's latent); loads issued early
             const bool last_t = t + 1 == Lw;
             const bool has_next = !last_t || j + 1 < j_hi;
@@ -428,8 +436,8 @@ __device__ __forceinline__ void dec_fwd_body(const IplanBehArgs& a, const DecTil
                 nx = ld_row_br<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)beh_y_step(a, j, t) * a.h_s_t * 4), valid, a.d, g);
                 if (FULL || valid) m = *reinterpret_cast<const float*>(c.mask + c.mask_lane + 4u * (uint32_t)beh_m_step(a, j, t));
             }
-            if (q == 0) st4<FULL>(sd_base, so + 4u * SD_X, valid, xin);
-            st4<FULL>(sd_base, so + 4u * (SD_U + 16 * q), valid, u[q]);
+            if (q == 0) st4<FULL>(sd_base, so + cgs * REC_CG(SD_X), valid, xin);
+            st4<FULL>(sd_base, so + cgs * REC_CG(SD_U + 16 * q), valid, u[q]);
             // gates of hidden tile q
             f32x4 ai[3], ah[3];
             ai[0] = bfrag_lds(s_b + 64, q) + bfrag_lds(s_b + 256, q);
@@ -441,15 +449,15 @@ __device__ __forceinline__ void dec_fwd_body(const IplanBehArgs& a, const DecTil
             ah[2] = bfrag_lds(s_b + 256, 2 * DT + q);
             dense_multi<3, DT>(s_whh, DLD, rows3, 0, h, ah);                                 // + W_hh h: pre_r, pre_z, gh_n
             const GruGates o = gru_gates(ah[0], ah[1], ai[2], ah[2], h[q]);
-            st4<FULL>(sd_base, so + 4u * (SD_R + 16 * q), valid, o.r);
-            st4<FULL>(sd_base, so + 4u * (SD_Z + 16 * q), valid, o.z);
-            st4<FULL>(sd_base, so + 4u * (SD_N + 16 * q), valid, o.n);
-            st4<FULL>(sd_base, so + 4u * (SD_HN + 16 * q), valid, o.hn);
-            st4<FULL>(sd_base, so + 4u * (SD_H + 16 * q), valid, o.h);
+            st4<FULL>(sd_base, so + cgs * REC_CG(SD_R + 16 * q), valid, o.r);
+            st4<FULL>(sd_base, so + cgs * REC_CG(SD_Z + 16 * q), valid, o.z);
+            st4<FULL>(sd_base, so + cgs * REC_CG(SD_N + 16 * q), valid, o.n);
+            st4<FULL>(sd_base, so + cgs * REC_CG(SD_HN + 16 * q), valid, o.hn);
+            st4<FULL>(sd_base, so + cgs * REC_CG(SD_H + 16 * q), valid, o.h);
             const f32x4 km = keep_tile(a, net, j, c.row, t, q, FULL || valid, c.rows);
             f32x4 act[1];
             for (int k = 0; k < 4; ++k) act[0][k] = tanh_f(o.h[k]) * (km[k] * inv_keep);
-            st4<FULL>(sd_base, so + 4u * (SD_A + 16 * q), valid, act[0]);
+            st4<FULL>(sd_base, so + cgs * REC_CG(SD_A + 16 * q), valid, act[0]);
             // y = W_out act + b: every quarter contracts its own tile, quarter 0 adds the partials up
             const f32x4 yp = dense_tile_k<1>(s_out, DLD, 0, 16 * q, act, q ? splat4(0.f) : bfrag_lds(s_b + 448, 0));
             put(XF_H + q, o.h);
@@ -465,7 +473,7 @@ __device__ __forceinline__ void dec_fwd_body(const IplanBehArgs& a, const DecTil
             const f32x4 xt = xin;                            // columns >= d hold the latent: masked out below
             xin = xin_next;
             if (q) continue;                                 // the rest of the step (output, loss terms) is quarter 0's
-            st4<FULL>(sd_base, so + 4u * SD_Y, valid, y);
+            st4<FULL>(sd_base, so + cgs * REC_CG(SD_Y), valid, y);
             if (dec_only) {
                 if (FULL || valid) {
                     float* po = a.pred_out + (grow * Lw + t) * a.d + 4 * g;
@@ -574,10 +582,10 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
     auto put = [&](int slot, f32x4 v) { *reinterpret_cast<f32x4*>(xch + slot * 256 + 4 * l) = v; };
     auto get = [&](int slot) { return *reinterpret_cast<const f32x4*>(xch + slot * 256 + 4 * l); };
     const int64_t steps_per_chain = (int64_t)J * Lw;
-    const char* sd_base = reinterpret_cast<const char*>(a.saved_dec + c.grow0 * steps_per_chain * SVD);
-    const uint32_t sd_lane = (uint32_t)((int64_t)c.n * steps_per_chain * SVD * 4) + 16u * (uint32_t)g;
-    char* dd_base = reinterpret_cast<char*>(a.dsave_dec + c.grow0 * steps_per_chain * DSD);
-    const uint32_t dd_lane = (uint32_t)((int64_t)c.n * steps_per_chain * DSD * 4) + 16u * (uint32_t)g;
+    const char* sd_base = reinterpret_cast<const char*>(a.saved_dec + c.trow0 * steps_per_chain * SVD);
+    const uint32_t sd_lane = 64u * (uint32_t)c.n + 16u * (uint32_t)g, cgs = (uint32_t)(steps_per_chain * 1024);
+    char* dd_base = reinterpret_cast<char*>(a.dsave_dec + c.trow0 * steps_per_chain * DSD);
+    const uint32_t dd_lane = sd_lane;
     char* dl_base = reinterpret_cast<char*>(a.dsave_lat + c.grow0 * J * DSL);
     const uint32_t dl_lane = (uint32_t)((int64_t)c.n * J * DSL * 4) + 16u * (uint32_t)g;
 
@@ -590,15 +598,15 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
     // straight-line fetch: no lane- or step-dependent branch around a load, no masking (mask_step does that at the top of
     // the step that consumes the record, one MFMA phase later)
     auto load_step = [&](int j, int t, StepIn& o) {
-        const uint32_t so = sd_lane + (uint32_t)(((int64_t)j * Lw + t) * SVD * 4);
+        const uint32_t so = sd_lane + (uint32_t)(((int64_t)j * Lw + t) * 1024);
         o.first = (j == 0 && t == 0);
-        o.r = ld4_raw<FULL>(sd_base, so + 4u * (SD_R + 16 * Q), valid);
-        o.z = ld4_raw<FULL>(sd_base, so + 4u * (SD_Z + 16 * Q), valid);
-        o.n = ld4_raw<FULL>(sd_base, so + 4u * (SD_N + 16 * Q), valid);
-        o.hn = ld4_raw<FULL>(sd_base, so + 4u * (SD_HN + 16 * Q), valid);
-        o.u = ld4_raw<FULL>(sd_base, so + 4u * (SD_U + 16 * Q), valid);
-        o.hp = ld4_raw<FULL>(sd_base, (o.first ? so : so - 4u * SVD) + 4u * (SD_H + 16 * Q), valid);   // h_{-1} = 0
-        o.y = ld4_raw<FULL>(sd_base, so + 4u * SD_Y, valid);
+        o.r = ld4_raw<FULL>(sd_base, so + cgs * REC_CG(SD_R + 16 * Q), valid);
+        o.z = ld4_raw<FULL>(sd_base, so + cgs * REC_CG(SD_Z + 16 * Q), valid);
+        o.n = ld4_raw<FULL>(sd_base, so + cgs * REC_CG(SD_N + 16 * Q), valid);
+        o.hn = ld4_raw<FULL>(sd_base, so + cgs * REC_CG(SD_HN + 16 * Q), valid);
+        o.u = ld4_raw<FULL>(sd_base, so + cgs * REC_CG(SD_U + 16 * Q), valid);
+        o.hp = ld4_raw<FULL>(sd_base, (o.first ? so : so - 1024u) + cgs * REC_CG(SD_H + 16 * Q), valid);   // h_{-1} = 0
+        o.y = ld4_raw<FULL>(sd_base, so + cgs * REC_CG(SD_Y), valid);
         o.nx = ld_row_raw<FULL>(c.hist, c.hist_lane + (uint32_t)((int64_t)beh_y_step(a, j, t) * a.h_s_t * 4), valid, a.d, g);
         o.m = *reinterpret_cast<const float*>(c.mask + c.mask_lane + 4u * (uint32_t)beh_m_step(a, j, t));
         o.has_xc = false;
@@ -627,12 +635,12 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
     f32x4 dhd = (j_hi < J && carry) ? *reinterpret_cast<const f32x4*>(carry + 4 * l) : splat4(0.f);
     StepIn cur;
     load_step(j_hi - 1, Lw - 1, cur);
-    f32x4 hcur = ld4<FULL>(sd_base, sd_lane + (uint32_t)((((int64_t)(j_hi - 1)) * Lw + (Lw - 1)) * SVD * 4) + 4u * (SD_H + 16 * Q), valid);
+    f32x4 hcur = ld4<FULL>(sd_base, sd_lane + (uint32_t)((((int64_t)(j_hi - 1)) * Lw + (Lw - 1)) * 1024) + cgs * REC_CG(SD_H + 16 * Q), valid);
     for (int j = j_hi - 1; j >= j_lo; --j) {
         const float scale = (float)(a.d * a.N) / (window_mask_sum(a, net, j) + BEPS) / (a.hard ? 1.0f : (float)J);
         f32x4 dlat = splat4(0.f);                           // d(loss)/d(latent_j) through this window's decoder inputs (own share)
         for (int t = Lw - 1; t >= 0; --t) {
-            const uint32_t dof = dd_lane + (uint32_t)(((int64_t)j * Lw + t) * DSD * 4);
+            const uint32_t dof = dd_lane + (uint32_t)(((int64_t)j * Lw + t) * 1024);
             // ---- part A: lane-local, consumes the step's record
             mask_step(cur);
             f32x4 dy[1];
@@ -658,7 +666,7 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
 #ifndef BWD_ABL
 #define BWD_ABL 0                        // timing ablations (scripts/build_variants.sh): 1 no dd stores, 2 no record prefetch,
 #endif                                   // 3 no part-B MFMAs, 4 no second barrier, 5 no first barrier (results are WRONG under them)
-            if (Q == 0 && BWD_ABL != 1) st4<FULL>(dd_base, dof + 4u * DD_DY, valid, dy[0]);
+            if (Q == 0 && BWD_ABL != 1) st4<FULL>(dd_base, dof + cgs * REC_CG(DD_DY), valid, dy[0]);
             const f32x4 da = dense_tile<1>(s_outT, 24, 16 * Q, dy, splat4(0.f));
             const f32x4 km = keep_tile(a, net, j, c.row, t, Q, FULL || valid, c.rows);
             f32x4 dht;
@@ -668,10 +676,10 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
             }
             const GruGrads o = gru_gates_bwd(dht, cur.r, cur.z, cur.n, cur.hn, cur.hp);
             if (BWD_ABL != 1) {
-                st4<FULL>(dd_base, dof + 4u * (DD_DR + 16 * Q), valid, o.dr);
-                st4<FULL>(dd_base, dof + 4u * (DD_DZ + 16 * Q), valid, o.dz);
-                st4<FULL>(dd_base, dof + 4u * (DD_DNI + 16 * Q), valid, o.dni);
-                st4<FULL>(dd_base, dof + 4u * (DD_DNH + 16 * Q), valid, o.dnh);
+                st4<FULL>(dd_base, dof + cgs * REC_CG(DD_DR + 16 * Q), valid, o.dr);
+                st4<FULL>(dd_base, dof + cgs * REC_CG(DD_DZ + 16 * Q), valid, o.dz);
+                st4<FULL>(dd_base, dof + cgs * REC_CG(DD_DNI + 16 * Q), valid, o.dni);
+                st4<FULL>(dd_base, dof + cgs * REC_CG(DD_DNH + 16 * Q), valid, o.dnh);
             }
             put(0 * 4 + Q, o.dr);
             put(1 * 4 + Q, o.dz);
@@ -714,7 +722,7 @@ __device__ __forceinline__ void dec_bwd_body(const IplanBehArgs& a, const DecTil
             }
             f32x4 dup[1];
             for (int k = 0; k < 4; ++k) dup[0][k] = u_own[k] > 0.f ? du[k] : 0.f;
-            if (BWD_ABL != 1) st4<FULL>(dd_base, dof + 4u * (DD_DU + 16 * Q), valid, dup[0]);
+            if (BWD_ABL != 1) st4<FULL>(dd_base, dof + cgs * REC_CG(DD_DU + 16 * Q), valid, dup[0]);
             dhd = o.dh_direct + pd;
             dlat = dense_tile_k<1>(s_latT, DLD, 0, 16 * Q, dup, dlat);                    // through the tiled latent input
             if (BWD_ABL != 4) tile_sync();
@@ -1138,6 +1146,7 @@ struct D2Ctx {
     int *hcnt, *ucnt, *ycnt, *rcnt, *gcnt, *bcnt;            // gcnt / bcnt: this wave's quarter
     int q, l, n, g, net, J, Lw, j_lo, j_hi, steps, YL, n_live;
     int64_t steps_per_chain;
+    uint32_t cgs;                 // byte distance of the record's 16-column groups: steps per chain * 1024
     const float* PD;
 };
 // piece exchange slots: writer = the quarter that owns 16-tile q of the vector (half of k-chunk q >> 1), reader = everyone
@@ -1161,10 +1170,10 @@ __device__ __forceinline__ f32x4* d2_gi_slot(const D2Ctx& x, int k, int slot, in
     return reinterpret_cast<f32x4*>(x.s_gi + (((k * 4 + x.q) * 2 + slot) * 3 + gate) * 256) + x.l;
 }
 __device__ __forceinline__ char* d2_sd_base(const IplanBehArgs& a, const D2Ctx& x, const DecTile& ct) {
-    return reinterpret_cast<char*>(a.saved_dec + ct.grow0 * x.steps_per_chain * SVD);
+    return reinterpret_cast<char*>(a.saved_dec + ct.trow0 * x.steps_per_chain * SVD);
 }
 __device__ __forceinline__ uint32_t d2_sd_off(const D2Ctx& x, int step) {
-    return (uint32_t)((int64_t)x.n * x.steps_per_chain * SVD * 4) + 16u * (uint32_t)x.g + (uint32_t)((int64_t)step * SVD * 4);
+    return 64u * (uint32_t)x.n + 16u * (uint32_t)x.g + (uint32_t)((int64_t)step * 1024);
 }
 
 // ---- B_q: the recurrence.  FAST = all three tiles exist and are full: no predication, no branch around any memory operation
@@ -1230,16 +1239,16 @@ __device__ __forceinline__ void d2_recurrent(const IplanBehArgs& a, const D2Ctx&
             const bool valid = FAST || c[k].valid;
             char* sdb = d2_sd_base(a, x, c[k]);
             if (!(D2_ABL & 1)) {
-                st4<FAST>(sdb, so + 4u * (SD_R + 16 * q), valid, o[k].r);
-                st4<FAST>(sdb, so + 4u * (SD_Z + 16 * q), valid, o[k].z);
-                st4<FAST>(sdb, so + 4u * (SD_N + 16 * q), valid, o[k].n);
-                st4<FAST>(sdb, so + 4u * (SD_HN + 16 * q), valid, o[k].hn);
-                st4<FAST>(sdb, so + 4u * (SD_H + 16 * q), valid, o[k].h);
+                st4<FAST>(sdb, so + x.cgs * REC_CG(SD_R + 16 * q), valid, o[k].r);
+                st4<FAST>(sdb, so + x.cgs * REC_CG(SD_Z + 16 * q), valid, o[k].z);
+                st4<FAST>(sdb, so + x.cgs * REC_CG(SD_N + 16 * q), valid, o[k].n);
+                st4<FAST>(sdb, so + x.cgs * REC_CG(SD_HN + 16 * q), valid, o[k].hn);
+                st4<FAST>(sdb, so + x.cgs * REC_CG(SD_H + 16 * q), valid, o[k].h);
             }
             const f32x4 km = keep_tile(a, net, j, c[k].row, t, q, valid, c[k].rows);
             f32x4 act;
             for (int i = 0; i < 4; ++i) act[i] = tanh_f(o[k].h[i]) * (km[i] * inv_keep);
-            if (!(D2_ABL & 1)) st4<FAST>(sdb, so + 4u * (SD_A + 16 * q), valid, act);
+            if (!(D2_ABL & 1)) st4<FAST>(sdb, so + x.cgs * REC_CG(SD_A + 16 * q), valid, act);
             yp[k] = mma_block(wout, act, bout);                                      // own share of y = W_out act + b
         }
         D2_CLK(3);
@@ -1339,7 +1348,7 @@ __device__ __forceinline__ void d2_input(const IplanBehArgs& a, const D2Ctx& x, 
         }
         d2_signal(x.rcnt);
         const f32x4 y = (yq[0] + yq[1]) + (yq[2] + yq[3]);
-        st4<FAST>(d2_sd_base(a, x, co), d2_sd_off(x, jj * Lw + tt) + 4u * SD_Y, ovalid, y);
+        st4<FAST>(d2_sd_base(a, x, co), d2_sd_off(x, jj * Lw + tt) + x.cgs * REC_CG(SD_Y), ovalid, y);
         const f32x4 nx = x_keep(in.nx, beh_y_step(a, jj, tt), vmo), xt = x_keep(in.xt, beh_x_step(a, jj, tt), vmo);
         const float m = __builtin_bit_cast(float, bits(in.m) & vmo);
         float d2 = 0.f;
@@ -1412,8 +1421,8 @@ __device__ __forceinline__ void d2_input(const IplanBehArgs& a, const D2Ctx& x, 
             for (int k = 0; k < D2_TILES; ++k) {
                 if (!FAST && !c[k].live) continue;
                 char* sdb = d2_sd_base(a, x, c[k]);
-                if (Q0) st4<FAST>(sdb, so + 4u * SD_X, FAST || c[k].valid, xk[k]);
-                st4<FAST>(sdb, so + 4u * (SD_U + 16 * q), FAST || c[k].valid, uk[k]);
+                if (Q0) st4<FAST>(sdb, so + x.cgs * REC_CG(SD_X), FAST || c[k].valid, xk[k]);
+                st4<FAST>(sdb, so + x.cgs * REC_CG(SD_U + 16 * q), FAST || c[k].valid, uk[k]);
             }
         }
         if (owner && s >= D2_LAG) {
@@ -1467,6 +1476,7 @@ __global__ __launch_bounds__(D2_THREADS, 2) void beh_dec_fwd2_kernel(IplanBehArg
     x.j_hi = a.fwd_j_hi > 0 ? imin(a.fwd_j_hi, x.J) : x.J;
     x.steps = (x.j_hi - x.j_lo) * x.Lw;
     x.steps_per_chain = (int64_t)x.J * x.Lw;
+    x.cgs = (uint32_t)(x.steps_per_chain * 1024);
     x.YL = 16 * ((a.d + 3) / 4);                                                      // lanes that hold real outputs
     x.hcnt = s_cnt + 0; x.ucnt = s_cnt + 1; x.ycnt = s_cnt + 2; x.rcnt = s_cnt + 3; x.gcnt = s_cnt + 4 + x.q; x.bcnt = s_cnt + 8 + x.q;
     x.n_live = 0;

@@ -76,6 +76,12 @@ __host__ __device__ inline WgradGeom wgrad_geom(const IplanWgradProblem& p, int 
 __device__ __forceinline__ int ocol(const IplanWgradProblem& p, int o) {
     return o < p.seg_split ? p.seg_c0 + o : p.seg_c1 + (o - p.seg_split);
 }
+// element offset of column c inside its row: plain, or column-grouped (16-column groups cg_stride elements apart)
+__device__ __forceinline__ uint32_t colmap(int c, int cg_stride) {
+    return cg_stride ? (uint32_t)(c >> 4) * (uint32_t)cg_stride + (uint32_t)(c & 15) : (uint32_t)c;
+}
+// rows in front of an outer index's first row that the shifted X operand may read in place (IplanWgradProblem.x_pre_valid)
+__device__ __forceinline__ int x_pre_rows(const IplanWgradProblem& p) { return (p.x_pre_valid && p.x_shift < 0) ? -p.x_shift : 0; }
 
 // jobs of one shape in a launch
 constexpr int WG_MAX_JOBS = 64;
@@ -121,13 +127,16 @@ __global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a, Wgr
     // reads (element (o, k) of the product depends on column o of dY and column k of X alone).
     const int o_lo = (int)(r_lo / p.n_inner);
     const char* __restrict__ abase = reinterpret_cast<const char*>(p.dy + (int64_t)net * p.dy_s_net + (int64_t)o_lo * p.dy_s_outer);
-    const char* __restrict__ xbase = p.x ? reinterpret_cast<const char*>(p.x + (int64_t)net * p.x_s_net + (int64_t)o_lo * p.x_s_outer) : nullptr;
+    // (pre = rows in front of inner index 0 that exist in memory: the base moves back by them, the offsets forward, so that the
+    // 32-bit byte offsets stay non-negative)
+    const int pre = x_pre_rows(p);
+    const char* __restrict__ xbase = p.x ? reinterpret_cast<const char*>(p.x + (int64_t)net * p.x_s_net + (int64_t)o_lo * p.x_s_outer - (int64_t)pre * p.x_s_inner) : nullptr;
     const float* __restrict__ x0 = p.x0 ? p.x0 + (int64_t)net * p.x0_s_net + (int64_t)o_lo * p.x0_s_outer : nullptr;
     uint32_t acolb[TO], bcolb[TK];
 #pragma unroll
-    for (int t = 0; t < TO; ++t) acolb[t] = 4u * (uint32_t)ocol(p, imin((ot0 + imin(t, not_ - 1)) * 16 + i, p.O - 1));
+    for (int t = 0; t < TO; ++t) acolb[t] = 4u * colmap(ocol(p, imin((ot0 + imin(t, not_ - 1)) * 16 + i, p.O - 1)), p.dy_cg_stride);
 #pragma unroll
-    for (int u = 0; u < TK; ++u) bcolb[u] = nkt > 0 ? 4u * (uint32_t)(p.x_col0 + imin((kt0 + imin(u, nkt - 1)) * 16 + i, p.K - 1)) : 0u;
+    for (int u = 0; u < TK; ++u) bcolb[u] = nkt > 0 ? 4u * colmap(p.x_col0 + imin((kt0 + imin(u, nkt - 1)) * 16 + i, p.K - 1), p.x_cg_stride) : 0u;
     // cursors of the rows this lane loads next, one per (block slot j, sub-step s): rows 16j + 4s + g of the block,
     // advanced by 16 * RB rows per reload without divisions
     int ri[RB][4], orel[RB][4];
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a, Wgr
             ri[j][s] = (int)(r - (int64_t)ro * p.n_inner);
             orel[j][s] = ro - o_lo;
             aoff[j][s] = (uint32_t)(4 * ((int64_t)orel[j][s] * p.dy_s_outer + (int64_t)ri[j][s] * p.dy_s_inner));
-            xoff[j][s] = (uint32_t)(4 * ((int64_t)orel[j][s] * p.x_s_outer + (int64_t)(ri[j][s] + p.x_shift) * p.x_s_inner));
+            xoff[j][s] = (uint32_t)(4 * ((int64_t)orel[j][s] * p.x_s_outer + (int64_t)(ri[j][s] + p.x_shift + pre) * p.x_s_inner));
         }
     const int adv_o = (16 * RB) / p.n_inner, adv_i = (16 * RB) % p.n_inner;
     const uint32_t a_adv = (uint32_t)(4 * ((int64_t)adv_o * p.dy_s_outer + (int64_t)adv_i * p.dy_s_inner));
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(64) void wgrad_partial_kernel(IplanWgradArgs a, Wgr
         xoff[j][s] += x_adv;
         if (ri[j][s] >= p.n_inner) { ri[j][s] -= p.n_inner; orel[j][s] += 1; aoff[j][s] += a_wrap; xoff[j][s] += x_wrap; }
         const bool rv = !tail || rb + 4 * s + g < r_hi;
-        const bool inr = !shifted || (unsigned)(inner + p.x_shift) < (unsigned)p.n_inner;
+        const bool inr = !shifted || (unsigned)(inner + p.x_shift + pre) < (unsigned)(p.n_inner + pre);
         if (tail) { ao = rv ? ao : 0u; }
         if (tail || shifted) { xo = (rv && inr) ? xo : 0u; }
 #pragma unroll
@@ -267,14 +276,15 @@ __global__ __launch_bounds__(64) void wgrad_partial_bf16_kernel(IplanWgradArgs a
     const char* __restrict__ abase = reinterpret_cast<const char*>(p.dy + (int64_t)net * p.dy_s_net + (int64_t)o_lo * p.dy_s_outer);
     // (a bias-only problem has no X: its B loads read dY's first row instead and are masked to zero)
     const bool has_x = nkt > 0 && p.x != nullptr;
-    const char* __restrict__ xbase = has_x ? reinterpret_cast<const char*>(p.x + (int64_t)net * p.x_s_net + (int64_t)o_lo * p.x_s_outer) : abase;
+    const int pre = x_pre_rows(p);
+    const char* __restrict__ xbase = has_x ? reinterpret_cast<const char*>(p.x + (int64_t)net * p.x_s_net + (int64_t)o_lo * p.x_s_outer - (int64_t)pre * p.x_s_inner) : abase;
     uint32_t acolb[TO], bcolb[TK];
 #pragma unroll
-    for (int t = 0; t < TO; ++t) acolb[t] = 4u * (uint32_t)ocol(p, imin((ot0 + imin(t, not_ - 1)) * 16 + i, p.O - 1));
+    for (int t = 0; t < TO; ++t) acolb[t] = 4u * colmap(ocol(p, imin((ot0 + imin(t, not_ - 1)) * 16 + i, p.O - 1)), p.dy_cg_stride);
 #pragma unroll
     for (int u = 0; u < TK; ++u) {
         const int kc = has_x ? imin((kt0 + imin(u, nkt - 1)) * 16 + i, p.K - 1) : 0;
-        bcolb[u] = has_x ? 4u * (uint32_t)(p.x_col0 + kc) : 0u;
+        bcolb[u] = has_x ? 4u * colmap(p.x_col0 + kc, p.x_cg_stride) : 0u;
     }
     // cursors of this lane's 8 rows of the block being LOADED (rows 8 g + j), advanced by 32 rows per block
     int ri[8];
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(64) void wgrad_partial_bf16_kernel(IplanWgradArgs a
         const int ro = (int)(r / p.n_inner);
         ri[j] = (int)(r - (int64_t)ro * p.n_inner);
         aoff[j] = (uint32_t)(4 * ((int64_t)(ro - o_lo) * p.dy_s_outer + (int64_t)ri[j] * p.dy_s_inner));
-        xoff[j] = (uint32_t)(4 * ((int64_t)(ro - o_lo) * p.x_s_outer + (int64_t)(ri[j] + p.x_shift) * p.x_s_inner));
+        xoff[j] = (uint32_t)(4 * ((int64_t)(ro - o_lo) * p.x_s_outer + (int64_t)(ri[j] + p.x_shift + pre) * p.x_s_inner));
     }
     const int adv_o = 32 / p.n_inner, adv_i = 32 % p.n_inner;
     const uint32_t a_adv = (uint32_t)(4 * ((int64_t)adv_o * p.dy_s_outer + (int64_t)adv_i * p.dy_s_inner));
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(64) void wgrad_partial_bf16_kernel(IplanWgradArgs a
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const bool rv = !tail || rb + 8 * g + j < r_hi;
-            const bool inr = !shifted || (unsigned)(ri[j] + p.x_shift) < (unsigned)p.n_inner;
+            const bool inr = !shifted || (unsigned)(ri[j] + p.x_shift + pre) < (unsigned)(p.n_inner + pre);
             ao[j] = rv ? aoff[j] : 0u;
             xo[j] = (rv && inr) ? xoff[j] : 0u;
             rvj[j] = rv;
@@ -439,6 +449,10 @@ extern "C" int iplan_wgrad(IplanWgradArgs* a, iplan_stream_t stream) {
         IplanWgradProblem& p = a->p[i];
         if (!p.dy || p.O < 1 || p.O > 1024 || p.K < 0 || p.K > 1024 || (p.K > 0 && !p.x) || p.n_outer < 1 || p.n_inner < 1)
             return fail(IPLAN_EINVAL, "iplan_wgrad: problem %d has unsupported dims O=%d K=%d", i, p.O, p.K);
+        if ((p.dy_cg_stride || p.x_cg_stride) && p.x0)
+            return fail(IPLAN_EINVAL, "iplan_wgrad: problem %d: an initial-state operand (x0) cannot be combined with column-grouped operands", i);
+        if (p.dy_cg_stride < 0 || p.x_cg_stride < 0 || (p.x_pre_valid && p.x0))
+            return fail(IPLAN_EINVAL, "iplan_wgrad: problem %d: bad cg strides / x_pre_valid with x0", i);
         const WgradGeom g = wgrad_geom(p, IPLAN_WGRAD_MAX_CHUNKS);
         if (g.to == WG_TO_WIDE) wide_jobs += g.jobs;
     }
@@ -465,8 +479,8 @@ extern "C" int iplan_wgrad(IplanWgradArgs* a, iplan_stream_t stream) {
         if (p.O * (p.K + 1) > max_elems) max_elems = p.O * (p.K + 1);
         // the kernel addresses a row chunk with 32-bit byte offsets from the chunk's first outer index
         const int64_t outers = g.vrows / p.n_inner + 2;
-        const int64_t span_dy = 4 * (outers * llabs(p.dy_s_outer) + (int64_t)(p.n_inner + 1) * llabs(p.dy_s_inner) + 2048);
-        const int64_t span_x = 4 * (outers * llabs(p.x_s_outer) + (int64_t)(p.n_inner + 1) * llabs(p.x_s_inner) + 2048);
+        const int64_t span_dy = 4 * (outers * llabs(p.dy_s_outer) + (int64_t)(p.n_inner + 1) * llabs(p.dy_s_inner) + 2048 + 65ll * p.dy_cg_stride);
+        const int64_t span_x = 4 * (outers * llabs(p.x_s_outer) + (int64_t)(p.n_inner + 1 + llabs(p.x_shift)) * llabs(p.x_s_inner) + 2048 + 65ll * p.x_cg_stride);
         if (p.dy_s_outer < 0 || p.dy_s_inner < 0 || p.x_s_outer < 0 || p.x_s_inner < 0 || span_dy >= (1ll << 32) || span_x >= (1ll << 32))
             return fail(IPLAN_EINVAL, "iplan_wgrad: problem %d: a row chunk spans more than 4 GiB (or negative strides)", i);
         const int kind = g.to == WG_TO_WIDE ? J_WIDE : (g.KT <= 1 ? J_THIN_K : (g.OT == 1 ? J_THIN_O : J_SQUARE));

@@ -440,7 +440,8 @@ class Wgrad:
         self.tag = tag                                      # KernelTimers key of the launches (bench.py's roofline entries)
 
     def add(self, dy, dy_strides, O, n_outer, n_inner, x=None, x_strides=(0, 0, 0), K=0, dw_off=-1, db_off=-1,
-            dw_ld=None, dw_col0=0, seg=None, x_col0=0, x_shift=0, x0=None, x0_strides=(0, 0), beta=0.0, scale=1.0):
+            dw_ld=None, dw_col0=0, seg=None, x_col0=0, x_shift=0, x0=None, x0_strides=(0, 0), beta=0.0, scale=1.0,
+            dy_cg_stride=0, x_cg_stride=0, x_pre_valid=False):
         p = L.WgradProblem()
         p.dy = dy.data_ptr() if torch.is_tensor(dy) else dy
         p.dy_s_net, p.dy_s_outer, p.dy_s_inner = dy_strides
@@ -457,6 +458,7 @@ class Wgrad:
         p.dw_ld = K if dw_ld is None else dw_ld
         p.dw_col0 = dw_col0
         p.beta, p.scale = beta, scale
+        p.dy_cg_stride, p.x_cg_stride, p.x_pre_valid = dy_cg_stride, x_cg_stride, int(bool(x_pre_valid))
         self.problems.append(p)
         self._keep += [dy, x, x0]
         return self
@@ -789,10 +791,16 @@ def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p,
     for i, k in enumerate(L.DEC_PARAM_ORDER):
         a.dec_off[i] = dec_arena.off(k)
     tiles = (rows + 15) // 16
-    out = dict(saved_dec=torch.empty(n_nets, rows, J, L_win, L.BEH_SAVE_DEC, **f32),
+    # decoder record, column-grouped: [net, chain tile, 16-column group (31), step (J * L), chain (16), 16] -- a wave's store of one
+    # 16-column group of its 16 chains is ONE contiguous 1 KiB block (5.6 instead of 3.3 TB/s of stores, scripts/ubench/
+    # record_store.hip), and a column group's rows are contiguous over (step, chain) for the weight-gradient contraction.  The chain
+    # slots of a ragged last tile are never written by the kernels: zeroed here, they add nothing to the gradients.
+    out = dict(saved_dec=torch.empty(n_nets, tiles, L.BEH_SAVE_DEC // 16, J * L_win, 16, 16, **f32),
                saved_enc=torch.empty(n_nets, rows, J, L_win, L.BEH_SAVE_ENC, **f32),
                saved_lat=torch.empty(n_nets, rows, J, L.BEH_SAVE_LAT, **f32),
                loss_part=torch.empty(n_nets, tiles, 2, **f32), loss=torch.empty(n_nets, 2, **f32))
+    if rows % 16:
+        out["saved_dec"][:, -1, :, :, rows % 16:].zero_()
     for k in ("saved_dec", "saved_enc", "saved_lat", "loss_part", "loss"):
         setattr(a, k, out[k].data_ptr())
     # Pipeline (GPU): the decoder holds 138 of the 256 CUs for the whole episode, so the forward runs in window pieces --
@@ -867,9 +875,11 @@ def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_nor
     J, rows = ((T // Lw - 1) if a.hard else (T - 1 - Lw)), E * N
     dev = fwd["loss"].device
     f32 = dict(dtype=torch.float32, device=dev)
-    dd = torch.empty(n_nets, rows, J, Lw, L.BEH_DSAVE_DEC, **f32)
-    dl = torch.empty(n_nets, rows, J, L.BEH_DSAVE_LAT, **f32)
     tiles = (rows + 15) // 16
+    dd = torch.empty(n_nets, tiles, L.BEH_DSAVE_DEC // 16, J * Lw, 16, 16, **f32)          # column-grouped like saved_dec (beh_forward)
+    if rows % 16:
+        dd[:, -1, :, :, rows % 16:].zero_()
+    dl = torch.empty(n_nets, rows, J, L.BEH_DSAVE_LAT, **f32)
     ep = torch.empty(n_nets, tiles, L.BEH_ENC_PART, **f32)
     a.dsave_dec, a.dsave_lat, a.enc_part = dd.data_ptr(), dl.data_ptr(), ep.data_ptr()
     a.enc_grad, a.enc_grad_s_net = enc_arena.grad.data_ptr(), enc_arena.grad.stride(0)
@@ -878,25 +888,28 @@ def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_nor
     SD, DD = L.BEH_SAVE_DEC, L.BEH_DSAVE_DEC
     n_in = J * Lw
     sd = fwd["saved_dec"].data_ptr()
-    sd_st, dd_st = (rows * n_in * SD, n_in * SD, SD), (rows * n_in * DD, n_in * DD, DD)
+    # rows of the contraction = (chain tile, step * 16 + chain): 16 floats apart inside a column group, groups n_in * 256 apart
+    cgs = n_in * 256
+    sd_st, dd_st = (tiles * n_in * 16 * SD, n_in * 16 * SD, 16), (tiles * n_in * 16 * DD, n_in * 16 * DD, 16)
     H = 64
     off = dec_arena.off
 
     def dec_wgrad(s0, s1, beta):
         """decoder weight gradients over the rows of steps [s0, s1) of every chain (accumulating when beta = 1)"""
         w = Wgrad(dec_arena.grad, n_nets, tag="iplan_wgrad:beh_dec")
-        ddp, sdp, n = dd.data_ptr() + 4 * s0 * DD, sd + 4 * s0 * SD, s1 - s0
-        w.add(ddp, dd_st, d, rows, n, x=sdp + 4 * 416, x_strides=sd_st, K=H, beta=beta,
-              dw_off=off("decoder.out.weight"), db_off=off("decoder.out.bias"))
-        w.add(ddp + 4 * 80, dd_st, 3 * H, rows, n, x=sdp + 4 * 32, x_strides=sd_st, K=H, beta=beta,
-              dw_off=off("decoder.rnn.weight_ih_l0"), db_off=off("decoder.rnn.bias_ih_l0"))
-        # recurrent operand = the previous step's hidden state; the step before a piece's first one is still in the record
-        w.add(ddp + 4 * 80, dd_st, 3 * H, rows, n, x=sdp + 4 * 352, x_strides=sd_st, K=H, x_shift=-1, beta=beta,
-              x0=(sdp + 4 * 352 - 4 * SD) if s0 > 0 else None, x0_strides=(sd_st[0], sd_st[1]),
-              dw_off=off("decoder.rnn.weight_hh_l0"), db_off=off("decoder.rnn.bias_hh_l0"), seg=(2 * H, 0, 3 * H))
+        ddp, sdp, n = dd.data_ptr() + 4 * s0 * 256, sd + 4 * s0 * 256, (s1 - s0) * 16
+        cg = dict(dy_cg_stride=cgs, x_cg_stride=cgs)
+        w.add(ddp, dd_st, d, tiles, n, x=sdp, x_strides=sd_st, K=H, x_col0=416, beta=beta,
+              dw_off=off("decoder.out.weight"), db_off=off("decoder.out.bias"), **cg)
+        w.add(ddp, dd_st, 3 * H, tiles, n, x=sdp, x_strides=sd_st, K=H, x_col0=32, beta=beta, seg=(3 * H, 80, 0),
+              dw_off=off("decoder.rnn.weight_ih_l0"), db_off=off("decoder.rnn.bias_ih_l0"), **cg)
+        # recurrent operand = the previous step's hidden state (16 rows back); the step before a range's first one is still in
+        # the record and is read in place, the step before step 0 is zero
+        w.add(ddp, dd_st, 3 * H, tiles, n, x=sdp, x_strides=sd_st, K=H, x_col0=352, x_shift=-16, x_pre_valid=s0 > 0, beta=beta,
+              dw_off=off("decoder.rnn.weight_hh_l0"), db_off=off("decoder.rnn.bias_hh_l0"), seg=(2 * H, 80, 80 + 3 * H), **cg)
         # input Linear: the record keeps its input row [x_t || latent] as one tile
-        w.add(ddp + 4 * 16, dd_st, H, rows, n, x=sdp, x_strides=sd_st, K=d + Z, beta=beta,
-              dw_off=off("decoder.linear.weight"), db_off=off("decoder.linear.bias"))
+        w.add(ddp, dd_st, H, tiles, n, x=sdp, x_strides=sd_st, K=d + Z, beta=beta, seg=(H, 16, 0),
+              dw_off=off("decoder.linear.weight"), db_off=off("decoder.linear.bias"), **cg)
         w._keep += [dd, fwd]
         w.run(lib)
 
@@ -989,7 +1002,7 @@ def bdec_forward(enc_arena, dec_arena, window, latent, hidden, drop_p=0.0, keep=
     a.n_nets, a.E, a.N, a.T, a.L, a.d, a.Z = n_nets, rows, 1, Lw + 2, Lw, d, Z
     a.win, a.lat_in, a.hd_in = window.data_ptr(), latent.data_ptr(), hidden.data_ptr()
     pred, hout = torch.empty(n_nets, rows, Lw, d, **f32), torch.empty(n_nets, rows, 64, **f32)
-    saved = torch.empty(n_nets, rows, 1, Lw, L.BEH_SAVE_DEC, **f32)
+    saved = torch.empty(n_nets, (rows + 15) // 16 * 16, 1, Lw, L.BEH_SAVE_DEC, **f32)        # (scratch record: column-grouped by chain tile)
     a.pred_out, a.hd_out, a.saved_dec = pred.data_ptr(), hout.data_ptr(), saved.data_ptr()
     if keep is not None:
         assert keep.dtype == torch.uint8 and keep.shape == (n_nets, 1, rows, Lw, 64) and keep.is_contiguous()

@@ -2,7 +2,9 @@
 // every 16-byte-per-lane store instruction lands as
 //   mode 0: 16 segments of 64 B, one per chain, chains 1.5 MB apart        (records [chain][step][496]: the round-2 layout)
 //   mode 1: 16 segments of 64 B, chains 1 984 B apart                      (records [step][chain][496])
-//   mode 2: one contiguous 1 KiB block                                      (records [step][column group][chain][16])
+//   mode 2: one contiguous 1 KiB block                                      (records [tile][step][column group][chain][16])
+//   mode 3: one contiguous 1 KiB block, column groups STEPS KiB apart      (records [tile][column group][step][chain][16]: rows of
+//           one column group contiguous over (step, chain) -- what a weight-gradient contraction would stream)
 // Build: hipcc --offload-arch=gfx950 -O3 record_store.hip -o record_store ; run: ./record_store
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -22,7 +24,8 @@ __global__ __launch_bounds__(512) void store_kernel(float* __restrict__ rec, int
                 size_t off;
                 if (MODE == 0) off = ((size_t)(tile * 16 + n) * STEPS + s) * COLS + cg * 16 + 4 * g;
                 else if (MODE == 1) off = ((size_t)((size_t)tile * STEPS + s) * 16 + n) * COLS + cg * 16 + 4 * g;
-                else off = ((((size_t)tile * STEPS + s) * GROUPS + cg) * 16 + n) * 16 + 4 * g;
+                else if (MODE == 2) off = ((((size_t)tile * STEPS + s) * GROUPS + cg) * 16 + n) * 16 + 4 * g;
+                else off = ((((size_t)tile * GROUPS + cg) * STEPS + s) * 16 + n) * 16 + 4 * g;
                 f32x4 v = {(float)s, (float)k, (float)cg, (float)l};
                 *reinterpret_cast<f32x4*>(rec + off) = v;
             }
@@ -41,7 +44,8 @@ __global__ __launch_bounds__(512) void load_kernel(const float* __restrict__ rec
                 size_t off;
                 if (MODE == 0) off = ((size_t)(tile * 16 + n) * STEPS + s) * COLS + cg * 16 + 4 * g;
                 else if (MODE == 1) off = ((size_t)((size_t)tile * STEPS + s) * 16 + n) * COLS + cg * 16 + 4 * g;
-                else off = ((((size_t)tile * STEPS + s) * GROUPS + cg) * 16 + n) * 16 + 4 * g;
+                else if (MODE == 2) off = ((((size_t)tile * STEPS + s) * GROUPS + cg) * 16 + n) * 16 + 4 * g;
+                else off = ((((size_t)tile * GROUPS + cg) * STEPS + s) * 16 + n) * 16 + 4 * g;
                 acc += *reinterpret_cast<const f32x4*>(rec + off);
             }
         }
@@ -73,6 +77,6 @@ int main() {
     hipMalloc(&rec, floats * 4); hipMalloc(&out, 16);
     const double bytes = (double)floats * 4;
     printf("%.2f GB, %d workgroups\n", bytes / 1e9, (tiles + 2) / 3);
-    run<0>(rec, tiles, bytes, out); run<1>(rec, tiles, bytes, out); run<2>(rec, tiles, bytes, out);
+    run<0>(rec, tiles, bytes, out); run<1>(rec, tiles, bytes, out); run<2>(rec, tiles, bytes, out); run<3>(rec, tiles, bytes, out);
     return 0;
 }

@@ -98,3 +98,30 @@ def test_wgrad_job_shapes_vs_torch(O, K, rows, n_inner, shift):
                 xs = torch.cat([xs[:, 1:], torch.zeros(rows, 1, K, dtype=torch.double)], 1)
             ref = torch.einsum("rto,rtk->ok", d, xs)
             assert torch.allclose(grad[n, :O * K].view(O, K).double(), ref, rtol=1e-5, atol=2e-4), (O, K)
+
+
+@pytest.mark.parametrize("O,K,s0", [(192, 64, 0), (192, 64, 3), (40, 13, 0), (5, 64, 2)])
+def test_wgrad_column_grouped_operands(O, K, s0):
+    """column-grouped operands (the behaviour decoder's records: [tile][16-column group][step][chain][16]; rows = (tile,
+    step * 16 + chain)), dY columns through the segment map, X through x_col0, and the recurrent operand read 16 rows back --
+    in place where the rows in front of a window range exist (x_pre_valid), zeros in front of step 0"""
+    torch.manual_seed(O + K + s0)
+    n_nets, tiles, steps, Gd, Gx = 2, 3, 7, 14, 9                 # 224 dY columns, 144 X columns
+    dy = torch.randn(n_nets, tiles, Gd, steps, 16, 16)
+    x = torch.randn(n_nets, tiles, Gx, steps, 16, 16)
+    c0, xc0 = 16, 32                                                # first dY column / first X column of the problem
+    n = steps - s0
+    grad = torch.zeros(n_nets, O * (K + 1) + 8)
+    w = ops.Wgrad(grad, n_nets)
+    st = lambda t, G: (tiles * G * steps * 256, G * steps * 256, 16)   # noqa: E731
+    w.add(dy.data_ptr() + 4 * s0 * 256, st(dy, Gd), O, tiles, n * 16, x=x.data_ptr() + 4 * s0 * 256, x_strides=st(x, Gx), K=K, x_col0=xc0,
+          x_shift=-16, x_pre_valid=s0 > 0, seg=(O, c0, 0), dw_off=0, db_off=O * K, dy_cg_stride=steps * 256, x_cg_stride=steps * 256)
+    w._keep += [dy, x]
+    w.run()
+    rows = lambda t: t.permute(0, 1, 3, 4, 2, 5).reshape(n_nets, tiles, steps, 16, -1).double()   # noqa: E731  [net, tile, step, chain, col]
+    d, xs = rows(dy)[..., c0:c0 + O], rows(x)[..., xc0:xc0 + K]
+    xprev = torch.cat([torch.zeros_like(xs[:, :, :1]), xs[:, :, :-1]], 2)                          # previous step of the same chain
+    for k in range(n_nets):
+        ref = torch.einsum("tsco,tsck->ok", d[k, :, s0:], xprev[k, :, s0:])
+        assert torch.allclose(grad[k, :O * K].view(O, K).double(), ref, rtol=1e-5, atol=2e-4), (O, K, s0)
+        assert torch.allclose(grad[k, O * K:O * K + O].double(), d[k, :, s0:].sum((0, 1, 2)), rtol=1e-5, atol=1e-4)
