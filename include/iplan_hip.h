@@ -612,11 +612,12 @@ int iplan_pdec_bwd(const IplanPdecArgs* args, iplan_stream_t stream);
  *   saved_dec  [x_t || latent] 0 (d+Z <= 16 cols) | 16 (16, unused) | u 32 | r 96 | z 160 | n 224 | hn 288 | h 352 | a 416 (64 each) | y 480 (16)
  *   saved_enc  u 0 | r 32 | z 64 | n 96 | hn 128 | h 160 (32 each)
  *   dsave_dec  dy 0 (16) | du 16 | dr 80 | dz 144 | dn_i 208 | dn_h 272 (64 each)
- * The two DECODER records are stored column-grouped: [n_nets, ceil(rows / 16) chain tiles, columns / 16 groups, J * L steps,
+ * The three per-step records are stored column-grouped: [n_nets, ceil(rows / 16) chain tiles, columns / 16 groups, J * L steps,
  * 16 chains, 16 floats] -- column c of (chain, step) at group c >> 4, float c & 15.  A wave's access to one 16-column group of
  * its 16 chains is then one contiguous 1 KiB block, and a group's rows are contiguous over (step, chain): the weight-gradient
  * contraction reads them as rows (tile, step * 16 + chain) with IplanWgradProblem.dy_cg_stride / x_cg_stride = J * L * 256.
- * The chain slots of a ragged last tile are never written: the caller zeroes them.  saved_enc stays [rows, J, L, 192].
+ * The chain slots of a ragged last tile are never written: the caller zeroes them in the decoder records (nothing reads them in
+ * saved_enc, which is stored the same way: 12 groups).
  */
 #define IPLAN_BEH_SAVE_DEC 496
 #define IPLAN_BEH_SAVE_ENC 192
@@ -641,7 +642,7 @@ typedef struct {
     int64_t dec_s_net;
     int64_t dec_off[IPLAN_DEC_NPARAM];
     float* saved_dec;           /* column-grouped (above): n_nets * ceil(rows/16)*16 * J * L * IPLAN_BEH_SAVE_DEC floats */
-    float* saved_enc;           /* [n_nets, rows, J, L, IPLAN_BEH_SAVE_ENC]                             */
+    float* saved_enc;           /* column-grouped: n_nets * ceil(rows/16)*16 * J * L * IPLAN_BEH_SAVE_ENC floats       */
     float* saved_lat;           /* [n_nets, rows, J, IPLAN_BEH_SAVE_LAT]  softmax output of window j    */
     float* loss_part;           /* [n_nets, ceil(rows/16), 2]                                           */
     float* loss;                /* [n_nets, 2]  behaviour error, stability error                        */

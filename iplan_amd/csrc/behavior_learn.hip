@@ -180,6 +180,8 @@ __global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
     };
     bool x_has = false;
     f32x4 x_raw = x_fetch(j_lo, 0, x_has);
+    const int64_t ecgs = (int64_t)J * a.L * 256;                                  // floats between the record's 16-column groups
+    float* enc_rec = a.saved_enc + ((int64_t)c.net * c.tiles + (c.tile < c.tiles ? c.tile : 0)) * (SVE / 16) * ecgs + 16 * c.n;
     for (int j = j_lo; j < j_hi; ++j) {
         float* sl = a.saved_lat + (c.grow * J + j) * SVL;
         vstore_a(sl + 16, valid, 0, lat);                      // the latent the decoder uses in window j
@@ -190,20 +192,22 @@ __global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
                 const bool last_t = t + 1 == a.L, more = j + 1 < j_hi;
                 x_raw = x_fetch(last_t && more ? j + 1 : j, last_t ? (more ? 0 : t) : t + 1, x_has);
             }
-            float* se = a.saved_enc + ((c.grow * J + j) * a.L + t) * SVE;
+            // the encoder record is column-grouped like the decoder's ([tile][16-column group][step][chain][16], include/iplan_hip.h):
+            // a store of one column group of the wave's 16 chains is one contiguous 1 KiB block
+            float* se = enc_rec + ((int64_t)j * a.L + t) * 256;
             f32x4 ue[ET];
             for (int T = 0; T < ET; ++T) {
                 ue[T] = relu4(dense_tile<1>(s_lin, 24, 16 * T, x1, bfrag_lds(s_b, T)));
-                vstore_a(se + SE_U, valid, T, ue[T]);
+                vstore_a(se + ((SE_U >> 4) + T) * ecgs, valid, 0, ue[T]);
             }
             GruGates ke[ET];
             gru_step_lds<ET, ET>(s_wih, ELDB, s_whh, ELDB, s_b + 32, s_b + 128, ue, he, ke);
             for (int T = 0; T < ET; ++T) {
-                vstore_a(se + SE_R, valid, T, ke[T].r);
-                vstore_a(se + SE_Z, valid, T, ke[T].z);
-                vstore_a(se + SE_N, valid, T, ke[T].n);
-                vstore_a(se + SE_HN, valid, T, ke[T].hn);
-                vstore_a(se + SE_H, valid, T, he[T]);
+                vstore_a(se + ((SE_R >> 4) + T) * ecgs, valid, 0, ke[T].r);
+                vstore_a(se + ((SE_Z >> 4) + T) * ecgs, valid, 0, ke[T].z);
+                vstore_a(se + ((SE_N >> 4) + T) * ecgs, valid, 0, ke[T].n);
+                vstore_a(se + ((SE_HN >> 4) + T) * ecgs, valid, 0, ke[T].hn);
+                vstore_a(se + ((SE_H >> 4) + T) * ecgs, valid, 0, he[T]);
             }
         }
         // latent head + soft / hard update (stable_behavior_policy.py:223-230, behavior_policy.py:174-176)
@@ -829,21 +833,23 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
         bool first, has_x;
     };
     const bool ok = valid && live;
-    const float* rec0 = a.saved_enc + c.grow * J * a.L * SVE + 4 * g;          // this lane's column group of its chain's first record
+    const int64_t ecgs = (int64_t)J * a.L * 256;                               // floats between the record's 16-column groups
+    // this lane's slice of its chain's first record (column-grouped: [tile][16-column group][step][chain][16])
+    const float* rec0 = a.saved_enc + ((int64_t)c.net * c.tiles + (c.tile < c.tiles ? c.tile : 0)) * (SVE / 16) * ecgs + 16 * c.n + 4 * g;
     // fetch only: the values are masked where they are consumed (mask_step) -- an AND behind the load would pull the wait for
     // it up to the load
     auto load_step = [&](int j, int t, EncIn& o) {
         const int64_t step = (int64_t)j * a.L + t;
         o.first = step == 0;
-        const float* se = rec0 + step * SVE;
-        const float* sp = o.first ? se : se - SVE;                             // h_{-1} = 0
+        const float* se = rec0 + step * 256;
+        const float* sp = o.first ? se : se - 256;                             // h_{-1} = 0
         for (int T = 0; T < ET; ++T) {
-            o.hp[T] = *reinterpret_cast<const f32x4*>(sp + SE_H + 16 * T);
-            o.u[T] = *reinterpret_cast<const f32x4*>(se + SE_U + 16 * T);
-            o.r[T] = *reinterpret_cast<const f32x4*>(se + SE_R + 16 * T);
-            o.z[T] = *reinterpret_cast<const f32x4*>(se + SE_Z + 16 * T);
-            o.n[T] = *reinterpret_cast<const f32x4*>(se + SE_N + 16 * T);
-            o.hn[T] = *reinterpret_cast<const f32x4*>(se + SE_HN + 16 * T);
+            o.hp[T] = *reinterpret_cast<const f32x4*>(sp + ((SE_H >> 4) + T) * ecgs);
+            o.u[T] = *reinterpret_cast<const f32x4*>(se + ((SE_U >> 4) + T) * ecgs);
+            o.r[T] = *reinterpret_cast<const f32x4*>(se + ((SE_R >> 4) + T) * ecgs);
+            o.z[T] = *reinterpret_cast<const f32x4*>(se + ((SE_Z >> 4) + T) * ecgs);
+            o.n[T] = *reinterpret_cast<const f32x4*>(se + ((SE_N >> 4) + T) * ecgs);
+            o.hn[T] = *reinterpret_cast<const f32x4*>(se + ((SE_HN >> 4) + T) * ecgs);
         }
         const int st = beh_x_step(a, j, t);
         o.has_x = st >= 0;
@@ -868,7 +874,7 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
     auto load_win = [&](int j, WinIn& o) {
         o.nl = *reinterpret_cast<const f32x4*>(a.saved_lat + (c.grow * J + j) * SVL + 4 * g);
         o.dl = *reinterpret_cast<const f32x4*>(a.dsave_lat + (c.grow * J + j) * DSL + 4 * g);
-        for (int T = 0; T < ET; ++T) o.hL[T] = *reinterpret_cast<const f32x4*>(rec0 + ((int64_t)j * a.L + (a.L - 1)) * SVE + SE_H + 16 * T);
+        for (int T = 0; T < ET; ++T) o.hL[T] = *reinterpret_cast<const f32x4*>(rec0 + ((int64_t)j * a.L + (a.L - 1)) * 256 + ((SE_H >> 4) + T) * ecgs);
     };
     EncIn cur;
     WinIn win;

@@ -796,7 +796,7 @@ def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p,
     # record_store.hip), and a column group's rows are contiguous over (step, chain) for the weight-gradient contraction.  The chain
     # slots of a ragged last tile are never written by the kernels: zeroed here, they add nothing to the gradients.
     out = dict(saved_dec=torch.empty(n_nets, tiles, L.BEH_SAVE_DEC // 16, J * L_win, 16, 16, **f32),
-               saved_enc=torch.empty(n_nets, rows, J, L_win, L.BEH_SAVE_ENC, **f32),
+               saved_enc=torch.empty(n_nets, tiles, L.BEH_SAVE_ENC // 16, J * L_win, 16, 16, **f32),     # column-grouped too
                saved_lat=torch.empty(n_nets, rows, J, L.BEH_SAVE_LAT, **f32),
                loss_part=torch.empty(n_nets, tiles, 2, **f32), loss=torch.empty(n_nets, 2, **f32))
     if rows % 16:
