@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(256) void beh_enc_grad_kernel(IplanBehArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Decoder forward, SECOND FORM (round 3; opt-in, IPLAN_DEC_FWD_V2=1: see iplan_beh_fwd for why the first form stays the default).
+// Decoder forward, SECOND FORM (round 3; the default where it applies, IPLAN_DEC_FWD_V1=1 selects the first form: see iplan_beh_fwd).
 //
 // The first form is bound by fp32-MFMA + VALU issue (v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate and takes the VALU's
 // slots: 416 of them per tile-step) and by LDS operand delivery (a weight fragment read from LDS serves 16 chains).  Here
@@ -1536,13 +1536,14 @@ extern "C" int iplan_beh_fwd(const IplanBehArgs* a, iplan_stream_t stream) {
     const dim3 dgrid((unsigned)((tiles + DEC_TILES - 1) / DEC_TILES), (unsigned)a->n_nets);  // decoder: 3 tiles x 4 quarter-waves
     const int ph = a->win ? 2 : a->fwd_phase;
     if (ph == 0 || ph == 1) hipLaunchKernelGGL(beh_enc_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
-    // The second form (split-bf16, register-resident weights, input projection ahead of the recurrence) is OPT-IN
-    // (IPLAN_DEC_FWD_V2=1; not in single-window mode, d <= 8): same results, and on MI355X the same time as the first form --
-    // 6.0 vs 5.9 ms per pass alone, 22.2 vs 22.5 ms per learn() -- because both end up behind the record stores: without them
-    // the second form takes 3.5 ms, the 13.8 GB of records alone 3.1 ms in this layout (scripts/ubench/record_store.hip:
-    // 4.4 TB/s; 6.8 TB/s as contiguous 1 KiB blocks), and a wave that waits for room in the store path issues nothing else,
-    // so the two add instead of overlapping (profiles/r03b_notes.md).
-    const bool v2 = !a->win && a->d <= 8 && (a->hard ? a->T / a->L - 1 : a->T - 1 - a->L) <= D2_MAX_WINDOWS && getenv("IPLAN_DEC_FWD_V2") != nullptr;
+    // The second form (split-bf16, register-resident weights, input projection ahead of the recurrence) is the DEFAULT where it
+    // applies (not in single-window mode, d <= 8, at most D2_MAX_WINDOWS windows); IPLAN_DEC_FWD_V1=1 selects the first form.
+    // History: on the chain-major records of rounds 1-2 both forms ended up behind the record stores (6.0 vs 5.9 ms per pass: the
+    // second form computes in 3.5 ms, the 13.8 GB of records took 3.1 - 4.1 ms as 64-byte pieces, and a wave that waits for room
+    // in the store path issues nothing else, so the two added up; profiles/r03b_notes.md).  With the records column-grouped
+    // (1 KiB blocks, 2.5 ms by the same probe) the second form runs 4.8 ms against the first form's 6.0 ms, behaviour learn
+    // 20.2 -> 18.6 ms, cycle 311-314 -> 304 ms on one box (profiles/r03c_notes.md, call r3ac).
+    const bool v2 = !a->win && a->d <= 8 && (a->hard ? a->T / a->L - 1 : a->T - 1 - a->L) <= D2_MAX_WINDOWS && getenv("IPLAN_DEC_FWD_V1") == nullptr;
     if ((ph == 0 || ph == 2) && v2) {
         const dim3 grid2((unsigned)((tiles + D2_TILES - 1) / D2_TILES), (unsigned)a->n_nets);
         const size_t lds = sizeof(float) * D2_LDS_FLOATS;

@@ -137,15 +137,16 @@ def test_ppo_loss_switches_vs_oracle():
     _log("ppo_loss_switches_all_off", check_ppo_train_vs_oracle(a, "cuda", seed=41, e32_factor=6.0))
 
 
-def test_behavior_learn_decoder_forward_second_form_gpu(monkeypatch):
-    """IPLAN_DEC_FWD_V2=1 at config-3 size (one agent, 32 envs, the whole episode) and at a ragged size (partial / missing
-    tiles in the last workgroup of a net) vs the fp64 oracle"""
+def test_behavior_learn_decoder_forward_first_form_gpu(monkeypatch):
+    """IPLAN_DEC_FWD_V1=1 (the fp32-MFMA form of the decoder forward; the split-bf16 second form is the default and is what every
+    other behaviour test here runs) at config-3 size (one agent, 32 envs, the whole episode) and at a ragged size (partial /
+    missing tiles in the last workgroup of a net) vs the fp64 oracle"""
     from tests.oracle_checks import check_behavior_learn_vs_oracle
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    monkeypatch.setenv("IPLAN_DEC_FWD_V2", "1")
-    _log("behavior_learn_cfg3_E32_agent0_dec_fwd_v2", check_behavior_learn_vs_oracle(_args(batch_size_run=32), 32, "cuda", seed=23, agents=(0,)))
+    monkeypatch.setenv("IPLAN_DEC_FWD_V1", "1")
+    _log("behavior_learn_cfg3_E32_agent0_dec_fwd_v1", check_behavior_learn_vs_oracle(_args(batch_size_run=32), 32, "cuda", seed=23, agents=(0,)))
     b = _args(max_vehicle_num=9, n_agents=2, episode_limit=20, batch_size_run=4)
-    _log("behavior_learn_ragged_dec_fwd_v2", check_behavior_learn_vs_oracle(b, 4, "cuda", seed=43))
+    _log("behavior_learn_ragged_dec_fwd_v1", check_behavior_learn_vs_oracle(b, 4, "cuda", seed=43))
 
 
 def test_fc1_split_vs_fp32_gpu():
