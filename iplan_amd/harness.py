@@ -262,6 +262,8 @@ class SyntheticLoop:
         if getattr(self, "_lstreams", None) is None:
             self._lstreams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
         fins = []
+        # the behaviour learner's data-movement head first: its tiny launches would otherwise sit behind the side learners' kernels
+        prep = self.behavior.prepare_learn(batch) if getattr(type(self.behavior), "learn_takes_prepared", False) else None
         ev = torch.cuda.Event()
         ev.record(main)
         for strm, fn in zip(self._lstreams, (
@@ -281,6 +283,8 @@ class SyntheticLoop:
         if self.behavior is not None:
             # the decoder's weight-gradient contraction + optimiser step run on beside the next rollout (see learn())
             kw = {"defer_decoder": True} if self.defer_decoder else {}
+            if prep is not None:
+                kw["prepared"] = prep
             if run_ahead:
                 # ... and the HOST does not wait for the device either: losses / norms are staged to pinned memory behind
                 # the enqueued work (streams.AsyncHost) and read one cycle later, so the next rollout's launches are

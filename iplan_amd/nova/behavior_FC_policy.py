@@ -22,6 +22,8 @@ EPS = 1e-10
 
 
 class Behavior_policy(_SoftBehaviorPolicy):
+    learn_takes_prepared = False
+
     def init_behavior_net(self):
         """nova/behavior_FC_policy.py:55-76."""
         a = self.args

@@ -16,6 +16,8 @@ from .stable_behavior_policy import Behavior_policy as _SoftBehaviorPolicy
 
 
 class Behavior_policy(_SoftBehaviorPolicy):
+    learn_takes_prepared = False
+
     def latent_update(self, history, encoder_hidden, prev_latent, out_latent=None, out_hidden=None):
         """nova/behavior_policy.py:78-115: new latent = softmax(encoder(history)), prev_latent is ignored."""
         as_np = isinstance(history, np.ndarray)

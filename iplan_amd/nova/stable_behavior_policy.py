@@ -132,7 +132,22 @@ class Behavior_policy:
             torch.cuda.current_stream(self.device).wait_event(ev)
             self._dec_done = None
 
-    def learn(self, batch, t_env, keep=None, defer_decoder=False, defer_readback=False):
+    learn_takes_prepared = True         # (subclasses with their own ``learn`` signature switch it off)
+
+    def prepare_learn(self, batch):
+        """The data-movement head of ``learn``: episode views, the [nA, E, T] float mask (polarity as the reference's, :190-193) and the
+        per-window mask sums (all ranks' in data-parallel runs).  A training loop that enqueues other learners beside ``learn`` calls
+        this FIRST and passes the result as ``learn(..., prepared=)``: these few tiny launches otherwise queue behind the other
+        learners' kernels at the head of the learn phase."""
+        a, dev = self.args, self.device
+        history = batch["history"][:, :-1].to(device=dev, dtype=torch.float32)     # [E, T, nA, N, d]
+        term = batch["terminated"][:, :-1].to(dev)                                 # [E, T, nA, 1]
+        mask = (1 - term[..., 0]) if a.env == "MPE" else term[..., 0]
+        mask = mask.permute(2, 0, 1).to(torch.float32).contiguous()                # [nA, E, T]
+        return dict(batch=batch, history=history, mask=mask, hist=history.permute(2, 0, 1, 3, 4),   # hist: [nA, E, T, N, d] view
+                    win_norm=self._global_window_sums(mask))
+
+    def learn(self, batch, t_env, keep=None, defer_decoder=False, defer_readback=False, prepared=None):
         """nova/stable_behavior_policy.py:161-279 for all agents at once: ONE persistent forward launch
         walks every (env, entity) chain through the T-1-L windows (decoder + encoder GRUs, soft latent
         update, masked L1), ONE backward launch does the BPTT, then weight-gradient contractions,
@@ -153,19 +168,16 @@ class Behavior_policy:
         a = self.args
         dev = self.device
         self.join_decoder()
-        history = batch["history"][:, :-1].to(device=dev, dtype=torch.float32)     # [E, T, nA, N, d]
-        term = batch["terminated"][:, :-1].to(dev)                                 # [E, T, nA, 1]
-        # mask polarity is env dependent in the reference (:190-193)
-        mask = (1 - term[..., 0]) if a.env == "MPE" else term[..., 0]
-        mask = mask.permute(2, 0, 1).to(torch.float32).contiguous()                # [nA, E, T]
-        hist = history.permute(2, 0, 1, 3, 4)                                       # [nA, E, T, N, d] view
+        if prepared is None or prepared["batch"] is not batch:
+            prepared = self.prepare_learn(batch)
+        history, mask, hist, wn_all = prepared["history"], prepared["mask"], prepared["hist"], prepared["win_norm"]
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if keep is None else 0
         E, N = history.shape[0], self.max_vehicle_num
         chunk = int(getattr(a, "behavior_env_chunk", 0) or os.environ.get("IPLAN_BEH_ENV_CHUNK", "128"))
         if E <= chunk:
             fwd = ops.beh_forward(self.enc_arena, self.dec_arena, hist, mask, self.max_history_len, self.latent_dim,
                                   self.soft_update_coef, self.thres_small_variation, a.decoder_dropout, keep=keep, seed=seed,
-                                  win_norm=self._global_window_sums(mask))
+                                  win_norm=wn_all)
             defer = bool(defer_decoder)
             bwd = ops.beh_backward(self.enc_arena, self.dec_arena, fwd, penalty=self.behavior_variation_penalty,
                                    E_norm=self._global_envs(E), defer_dec_wgrad=defer)
@@ -179,7 +191,7 @@ class Behavior_policy:
             # Large batches (config 4's 256 envs on one GPU: 230 GB of BPTT records at once): env chunks run one after the
             # other -- chains never interact; the loss normalisers are the window mask sums over ALL envs (and ranks), so
             # the chunk gradients simply add up in the arenas -- and one clip + Adam step follows.
-            wn = self._global_window_sums(mask)
+            wn = wn_all
             loss_dev = None
             for c, lo in enumerate(range(0, E, chunk)):
                 hi = min(E, lo + chunk)

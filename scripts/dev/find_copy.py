@@ -16,6 +16,9 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     with contextlib.redirect_stdout(io.StringIO()):
         loop.cycle()
     torch.cuda.synchronize()
-evs = [e for e in prof.events() if e.device_time_total > 100 and ("copy" in e.name or "to" == e.name or "contiguous" in e.name or "fill" in e.name or "zero" in e.name)]
-for e in sorted(evs, key=lambda e: -e.device_time_total)[:12]:
-    print(f"{e.name:28s} dev {e.device_time_total:8.1f} us  shapes {e.input_shapes}  stack {[s for s in (e.stack or []) if 'iplan_amd' in s][:3]}")
+rows = []
+for e in prof.events():
+    if e.device_time_total > 150 and e.cpu_parent is not None:
+        rows.append((e.device_time_total, e.name, e.input_shapes, [s for s in (e.stack or []) if "iplan_amd" in s][:2]))
+for r in sorted(rows, key=lambda r: -r[0])[:25]:
+    print(f"{r[0]:9.1f} us  {r[1]:32s} {r[2]}  {r[3]}")
