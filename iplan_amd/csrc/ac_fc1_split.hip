@@ -145,8 +145,9 @@ __global__ __launch_bounds__(256) void ac_fc1_wbeta_kernel(IplanAcFc1SplitArgs a
 }
 
 // ---- forward: z1[which][net][row][o] = sum_k (W o gamma)[o][k] xhat[row][k] + (W beta)[o] ---------------------------
-// grid (ceil(row tiles / (2 NW)), n_agents), NW waves: wave w owns row tiles 2 (NW b + w), + 1 and all 8 output tiles (64
-// accumulator registers); the 24 KiB of weight pieces of a K step are staged once per workgroup.
+// grid (ceil(row tiles / (SF_RT NW)), n_agents), NW waves: wave w owns SF_RT consecutive row tiles and all 8 output tiles
+// (SF_RT x 32 accumulator registers: 128 at the adopted 8 waves x 4 tiles); the 24 KiB of weight pieces of a K step are staged
+// once per workgroup.
 #ifndef AC_SPLIT_RT
 #define AC_SPLIT_RT 4
 #endif
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(64 * NW) void ac_fc1_split_fwd_kernel(IplanAcFc1Spl
 }
 
 // ---- weight gradient: G[which][net][m][k] = sum_rows dz1[row][m] xhat[row][k] ----------------------------------------
-// grid (ceil(KT / (2 NW)), row chunks, n_agents), NW waves: wave w owns k-tiles 2 (NW b + w), + 1 and all 8 output tiles of
+// grid (ceil(KT / (SW_NF NW)), row chunks, n_agents), NW waves: wave w owns SW_NF consecutive k-tiles and all 8 output tiles of
 // (actor | critic); per 32-row step the dz1 pieces (every wave loads, splits and stages 8 / NW output tiles) are shared through LDS.
 // Partial tiles per row chunk in iplan_ac_bwd_fc1's g_part layout, summed in chunk order by iplan_ac_bwd_fc1_finalize.
 constexpr int SW_NF = AC_SPLIT_RT;

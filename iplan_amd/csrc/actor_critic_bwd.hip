@@ -5,7 +5,9 @@
 //      emits the row-level pre-activation gradients (dz1, dz2, GRU gates, head) and per-tile
 //      LayerNorm-parameter partial sums.  Weight gradients of the 64-wide layers are then plain
 //      dY^T X contractions (wgrad.hip).
-//   2. ac_fc1_wgrad_kernel  the one big contraction G[m][c] = sum_r dz1[r][m] * xhat[r][c]
+//   2. the one big contraction G[m][c] = sum_r dz1[r][m] * xhat[r][c]: in the full-batch PPO epochs
+//      ac_fc1_split_wgrad_kernel (ac_fc1_split.hip: split-bf16, packed xhat, actor and critic in one pass); otherwise
+//      ac_fc1_wgrad_kernel here
 //      (M = 64, F = 2485 at Highway chaotic, 22 950 rows per agent) on MFMA, with the normalised
 //      feature row xhat gathered straight from the episode-buffer fields exactly like the forward
 //      (the [rows, F] matrix is never materialised).

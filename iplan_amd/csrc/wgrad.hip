@@ -17,8 +17,10 @@
 // that read the same rows drift apart by far more than the L2 a streaming wave can count on, i.e. sharing
 // through the cache does not happen.  Hence two job shapes:
 //   wide   12 x 4 tiles (192 accumulator registers, one wave per SIMD): a GRU weight [192 x 64] is ONE job --
-//          its dY rows and its X rows are read exactly once; the 192 MFMAs of a 16-row block (2.6 us) cover
-//          the latency of the next block's loads, so one wave per SIMD is enough
+//          its dY rows and its X rows are read exactly once.  Since round 3 these jobs run on the bf16 matrix cores
+//          (wgrad_partial_bf16_kernel below: fp32-exact split-bf16 products, 32-row blocks); the fp32 kernel keeps the
+//          problems with an initial-state operand (x0) -- there the 192 MFMAs of a 16-row block (2.6 us) cover the
+//          latency of the next block's loads
 //   narrow  4 x 4 tiles, three waves per SIMD: the small heads (a few MFMAs per block) are latency
 //          bound and get their parallelism from loads in flight and several waves per SIMD instead
 #include "api_util.h"
