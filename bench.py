@@ -56,18 +56,21 @@ def load_pmc_traffic(envs_per_gpu):
     the kernel sources it was taken on, and a file whose hash is not this checkout's is REFUSED (traffic = null) rather than
     quoted for kernels it never saw.  -> ({bench key: bytes per launch}, source note)"""
     import glob
-    best = None
+    best, sha = None, csrc_sha16()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        best = (f, d)
+        # the summary measured on THIS build's kernel sources wins, whatever its name sorts as (ADVICE r3); failing that the
+        # lexicographically last one is named in the refusal below
+        if best is None or d.get("csrc_sha16") == sha or best[1].get("csrc_sha16") != sha:
+            best = (f, d)
     if best is None:
         return {}, "no profiles/*_pmc_summary.json"
     f, d = best
-    if d.get("csrc_sha16") != csrc_sha16():
-        return {}, f"{os.path.basename(f)} was measured on kernel sources {d.get('csrc_sha16')}, this build is {csrc_sha16()}: refused"
+    if d.get("csrc_sha16") != sha:
+        return {}, f"{os.path.basename(f)} was measured on kernel sources {d.get('csrc_sha16')}, this build is {sha}: refused"
     if d.get("envs_per_gpu") != envs_per_gpu:
         return {}, f"{os.path.basename(f)} was measured at {d.get('envs_per_gpu')} envs per GPU"
     return {k: v["bytes"] for k, v in d["per_launch"].items()}, f"{os.path.basename(f)} (series {d.get('series')}, kernel sources {d.get('csrc_sha16')})"

@@ -273,6 +273,23 @@ class IPPOLearner:
         # which evaluates one network twice); the other paths need them up front.
         split = self.num_mini_batch == 1 and not os.environ.get("IPLAN_PPO_FC1_FP32")
         if split:
+            # The split path keeps two packed copies of the normalised rows for the whole train() (2 x rows x Kpad x 4 bytes per
+            # agent + the pre-activations: 2.3 GB at config 3, 18 GB for config 4 on one GPU -- sized for 288 GB of HBM3E).  On
+            # a device where that estimate does not fit the budget (IPLAN_PPO_XHAT_BUDGET_GB, default a quarter of the device's
+            # memory) the fp32 contraction, which streams the episode fields in place, runs instead: same results to fp32
+            # round-off (tests/...::test_fc1_split_vs_fp32_*), ~1.8x the time.
+            F_est = sum(w for _, w in mac._widths()) * a.max_vehicle_num + (a.n_actions if a.obs_last_action else 0) + (nA if a.obs_agent_id else 0)
+            need = nA * self.batch_size * T * (2 * (F_est + 32) + 2 * 64) * 4
+            budget = os.environ.get("IPLAN_PPO_XHAT_BUDGET_GB")
+            if budget is not None:
+                budget = float(budget) * 2 ** 30
+            elif dev.type == "cuda":
+                budget = th.cuda.get_device_properties(dev).total_memory / 4
+            else:
+                budget = float("inf")
+            if need > budget:
+                split = False
+        if split:
             old_logp = th.zeros(nA, bs * T, **f32)
         else:
             old_logp = ops.ac_forward(mac.actor_arena, None, 0, spec, rows, nA, packed=mac.fc1_pack.get(spec), **fwd_kw)["logp"]
@@ -431,8 +448,8 @@ class IPPOLearner:
 
     def _train_minibatches_dp(self, t_env, rows, last, ln_stats, old_logp, adv, returns, vpred, mask):
         """num_mini_batch > 1 under data parallelism: the minibatches are those of ONE process holding the
-        union of the ranks' rows.  Rank 0 draws the reference's permutations of the GLOBAL row range (agent-major, one per
-        epoch, torch's global CPU generator -- exactly what the single process would draw) and broadcasts them; minibatch i of
+        union of the ranks' rows.  Every rank draws the reference's permutations of the GLOBAL row range (agent-major, one per
+        epoch, torch's global CPU generator -- exactly what the single process would draw), rank 0's are broadcast; minibatch i of
         an epoch is the global rows ``perm[i * mbs : (i + 1) * mbs]``, and every rank trains on the ones that fall into its own
         row range.  Their number differs per agent and rank, while one fused launch covers all agents with one row count: each
         agent's selection is padded to the launch's row count with rows of ZERO weight (mask 0 -> no policy / value term,
@@ -449,15 +466,16 @@ class IPPOLearner:
         # this rank's place in the union's row order: ranks in order, each with its own rows
         counts = th.zeros(dp.world, dtype=th.int64, device=dev)
         counts[dp.rank] = rows
-        counts = dp.all_reduce_sum(counts.to(th.float32)).to(th.int64).cpu()
+        counts = dp.all_reduce_sum(counts).cpu()                              # (int64: exact at any row count)
         G = int(counts.sum())
         if self.dp_global_rows is not None:
             assert G == int(self.dp_global_rows), (G, self.dp_global_rows)
         off = int(counts[:dp.rank].sum())
         mbs = G // nmb
-        perms = th.empty(nA, self.ppo_epoch, G, dtype=th.int64)
-        if dp.rank == 0:
-            perms = th.stack([th.stack([th.randperm(G) for _ in range(self.ppo_epoch)]) for _ in range(nA)])
+        # EVERY rank draws (the ranks' CPU generators then stay in step for whatever is drawn from them next: the gumbel seed,
+        # the dropout seed, the prediction samples); rank 0's draw is the one used -- identical to the others' when the ranks
+        # were seeded alike, and the broadcast makes it so when they were not
+        perms = th.stack([th.stack([th.randperm(G) for _ in range(self.ppo_epoch)]) for _ in range(nA)])
         perms = dp.broadcast_tensor(perms.to(dev))
         steps = self.ppo_epoch * nmb
         mb = perms[:, :, :mbs * nmb].reshape(nA, steps, mbs)                  # global rows of every (agent, step)

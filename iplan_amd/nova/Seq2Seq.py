@@ -52,8 +52,10 @@ class Seq2Seq(nn.Module):
         (nova/Seq2Seq.py:52-70).  One ``np.random.random()`` coin per step decides teacher forcing, drawn in the reference's
         order.  Dropout is active in train() mode like the reference's; ``keep`` ([pred_length, N*V, H] keep flags) may be
         injected, otherwise it is drawn from torch's generator on the input's device."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and in_data.requires_grad:
-            raise NotImplementedError("iplan_amd.nova.Seq2Seq is inference only")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # a training loop would get a graph-less tensor back: refuse loudly, whatever the inputs' own requires_grad
+            raise NotImplementedError("iplan_amd.nova.Seq2Seq is inference only (forward kernel, no backward): call it under "
+                                      "torch.no_grad() or freeze its parameters")
         dev = in_data.device
         arena = self._own_arena(dev)
         rows, T_in, In = in_data.shape

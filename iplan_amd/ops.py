@@ -378,6 +378,16 @@ class Fc1Pack:
 # ---- weight gradients ----------------------------------------------------------------------------------
 _WORKSPACES = {}
 _SIDE_STREAMS = {}
+
+def _side_stream(dev, *key):
+    """one side stream per (device, caller's stream, tag), created on first use (dict.setdefault would construct -- and
+    discard -- a stream per call and walk torch's 32-entry stream pool into aliasing streams already held)"""
+    k = (str(dev),) + key
+    s = _SIDE_STREAMS.get(k)
+    if s is None:
+        s = _SIDE_STREAMS[k] = torch.cuda.Stream(dev)
+    return s
+
 _KSPLIT_BUFS = {}
 
 
@@ -583,7 +593,7 @@ def ac_backward(fwd, actor_arena, critic_arena, g_logp=None, g_entropy=0.0, g_va
     side = None
     if which == 2 and dev.type == "cuda" and not os.environ.get("IPLAN_AC_WGRAD_SERIAL"):
         main = torch.cuda.current_stream(dev)
-        side = _SIDE_STREAMS.setdefault((str(dev), main.cuda_stream, "ac"), torch.cuda.Stream(dev))
+        side = _side_stream(dev, main.cuda_stream, "ac")
         side.wait_event(ev_tail)
     if which != 1:
         w = Wgrad(actor_arena.grad, n_agents)
@@ -808,7 +818,7 @@ def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p,
     side = None
     if dev.type == "cuda" and not os.environ.get("IPLAN_BEH_SERIAL"):
         main = torch.cuda.current_stream(dev)
-        side = _SIDE_STREAMS.setdefault((str(dev), main.cuda_stream), torch.cuda.Stream(dev))
+        side = _side_stream(dev, main.cuda_stream)
     pieces = max(1, min(_beh_pieces("FWD", 4 if side is not None else 1), J))
     stream = L.current_stream(dev)
     if pieces == 1:
@@ -919,8 +929,8 @@ def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_nor
     side = side2 = None
     if dev.type == "cuda" and not os.environ.get("IPLAN_BEH_SERIAL"):       # (the knob is for kernel timing experiments)
         main = torch.cuda.current_stream(dev)
-        side = _SIDE_STREAMS.setdefault((str(dev), main.cuda_stream), torch.cuda.Stream(dev))
-        side2 = _SIDE_STREAMS.setdefault((str(dev), main.cuda_stream, 2), torch.cuda.Stream(dev))
+        side = _side_stream(dev, main.cuda_stream)
+        side2 = _side_stream(dev, main.cuda_stream, 2)
     if defer_dec_wgrad and side is None and dev.type == "cuda":
         main = torch.cuda.current_stream(dev)
     pieces = max(1, min(_beh_pieces("BWD", 6 if side is not None else 1), J))

@@ -6,10 +6,11 @@ inputs).  The CPU suite calls them at small sizes through the host emulator; the
 Tolerances (north_star: 1e-5 fp32): losses and outputs <= 1e-5 * max(1, |ref|); gradients <= 1e-5 of the tensor's own max;
 post-Adam parameters <= 1e-6 (one step) / 1e-5 (PPO epochs).  Ground truth for gradients is the oracle in FP64; the fp32
 oracle (= the reference's own arithmetic) is run beside it, and where the reference's own fp32 rounding error e32 on a
-parameter group exceeds 2.5e-6 the bound widens to 4 x e32 ("no worse than four times the reference's own distance from the
-exact result"): gradients through the tau = 0.01 gumbel-softmax gate and second-epoch PPO gradients are conditioned such
-that NO fp32 implementation, the reference included, reproduces them to 1e-5.  Every check returns the worst errors it saw
-(kernel vs fp64, fp32 oracle vs fp64) so the GPU run can log them (profiles/*_parity_errors.json)."""
+parameter group exceeds 6.7e-6 the bound widens to E32_FACTOR = 1.5 x e32 ("no worse than one and a half times the
+reference's own distance from the exact result"; 4 x until round 3 -- measured kernel errors are 0.1 ... 0.5 x e32,
+profiles/r03d_parity_errors.json): gradients through the tau = 0.01 gumbel-softmax gate and second-epoch PPO gradients are
+conditioned such that NO fp32 implementation, the reference included, reproduces them to 1e-5.  Every check returns the
+worst errors it saw (kernel vs fp64, fp32 oracle vs fp64) so the GPU run can log them (profiles/*_parity_errors.json)."""
 from types import SimpleNamespace
 
 import numpy as np
@@ -17,6 +18,9 @@ import torch
 
 from iplan_amd import synth
 from oracle import iplan_oracle as O
+
+E32_FACTOR = 1.5          # gradient bound = max(tol, E32_FACTOR x the fp32 oracle's own error vs fp64), every learner, every tensor
+RELU_HINT_MAX = 8         # ReLU branches the PPO oracle may take from the learner's own forward pass, per replayed agent
 
 
 class _Log:
@@ -90,7 +94,7 @@ def check_behavior_learn_vs_oracle(args, E, device, seed=0, tol=1e-5, post_tol=1
         if with_fp64:
             e32 = max(_grad_err(p32[k].grad, pt[k].grad) for p32, pt in ((ep32, ep_t), (dp32, dp_t)) for k in pt)
             worst["fp32_oracle_grad_vs_fp64"] = max(worst["fp32_oracle_grad_vs_fp64"], e32)
-            gtol = max(tol, 4.0 * e32)
+            gtol = max(tol, E32_FACTOR * e32)
         for name, prm, prm32, arena, mods in (("enc", ep_t, ep32, pol.enc_arena, pol.behavior_encoder),
                                               ("dec", dp_t, dp32, pol.dec_arena, pol.behavior_decoder)):
             sd = mods[i].state_dict()
@@ -179,11 +183,11 @@ def check_prediction_learn_vs_oracle(args, E, device, seed=0, tol=1e-5, post_tol
         # The hard-attention gate is a gumbel-softmax at tau = 0.01: d(gate)/d(logit) = 100 gate (1 - gate), so a 1-ulp
         # difference in a logit moves the few unsaturated gates' derivatives -- which dominate every gradient that flows
         # through the gate -- by ~1e-5 relative.  The fp32 reference itself carries that error (measured here against the
-        # fp64 oracle), so the GAT group's bound is max(tol, 4 x the fp32 oracle's own worst error); the decoder group
+        # fp64 oracle), so the GAT group's bound is max(tol, E32_FACTOR x the fp32 oracle's own worst error); the decoder group
         # (no gate on its path) stays at tol.
         e32 = max(_grad_err(gp32[k].grad, gp64[k].grad) for k in gp32)
         worst["gat_fp32_oracle_vs_fp64"] = max(worst["gat_fp32_oracle_vs_fp64"], e32)
-        gat_tol = max(tol, 4.0 * e32)
+        gat_tol = max(tol, E32_FACTOR * e32)
         for name, prm, prm32, arena, mods, gtol in (("gat", gp64, gp32, pol.gat_arena, pol.pred_GAT, gat_tol),
                                                     ("dec", dp64, dp32, pol.dec_arena, pol.pred_decoder, tol)):
             sd = mods[i].state_dict()
@@ -217,7 +221,7 @@ def probe_dicts(learner, mac, pre, i):
 
 
 def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, terminated_p=0.15, also_fp32=True, agents=None,
-                              e32_factor=1.5, table=None, assert_grads=True):
+                              e32_factor=E32_FACTOR, table=None, assert_grads=True):
     """insert buffer_size episodes -> train() (ppo_epoch fused epochs x num_mini_batch steps) vs oracle.ppo_train_agent, every
     agent: clipped gradients of the LAST optimiser step and the post-train parameters.
 
@@ -288,7 +292,11 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
         O.RELU_HINT_LOG.clear()
         r64 = O.ppo_train_agent(i, ap, cp, f64, args, row_index_lists=il, probe_last_step=probe, probe_relu_hint=hint)
         worst["relu_units_near_kink"] = worst.get("relu_units_near_kink", 0) + sum(n for n, _ in O.RELU_HINT_LOG)
-        worst["relu_branches_from_hint"] = worst.get("relu_branches_from_hint", 0) + sum(n for _, n in O.RELU_HINT_LOG)
+        n_hint = sum(n for _, n in O.RELU_HINT_LOG)
+        worst["relu_branches_from_hint"] = worst.get("relu_branches_from_hint", 0) + n_hint
+        # the hint is for the handful of units that sit ON the kink; a count that grows is a forward-pass regression hiding
+        # behind it (config 3, 1.5 M units per layer: 213 in the band, 1 taken from the hint)
+        assert n_hint <= RELU_HINT_MAX, ("ReLU branches taken from the implementation under test", i, n_hint)
         g64 = r64["probe_grads"] if probe is not None else [{k: p[k].grad for k in p if p[k].grad is not None} for p in (ap, cp)]
         g32 = None
         e32 = 0.0
@@ -326,8 +334,14 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
                                           fp32_oracle=None if g32 is None else _grad_err(g32[gi][k], g64[gi][k]),
                                           kernel_vs_trajectory=et, post=pe))
                     assert e <= gtol or not assert_grads, ("clipped grad (last step, at the learner's own parameters) vs fp64 oracle", name, i, k, e, gtol)
+                    # the old comparison -- against the fp64 oracle's OWN trajectory -- measures the conditioning of Adam's
+                    # first steps rather than the kernels (docstring), but an error in an EARLIER step shows up only there and
+                    # in the post-train parameters: held to a documented loose bound, 1e-2 of the tensor's max or 20 x the
+                    # fp32 oracle's own trajectory distance (config 3, two epochs: kernels 1.65e-3, fp32 oracle 2.4e-4)
+                    ttol = max(1e-2, 20.0 * worst["fp32_oracle_grad_vs_fp64_trajectory"])
+                    assert et <= ttol, ("clipped grad vs the fp64 oracle's own trajectory", name, i, k, et, ttol)
                 worst["post"] = max(worst["post"], pe)
-                assert pe <= ptol or not assert_grads, ("post", name, i, k, pe, ptol)
+                assert pe <= ptol, ("post", name, i, k, pe, ptol)
     return worst
 
 
@@ -360,7 +374,7 @@ def check_gat_fwd_bwd_vs_oracle(B, N, D, device, seed=0, tol=1e-5):
     worst = dict(out=_rel(out.detach(), o64.detach()), out_vs_fp32_oracle=_rel(out.detach(), o32.detach()), grad=0.0,
                  fp32_oracle_out_vs_fp64=_rel(o32.detach(), o64.detach()), fp32_oracle_grad_vs_fp64=e32)
     assert worst["out"] <= tol, worst
-    gtol = max(tol, 4.0 * e32)              # tau = 0.01 gate conditioning: see check_prediction_learn_vs_oracle
+    gtol = max(tol, E32_FACTOR * e32)       # tau = 0.01 gate conditioning: see check_prediction_learn_vs_oracle
     for k, p in net.named_parameters():
         e = (p.grad.double().cpu() - p64[k].grad).abs().max().item() / gscale(k)
         worst["grad"] = max(worst["grad"], e)

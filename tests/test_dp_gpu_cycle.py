@@ -22,3 +22,16 @@ def test_data_parallel_two_processes_one_gpu_p2p():
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
     assert r.stdout.count("ok") == 2
+
+
+@pytest.mark.gpu
+def test_default_rccl_path_one_rank_group_stream_ordering():
+    """VERDICT r3 "next" #9: three full multi-stream training cycles through a 1-rank RCCL group (the default collective path:
+    dist.all_reduce(async_op=True) from the four producer streams, as bench.py --emulate-rank-of sets it up) end with all six
+    arenas bit-identical to the same cycles without data-parallel hooks (tests/dp_rccl_1rank_worker.py)."""
+    env = dict(os.environ, IPLAN_ROOT=ROOT, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("IPLAN_P2P_ALLREDUCE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_rccl_1rank_worker.py")], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
+    assert "rccl-1rank ok" in r.stdout

@@ -329,6 +329,9 @@ def check_seq2seq(golden, device):
         with torch.no_grad():
             out = net(g["x"].to(device), g["last"].to(device), g["teacher"].to(device), keep=g["masks"].reshape(d["P"], d["R"], d["H"]).to(device))
         assert out.shape == g["out"].shape and rel_err(out.cpu(), g["out"]) < 1e-5, (g["tag"], rel_err(out.cpu(), g["out"]))
+        import pytest
+        with pytest.raises(NotImplementedError):             # inference only: a training loop must not get a graph-less tensor back
+            net(g["x"].to(device), g["last"].to(device), g["teacher"].to(device))
         x4 = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)          # the reshape helpers (N, C, T, V)
         assert net.reshape_for_rnn(x4).shape == (10, 4, 3)
         assert torch.equal(net.reshape_from_rnn(net.reshape_for_rnn(x4)), x4)

@@ -2,8 +2,10 @@
 
 * the device-resident rollout (SyntheticLoop._rollout_body: write_back / out= launches, two streams) against the oracle
   stepped the same way -- BASELINE config 3 (32 envs x 5 agents x 55 entities) and config 2 (16 envs, Behaviour off);
-* one agent of each learner at config 3 size against the oracle (fp64 ground truth, fp32 oracle beside it):
-  Behavior_policy.learn at E = 32, IPPOLearner.train on 255 x 90 = 22 950 rows, Prediction_policy.learn at 64 x 55;
+* each learner at config 3 size against the oracle (fp64 ground truth, fp32 oracle beside it), ALL FIVE agents of the fused
+  launches (round 4; agent 0 alone in the round-3 tests that stay): Behavior_policy.learn at E = 32 over the whole episode,
+  IPPOLearner.train on 255 x 90 = 22 950 rows (one epoch every agent, two epochs agents 0 and 4), Prediction_policy.learn at
+  64 x 55; and the rollout body over the FULL 90-step episode;
 * config 2 (F = 2045) and config 5 (N = 64, D = 128) forward + backward;
 * the reference-shaped per-agent PPO methods (a13) on the GPU.
 Worst errors are appended to gpurun_out/parity_errors.json (copied to profiles/ as the tolerance evidence)."""
@@ -42,6 +44,15 @@ def test_rollout_body_config3_vs_oracle():
     _log("rollout_body_cfg3_E32_T4", check_rollout_body(_args(episode_limit=4, batch_size_run=32), 32, "cuda", seed=21))
 
 
+def test_rollout_body_config3_full_episode_vs_oracle():
+    """VERDICT r3 "next" #4: the WHOLE episode the benchmark times -- config 3, 32 envs x 5 agents x 55 entities, T = 90 vector
+    steps, gumbel noise and the action race injected -- every field of every step against the oracle: the error growth of the
+    tau = 0.01 gate and of the carried recurrent states over 90 dependent steps (actions bit-equal, states <= 1e-5)"""
+    from tests.rollout_oracle import check_rollout_body
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    _log("rollout_body_cfg3_E32_T90", check_rollout_body(_args(batch_size_run=32), 32, "cuda", seed=31))
+
+
 def test_rollout_body_config2_vs_oracle():
     from tests.rollout_oracle import check_rollout_body
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -54,6 +65,14 @@ def test_behavior_learn_config3_one_agent_vs_oracle():
     _log("behavior_learn_cfg3_E32_agent0", check_behavior_learn_vs_oracle(_args(batch_size_run=32), 32, "cuda", seed=23, agents=(0,)))
 
 
+def test_behavior_learn_config3_all_agents_vs_oracle():
+    """the other four nets of the SAME launch (agents 1 .. 4: the tiles behind agent 0's in every arena, record and partial
+    buffer, the last one at the arena's end) at the full config-3 size, another seed"""
+    from tests.oracle_checks import check_behavior_learn_vs_oracle
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    _log("behavior_learn_cfg3_E32_agents1to4", check_behavior_learn_vs_oracle(_args(batch_size_run=32), 32, "cuda", seed=33, agents=(1, 2, 3, 4)))
+
+
 def test_ppo_train_config3_one_agent_vs_oracle():
     """255 x 90 = 22 950 rows x F = 2485: one PPO epoch (gradients to 1e-5 of the fp64 oracle), then two epochs (the second
     runs on the first one's Adam-updated weights: post-train parameters asserted against the fp64 trajectory, the second
@@ -64,10 +83,19 @@ def test_ppo_train_config3_one_agent_vs_oracle():
     _log("ppo_train_cfg3_22950rows_agent0_2epochs", check_ppo_train_vs_oracle(_args(ppo_epoch=2), "cuda", seed=24, agents=(0,)))
 
 
+def test_ppo_train_config3_all_agents_vs_oracle():
+    """all five agents of the one fused launch at the full config-3 size (22 950 rows x F = 2485): one epoch on every agent,
+    two epochs on the agents at the arena's ends"""
+    from tests.oracle_checks import check_ppo_train_vs_oracle
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    _log("ppo_train_cfg3_22950rows_agents1to4_1epoch", check_ppo_train_vs_oracle(_args(ppo_epoch=1), "cuda", seed=34, agents=(1, 2, 3, 4)))
+    _log("ppo_train_cfg3_22950rows_agents0and4_2epochs", check_ppo_train_vs_oracle(_args(ppo_epoch=2), "cuda", seed=35, agents=(0, 4)))
+
+
 def test_prediction_learn_config3_vs_oracle():
     from tests.oracle_checks import check_prediction_learn_vs_oracle
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    _log("prediction_learn_cfg3_S64_N55", check_prediction_learn_vs_oracle(_args(batch_size_run=32), 32, "cuda", seed=25, agents=(0, 3)))
+    _log("prediction_learn_cfg3_S64_N55", check_prediction_learn_vs_oracle(_args(batch_size_run=32), 32, "cuda", seed=25))     # all five agents
 
 
 def test_config2_learners_vs_oracle():
