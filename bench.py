@@ -99,6 +99,131 @@ def cpu_baseline(args, E):
                 sample=m["sample"] + "; oracle-vs-reference speed on identical inputs: profiles/r03_cpu_baseline_anchor.json")
 
 
+def config5_object():
+    """BASELINE.json configs[4] ("Synthetic 64 agents x 63 neighbours x obs_dim 128, GAT+behavior forward/backward only, rocprof
+    roofline run"): iplan_amd/config5.py's four measurements at B = 32 and B = 256 env rows (the same function scripts/cfg5_bench.py
+    runs under rocprofv3 for profiles/*_cfg5_*), fewer repetitions.  Fractions are of the fp32 MFMA peak, algorithmic FLOPs by
+    SURVEY.md section 8d's convention (backward = 2x forward)."""
+    from iplan_amd.config5 import measure
+    rows = measure((32, 256), ("gat", "beh"), reps=0.6)
+    return {"what": "BASELINE configs[4]: 5 nets x B env rows x 64 entities x 63 neighbours x obs_dim 128; GAT forward (rollout form), GAT "
+                    "forward + backward + weight gradients (training form), behaviour encoder / decoder forward and forward + BPTT + weight "
+                    "gradients (90-step episode at B = 32, 30-step at B = 256); HIP events around each call, outside the timed region",
+            "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+            "rows": [{"piece": r["piece"], "B": r["B"], "ms": round(r["ms"], 4), "algorithmic_gflop": round(r["gflop"], 2),
+                      "tflops": round(r["tflops"], 2), "frac": round(r["frac"], 4)} for r in rows]}
+
+
+def strong_loop(total_envs, shard_world, rank, world, emu_world, dev, seed):
+    """config 4: the env rows of ONE ``total_envs``-env run sharded over ``shard_world`` ranks; a rank stores its own episodes of
+    the global buffer, and the reference's "first batch_size = buffer_size - 1 episodes" drops the last episode of the last rank"""
+    from iplan_amd.harness import SyntheticLoop
+    assert total_envs % shard_world == 0, "--total-envs must be divisible by the number of GPUs"
+    E = total_envs // shard_world
+    base = default_args("highway")
+    drop = base.buffer_size - base.batch_size               # 1: train() uses the first buffer_size - 1 episodes
+    args = default_args("highway", use_cuda=True, batch_size_run=E, buffer_size=E,
+                        batch_size=E - (drop if (rank == world - 1 and not emu_world) else 0))
+    return SyntheticLoop(args, E, seed=seed, device=dev), args, E, drop
+
+
+def config4_n1_object(opt, dev, steps=3, warmup=1):
+    """BASELINE.json configs[3] on ONE GPU (= `bench.py --scaling strong` at N = 1): 256 envs, one global 256-episode buffer,
+    step = 1 rollout + the three learners (train() on 255 x 90 rows x 5 agents).  The denominator of the strong-scaling curve."""
+    loop, args, E, _ = strong_loop(opt.total_envs, 1, 0, 1, 0, dev, 4321)
+    with contextlib.redirect_stdout(io.StringIO()):
+        for _ in range(warmup):
+            loop.cycle()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loop.cycle()
+        loop.finish()
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del loop
+    torch.cuda.empty_cache()
+    return {"what": f"BASELINE configs[3] on one GPU ({E} envs, one global {E}-episode buffer; 1 rollout + Behavior_policy.learn in two "
+                    "128-env chunks + Prediction_policy.learn + IPPOLearner.train per step), run after the timed region",
+            "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3, "value": E * args.episode_limit / dt, "unit": "env-steps/s"}
+
+
+def projection_split(loop, args, E, dev, dist, step_s, emu_world, opt):
+    """``--emulate-rank-of W``: where the rank step goes, and what it projects to.  In the cycle (events on the main stream, the
+    side learners run beside): the rollout, then everything up to the join before the next rollout.  Alone (nothing else on the GPU):
+    the three learners and the step's collectives (the same count and sizes, back to back on the 1-rank RCCL group: launch cost
+    only).  ``projected_speedup`` = config 4's N = 1 step on THIS box / this rank's step."""
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    reps = 4
+
+    def alone(fn, pre=None):
+        tot = 0.0
+        for it in range(reps + 1):
+            if pre is not None:
+                pre()
+            torch.cuda.synchronize()
+            e0, e1 = ev(), ev()
+            e0.record()
+            with contextlib.redirect_stdout(io.StringIO()):
+                r = fn()
+            if callable(r):
+                r()
+            e1.record()
+            torch.cuda.synchronize()
+            if it:
+                tot += e0.elapsed_time(e1)
+        return tot / reps
+    with contextlib.redirect_stdout(io.StringIO()):
+        loop.phase_events = []
+        for _ in range(reps):
+            loop.cycle()
+        loop.finish()
+        torch.cuda.synchronize()
+        ph = loop.phase_events
+        loop.phase_events = None
+    roll = sum(a.elapsed_time(b) for a, b, _ in ph) / len(ph)
+    rest = sum(b.elapsed_time(c) for _, b, c in ph) / len(ph)
+    batch = loop.rollout()
+    t_roll = alone(lambda: loop.rollout())
+
+    def beh():
+        loop.behavior.learn(batch, 0, defer_decoder=True)
+        loop.behavior.join_decoder()
+    t_beh = alone(beh)
+    t_pred = alone(lambda: loop.prediction.learn(batch, 0))
+
+    def fill():
+        loop.learner.store.clear()
+        loop.learner.insert_episode_batch(batch)
+    t_ppo = alone(lambda: loop.learner.train(0), pre=fill)
+    # the step's collectives: behaviour 2 arenas (+ the [nA, J] window sums), prediction 2 (+ [nA]), PPO 2 x 15 (+ 3 scalars vectors)
+    arenas = [loop.behavior.enc_arena, loop.behavior.dec_arena, loop.prediction.gat_arena, loop.prediction.dec_arena]
+    ppo = [loop.mac.actor_arena, loop.mac.critic_arena]
+    small = torch.zeros(args.n_agents, device=dev)
+    dp = loop.learner.dp
+
+    def colls():
+        for a in arenas:
+            dp.all_reduce_grads(a)
+        for _ in range(args.ppo_epoch):
+            dp.all_reduce_grads(*ppo)
+        for _ in range(5):
+            dp.all_reduce_sum(small)
+    t_coll = alone(colls)
+    n1 = config4_n1_object(opt, dev)
+    return {"rank_step_ms": step_s * 1e3,
+            "in_cycle_ms": {"rollout": roll, "learn_phase_until_next_rollout": rest,
+                            "note": "HIP events on the main stream; Behavior_policy.learn on the main stream with Prediction_policy.learn and "
+                                    "IPPOLearner.train beside it on two side streams, the deferred decoder update beside the next rollout"},
+            "alone_ms": {"rollout": t_roll, "behaviour_learn": t_beh, "prediction_learn": t_pred, "ppo_train": t_ppo,
+                         "collectives_launch_only": t_coll,
+                         "note": f"each piece alone on the GPU; collectives = the step's {len(arenas) + 2 * args.ppo_epoch} gradient-arena and 5 "
+                                 "normaliser all-reduces issued back to back on the 1-rank RCCL group"},
+            "config4_n1_same_box": n1,
+            "projected_speedup": n1["ms_per_step"] / (step_s * 1e3),
+            "target": "north_star: >= 6x strong scaling at 8 GPUs (rank step <= config4_n1 step / 6)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +241,9 @@ def main():
                          "slice of the global buffer, the union's normalisers, every collective launched on a 1-rank RCCL group) and "
                          "report the PROJECTED W-GPU strong-scaling figure next to this GPU's own number")
     ap.add_argument("--rollout-only", action="store_true", help="diagnostic: time rollout inference without the learners")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the two objects appended AFTER the timed region at N = 1 (outside `value`): `config5` (BASELINE configs[4], "
+                         "iplan_amd/config5.py at B = 32 / 256) and `config4_n1` (configs[3]'s 256 envs + global buffer on this one GPU)")
     opt = ap.parse_args()
     if os.environ.get("IPLAN_BENCH_WATCHDOG"):
         import faulthandler
@@ -137,20 +265,13 @@ def main():
 
     strong = opt.scaling == "strong"
     shard_world = emu_world or world                             # how many ranks the global run is split over
+    from iplan_amd.harness import SyntheticLoop
     if strong:
-        # config 4: the env rows of ONE 256-env run are sharded over the ranks; rank r stores its own episodes of the global
-        # buffer, the reference's "first batch_size = buffer_size - 1 episodes" drops the last episode of the last rank
-        assert opt.total_envs % shard_world == 0, "--total-envs must be divisible by the number of GPUs"
-        E = opt.total_envs // shard_world
-        base = default_args("highway")
-        drop = base.buffer_size - base.batch_size               # 1: train() uses the first buffer_size - 1 episodes
-        args = default_args("highway", use_cuda=True, batch_size_run=E, buffer_size=E,
-                            batch_size=E - (drop if (rank == world - 1 and not emu_world) else 0))
+        loop, args, E, drop = strong_loop(opt.total_envs, shard_world, rank, world, emu_world, dev, 1234 + rank)
     else:
         E = opt.envs
         args = default_args("highway", use_cuda=True, batch_size_run=E)
-    from iplan_amd.harness import SyntheticLoop
-    loop = SyntheticLoop(args, E, seed=1234 + rank, device=dev)
+        loop = SyntheticLoop(args, E, seed=1234 + rank, device=dev)
     if world > 1 or emu_world:
         from iplan_amd.parallel import DataParallel
         DataParallel(dist.group.WORLD).attach(loop)
@@ -225,6 +346,15 @@ def main():
                         "xGMI transfer or straggler wait); projected value = total envs x 90 / this rank's step time",
                 "emulated_world": emu_world, "projected_value": per_rank * emu_world, "unit": "env-steps/s",
                 "not_included": "xGMI transfer and rank skew of the 2 + 2 + 30 small all-reduces per step (0.3-4 MB each)"}
+        if emu_world and not opt.no_extras:
+            line["projection"].update(projection_split(loop, args, E, dev, dist, dt / opt.steps, emu_world, opt))
+        if world == 1 and not emu_world and not strong and not opt.rollout_only and not opt.no_extras:
+            # BASELINE.json's other GPU configs on the same box, same build, AFTER the timed region (never part of `value`)
+            del loop
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            line["config5"] = config5_object()
+            line["config4_n1"] = config4_n1_object(opt, dev)
         if not opt.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, E)
 

@@ -31,6 +31,9 @@ class DcntrlMAC:
         self._build_critics(input_shape)
         self.actor_arena = ParamArena(self.agents, self.device)
         self.critic_arena = ParamArena(self.critics, self.device)
+        # actor + critic gradients in ONE buffer: a data-parallel PPO step exchanges them as one collective (15 per train()
+        # instead of 30; the exchange is latency-bound)
+        ParamArena.colocate_grads([self.actor_arena, self.critic_arena])
         for i in range(self.n_agents):
             self.agents[i].attach(self.actor_arena, i)
             self.critics[i].attach(self.critic_arena, i)

@@ -241,7 +241,13 @@ class SyntheticLoop:
                 return n
         # (the rollout itself is NOT masked to the complement: measured slower -- it can use the decoder update's CUs again
         # as soon as that is done; the update's long-lived 372-register waves keep other workgroups off its CUs meanwhile)
+        pe = getattr(self, "phase_events", None)             # diagnostics (bench.py's projection split): events at the phase boundaries
+        if pe is not None and dev.type == "cuda":
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
         batch = self.rollout()
+        if pe is not None and dev.type == "cuda":
+            e1.record()
         self.t_env += self.E * self.args.episode_limit
         self.learner.insert_episode_batch(batch)
         # (Data-parallel runs overlap the learners too: the host issues the gradient all-reduces in the same order on
@@ -299,6 +305,9 @@ class SyntheticLoop:
         for f in getattr(self, "_late", ()):                 # the previous cycle's read-backs: long complete, no waiting
             f()
         self._late = late
+        if pe is not None:
+            e2.record()
+            pe.append((e0, e1, e2))
         return self.E * self.args.episode_limit
 
     def finish(self):

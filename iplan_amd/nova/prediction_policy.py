@@ -61,6 +61,7 @@ class Prediction_policy:
                 dropout=a.decoder_dropout))
         self.gat_arena = ParamArena(self.pred_GAT, self.device)
         self.dec_arena = ParamArena(self.pred_decoder, self.device)
+        ParamArena.colocate_grads([self.gat_arena, self.dec_arena])      # one gradient collective per learn() instead of two
         for i in range(self.n_agents):
             self.pred_GAT[i].attach(self.gat_arena, i)
             self.pred_decoder[i].attach(self.dec_arena, i)

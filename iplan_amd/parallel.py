@@ -150,6 +150,13 @@ class P2PAllReduce:
             pass
 
 
+class _Bucket:
+    """a gradient buffer with the one attribute all_reduce_grads reads of an arena"""
+
+    def __init__(self, grad):
+        self.grad = grad
+
+
 class DataParallel:
     def __init__(self, group=None):
         self.group = group
@@ -213,9 +220,25 @@ class DataParallel:
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
         return tensor
 
+    @staticmethod
+    def _buckets(arenas):
+        """the tensors to exchange for ``arenas``: arenas whose gradients live in one contiguous buffer
+        (ParamArena.colocate_grads) and are ALL part of this call go as that one buffer -- one collective instead of one each"""
+        out, seen = [], set()
+        for a in arenas:
+            grp = getattr(a, "_grad_group", None)
+            if grp is not None and all(any(m is b for b in arenas) for m in grp[1]):
+                if id(grp[0]) not in seen:
+                    seen.add(id(grp[0]))
+                    out.append(grp[0])
+            else:
+                out.append(a.grad)
+        return out
+
     def all_reduce_grads(self, *arenas):
-        """Sum the gradient arenas over the ranks (the local losses are already scaled by the global normalisers): one
-        collective per arena, in place."""
+        """Sum the gradient arenas over the ranks (the local losses are already scaled by the global normalisers), in place:
+        one collective per gradient BUFFER (co-located arenas of one call share one, see ``_buckets``)."""
+        arenas = [_Bucket(t) for t in self._buckets(arenas)]
         if self.use_p2p and self.world > 1 and arenas and arenas[0].grad.is_cuda:
             if self.p2p is None:
                 def exchange(obj):

@@ -54,7 +54,15 @@ with contextlib.redirect_stdout(io.StringIO()):
     batch = loop.rollout()
 tm("select_actions", lambda: loop.mac.select_actions_ippo(batch, 3, test_mode=False, as_numpy=False), n=50)
 tm("rollout", lambda: loop.rollout(), n=2, warm=1)
-tm("behavior_learn", lambda: loop.behavior.learn(batch, 0), n=3, warm=1)
+if os.environ.get("MB_DEFER"):
+    # the form the training cycle runs (harness.cycle): decoder weight gradients + optimiser step as ONE deferred iplan_wgrad call
+    # on the side stream -- the PMC passes use it so that the per-kernel counters are those of the kernels bench.py times
+    def beh_learn():
+        loop.behavior.learn(batch, 0, defer_decoder=True)
+        loop.behavior.join_decoder()
+    tm("behavior_learn", beh_learn, n=3, warm=1)
+else:
+    tm("behavior_learn", lambda: loop.behavior.learn(batch, 0), n=3, warm=1)
 tm("prediction_learn", lambda: loop.prediction.learn(batch, 0), n=5, warm=1)
 
 

@@ -41,13 +41,16 @@ for key, sub in (("gat_enc_fwd_kernel", "gat_enc_fwd_kernel"), ("beh_dec_bwd_ker
     k = find(sub)[0]
     b, n = bytes_of(k)
     per_launch[key] = dict(bytes=int(b), dispatches=n, kernel=k)
-# iplan_wgrad over one whole decoder BPTT: every wgrad kernel of the behaviour piece, per learn() (one beh_enc_grad launch each)
+# iplan_wgrad over one whole decoder BPTT: every wgrad kernel of the behaviour piece, per learn() (one beh_enc_grad launch each).
+# The piece runs learn(defer_decoder=True) (scripts/gpu_pmc_all.sh: MB_DEFER=1), so these ARE the kernels of the ONE deferred
+# iplan_wgrad call that bench.py times as "iplan_wgrad:beh_dec" (the encoder accumulates its weight gradients in its BPTT kernel
+# and launches no wgrad kernel): traffic / us_per_launch of that line is a bandwidth that can be compared with the HBM peak.
 learns = merged[find("beh_enc_grad_kernel")[0]]["FETCH_SIZE"][1]
 tot = 0.0
 for k in find("wgrad_"):
     b, n = bytes_of(k)
     tot += b * n
-per_launch["iplan_wgrad:beh_dec"] = dict(bytes=int(tot / learns), dispatches=learns, kernel="wgrad_partial_kernel<*> + wgrad_reduce_kernel, per learn()")
+per_launch["iplan_wgrad:beh_dec"] = dict(bytes=int(tot / learns), dispatches=learns, kernel="wgrad_partial_*kernel<*> + wgrad_reduce_kernel of the deferred decoder update, per learn()")
 out = dict(series=series, csrc_sha16=csrc_sha16(), envs_per_gpu=envs, per_launch=per_launch, counters=merged)
 path = os.path.join(ROOT, "profiles", f"{series}_pmc_summary.json")
 with open(path, "w") as f:

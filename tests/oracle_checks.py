@@ -141,7 +141,11 @@ def check_deferred_equals_inline(args, E, device, seed=23):
 
 
 # ------------------------------------------------------------------------------------------------ Prediction_policy.learn
-def check_prediction_learn_vs_oracle(args, E, device, seed=0, tol=1e-5, post_tol=1e-6, agents=None):
+def check_prediction_learn_vs_oracle(args, E, device, seed=0, tol=1e-5, post_tol=1e-6, agents=None, gate_e32_factor=E32_FACTOR):
+    """``gate_e32_factor``: bound of the GAT group = max(tol, factor x the fp32 oracle's own error).  E32_FACTOR at the BASELINE
+    config sizes (thousands of gates average: kernels measured at 0.1 x e32).  The SMALL emulated cases pass 4: with a handful of
+    entities the gradient through the tau = 0.01 gate hangs on one or two unsaturated gates, and the kernel's and the fp32
+    oracle's rounding errors on them are two independent draws of the same size -- their ratio exceeds 1.5 as often as not."""
     from iplan_amd.nova.prediction_policy import Prediction_policy
     args = SimpleNamespace(**dict(vars(args), use_cuda=(torch.device(device).type == "cuda")))
     torch.manual_seed(seed)
@@ -187,7 +191,7 @@ def check_prediction_learn_vs_oracle(args, E, device, seed=0, tol=1e-5, post_tol
         # (no gate on its path) stays at tol.
         e32 = max(_grad_err(gp32[k].grad, gp64[k].grad) for k in gp32)
         worst["gat_fp32_oracle_vs_fp64"] = max(worst["gat_fp32_oracle_vs_fp64"], e32)
-        gat_tol = max(tol, E32_FACTOR * e32)
+        gat_tol = max(tol, gate_e32_factor * e32)
         for name, prm, prm32, arena, mods, gtol in (("gat", gp64, gp32, pol.gat_arena, pol.pred_GAT, gat_tol),
                                                     ("dec", dp64, dp32, pol.dec_arena, pol.pred_decoder, tol)):
             sd = mods[i].state_dict()
@@ -346,7 +350,7 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
 
 
 # ------------------------------------------------------------------------------------------------ GAT forward + backward
-def check_gat_fwd_bwd_vs_oracle(B, N, D, device, seed=0, tol=1e-5):
+def check_gat_fwd_bwd_vs_oracle(B, N, D, device, seed=0, tol=1e-5, gate_e32_factor=E32_FACTOR):
     """One GAT_Net (random weights) forward + backward through the module's autograd path vs the oracle in fp64 (the
     kernel must be as close to the exact result as the fp32 reference is)."""
     from iplan_amd.config import default_args
@@ -374,7 +378,7 @@ def check_gat_fwd_bwd_vs_oracle(B, N, D, device, seed=0, tol=1e-5):
     worst = dict(out=_rel(out.detach(), o64.detach()), out_vs_fp32_oracle=_rel(out.detach(), o32.detach()), grad=0.0,
                  fp32_oracle_out_vs_fp64=_rel(o32.detach(), o64.detach()), fp32_oracle_grad_vs_fp64=e32)
     assert worst["out"] <= tol, worst
-    gtol = max(tol, E32_FACTOR * e32)       # tau = 0.01 gate conditioning: see check_prediction_learn_vs_oracle
+    gtol = max(tol, gate_e32_factor * e32)  # tau = 0.01 gate conditioning: see check_prediction_learn_vs_oracle
     for k, p in net.named_parameters():
         e = (p.grad.double().cpu() - p64[k].grad).abs().max().item() / gscale(k)
         worst["grad"] = max(worst["grad"], e)

@@ -42,3 +42,25 @@ def test_prediction_batch_wrapper_matches_reference(g):
     out = pol.prediction_batch_wrapper(g["history"], g["attention"], g["mask"], g["latent"])
     for a, b in zip(out, g["pred"]):
         assert a.shape == b.shape and torch.equal(a.to(b.dtype), b)
+
+
+def test_colocated_gradient_arenas_one_bucket():
+    """ParamArena.colocate_grads: actor + critic (and GAT + prediction decoder) gradients live in one contiguous buffer, the
+    Parameters' .grad views follow it, and DataParallel exchanges the arenas of one call as ONE buffer (VERDICT r3 next #2)."""
+    import torch
+    from iplan_amd.arena import ParamArena
+    from iplan_amd.parallel import DataParallel
+    mk = lambda: [torch.nn.Linear(5, 3) for _ in range(2)]  # noqa: E731
+    a, b, c = ParamArena(mk(), "cpu"), ParamArena(mk(), "cpu"), ParamArena(mk(), "cpu")
+    flat = ParamArena.colocate_grads([a, b])
+    assert flat.numel() == a.grad.numel() + b.grad.numel()
+    assert a.grad.data_ptr() == flat.data_ptr() and b.grad.data_ptr() == flat.data_ptr() + 4 * a.grad.numel()
+    a.modules[1].weight.grad.fill_(2.0)
+    b.modules[0].bias.grad.fill_(3.0)
+    assert float(a.grad_of(1, "weight").sum()) == 30.0 and float(flat.sum()) == 30.0 + 9.0
+    bk = DataParallel._buckets([a, b])
+    assert len(bk) == 1 and bk[0] is flat                      # both members present: one exchange
+    bk = DataParallel._buckets([a])
+    assert len(bk) == 1 and bk[0] is a.grad                    # a lone member goes by itself
+    bk = DataParallel._buckets([a, c, b])
+    assert len(bk) == 2 and bk[0] is flat and bk[1] is c.grad
