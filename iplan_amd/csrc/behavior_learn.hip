@@ -143,15 +143,23 @@ __device__ __forceinline__ bool beh_chain(const IplanBehArgs& a, BehChain& c) {
 
 // ------------------------------------------------------------------------------------------------------------
 // encoder forward over the whole episode: records per step (saved_enc) and per window (saved_lat)
+// BF3 (default since round 4; IPLAN_ENC_FP32=1 selects the fp32-MFMA form): the GRU32's two contractions W_ih u, W_hh h in the
+// fp32-exact split-bf16 form (wave_tile.h) with ALL weight pieces register-resident -- 2 x 6 row tiles x one K = 32 chunk = 144
+// registers; u and h are split once per step (the 8 D-layout values a lane holds of a 32-vector are the 8 K slots of its lane
+// group).  72 bf16 MFMAs (~17 cycles each) replace 96 fp32 MFMAs (32 cycles each, and they take the VALU's issue slots): the
+// shape that took the GAT recurrence from 156 to 115 us (gat.hip).  The 5-wide input Linear stays on fp32 MFMA (8 per step).
+template <bool BF3>
 __global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_wih[3 * EHd * ELDB];
-    __shared__ __attribute__((aligned(16))) float s_whh[3 * EHd * ELDB];
+    __shared__ __attribute__((aligned(16))) float s_wih[BF3 ? 16 : 3 * EHd * ELDB];
+    __shared__ __attribute__((aligned(16))) float s_whh[BF3 ? 16 : 3 * EHd * ELDB];
     __shared__ __attribute__((aligned(16))) float s_lin[EHd * 24];
     __shared__ __attribute__((aligned(16))) float s_out[16 * ELDB];
     __shared__ __attribute__((aligned(16))) float s_b[32 + 96 + 96 + 16];
     const float* __restrict__ PE = a.enc_params + (int64_t)blockIdx.y * a.enc_s_net;
-    stage_matrix(s_wih, ELDB, 3 * EHd, PE + a.enc_off[IPLAN_ENC_WIH], 3 * EHd, EHd);
-    stage_matrix(s_whh, ELDB, 3 * EHd, PE + a.enc_off[IPLAN_ENC_WHH], 3 * EHd, EHd);
+    if (!BF3) {
+        stage_matrix(s_wih, ELDB, 3 * EHd, PE + a.enc_off[IPLAN_ENC_WIH], 3 * EHd, EHd);
+        stage_matrix(s_whh, ELDB, 3 * EHd, PE + a.enc_off[IPLAN_ENC_WHH], 3 * EHd, EHd);
+    }
     stage_matrix(s_lin, 24, EHd, PE + a.enc_off[IPLAN_ENC_LIN_W], EHd, a.d);
     stage_matrix(s_out, ELDB, 16, PE + a.enc_off[IPLAN_ENC_OUT_W], a.Z, EHd);
     stage_vector(s_b, 32, PE + a.enc_off[IPLAN_ENC_LIN_B], 32);
@@ -182,6 +190,17 @@ __global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
     f32x4 x_raw = x_fetch(j_lo, 0, x_has);
     const int64_t ecgs = (int64_t)J * a.L * 256;                                  // floats between the record's 16-column groups
     float* enc_rec = a.saved_enc + ((int64_t)c.net * c.tiles + (c.tile < c.tiles ? c.tile : 0)) * (SVE / 16) * ecgs + 16 * c.n;
+    // split-bf16 form: weight pieces of row tile c (c = 0, 1: r; 2, 3: z; 4, 5: n -- PyTorch's gate order) and the gate biases
+    Bf3 wih[BF3 ? 6 : 1], whh[BF3 ? 6 : 1];
+    f32x4 b_rz[4], b_in[2], b_hn[2];
+    if (BF3) {
+        for (int t = 0; t < 6; ++t) {
+            wih[t] = wfrag_bf3(PE + a.enc_off[IPLAN_ENC_WIH], EHd, 3 * EHd, 16 * t, 0);
+            whh[t] = wfrag_bf3(PE + a.enc_off[IPLAN_ENC_WHH], EHd, 3 * EHd, 16 * t, 0);
+        }
+        for (int t = 0; t < 4; ++t) b_rz[t] = bfrag_lds(s_b + 32, t) + bfrag_lds(s_b + 128, t);
+        for (int t = 0; t < 2; ++t) { b_in[t] = bfrag_lds(s_b + 32, 4 + t); b_hn[t] = bfrag_lds(s_b + 128, 4 + t); }
+    }
     for (int j = j_lo; j < j_hi; ++j) {
         float* sl = a.saved_lat + (c.grow * J + j) * SVL;
         vstore_a(sl + 16, valid, 0, lat);                      // the latent the decoder uses in window j
@@ -201,7 +220,27 @@ __global__ __launch_bounds__(256) void beh_enc_fwd_kernel(IplanBehArgs a) {
                 vstore_a(se + ((SE_U >> 4) + T) * ecgs, valid, 0, ue[T]);
             }
             GruGates ke[ET];
-            gru_step_lds<ET, ET>(s_wih, ELDB, s_whh, ELDB, s_b + 32, s_b + 128, ue, he, ke);
+            if (BF3) {
+                const Bf3 us = split_bf3(ue[0], ue[1]), hs = split_bf3(he[0], he[1]);
+                f32x4 acc[6] = {b_rz[0], b_rz[1], b_rz[2], b_rz[3], b_in[0], b_in[1]}, ahn[2] = {b_hn[0], b_hn[1]};
+                // smallest piece products first (fp32 accumulators), the chains issued round-robin; the input half first: it
+                // does not wait for the previous step's gates
+#define ENC_BF3_ROUND(WP, XP)                                                          \
+    for (int cc = 0; cc < 6; ++cc) acc[cc] = mfma_bf16(wih[cc].WP, us.XP, acc[cc]);
+                ENC_BF3_ROUND(p2, p0) ENC_BF3_ROUND(p0, p2) ENC_BF3_ROUND(p1, p1) ENC_BF3_ROUND(p1, p0) ENC_BF3_ROUND(p0, p1) ENC_BF3_ROUND(p0, p0)
+#undef ENC_BF3_ROUND
+#define ENC_BF3_ROUND(WP, XP)                                                          \
+    for (int cc = 0; cc < 4; ++cc) acc[cc] = mfma_bf16(whh[cc].WP, hs.XP, acc[cc]);    \
+    for (int cc = 0; cc < 2; ++cc) ahn[cc] = mfma_bf16(whh[4 + cc].WP, hs.XP, ahn[cc]);
+                ENC_BF3_ROUND(p2, p0) ENC_BF3_ROUND(p0, p2) ENC_BF3_ROUND(p1, p1) ENC_BF3_ROUND(p1, p0) ENC_BF3_ROUND(p0, p1) ENC_BF3_ROUND(p0, p0)
+#undef ENC_BF3_ROUND
+                for (int T = 0; T < ET; ++T) {
+                    ke[T] = gru_gates(acc[T], acc[2 + T], acc[4 + T], ahn[T], he[T]);
+                    he[T] = ke[T].h;
+                }
+            } else {
+                gru_step_lds<ET, ET>(s_wih, ELDB, s_whh, ELDB, s_b + 32, s_b + 128, ue, he, ke);
+            }
             for (int T = 0; T < ET; ++T) {
                 vstore_a(se + ((SE_R >> 4) + T) * ecgs, valid, 0, ke[T].r);
                 vstore_a(se + ((SE_Z >> 4) + T) * ecgs, valid, 0, ke[T].z);
@@ -783,15 +822,35 @@ __global__ __launch_bounds__(DEC_THREADS) void beh_dec_bwd_kernel(IplanBehArgs a
 constexpr int EP_WIH = 0, EP_WHH = 3072, EP_BIH = 6144, EP_BHH = 6240, EP_LINW = 6336, EP_LINB = 6848, EP_OUTW = 6880, EP_OUTB = 7392;
 static_assert(IPLAN_BEH_ENC_PART == 7408, "enc_part layout");
 
+// BF3 (default since round 4; IPLAN_ENC_FP32=1 selects the fp32-MFMA form): the two backward-data products of a step,
+//      du = W_ih^T [dr dz dn_i],    dh_prev = W_hh^T [dr dz dn_h] + z * dh        (K = 96: three K = 32 chunks each),
+// in the fp32-exact split-bf16 form: 72 bf16 MFMAs instead of 96 fp32 ones.  The kernel already holds 28 weight-gradient
+// accumulator tiles (112 registers) plus the bias sums, so the weights' pieces are NOT register-resident here: they are staged
+// once per workgroup in LDS in fragment order ([matrix][out tile][chunk][piece][lane] bf16x8: 36 KB) and read as 16 bytes per
+// lane -- 36 ds_read_b128 per step for one wave per SIMD, nowhere near the LDS rate.  The gate gradients are split once per
+// step ([dr], [dz] serve both products).  The weight-gradient accumulation stays on fp32 MFMA (operands turned through LDS).
+constexpr int EB_FRAGS = 2 * 2 * 3;                          // matrix (ih | hh) x out tile x chunk
+template <bool BF3>
 __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
     constexpr int TLE = 3 * EHd + 8;                        // 104
-    __shared__ __attribute__((aligned(16))) float s_wihT[EHd * TLE];
-    __shared__ __attribute__((aligned(16))) float s_whhT[EHd * TLE];
+    __shared__ __attribute__((aligned(16))) float s_wihT[BF3 ? 16 : EHd * TLE];
+    __shared__ __attribute__((aligned(16))) float s_whhT[BF3 ? 16 : EHd * TLE];
+    __shared__ __attribute__((aligned(16))) bf16x8 s_wp[BF3 ? EB_FRAGS * 3 * 64 : 1];
     __shared__ __attribute__((aligned(16))) float s_outT[EHd * 24];
     __shared__ __attribute__((aligned(16))) float s_turn[4][15][256];      // per wave: 8 dg + 2 du + 2 u + 2 hp + 1 x tiles
     const float* __restrict__ PE = a.enc_params + (int64_t)blockIdx.y * a.enc_s_net;
-    stage_matrix_t(s_wihT, TLE, EHd, PE + a.enc_off[IPLAN_ENC_WIH], 3 * EHd, EHd);
-    stage_matrix_t(s_whhT, TLE, EHd, PE + a.enc_off[IPLAN_ENC_WHH], 3 * EHd, EHd);
+    if (BF3) {
+        for (int f = wave_id(); f < EB_FRAGS; f += 4) {      // fragment f = (matrix * 2 + T) * 3 + ch
+            const int mtx = f / 6, T = (f / 3) & 1, ch = f % 3;
+            const Bf3 w = wfrag_t_bf3(PE + a.enc_off[mtx ? IPLAN_ENC_WHH : IPLAN_ENC_WIH], EHd, 16 * T, 32 * ch);
+            s_wp[(f * 3 + 0) * 64 + lane_id()] = w.p0;
+            s_wp[(f * 3 + 1) * 64 + lane_id()] = w.p1;
+            s_wp[(f * 3 + 2) * 64 + lane_id()] = w.p2;
+        }
+    } else {
+        stage_matrix_t(s_wihT, TLE, EHd, PE + a.enc_off[IPLAN_ENC_WIH], 3 * EHd, EHd);
+        stage_matrix_t(s_whhT, TLE, EHd, PE + a.enc_off[IPLAN_ENC_WHH], 3 * EHd, EHd);
+    }
     stage_matrix_t(s_outT, 24, EHd, PE + a.enc_off[IPLAN_ENC_OUT_W], a.Z, EHd);
     __syncthreads();
     BehChain c;
@@ -923,9 +982,31 @@ __global__ __launch_bounds__(256) void beh_enc_bwd_kernel(IplanBehArgs a) {
             const int oe[ET] = {0, 16};
             f32x4 du[ET], dup[ET];
             for (int T = 0; T < ET; ++T) { du[T] = splat4(0.f); dhe[T] = dd[T]; }
-            dense_multi<ET, 3 * ET>(s_wihT, TLE, oe, 0, dg, du);                          // W_ih^T [dr dz dn_i]
-            dense_multi<ET, 2 * ET>(s_whhT, TLE, oe, 0, dg, dhe);                         // W_hh^T [dr dz | dn_h]
-            dense_multi<ET, ET>(s_whhT, TLE, oe, 2 * EHd, dg + 3 * ET, dhe);
+            if (BF3) {
+                // chunk ch of the gate-gradient vector: [dr] | [dz] | [dn_i] (input side) or [dn_h] (recurrent side)
+                for (int ch = 0; ch < 3; ++ch) {
+                    const Bf3 gi = split_bf3(dg[2 * ch], dg[2 * ch + 1]);
+                    const Bf3 gh = ch < 2 ? gi : split_bf3(dg[3 * ET], dg[3 * ET + 1]);
+                    Bf3 wi[ET], wh[ET];
+                    for (int T = 0; T < ET; ++T) {
+                        const bf16x8* fi = s_wp + ((0 * 2 + T) * 3 + ch) * 3 * 64 + l;
+                        const bf16x8* fh = s_wp + ((1 * 2 + T) * 3 + ch) * 3 * 64 + l;
+                        wi[T].p0 = fi[0]; wi[T].p1 = fi[64]; wi[T].p2 = fi[128];
+                        wh[T].p0 = fh[0]; wh[T].p1 = fh[64]; wh[T].p2 = fh[128];
+                    }
+#define ENCB_ROUND(WP, XP)                                                           \
+    for (int T = 0; T < ET; ++T) {                                                   \
+        du[T] = mfma_bf16(wi[T].WP, gi.XP, du[T]);                                   \
+        dhe[T] = mfma_bf16(wh[T].WP, gh.XP, dhe[T]);                                 \
+    }
+                    ENCB_ROUND(p2, p0) ENCB_ROUND(p0, p2) ENCB_ROUND(p1, p1) ENCB_ROUND(p1, p0) ENCB_ROUND(p0, p1) ENCB_ROUND(p0, p0)
+#undef ENCB_ROUND
+                }
+            } else {
+                dense_multi<ET, 3 * ET>(s_wihT, TLE, oe, 0, dg, du);                      // W_ih^T [dr dz dn_i]
+                dense_multi<ET, 2 * ET>(s_whhT, TLE, oe, 0, dg, dhe);                     // W_hh^T [dr dz | dn_h]
+                dense_multi<ET, ET>(s_whhT, TLE, oe, 2 * EHd, dg + 3 * ET, dhe);
+            }
             for (int T = 0; T < ET; ++T) {
                 for (int q = 0; q < 4; ++q) dup[T][q] = u[T][q] > 0.f ? du[T][q] : 0.f;
                 bU[T] += dup[T];
@@ -1535,7 +1616,10 @@ extern "C" int iplan_beh_fwd(const IplanBehArgs* a, iplan_stream_t stream) {
     const dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)a->n_nets);                       // encoder: 4 tiles per workgroup
     const dim3 dgrid((unsigned)((tiles + DEC_TILES - 1) / DEC_TILES), (unsigned)a->n_nets);  // decoder: 3 tiles x 4 quarter-waves
     const int ph = a->win ? 2 : a->fwd_phase;
-    if (ph == 0 || ph == 1) hipLaunchKernelGGL(beh_enc_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    if (ph == 0 || ph == 1) {
+        if (getenv("IPLAN_ENC_FP32") == nullptr) hipLaunchKernelGGL(beh_enc_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+        else hipLaunchKernelGGL(beh_enc_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    }
     // The second form (split-bf16, register-resident weights, input projection ahead of the recurrence) is the DEFAULT where it
     // applies (not in single-window mode, d <= 8, at most D2_MAX_WINDOWS windows); IPLAN_DEC_FWD_V1=1 selects the first form.
     // History: on the chain-major records of rounds 1-2 both forms ended up behind the record stores (6.0 vs 5.9 ms per pass: the
@@ -1587,7 +1671,8 @@ extern "C" int iplan_beh_bwd(const IplanBehArgs* a, iplan_stream_t stream) {
 #endif
     if (a->bwd_phase != 2) hipLaunchKernelGGL(beh_dec_bwd_kernel, dgrid, dim3(DEC_THREADS), lds, (hipStream_t)stream, *a);
     if (a->bwd_phase != 1) {
-        hipLaunchKernelGGL(beh_enc_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+        if (getenv("IPLAN_ENC_FP32") == nullptr) hipLaunchKernelGGL(beh_enc_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+        else hipLaunchKernelGGL(beh_enc_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *a);
         if (a->bwd_j_lo <= 0) {                             // the last (or only) piece: reduce the wave partials
             const int p_enc = 32 * a->d + 32 + 2 * 96 * 32 + 2 * 96 + a->Z * 32 + a->Z;
             hipLaunchKernelGGL(beh_enc_grad_kernel, dim3((unsigned)((p_enc + 255) / 256), (unsigned)a->n_nets), dim3(256), 0,

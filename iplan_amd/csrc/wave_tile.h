@@ -129,6 +129,16 @@ __device__ __forceinline__ Bf3 wfrag_bf3(const float* __restrict__ W, int ld, in
     return split_bf3(lo, hi);
 }
 
+// Same for the TRANSPOSE of a row-major matrix (A operand of y = W^T x): output rows o0..o0+15 of W^T = columns of W, K slots
+// k0..k0+31 = rows of W (full tiles only; strided loads, done once per launch).
+__device__ __forceinline__ Bf3 wfrag_t_bf3(const float* __restrict__ W, int ld, int o0, int k0) {
+    const int l = lane_id();
+    const float* p = W + (size_t)(k0 + 4 * (l >> 4)) * ld + o0 + (l & 15);
+    f32x4 lo, hi;
+    for (int j = 0; j < 4; ++j) { lo[j] = p[(size_t)j * ld]; hi[j] = p[(size_t)(16 + j) * ld]; }
+    return split_bf3(lo, hi);
+}
+
 __device__ __forceinline__ f32x4 splat4(float v) {
     f32x4 r = {v, v, v, v};
     return r;

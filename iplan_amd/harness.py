@@ -272,6 +272,17 @@ class SyntheticLoop:
         prep = self.behavior.prepare_learn(batch) if getattr(type(self.behavior), "learn_takes_prepared", False) else None
         ev = torch.cuda.Event()
         ev.record(main)
+        # IPLAN_BEH_FIRST=1 (A/B knob): behaviour learning -- the critical path of the phase -- is enqueued BEFORE the side
+        # learners (read-back staged, so the host goes straight on to them): its first kernels then start ~0.2 ms after the
+        # rollout instead of behind prediction learning's ~1.2 ms of host-side sampling + enqueue
+        beh_first = self.behavior is not None and bool(os.environ.get("IPLAN_BEH_FIRST"))
+        late = []                                            # host read-backs of this cycle, delivered during the next one
+        beh_fin = None
+        if beh_first:
+            kw = {"defer_decoder": True} if self.defer_decoder else {}
+            if prep is not None:
+                kw["prepared"] = prep
+            beh_fin = self.behavior.learn(batch, self.t_env, defer_readback=True, **kw)
         for strm, fn in zip(self._lstreams, (
                 (lambda: self.prediction.learn(batch, self.t_env, defer=True)) if self.prediction is not None else None,
                 lambda: self.learner.train(self.t_env, defer=True))):
@@ -285,8 +296,9 @@ class SyntheticLoop:
             fins.append((f, done))
         # IPLAN_RUN_AHEAD=1 (opt-in; measured 362-364 vs 358 ms per cycle with it off, profiles/r02h_notes.md)
         run_ahead = self.behavior is not None and self.defer_decoder and bool(os.environ.get("IPLAN_RUN_AHEAD"))
-        late = []                                            # host read-backs of this cycle, delivered during the next one
-        if self.behavior is not None:
+        if beh_fin is not None:
+            late.append(beh_fin) if run_ahead else beh_fin()
+        elif self.behavior is not None:
             # the decoder's weight-gradient contraction + optimiser step run on beside the next rollout (see learn())
             kw = {"defer_decoder": True} if self.defer_decoder else {}
             if prep is not None:

@@ -134,6 +134,7 @@ class IPPOLearner:
         # step (``last_step_params``), so that the last step's gradients can be checked at that exact parameter point
         self.probe_last_step = False
         self.last_step_params = None
+        self.last_step_moments = None                        # ((exp_avg, exp_avg_sq, steps taken) of the actor arena, same of the critic arena)
         self.last_step_relu = None                           # ([2, nA, rows, M] bool, same): which side of the fc1 / fc2 ReLU kink each unit took
 
         self.clip_param = args.clip_param
@@ -167,6 +168,13 @@ class IPPOLearner:
         # the first 255 episodes are trained on -> the last rank drops one): the global row counts, set by the caller
         self.dp_global_rows = None      # PPO rows of all ranks (default: rows * world)
         self.dp_global_count = None     # stored (episode, step) entries of all ranks (default: bs * T * world)
+
+    def _moment_snapshot(self):
+        """diagnostics (``probe_last_step``): Adam's first / second moments of both arenas and the step counts as they are
+        BEFORE the next optimiser step -- with ``last_step_params`` the complete state the last step started from"""
+        from ..optim import _moments
+        return tuple(tuple(t.clone() for t in _moments(arena)) + (opts[0]._steps,)
+                     for arena, opts in ((self.mac.actor_arena, self.actor_optimizers), (self.mac.critic_arena, self.critic_optimizers)))
 
     def lr_decay(self, episode, episodes):
         for n in range(self.n_agents):
@@ -272,6 +280,11 @@ class IPPOLearner:
         # path takes them from its own first epoch (same parameters, same kernels: ratio == 1 there, as in the reference,
         # which evaluates one network twice); the other paths need them up front.
         split = self.num_mini_batch == 1 and not os.environ.get("IPLAN_PPO_FC1_FP32")
+        # The split-bf16 fc1 kernels are shaped for the full buffer (512 rows per workgroup, the whole K loop in one workgroup):
+        # below IPLAN_PPO_SPLIT_MIN_ROWS rows per agent (a data-parallel rank's share of config 4: 2 880) their few workgroups
+        # are one long latency chain each and the streaming fp32 form (16 rows per wave) is the faster one.
+        if split and self.batch_size * T < int(os.environ.get("IPLAN_PPO_SPLIT_MIN_ROWS", "0")):
+            split = False
         if split:
             # The split path keeps two packed copies of the normalised rows for the whole train() (2 x rows x Kpad x 4 bytes per
             # agent + the pre-activations: 2.3 GB at config 3, 18 GB for config 4 on one GPU -- sized for 288 GB of HBM3E).  On
@@ -337,6 +350,7 @@ class IPPOLearner:
                 self.dp.all_reduce_grads(mac.actor_arena, mac.critic_arena)
             if self.probe_last_step and ep == self.ppo_epoch - 1:
                 self.last_step_params = (mac.actor_arena.data.clone(), mac.critic_arena.data.clone())
+                self.last_step_moments = self._moment_snapshot()
                 self.last_step_relu = (out["saved"][..., 0:64] > 0, out["saved"][..., 128:192] > 0)       # fc1 / fc2 ReLU branches taken
             sq_a = step_all(self.actor_optimizers, max_norm)
             norms[ep, 0] = sq_a[:, 0]
@@ -425,6 +439,7 @@ class IPPOLearner:
                 ops.ac_backward(out, mac.actor_arena, mac.critic_arena, g_logp=g_logp, g_entropy=-self.entropy_coef / float(mbs), g_values=g_v)
                 if self.probe_last_step and k == self.ppo_epoch * nmb - 1:
                     self.last_step_params = (mac.actor_arena.data.clone(), mac.critic_arena.data.clone())
+                    self.last_step_moments = self._moment_snapshot()
                     self.last_step_relu = (out["saved"][..., 0:64] > 0, out["saved"][..., 128:192] > 0)
                 norms[k, 0] = step_all(self.actor_optimizers, max_norm)[:, 0]
                 norms[k, 1] = step_all(self.critic_optimizers, max_norm)[:, 0]
@@ -535,6 +550,7 @@ class IPPOLearner:
             dp.all_reduce_grads(mac.actor_arena, mac.critic_arena)
             if self.probe_last_step and k == steps - 1:
                 self.last_step_params = (mac.actor_arena.data.clone(), mac.critic_arena.data.clone())
+                self.last_step_moments = self._moment_snapshot()
                 self.last_step_relu = (out["saved"][..., 0:64] > 0, out["saved"][..., 128:192] > 0)
             norms[k, 0] = step_all(self.actor_optimizers, max_norm)[:, 0]
             norms[k, 1] = step_all(self.critic_optimizers, max_norm)[:, 0]

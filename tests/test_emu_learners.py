@@ -419,3 +419,21 @@ def test_behavior_learn_decoder_forward_both_forms_emulated(monkeypatch):
     for w in (w1, w2):
         assert w["grad"] < 1e-5 and w["loss"] < 1e-5, (w1, w2)
     assert abs(w2["grad"] - w1["grad"]) < 1e-6, (w1, w2)
+
+
+def test_behavior_learn_encoder_both_forms_emulated(monkeypatch):
+    """the behaviour encoder's forward and BPTT in their two forms -- the default split-bf16 form (round 4: W_ih u / W_hh h and
+    the two backward-data products on the bf16 matrix cores, fp32-exact) and the fp32-MFMA form (IPLAN_ENC_FP32=1) -- both
+    within 1e-5 of the fp64 oracle, at a ragged size (partial tile) and through BPTT window pieces"""
+    from tests.oracle_checks import check_behavior_learn_vs_oracle
+    kw = dict(max_vehicle_num=7, episode_limit=14, max_history_len=4)
+    w2 = check_behavior_learn_vs_oracle(_small(**kw), 3, "cpu", seed=5)
+    monkeypatch.setenv("IPLAN_ENC_FP32", "1")
+    w1 = check_behavior_learn_vs_oracle(_small(**kw), 3, "cpu", seed=5)
+    monkeypatch.delenv("IPLAN_ENC_FP32")
+    for w in (w1, w2):
+        assert w["grad"] < 1e-5 and w["loss"] < 1e-5, (w1, w2)
+    assert abs(w2["grad"] - w1["grad"]) < 1e-6, (w1, w2)
+    monkeypatch.setenv("IPLAN_BEH_PIECES", "3")
+    w3 = check_behavior_learn_vs_oracle(_small(**kw), 3, "cpu", seed=5)
+    assert w3["grad"] < 1e-5, w3

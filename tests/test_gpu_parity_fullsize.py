@@ -182,3 +182,14 @@ def test_fc1_split_vs_fp32_gpu():
     count) against the fp32 MFMA kernels and an fp64 evaluation -- forward pre-activation and the fc1 / feature_norm gradients"""
     from tests.test_emu_kernels import check_fc1_split_vs_fp32
     check_fc1_split_vs_fp32("cuda", rows_per_ep=37, n_eps=29, seed=5, N=55, log=lambda w: _log("fc1_split_vs_fp32", w))
+
+
+def test_behavior_learn_encoder_fp32_form_gpu(monkeypatch):
+    """IPLAN_ENC_FP32=1 (the fp32-MFMA form of the behaviour encoder's forward and BPTT; the split-bf16 form is the default since
+    round 4 and is what every other behaviour test here runs) at config-3 size and at a ragged size vs the fp64 oracle"""
+    from tests.oracle_checks import check_behavior_learn_vs_oracle
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    monkeypatch.setenv("IPLAN_ENC_FP32", "1")
+    _log("behavior_learn_cfg3_E32_agent2_enc_fp32", check_behavior_learn_vs_oracle(_args(batch_size_run=32), 32, "cuda", seed=23, agents=(2,)))
+    b = _args(max_vehicle_num=9, n_agents=2, episode_limit=20, batch_size_run=4)
+    _log("behavior_learn_ragged_enc_fp32", check_behavior_learn_vs_oracle(b, 4, "cuda", seed=43))
