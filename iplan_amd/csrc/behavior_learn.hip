@@ -1586,6 +1586,380 @@ __global__ __launch_bounds__(D2_THREADS, 2) void beh_dec_fwd2_kernel(IplanBehArg
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Decoder BPTT, SECOND FORM (round 4; the default where it applies, IPLAN_DEC_BWD_V1=1 selects the first form: see iplan_beh_bwd).
+//
+// Same reasoning as the forward's second form: the first form is bound by fp32-MFMA + VALU issue (104 v_mfma_f32_16x16x4_f32
+// per quarter-step, 3 quarter-waves per SIMD).  Here the two backward-data products of a step,
+//      du = W_ih^T [dr dz dn_i]          dh_prev = W_hh^T [dr dz dn_h] + z * dh          (K = 192 = six K = 32 chunks each),
+// run in the fp32-exact split-bf16 form with ALL weight pieces register-resident: a chain tile's step is split over EIGHT waves by
+// (hidden quarter q) x (matrix) -- wave B_q owns output rows 16q .. 16q+15 of W_hh^T (72 piece registers), the gate backward of
+// its 16 hidden units and the recurrence  d loss / d h;  wave A_q owns the same rows of W_ih^T, the ReLU / Linear backward of its
+// 16 units of u and the step's share of d loss / d latent.  A 512-thread workgroup = 4 B-waves + 4 A-waves carries B2_TILES = 3
+// chain tiles that every wave walks one after the other.
+//  * the gate gradients of a step cross the tile as bf16 PIECES ([dr | dz | dn_i | dn_h]: 8 K-chunks x 3 pieces x 1 KiB per
+//    tile, written once by the B-wave that owns the units, read by the 3 other B-waves and the 4 A-waves);
+//  * nothing on the recurrent path needs du: the A-waves consume the pieces behind the B-waves and never hold them up;
+//  * hand-offs are monotonic LDS counters (gcnt: pieces of step s written, 4 per step; rcnt: pieces of step s read, 8 per step --
+//    a B-wave overwrites the slots only when rcnt says every reader is done), no workgroup barrier inside the episode;
+//  * record loads are issued one step ahead, branch-free, masked where they are consumed (as in the first form).
+// Same arithmetic results as the first form up to fp32 round-off of the split products; same records.
+constexpr int B2_TILES = 3, B2_THREADS = 512;
+constexpr int B2_GX = B2_TILES * 8 * 3 * 256;               // floats: [tile][chunk = gate * 2 + half][piece][64 lanes x bf16x8]
+constexpr int B2_LX = 2 * B2_TILES * 4 * 256;               //         [window parity][tile][q][64 lanes x f32x4]  d loss / d latent shares
+constexpr int B2_DY = 4 * B2_TILES * 256;                   //         [step & 3][tile][64 lanes x f32x4]  loss gradient of a step (published 2 ahead)
+constexpr int B2_CNT_INTS = 16;                             // gcnt | rcnt | lcnt | ocnt | dcnt | pad
+constexpr int B2_LDS_FLOATS = B2_GX + B2_LX + B2_DY + B2_CNT_INTS + D2_MAX_WINDOWS;
+
+struct B2Ctx {
+    float *s_gx, *s_lx, *s_dy, *s_scale;
+    int *gcnt, *rcnt, *lcnt, *ocnt, *dcnt;
+    int q, l, n, g, net, J, Lw, j_lo, j_hi, steps, n_live;
+    int64_t steps_per_chain;
+    uint32_t cgs;
+    const float* PD;
+};
+// pieces of the own 16 units of gate `gate` (0 dr, 1 dz, 2 dn_i, 3 dn_h) of tile k: half (q & 1) of chunk gate * 2 + (q >> 1)
+__device__ __forceinline__ void b2_g_write(const B2Ctx& x, int k, int gate, f32x4 v) {
+    bf16x4 p0, p1, p2;
+    split_bf3_half(v, p0, p1, p2);
+    char* slot = reinterpret_cast<char*>(x.s_gx + ((k * 8 + gate * 2 + (x.q >> 1)) * 3) * 256) + 16 * x.l + 8 * (x.q & 1);
+    *reinterpret_cast<bf16x4*>(slot) = p0;
+    *reinterpret_cast<bf16x4*>(slot + 1024) = p1;
+    *reinterpret_cast<bf16x4*>(slot + 2048) = p2;
+}
+__device__ __forceinline__ Bf3 b2_g_read(const B2Ctx& x, int k, int chunk) {
+    const char* slot = reinterpret_cast<const char*>(x.s_gx + ((k * 8 + chunk) * 3) * 256) + 16 * x.l;
+    Bf3 v;
+    v.p0 = *reinterpret_cast<const bf16x8*>(slot);
+    v.p1 = *reinterpret_cast<const bf16x8*>(slot + 1024);
+    v.p2 = *reinterpret_cast<const bf16x8*>(slot + 2048);
+    return v;
+}
+// acc += W^T[own 16 rows][chunk] . g[chunk]: six piece products, smallest first
+__device__ __forceinline__ f32x4 b2_chunk(const Bf3& W, const Bf3& G, f32x4 acc) {
+    acc = mfma_bf16(W.p2, G.p0, acc); acc = mfma_bf16(W.p0, G.p2, acc); acc = mfma_bf16(W.p1, G.p1, acc);
+    acc = mfma_bf16(W.p1, G.p0, acc); acc = mfma_bf16(W.p0, G.p1, acc); acc = mfma_bf16(W.p0, G.p0, acc);
+    return acc;
+}
+
+// ---- B_q: gate backward of the own 16 hidden units + the recurrence.  FAST = all three tiles exist and are full.
+// Register budget (two waves per SIMD: 256): 72 weight-piece registers + the prefetched record of the NEXT step for three tiles
+// (r, z, n, hn, h_prev: 60) + the carried d loss / d h and tanh' inputs (24).  The loss gradient dy of a step needs three more
+// record fields (y, target, mask) and does not depend on the recurrence: the A-wave that owns a tile computes it one step AHEAD
+// and hands it over through LDS (b2_input), which keeps those fields out of this wave's registers.
+template <bool FAST>
+__device__ __forceinline__ void b2_recurrent(const IplanBehArgs& a, const B2Ctx& x, const DecTile (&c)[B2_TILES]) {
+    const int q = x.q, l = x.l, g = x.g, net = x.net, Lw = x.Lw, J = x.J;
+    const float* Whh = x.PD + a.dec_off[IPLAN_DEC_WHH];
+    Bf3 W[6];
+    for (int ch = 0; ch < 6; ++ch) W[ch] = wfrag_t_bf3(Whh, DHd, 16 * q, 32 * ch);
+    // W_out^T rows 16q .. (hidden units) x K = the d outputs: lane (m, g) holds W_out[4g + r][16q + m]
+    f32x4 woutT;
+    {
+        const float* Wo = x.PD + a.dec_off[IPLAN_DEC_OUT_W];
+        for (int r = 0; r < 4; ++r) woutT[r] = (4 * g + r < a.d) ? Wo[(int64_t)(4 * g + r) * DHd + 16 * q + (l & 15)] : 0.f;
+    }
+    const float inv_keep = 1.0f / (1.0f - a.drop_p);
+    const uint32_t sd_lane = 64u * (uint32_t)x.n + 16u * (uint32_t)g;
+    struct StepIn {
+        f32x4 r, z, n, hn, hp;
+    };
+    const char* sdb[B2_TILES];
+    char* ddb[B2_TILES];
+    f32x4 dhd[B2_TILES], hcur[B2_TILES], dhdir[B2_TILES];
+    StepIn cur[B2_TILES];
+    auto load_step = [&](int k, int j, int t, StepIn& o) {       // straight-line fetch, masked where it is consumed
+        const bool valid = FAST || c[k].valid;
+        const uint32_t so = sd_lane + (uint32_t)(((int64_t)j * Lw + t) * 1024);
+        const bool first = (j == 0 && t == 0);
+        o.r = ld4_raw<FAST>(sdb[k], so + x.cgs * REC_CG(SD_R + 16 * q), valid);
+        o.z = ld4_raw<FAST>(sdb[k], so + x.cgs * REC_CG(SD_Z + 16 * q), valid);
+        o.n = ld4_raw<FAST>(sdb[k], so + x.cgs * REC_CG(SD_N + 16 * q), valid);
+        o.hn = ld4_raw<FAST>(sdb[k], so + x.cgs * REC_CG(SD_HN + 16 * q), valid);
+        o.hp = ld4_raw<FAST>(sdb[k], (first ? so : so - 1024u) + x.cgs * REC_CG(SD_H + 16 * q), valid);
+    };
+#pragma unroll
+    for (int k = 0; k < B2_TILES; ++k) {
+        sdb[k] = reinterpret_cast<const char*>(a.saved_dec + c[k].trow0 * x.steps_per_chain * SVD);
+        ddb[k] = reinterpret_cast<char*>(a.dsave_dec + c[k].trow0 * x.steps_per_chain * DSD);
+        dhd[k] = splat4(0.f);
+        hcur[k] = splat4(0.f);
+        dhdir[k] = splat4(0.f);
+        if (!FAST && !c[k].live) continue;
+        if (x.j_hi < J && a.dec_carry)
+            dhd[k] = *reinterpret_cast<const f32x4*>(a.dec_carry + ((int64_t)net * c[k].tiles + c[k].tile) * 1024 + 256 * q + 4 * l);
+        load_step(k, x.j_hi - 1, Lw - 1, cur[k]);
+        hcur[k] = ld4<FAST>(sdb[k], sd_lane + (uint32_t)((((int64_t)(x.j_hi - 1)) * Lw + (Lw - 1)) * 1024) + x.cgs * REC_CG(SD_H + 16 * q),
+                            FAST || c[k].valid);
+    }
+    int j = x.j_hi - 1, t = Lw - 1;
+    for (int s = 0; s < x.steps; ++s) {
+        const bool first = (j == 0 && t == 0);
+        const uint32_t dof = sd_lane + (uint32_t)(((int64_t)j * Lw + t) * 1024);
+        int jn = j, tn = t - 1;                                   // the step fetched now (the last one re-reads itself: no branch)
+        if (tn < 0) { tn = Lw - 1; --jn; }
+        if (s + 1 >= x.steps) { jn = j; tn = t; }
+        d2_wait(x.rcnt, 8 * s);                                   // every reader is done with step s - 1's pieces: the slots are free
+        d2_wait(x.dcnt, x.n_live * (s + 1));                      // dy of step s is there (published a step ahead)
+        // ---- lane-local: output / tanh / dropout backward, gate backward of the own units; pieces published tile by tile
+#pragma unroll
+        for (int k = 0; k < B2_TILES; ++k) {
+            if (!FAST && !c[k].live) continue;
+            const bool valid = FAST || c[k].valid;
+            StepIn in = cur[k];
+            in.hp = zero_unless(!first, in.hp);
+            if (!FAST) {
+                in.r = zero_unless(valid, in.r); in.z = zero_unless(valid, in.z); in.n = zero_unless(valid, in.n);
+                in.hn = zero_unless(valid, in.hn); in.hp = zero_unless(valid, in.hp);
+            }
+            const f32x4 dy = *(reinterpret_cast<const f32x4*>(x.s_dy + ((s & 3) * B2_TILES + k) * 256) + l);
+            const f32x4 da = mma_block(woutT, dy, splat4(0.f));
+            const f32x4 km = keep_tile(a, net, j, c[k].row, t, q, valid, c[k].rows);
+            f32x4 dht;
+            for (int i = 0; i < 4; ++i) {
+                const float th = tanh_f(hcur[k][i]);
+                dht[i] = fmaf(da[i] * km[i] * inv_keep, 1.0f - th * th, dhd[k][i]);
+            }
+            const GruGrads o = gru_gates_bwd(dht, in.r, in.z, in.n, in.hn, in.hp);
+            st4<FAST>(ddb[k], dof + x.cgs * REC_CG(DD_DR + 16 * q), valid, o.dr);
+            st4<FAST>(ddb[k], dof + x.cgs * REC_CG(DD_DZ + 16 * q), valid, o.dz);
+            st4<FAST>(ddb[k], dof + x.cgs * REC_CG(DD_DNI + 16 * q), valid, o.dni);
+            st4<FAST>(ddb[k], dof + x.cgs * REC_CG(DD_DNH + 16 * q), valid, o.dnh);
+            b2_g_write(x, k, 0, o.dr);
+            b2_g_write(x, k, 1, o.dz);
+            b2_g_write(x, k, 2, o.dni);
+            b2_g_write(x, k, 3, o.dnh);
+            dhdir[k] = o.dh_direct;
+            hcur[k] = in.hp;                                      // h_{t-1}: the next step's "current" hidden state
+            load_step(k, jn, tn, cur[k]);                         // next step's record: in flight across the exchange and the MFMAs
+        }
+        d2_signal(x.gcnt);
+        d2_wait(x.gcnt, 4 * (s + 1));
+        // ---- own output rows of W_hh^T [dr dz dn_h] (pieces read chunk by chunk)
+#pragma unroll
+        for (int k = 0; k < B2_TILES; ++k) {
+            if (!FAST && !c[k].live) continue;
+            f32x4 pd = dhdir[k];
+            for (int ch = 0; ch < 6; ++ch) pd = b2_chunk(W[ch], b2_g_read(x, k, ch < 4 ? ch : ch + 2), pd);
+            dhd[k] = pd;
+        }
+        d2_signal(x.rcnt);                                         // (waits for this wave's LDS reads, not for its MFMAs)
+        if (--t < 0) { t = Lw - 1; --j; }
+    }
+#pragma unroll
+    for (int k = 0; k < B2_TILES; ++k)
+        if ((FAST || c[k].live) && x.j_lo > 0 && a.dec_carry)
+            *reinterpret_cast<f32x4*>(a.dec_carry + ((int64_t)net * c[k].tiles + c[k].tile) * 1024 + 256 * q + 4 * l) = dhd[k];
+}
+
+// ---- A_q: du = W_ih^T [dr dz dn_i] for the own 16 units of u, ReLU backward, the step's share of d loss / d latent.
+// A_k (k < B2_TILES) owns tile k's bookkeeping: it computes the loss gradient dy of every step ONE STEP AHEAD of the recurrence
+// (dy depends on the forward's record alone) and publishes it for the four B-waves through a 2-slot LDS ring, stores it for the
+// weight-gradient contraction, and adds up the four quarters' shares of d loss / d latent_j at every window's end.
+template <bool FAST>
+__device__ __forceinline__ void b2_input(const IplanBehArgs& a, const B2Ctx& x, const DecTile (&c)[B2_TILES]) {
+    const int q = x.q, l = x.l, g = x.g, Lw = x.Lw, J = x.J, din = a.d + a.Z;
+    const float* Wih = x.PD + a.dec_off[IPLAN_DEC_WIH];
+    Bf3 W[6];
+    for (int ch = 0; ch < 6; ++ch) W[ch] = wfrag_t_bf3(Wih, DHd, 16 * q, 32 * ch);
+    // (W_lin[:, d : d + Z])^T rows z x K = the own 16 units: lane (m = z, g) holds W_lin[16q + 4g + r][d + z]
+    f32x4 wlatT;
+    {
+        const float* Wl = x.PD + a.dec_off[IPLAN_DEC_LIN_W];
+        const int z = l & 15;
+        for (int r = 0; r < 4; ++r) wlatT[r] = z < a.Z ? Wl[(int64_t)(16 * q + 4 * g + r) * din + a.d + z] : 0.f;
+    }
+    const uint32_t sd_lane = 64u * (uint32_t)x.n + 16u * (uint32_t)g;
+    const char* sdb[B2_TILES];
+    char* ddb[B2_TILES];
+    f32x4 u[B2_TILES], dlat[B2_TILES];
+#pragma unroll
+    for (int k = 0; k < B2_TILES; ++k) {
+        sdb[k] = reinterpret_cast<const char*>(a.saved_dec + c[k].trow0 * x.steps_per_chain * SVD);
+        ddb[k] = reinterpret_cast<char*>(a.dsave_dec + c[k].trow0 * x.steps_per_chain * DSD);
+        dlat[k] = splat4(0.f);
+        u[k] = splat4(0.f);
+        if (!FAST && !c[k].live) continue;
+        u[k] = ld4_raw<FAST>(sdb[k], sd_lane + (uint32_t)((((int64_t)(x.j_hi - 1)) * Lw + (Lw - 1)) * 1024) + x.cgs * REC_CG(SD_U + 16 * q),
+                             FAST || c[k].valid);
+    }
+    // the tile this wave keeps the books of (selected, not indexed: a run-time index would put c[] into scratch)
+    DecTile co = c[0];
+    if (q == 1) co = c[1];
+    if (q == 2) co = c[B2_TILES - 1];
+    const int ko = q < B2_TILES ? q : 0;
+    const bool owner = q < B2_TILES && (FAST || co.live);
+    const bool ovalid = FAST || co.valid;
+    const char* sdo = reinterpret_cast<const char*>(a.saved_dec + co.trow0 * x.steps_per_chain * SVD);
+    char* ddo = reinterpret_cast<char*>(a.dsave_dec + co.trow0 * x.steps_per_chain * DSD);
+    char* dl_base = reinterpret_cast<char*>(a.dsave_lat + co.grow0 * J * DSL);
+    const uint32_t dl_lane = (uint32_t)((int64_t)co.n * J * DSL * 4) + 16u * (uint32_t)g;
+    const float pen = a.penalty / (float)J / (float)(a.E_norm > 0 ? a.E_norm : a.E) / (float)Lw;
+    struct YIn {
+        f32x4 y, nx, xc;
+        float m;
+    };
+    auto y_fetch = [&](YIn& o, int jj, int tt) {               // what dy of step (jj, tt) needs; masked where it is consumed
+        const uint32_t so = sd_lane + (uint32_t)(((int64_t)jj * Lw + tt) * 1024);
+        o.y = ld4_raw<FAST>(sdo, so + x.cgs * REC_CG(SD_Y), ovalid);
+        o.nx = ld_row_raw<FAST>(co.hist, co.hist_lane + (uint32_t)((int64_t)beh_y_step(a, jj, tt) * a.h_s_t * 4), ovalid, a.d, g);
+        o.m = *reinterpret_cast<const float*>(co.mask + (ovalid ? co.mask_lane : 0u) + 4u * (uint32_t)beh_m_step(a, jj, tt));
+        o.xc = splat4(0.f);
+        if (a.penalty != 0.f) {
+            const int st = beh_x_step(a, jj, tt);
+            o.xc = ld_row_raw<FAST>(co.hist, co.hist_lane + (uint32_t)((int64_t)(st < 0 ? 0 : st) * a.h_s_t * 4), ovalid, a.d, g);
+        }
+    };
+    // dy of step (jj, tt) = index sidx of this launch: into ring slot sidx & 1, and into the row-gradient record
+    auto publish_dy = [&](const YIn& in, int jj, int tt, int sidx) {
+        const float scale = x.s_scale[jj - x.j_lo];
+        f32x4 dy;
+        for (int i = 0; i < 4; ++i) {
+            float v = 0.f;
+            if (ovalid && 4 * g + i < a.d) {
+                const float er = in.nx[i] - in.y[i];
+                v = -((er > 0.f) ? 1.0f : (er < 0.f ? -1.0f : 0.0f)) * in.m * scale;
+            }
+            dy[i] = v;
+        }
+        if (a.penalty != 0.f) {                                // d/dy of max(||x - y||_2 - thres, 0): -(x - y) / ||x - y|| where active
+            const bool has_xc = beh_x_step(a, jj, tt) >= 0;
+            float d2 = 0.f;
+            f32x4 df;
+            for (int i = 0; i < 4; ++i) {
+                df[i] = (ovalid && 4 * g + i < a.d) ? (has_xc ? in.xc[i] : 0.f) - in.y[i] : 0.f;
+                d2 = fmaf(df[i], df[i], d2);
+            }
+            const float nrm = sqrtf(group_sum(d2));
+            if (ovalid && nrm > a.thres)
+                for (int i = 0; i < 4; ++i) dy[i] -= pen * df[i] / nrm;
+        }
+        *(reinterpret_cast<f32x4*>(x.s_dy + ((sidx & 3) * B2_TILES + ko) * 256) + l) = dy;
+        d2_signal(x.dcnt);
+        st4<FAST>(ddo, sd_lane + (uint32_t)(((int64_t)jj * Lw + tt) * 1024) + x.cgs * REC_CG(DD_DY), ovalid, dy);
+    };
+    int j = x.j_hi - 1, t = Lw - 1, w = 0;                          // w: windows finished in this launch
+    // (jy, ty): the step whose dy is published next; the ring runs TWO steps ahead of the recurrence, fed at the END of an
+    // iteration -- the fields' loads then have a whole iteration to land, and the hand-off is never what a B-wave waits for
+    int jy = j, ty = t, sy = 0;
+    auto y_prev = [&]() { if (--ty < 0) { ty = Lw - 1; --jy; } };
+    YIn yin;
+    if (owner) {
+        y_fetch(yin, jy, ty);
+        publish_dy(yin, jy, ty, sy++);
+        if (x.steps > 1) {
+            y_prev();
+            y_fetch(yin, jy, ty);
+            publish_dy(yin, jy, ty, sy++);
+        }
+        if (x.steps > 2) {
+            y_prev();
+            y_fetch(yin, jy, ty);                                  // step 2's fields, published at the end of iteration 0
+        }
+    }
+    for (int s = 0; s < x.steps; ++s) {
+        const uint32_t dof = sd_lane + (uint32_t)(((int64_t)j * Lw + t) * 1024);
+        int jn = j, tn = t - 1;
+        if (tn < 0) { tn = Lw - 1; --jn; }
+        if (s + 1 >= x.steps) { jn = j; tn = t; }
+        d2_wait(x.gcnt, 4 * (s + 1));
+        f32x4 duk[B2_TILES];
+#pragma unroll
+        for (int k = 0; k < B2_TILES; ++k) {
+            duk[k] = splat4(0.f);
+            if (!FAST && !c[k].live) continue;
+            for (int ch = 0; ch < 6; ++ch) duk[k] = b2_chunk(W[ch], b2_g_read(x, k, ch), duk[k]);
+        }
+        d2_signal(x.rcnt);
+#pragma unroll
+        for (int k = 0; k < B2_TILES; ++k) {
+            if (!FAST && !c[k].live) continue;
+            const bool valid = FAST || c[k].valid;
+            const f32x4 du = duk[k];
+            const f32x4 uu = FAST ? u[k] : zero_unless(valid, u[k]);
+            f32x4 dup;
+            for (int i = 0; i < 4; ++i) dup[i] = uu[i] > 0.f ? du[i] : 0.f;
+            st4<FAST>(ddb[k], dof + x.cgs * REC_CG(DD_DU + 16 * q), valid, dup);
+            dlat[k] = mma_block(wlatT, dup, dlat[k]);
+            u[k] = ld4_raw<FAST>(sdb[k], sd_lane + (uint32_t)(((int64_t)jn * Lw + tn) * 1024) + x.cgs * REC_CG(SD_U + 16 * q), valid);
+        }
+        if (owner && s + 2 < x.steps) {
+            // dy of step s + 2 into the slot of step s - 2 (every B-wave passed that step long ago); then the fields of step s + 3
+            publish_dy(yin, jy, ty, sy++);
+            if (s + 3 < x.steps) {
+                y_prev();
+                y_fetch(yin, jy, ty);
+            }
+        }
+        if (t == 0) {
+            // ---- window j done: d loss / d latent_j = the four quarters' shares (double buffered by window parity; a slot
+            // is free once the owners have read window w - 2)
+            if (w >= 2) d2_wait(x.ocnt, x.n_live * (w - 1));
+            float* lx = x.s_lx + (w & 1) * (B2_TILES * 4 * 256);
+#pragma unroll
+            for (int k = 0; k < B2_TILES; ++k) {
+                if (!FAST && !c[k].live) continue;
+                *reinterpret_cast<f32x4*>(lx + (k * 4 + q) * 256 + 4 * l) = dlat[k];
+                dlat[k] = splat4(0.f);
+            }
+            d2_signal(x.lcnt);
+            if (owner) {
+                d2_wait(x.lcnt, 4 * (w + 1));
+                const float* p = lx + ko * 4 * 256 + 4 * l;
+                const f32x4 sum = (*reinterpret_cast<const f32x4*>(p) + *reinterpret_cast<const f32x4*>(p + 256)) +
+                                  (*reinterpret_cast<const f32x4*>(p + 512) + *reinterpret_cast<const f32x4*>(p + 768));
+                d2_signal(x.ocnt);
+                st4<FAST>(dl_base, dl_lane + (uint32_t)j * (uint32_t)(DSL * 4), ovalid, sum);
+            }
+            ++w;
+        }
+        if (--t < 0) { t = Lw - 1; --j; }
+    }
+}
+
+__global__ __launch_bounds__(B2_THREADS, 2) void beh_dec_bwd2_kernel(IplanBehArgs a) {
+    IPLAN_DYN_LDS(smem);
+    B2Ctx x;
+    x.s_gx = smem;
+    x.s_lx = x.s_gx + B2_GX;
+    x.s_dy = x.s_lx + B2_LX;
+    int* s_cnt = reinterpret_cast<int*>(x.s_dy + B2_DY);
+    x.s_scale = reinterpret_cast<float*>(s_cnt + B2_CNT_INTS);
+    if (threadIdx.x < B2_CNT_INTS) s_cnt[threadIdx.x] = 0;
+    const int w = uniform_i(wave_id()), role = w >> 2;                                // role 0: recurrent wave B_q, 1: input-side wave A_q
+    x.q = w & 3;
+    x.l = lane_id(); x.n = x.l & 15; x.g = x.l >> 4; x.net = (int)blockIdx.y;
+    x.PD = a.dec_params + (int64_t)x.net * a.dec_s_net;
+    x.Lw = a.L;
+    DecTile c[B2_TILES];
+#pragma unroll
+    for (int k = 0; k < B2_TILES; ++k) dec_tile(a, c[k], (int)blockIdx.x * B2_TILES + k);
+    x.J = c[0].J;
+    x.j_lo = imax(a.bwd_j_lo, 0);
+    x.j_hi = a.bwd_j_hi > 0 ? imin(a.bwd_j_hi, x.J) : x.J;
+    x.steps = (x.j_hi - x.j_lo) * x.Lw;
+    x.steps_per_chain = (int64_t)x.J * x.Lw;
+    x.cgs = (uint32_t)(x.steps_per_chain * 1024);
+    x.gcnt = s_cnt + 0; x.rcnt = s_cnt + 1; x.lcnt = s_cnt + 2; x.ocnt = s_cnt + 3; x.dcnt = s_cnt + 4;
+    x.n_live = 0;
+    bool fast = true;
+#pragma unroll
+    for (int k = 0; k < B2_TILES; ++k) { x.n_live += c[k].live ? 1 : 0; fast = fast && c[k].full; }
+    // the loss scale of every window of this launch: d N / (sum of the window's mask + eps) / J  (wave w: windows w, w + 8, ...)
+    for (int jj = x.j_lo + w; jj < x.j_hi; jj += B2_THREADS / 64) {
+        const float sc = (float)(a.d * a.N) / (window_mask_sum(a, x.net, jj) + BEPS) / (a.hard ? 1.0f : (float)x.J);
+        if (x.l == 0) x.s_scale[jj - x.j_lo] = sc;
+    }
+    __syncthreads();
+    const bool fastu = uniform_i(fast ? 1 : 0) != 0;
+    if (role == 0) {
+        if (fastu) b2_recurrent<true>(a, x, c); else b2_recurrent<false>(a, x, c);
+    } else {
+        if (fastu) b2_input<true>(a, x, c); else b2_input<false>(a, x, c);
+    }
+}
+
 static int check_beh(const IplanBehArgs* a, const char* what) {
     if (!a) return fail(IPLAN_EINVAL, "%s: null args", what);
     if (a->n_nets < 1 || a->E < 1 || a->N < 1 || a->L < 1 || (a->hard ? a->T / a->L - 1 : a->T - 1 - a->L) < 1 || a->d < 1 || a->Z < 1 ||
@@ -1669,7 +2043,20 @@ extern "C" int iplan_beh_bwd(const IplanBehArgs* a, iplan_stream_t stream) {
 #ifndef IPLAN_HOST_EMULATION
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_dec_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
-    if (a->bwd_phase != 2) hipLaunchKernelGGL(beh_dec_bwd_kernel, dgrid, dim3(DEC_THREADS), lds, (hipStream_t)stream, *a);
+    // The second form (split-bf16 backward-data products, register-resident weight pieces, role-split waves) is the DEFAULT
+    // where it applies (at most D2_MAX_WINDOWS windows per launch); IPLAN_DEC_BWD_V1=1 selects the first form.
+    const int jn_hi = a->bwd_j_hi > 0 ? a->bwd_j_hi : (a->hard ? a->T / a->L - 1 : a->T - 1 - a->L);
+    const bool v2 = jn_hi - (a->bwd_j_lo > 0 ? a->bwd_j_lo : 0) <= D2_MAX_WINDOWS && getenv("IPLAN_DEC_BWD_V1") == nullptr;
+    if (a->bwd_phase != 2 && v2) {
+        const dim3 grid2((unsigned)((tiles + B2_TILES - 1) / B2_TILES), (unsigned)a->n_nets);
+        const size_t lds2 = sizeof(float) * B2_LDS_FLOATS;
+#ifndef IPLAN_HOST_EMULATION
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_dec_bwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+#endif
+        hipLaunchKernelGGL(beh_dec_bwd2_kernel, grid2, dim3(B2_THREADS), lds2, (hipStream_t)stream, *a);
+    } else if (a->bwd_phase != 2) {
+        hipLaunchKernelGGL(beh_dec_bwd_kernel, dgrid, dim3(DEC_THREADS), lds, (hipStream_t)stream, *a);
+    }
     if (a->bwd_phase != 1) {
         if (getenv("IPLAN_ENC_FP32") == nullptr) hipLaunchKernelGGL(beh_enc_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *a);
         else hipLaunchKernelGGL(beh_enc_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *a);

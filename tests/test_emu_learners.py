@@ -437,3 +437,25 @@ def test_behavior_learn_encoder_both_forms_emulated(monkeypatch):
     monkeypatch.setenv("IPLAN_BEH_PIECES", "3")
     w3 = check_behavior_learn_vs_oracle(_small(**kw), 3, "cpu", seed=5)
     assert w3["grad"] < 1e-5, w3
+
+
+def test_behavior_learn_decoder_bptt_both_forms_emulated(monkeypatch):
+    """the decoder BPTT's two forms -- the default second form (round 4: split-bf16 backward-data products, register-resident
+    weight pieces, eight role-split waves per tile set, LDS-counter hand-offs) and the first form (IPLAN_DEC_BWD_V1=1: fp32 MFMA,
+    weights in LDS, four quarter-waves per tile) -- both within 1e-5 of the fp64 oracle: a ragged size (partial and missing tiles
+    in a workgroup), BPTT window pieces (carry of d loss / d h), the stability penalty, more than three tiles per net"""
+    from tests.oracle_checks import check_behavior_learn_vs_oracle
+    kw = dict(max_vehicle_num=7, episode_limit=14, max_history_len=4)
+    for extra, E, seed in ((dict(), 3, 3), (dict(behavior_variation_penalty=0.3, thres_small_variation=0.05), 3, 17),
+                           (dict(max_vehicle_num=13), 9, 7)):                     # 117 chains = 8 tiles (3 workgroups, last: 2 tiles, ragged)
+        args = dict(kw, **extra)
+        w2 = check_behavior_learn_vs_oracle(_small(**args), E, "cpu", seed=seed)
+        monkeypatch.setenv("IPLAN_DEC_BWD_V1", "1")
+        w1 = check_behavior_learn_vs_oracle(_small(**args), E, "cpu", seed=seed)
+        monkeypatch.delenv("IPLAN_DEC_BWD_V1")
+        for w in (w1, w2):
+            assert w["grad"] < 1e-5 and w["loss"] < 1e-5, (w1, w2)
+        assert abs(w2["grad"] - w1["grad"]) < 1e-6, (w1, w2)
+    monkeypatch.setenv("IPLAN_BEH_PIECES", "3")
+    w3 = check_behavior_learn_vs_oracle(_small(**kw), 3, "cpu", seed=3)
+    assert w3["grad"] < 1e-5, w3
