@@ -624,6 +624,7 @@ int iplan_pdec_bwd(const IplanPdecArgs* args, iplan_stream_t stream);
 #define IPLAN_BEH_SAVE_LAT 32        /* per (row, window): softmax output 0 (16) | latent used by the decoder 16 (16) */
 #define IPLAN_BEH_DSAVE_DEC 336
 #define IPLAN_BEH_DSAVE_LAT 16
+#define IPLAN_BEH_DEC_THIN_PART 2144 /* per workgroup of the BPTT's second form: out.weight [16][64] | out.bias [16] | linear.weight [64][16] | linear.bias [64] */
 #define IPLAN_BEH_ENC_PART 7408       /* per-wave encoder weight-gradient partial: W_ih 0 | W_hh 3072 | b_ih 6144 | b_hh 6240
                                          | lin.W [32][16] 6336 | lin.b 6848 | out.W [16][32] 6880 | out.b 7392          */
 
@@ -689,6 +690,16 @@ typedef struct {
                                    mean_j sum_{chain, t} max(||x_t - y_t||_2 - thres, 0) / (E_norm L) in the differentiated loss
                                    (nova/stable_behavior_policy.py:238-246); 0 = the shipped configuration       */
     int32_t E_norm;             /* envs the stability term is averaged over (all chunks / ranks); 0 = E           */
+    /* Round 4 (decoder BPTT, second form): the THIN decoder weight gradients -- out.weight / out.bias (d x 64) and
+     * linear.weight / linear.bias (64 x (d + Z)) -- accumulated IN the BPTT kernel (its waves hold dy, the output-layer input
+     * and the Linear's gradient in registers) instead of from row gradients by iplan_wgrad: dec_thin_part != NULL switches it
+     * on, the kernel then does NOT store the dy / du columns of dsave_dec, window-range pieces accumulate in the partials, and
+     * the piece with bwd_j_lo == 0 reduces them (workgroup order: reproducible) into dec_grad at dec_off[] as
+     * dec_grad_beta * old + sum.  Only the second form supports it (iplan_beh_bwd fails if it cannot run that form).   */
+    float* dec_thin_part;       /* [n_nets, ceil(ceil(rows/16) / 3), IPLAN_BEH_DEC_THIN_PART] or NULL              */
+    float* dec_grad;            /* decoder gradient arena                                                          */
+    int64_t dec_grad_s_net;
+    float dec_grad_beta;
 } IplanBehArgs;
 
 int iplan_beh_fwd(const IplanBehArgs* args, iplan_stream_t stream);

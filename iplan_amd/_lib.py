@@ -338,6 +338,7 @@ class PdecArgs(C.Structure):
 BEH_SAVE_DEC, BEH_SAVE_ENC, BEH_SAVE_LAT = 496, 192, 32
 BEH_ENC_PART = 7408
 BEH_DSAVE_DEC, BEH_DSAVE_LAT = 336, 16
+BEH_DEC_THIN_PART, BEH_DEC_BWD2_TILES = 2144, 3
 
 
 class BehArgs(C.Structure):
@@ -355,6 +356,7 @@ class BehArgs(C.Structure):
         ("bwd_j_lo", i32), ("bwd_j_hi", i32), ("dec_carry", fp),
         ("fwd_phase", i32), ("fwd_j_lo", i32), ("fwd_j_hi", i32), ("enc_carry", fp), ("win_norm", fp),
         ("enc_grad_beta", C.c_float), ("penalty", C.c_float), ("E_norm", i32),
+        ("dec_thin_part", fp), ("dec_grad", fp), ("dec_grad_s_net", i64), ("dec_grad_beta", C.c_float),
     ]
 
 

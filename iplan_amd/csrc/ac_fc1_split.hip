@@ -12,6 +12,8 @@
 //   * the actor and the critic of an agent see the same rows: one pass over xhat feeds both (M = 128 outputs);
 //   * the operand every wave of a workgroup shares (forward: the weight pieces; gradient: the dz1 pieces) goes through
 //     LDS, double-buffered, one barrier per K step of 32.
+#include <cstdlib>
+
 #include "api_util.h"
 #include "ac_kmap.h"
 
@@ -155,7 +157,9 @@ constexpr int SF_RT = AC_SPLIT_RT;                // row tiles (forward) / k-til
 #ifndef AC_SPLIT_NW
 #define AC_SPLIT_NW 8                     // waves per workgroup of the two contraction kernels
 #endif
-template <int NW>
+// RT = row tiles per wave: RT for the full buffer; 1 for small batches (a data-parallel rank's 2 880 rows: 4 row tiles per wave
+// leave 30 workgroups on the chip, each one long K chain -- with one tile per wave there are four times as many)
+template <int NW, int RT>
 __global__ __launch_bounds__(64 * NW) void ac_fc1_split_fwd_kernel(IplanAcFc1SplitArgs a) {
     constexpr int NTH = 64 * NW, WST = S_FRAG / NTH;
     __shared__ __attribute__((aligned(16))) bf16x8 s_w[2][S_FRAG];
@@ -173,21 +177,21 @@ __global__ __launch_bounds__(64 * NW) void ac_fc1_split_fwd_kernel(IplanAcFc1Spl
     const int l = lane_id(), w = uniform_i(wave_id()), n = l & 15, g = l >> 4;
     const int KT = split_kt(a.feat), KS = (KT + 1) / 2;
     const int tiles = (a.rows + 15) / 16, tiles_alloc = 2 * ((a.rows + 31) / 32);
-    int tile[SF_RT];
-    const float* __restrict__ xp[SF_RT];
-    for (int t = 0; t < SF_RT; ++t) {
-        tile[t] = (bx * NW + w) * SF_RT + t;
+    int tile[RT];
+    const float* __restrict__ xp[RT];
+    for (int t = 0; t < RT; ++t) {
+        tile[t] = (bx * NW + w) * RT + t;
         xp[t] = a.xf + (((int64_t)net * tiles_alloc + imin(tile[t], tiles_alloc - 1)) * KS) * 512 + l * 8;
     }
     const bf16x8* __restrict__ wsrc = reinterpret_cast<const bf16x8*>(a.wsplit) + (int64_t)net * KS * S_FRAG;
     const int tx = (int)threadIdx.x;
-    f32x4 acc[SF_RT][S_OT];
-    for (int t = 0; t < SF_RT; ++t)
+    f32x4 acc[RT][S_OT];
+    for (int t = 0; t < RT; ++t)
         for (int o = 0; o < S_OT; ++o) acc[t][o] = splat4(0.f);
     bf16x8 wst[WST];
-    f32x4 xr[SF_RT][2];
+    f32x4 xr[RT][2];
     for (int i = 0; i < WST; ++i) wst[i] = wsrc[tx + NTH * i];
-    for (int t = 0; t < SF_RT; ++t) {
+    for (int t = 0; t < RT; ++t) {
         xr[t][0] = *reinterpret_cast<const f32x4*>(xp[t]);
         xr[t][1] = *reinterpret_cast<const f32x4*>(xp[t] + 4);
     }
@@ -196,22 +200,22 @@ __global__ __launch_bounds__(64 * NW) void ac_fc1_split_fwd_kernel(IplanAcFc1Spl
     for (int ks = 0; ks < KS; ++ks) {
         const int cur = ks & 1;
         const bool more = ks + 1 < KS;
-        Bf3 xs[SF_RT];
+        Bf3 xs[RT];
 #if AC_SPLIT_ABL == 1
-        for (int t = 0; t < SF_RT; ++t) {
+        for (int t = 0; t < RT; ++t) {
             xs[t].p0 = __builtin_bit_cast(bf16x8, xr[t][0]);
             xs[t].p1 = __builtin_bit_cast(bf16x8, xr[t][1]);
             xs[t].p2 = __builtin_bit_cast(bf16x8, xr[t][0] + xr[t][1]);
         }
 #else
-        for (int t = 0; t < SF_RT; ++t) xs[t] = split_bf3(xr[t][0], xr[t][1]);
+        for (int t = 0; t < RT; ++t) xs[t] = split_bf3(xr[t][0], xr[t][1]);
 #endif
         if (more) {                                              // next step's operands: in flight under this step's MFMAs
 #if AC_SPLIT_ABL != 3
             for (int i = 0; i < WST; ++i) wst[i] = wsrc[(int64_t)(ks + 1) * S_FRAG + tx + NTH * i];
 #endif
 #if AC_SPLIT_ABL != 2
-            for (int t = 0; t < SF_RT; ++t) {
+            for (int t = 0; t < RT; ++t) {
                 xr[t][0] = *reinterpret_cast<const f32x4*>(xp[t] + (int64_t)(ks + 1) * 512);
                 xr[t][1] = *reinterpret_cast<const f32x4*>(xp[t] + (int64_t)(ks + 1) * 512 + 4);
             }
@@ -221,10 +225,10 @@ __global__ __launch_bounds__(64 * NW) void ac_fc1_split_fwd_kernel(IplanAcFc1Spl
         for (int o = 0; o < S_OT; o += 2) {
             const bf16x8* sw = &s_w[AC_SPLIT_ABL == 3 ? 0 : cur][o * 192 + l];
             const bf16x8 wp[2][3] = {{sw[0], sw[64], sw[128]}, {sw[192], sw[256], sw[320]}};
-            f32x4* ap[2][SF_RT];
+            f32x4* ap[2][RT];
 #pragma unroll
-            for (int t = 0; t < SF_RT; ++t) { ap[0][t] = &acc[t][o]; ap[1][t] = &acc[t][o + 1]; }
-            mma6_rr<2, SF_RT>(wp, xs, ap);
+            for (int t = 0; t < RT; ++t) { ap[0][t] = &acc[t][o]; ap[1][t] = &acc[t][o + 1]; }
+            mma6_rr<2, RT>(wp, xs, ap);
         }
 #if AC_SPLIT_ABL != 3
         if (more)
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(64 * NW) void ac_fc1_split_fwd_kernel(IplanAcFc1Spl
     for (int o = 0; o < S_OT; ++o) {
         const int which = o >> 2, oc = 16 * (o & 3) + 4 * g;
         const f32x4 c = *reinterpret_cast<const f32x4*>(a.wbeta + ((int64_t)which * a.n_agents + net) * SM + oc);
-        for (int t = 0; t < SF_RT; ++t) {
+        for (int t = 0; t < RT; ++t) {
             const int r = tile[t] * 16 + n;
             if (tile[t] < tiles && r < a.rows)
                 *reinterpret_cast<f32x4*>(a.z1 + (((int64_t)which * a.n_agents + net) * a.rows + r) * SM + oc) = acc[t][o] + c;
@@ -365,7 +369,15 @@ extern "C" int iplan_ac_fc1_split_fwd(const IplanAcFc1SplitArgs* a, iplan_stream
     hipLaunchKernelGGL(ac_fc1_wsplit_kernel, dim3((unsigned)KS, (unsigned)a->n_agents, 2), dim3(256), 0, (hipStream_t)stream, *a);
     hipLaunchKernelGGL(ac_fc1_wbeta_kernel, dim3((unsigned)a->n_agents, 2, SM / 8), dim3(256), 0, (hipStream_t)stream, *a);
     constexpr int TPW = AC_SPLIT_NW * SF_RT;                       // row tiles per workgroup
-    hipLaunchKernelGGL(ac_fc1_split_fwd_kernel<AC_SPLIT_NW>, dim3((unsigned)((tiles + TPW - 1) / TPW), (unsigned)a->n_agents), dim3(64 * AC_SPLIT_NW), 0,
+    // small batches: one row tile per wave (IPLAN_AC_SPLIT_SHAPE=full / small forces a shape: tests run both at one size)
+    const char* shape = getenv("IPLAN_AC_SPLIT_SHAPE");
+    const bool small = shape ? shape[0] == 's' : tiles * a->n_agents <= 2 * 256 * AC_SPLIT_NW;
+    if (small) {
+        hipLaunchKernelGGL((ac_fc1_split_fwd_kernel<AC_SPLIT_NW, 1>), dim3((unsigned)((tiles + AC_SPLIT_NW - 1) / AC_SPLIT_NW), (unsigned)a->n_agents),
+                           dim3(64 * AC_SPLIT_NW), 0, (hipStream_t)stream, *a);
+        return check_launch("iplan_ac_fc1_split_fwd");
+    }
+    hipLaunchKernelGGL((ac_fc1_split_fwd_kernel<AC_SPLIT_NW, SF_RT>), dim3((unsigned)((tiles + TPW - 1) / TPW), (unsigned)a->n_agents), dim3(64 * AC_SPLIT_NW), 0,
                        (hipStream_t)stream, *a);
     return check_launch("iplan_ac_fc1_split_fwd");
 }

@@ -1608,11 +1608,15 @@ constexpr int B2_TILES = 3, B2_THREADS = 512;
 constexpr int B2_GX = B2_TILES * 8 * 3 * 256;               // floats: [tile][chunk = gate * 2 + half][piece][64 lanes x bf16x8]
 constexpr int B2_LX = 2 * B2_TILES * 4 * 256;               //         [window parity][tile][q][64 lanes x f32x4]  d loss / d latent shares
 constexpr int B2_DY = 4 * B2_TILES * 256;                   //         [step & 3][tile][64 lanes x f32x4]  loss gradient of a step (published 2 ahead)
+constexpr int B2_TURN = 8 * 2 * 256;                        //         [wave][2][16 x 16]  operand tiles turned into MFMA A / B order (thin weight gradients)
 constexpr int B2_CNT_INTS = 16;                             // gcnt | rcnt | lcnt | ocnt | dcnt | pad
-constexpr int B2_LDS_FLOATS = B2_GX + B2_LX + B2_DY + B2_CNT_INTS + D2_MAX_WINDOWS;
+constexpr int B2_LDS_FLOATS = B2_GX + B2_LX + B2_DY + B2_TURN + B2_CNT_INTS + D2_MAX_WINDOWS;
+// thin weight-gradient partials of a workgroup (IplanBehArgs.dec_thin_part)
+constexpr int TP_WOUT = 0, TP_BOUT = 1024, TP_WLIN = 1040, TP_BLIN = 2064;
+static_assert(IPLAN_BEH_DEC_THIN_PART >= TP_BLIN + 64 && IPLAN_BEH_DEC_THIN_PART % 16 == 0, "dec_thin_part layout");
 
 struct B2Ctx {
-    float *s_gx, *s_lx, *s_dy, *s_scale;
+    float *s_gx, *s_lx, *s_dy, *s_turn, *s_scale;                // s_turn: this wave's two 16 x 16 turn tiles
     int *gcnt, *rcnt, *lcnt, *ocnt, *dcnt;
     int q, l, n, g, net, J, Lw, j_lo, j_hi, steps, n_live;
     int64_t steps_per_chain;
@@ -1643,6 +1647,32 @@ __device__ __forceinline__ f32x4 b2_chunk(const Bf3& W, const Bf3& G, f32x4 acc)
     return acc;
 }
 
+// Thin weight gradients in the kernel (IplanBehArgs.dec_thin_part): dW[o][k] += sum over the tile's 16 chains of P[chain][o] Q[chain][k]
+// for two per-chain tiles P, Q held in the D layout (lane (n = chain, g): columns 4g .. 4g+3) -- both are turned through a
+// wave-private LDS tile into MFMA operand order (A[o][chain], B[chain][k]: the contraction runs over the chains), 4 fp32 MFMAs.
+// Parked tiles use the encoder BPTT's rotation (conflict-free ds_write_b128 / ds_read_b32, see beh_enc_bwd_kernel).
+__device__ __forceinline__ f32x4 b2_outer_acc(const B2Ctx& x, f32x4 P, f32x4 Q, f32x4 acc) {
+    const int n = x.n, g = x.g;
+    float* t0 = x.s_turn;
+    float* t1 = x.s_turn + 256;
+    *reinterpret_cast<f32x4*>(&t0[n * 16 + ((4 * g + 4 * (n >> 1)) & 15)]) = P;
+    *reinterpret_cast<f32x4*>(&t1[n * 16 + ((4 * g + 4 * (n >> 1)) & 15)]) = Q;
+    IPLAN_WAVE_SYNC();
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int r = 4 * s4 + g, o = r * 16 + ((n + 4 * (r >> 1)) & 15);
+        acc = mfma4(t0[o], t1[o], acc);
+    }
+    IPLAN_WAVE_SYNC();
+    return acc;
+}
+// partial tile (D layout: rows 4g + r, column n) and bias sums into the workgroup's slot; `add`: a later window-range piece
+__device__ __forceinline__ void b2_store_thin(float* part, bool add, f32x4 acc, int row0, int ld, int col0, int n, int g) {
+    for (int r = 0; r < 4; ++r) {
+        float* p = part + (row0 + 4 * g + r) * ld + col0 + n;
+        *p = add ? *p + acc[r] : acc[r];
+    }
+}
+
 // ---- B_q: gate backward of the own 16 hidden units + the recurrence.  FAST = all three tiles exist and are full.
 // Register budget (two waves per SIMD: 256): 72 weight-piece registers + the prefetched record of the NEXT step for three tiles
 // (r, z, n, hn, h_prev: 60) + the carried d loss / d h and tanh' inputs (24).  The loss gradient dy of a step needs three more
@@ -1669,6 +1699,8 @@ __device__ __forceinline__ void b2_recurrent(const IplanBehArgs& a, const B2Ctx&
     char* ddb[B2_TILES];
     f32x4 dhd[B2_TILES], hcur[B2_TILES], dhdir[B2_TILES];
     StepIn cur[B2_TILES];
+    const bool thin = a.dec_thin_part != nullptr;               // (uniform) out.weight / out.bias gradients accumulated here
+    f32x4 gWout = splat4(0.f), gbout = splat4(0.f);              // (one accumulator for the three tiles: this wave is at its register budget)
     auto load_step = [&](int k, int j, int t, StepIn& o) {       // straight-line fetch, masked where it is consumed
         const bool valid = FAST || c[k].valid;
         const uint32_t so = sd_lane + (uint32_t)(((int64_t)j * Lw + t) * 1024);
@@ -1716,10 +1748,15 @@ __device__ __forceinline__ void b2_recurrent(const IplanBehArgs& a, const B2Ctx&
             const f32x4 dy = *(reinterpret_cast<const f32x4*>(x.s_dy + ((s & 3) * B2_TILES + k) * 256) + l);
             const f32x4 da = mma_block(woutT, dy, splat4(0.f));
             const f32x4 km = keep_tile(a, net, j, c[k].row, t, q, valid, c[k].rows);
-            f32x4 dht;
+            f32x4 dht, act;
             for (int i = 0; i < 4; ++i) {
                 const float th = tanh_f(hcur[k][i]);
+                act[i] = th * (km[i] * inv_keep);                  // the output layer's input, as the forward formed it
                 dht[i] = fmaf(da[i] * km[i] * inv_keep, 1.0f - th * th, dhd[k][i]);
+            }
+            if (thin) {                                            // d out.weight[:, own units] += dy^T act  (dy is zero for absent chains)
+                gWout = b2_outer_acc(x, dy, act, gWout);
+                if (q == 0) gbout += dy;
             }
             const GruGrads o = gru_gates_bwd(dht, in.r, in.z, in.n, in.hn, in.hp);
             st4<FAST>(ddb[k], dof + x.cgs * REC_CG(DD_DR + 16 * q), valid, o.dr);
@@ -1751,6 +1788,16 @@ __device__ __forceinline__ void b2_recurrent(const IplanBehArgs& a, const B2Ctx&
     for (int k = 0; k < B2_TILES; ++k)
         if ((FAST || c[k].live) && x.j_lo > 0 && a.dec_carry)
             *reinterpret_cast<f32x4*>(a.dec_carry + ((int64_t)net * c[k].tiles + c[k].tile) * 1024 + 256 * q + 4 * l) = dhd[k];
+    if (thin) {
+        float* part = a.dec_thin_part + ((int64_t)net * gridDim.x + blockIdx.x) * IPLAN_BEH_DEC_THIN_PART;
+        const bool add = x.j_hi < J;
+        b2_store_thin(part + TP_WOUT, add, gWout, 0, DHd, 16 * q, x.n, g);          // [output 4g + r][unit 16q + n]
+        if (q == 0)
+            for (int r = 0; r < 4; ++r) {
+                const float sum = chain_sum_b(gbout[r]);
+                if (x.n == 0) part[TP_BOUT + 4 * g + r] = add ? part[TP_BOUT + 4 * g + r] + sum : sum;
+            }
+    }
 }
 
 // ---- A_q: du = W_ih^T [dr dz dn_i] for the own 16 units of u, ReLU backward, the step's share of d loss / d latent.
@@ -1773,16 +1820,20 @@ __device__ __forceinline__ void b2_input(const IplanBehArgs& a, const B2Ctx& x, 
     const uint32_t sd_lane = 64u * (uint32_t)x.n + 16u * (uint32_t)g;
     const char* sdb[B2_TILES];
     char* ddb[B2_TILES];
-    f32x4 u[B2_TILES], dlat[B2_TILES];
+    f32x4 u[B2_TILES], xin[B2_TILES], dlat[B2_TILES];
+    const bool thin = a.dec_thin_part != nullptr;               // (uniform) linear.weight / linear.bias gradients accumulated here
+    f32x4 gWlin[B2_TILES], gblin = splat4(0.f);
+    for (int k = 0; k < B2_TILES; ++k) gWlin[k] = splat4(0.f);
 #pragma unroll
     for (int k = 0; k < B2_TILES; ++k) {
         sdb[k] = reinterpret_cast<const char*>(a.saved_dec + c[k].trow0 * x.steps_per_chain * SVD);
         ddb[k] = reinterpret_cast<char*>(a.dsave_dec + c[k].trow0 * x.steps_per_chain * DSD);
         dlat[k] = splat4(0.f);
-        u[k] = splat4(0.f);
+        u[k] = xin[k] = splat4(0.f);
         if (!FAST && !c[k].live) continue;
-        u[k] = ld4_raw<FAST>(sdb[k], sd_lane + (uint32_t)((((int64_t)(x.j_hi - 1)) * Lw + (Lw - 1)) * 1024) + x.cgs * REC_CG(SD_U + 16 * q),
-                             FAST || c[k].valid);
+        const uint32_t so = sd_lane + (uint32_t)((((int64_t)(x.j_hi - 1)) * Lw + (Lw - 1)) * 1024);
+        u[k] = ld4_raw<FAST>(sdb[k], so + x.cgs * REC_CG(SD_U + 16 * q), FAST || c[k].valid);
+        xin[k] = ld4_raw<FAST>(sdb[k], so + x.cgs * REC_CG(SD_X), FAST || c[k].valid);     // the Linear's input row [x_t || latent_j]
     }
     // the tile this wave keeps the books of (selected, not indexed: a run-time index would put c[] into scratch)
     DecTile co = c[0];
@@ -1837,7 +1888,7 @@ __device__ __forceinline__ void b2_input(const IplanBehArgs& a, const B2Ctx& x, 
         }
         *(reinterpret_cast<f32x4*>(x.s_dy + ((sidx & 3) * B2_TILES + ko) * 256) + l) = dy;
         d2_signal(x.dcnt);
-        st4<FAST>(ddo, sd_lane + (uint32_t)(((int64_t)jj * Lw + tt) * 1024) + x.cgs * REC_CG(DD_DY), ovalid, dy);
+        if (!thin) st4<FAST>(ddo, sd_lane + (uint32_t)(((int64_t)jj * Lw + tt) * 1024) + x.cgs * REC_CG(DD_DY), ovalid, dy);
     };
     int j = x.j_hi - 1, t = Lw - 1, w = 0;                          // w: windows finished in this launch
     // (jy, ty): the step whose dy is published next; the ring runs TWO steps ahead of the recurrence, fed at the END of an
@@ -1880,9 +1931,16 @@ __device__ __forceinline__ void b2_input(const IplanBehArgs& a, const B2Ctx& x, 
             const f32x4 uu = FAST ? u[k] : zero_unless(valid, u[k]);
             f32x4 dup;
             for (int i = 0; i < 4; ++i) dup[i] = uu[i] > 0.f ? du[i] : 0.f;
-            st4<FAST>(ddb[k], dof + x.cgs * REC_CG(DD_DU + 16 * q), valid, dup);
+            if (thin) {                                            // d linear.weight[own units, :] += dup^T [x || latent]  (dup is zero for absent chains)
+                gWlin[k] = b2_outer_acc(x, dup, xin[k], gWlin[k]);
+                gblin += dup;
+            } else {
+                st4<FAST>(ddb[k], dof + x.cgs * REC_CG(DD_DU + 16 * q), valid, dup);
+            }
             dlat[k] = mma_block(wlatT, dup, dlat[k]);
-            u[k] = ld4_raw<FAST>(sdb[k], sd_lane + (uint32_t)(((int64_t)jn * Lw + tn) * 1024) + x.cgs * REC_CG(SD_U + 16 * q), valid);
+            const uint32_t sn = sd_lane + (uint32_t)(((int64_t)jn * Lw + tn) * 1024);
+            u[k] = ld4_raw<FAST>(sdb[k], sn + x.cgs * REC_CG(SD_U + 16 * q), valid);
+            xin[k] = ld4_raw<FAST>(sdb[k], sn + x.cgs * REC_CG(SD_X), valid);
         }
         if (owner && s + 2 < x.steps) {
             // dy of step s + 2 into the slot of step s - 2 (every B-wave passed that step long ago); then the fields of step s + 3
@@ -1916,6 +1974,41 @@ __device__ __forceinline__ void b2_input(const IplanBehArgs& a, const B2Ctx& x, 
         }
         if (--t < 0) { t = Lw - 1; --j; }
     }
+    if (thin) {
+        float* part = a.dec_thin_part + ((int64_t)x.net * gridDim.x + blockIdx.x) * IPLAN_BEH_DEC_THIN_PART;
+        const bool add = x.j_hi < J;
+        b2_store_thin(part + TP_WLIN, add, (gWlin[0] + gWlin[1]) + gWlin[B2_TILES - 1], 16 * q, 16, 0, x.n, g);    // [unit 16q + 4g + r][input n]
+        for (int r = 0; r < 4; ++r) {
+            const float sum = chain_sum_b(gblin[r]);
+            if (x.n == 0) part[TP_BLIN + 16 * q + 4 * g + r] = add ? part[TP_BLIN + 16 * q + 4 * g + r] + sum : sum;
+        }
+    }
+}
+
+// decoder gradient arena <- sum over the workgroups' thin partials, in workgroup order.  grid: (ceil(P / 256), n_nets)
+__global__ __launch_bounds__(256) void beh_dec_thin_grad_kernel(IplanBehArgs a, int n_wg) {
+    const int net = (int)blockIdx.y, din = a.d + a.Z;
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int sizes[4] = {a.d * DHd, a.d, DHd * din, DHd};
+    const int which_of[4] = {IPLAN_DEC_OUT_W, IPLAN_DEC_OUT_B, IPLAN_DEC_LIN_W, IPLAN_DEC_LIN_B};
+    int rem = idx, k = -1;
+    for (int i = 0; i < 4; ++i) {
+        if (rem < sizes[i]) { k = i; break; }
+        rem -= sizes[i];
+    }
+    if (k < 0) return;
+    int src;
+    switch (k) {
+        case 0: src = TP_WOUT + rem; break;                                  // [o][64] rows o < d
+        case 1: src = TP_BOUT + rem; break;
+        case 2: src = TP_WLIN + (rem / din) * 16 + rem % din; break;        // [unit][16] columns < d + Z
+        default: src = TP_BLIN + rem; break;
+    }
+    const float* part = a.dec_thin_part + (int64_t)net * n_wg * IPLAN_BEH_DEC_THIN_PART + src;
+    float s = 0.f;
+    for (int w = 0; w < n_wg; ++w) s += part[(int64_t)w * IPLAN_BEH_DEC_THIN_PART];
+    float* dst = a.dec_grad + (int64_t)net * a.dec_grad_s_net + a.dec_off[which_of[k]] + rem;
+    *dst = a.dec_grad_beta != 0.f ? fmaf(a.dec_grad_beta, *dst, s) : s;
 }
 
 __global__ __launch_bounds__(B2_THREADS, 2) void beh_dec_bwd2_kernel(IplanBehArgs a) {
@@ -1924,7 +2017,8 @@ __global__ __launch_bounds__(B2_THREADS, 2) void beh_dec_bwd2_kernel(IplanBehArg
     x.s_gx = smem;
     x.s_lx = x.s_gx + B2_GX;
     x.s_dy = x.s_lx + B2_LX;
-    int* s_cnt = reinterpret_cast<int*>(x.s_dy + B2_DY);
+    x.s_turn = x.s_dy + B2_DY + uniform_i(wave_id()) * 512;
+    int* s_cnt = reinterpret_cast<int*>(x.s_dy + B2_DY + B2_TURN);
     x.s_scale = reinterpret_cast<float*>(s_cnt + B2_CNT_INTS);
     if (threadIdx.x < B2_CNT_INTS) s_cnt[threadIdx.x] = 0;
     const int w = uniform_i(wave_id()), role = w >> 2;                                // role 0: recurrent wave B_q, 1: input-side wave A_q
@@ -2054,7 +2148,14 @@ extern "C" int iplan_beh_bwd(const IplanBehArgs* a, iplan_stream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(beh_dec_bwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
 #endif
         hipLaunchKernelGGL(beh_dec_bwd2_kernel, grid2, dim3(B2_THREADS), lds2, (hipStream_t)stream, *a);
+        if (a->dec_thin_part && a->bwd_j_lo <= 0) {          // the last (or only) piece: reduce the thin weight-gradient partials
+            if (!a->dec_grad) return fail(IPLAN_EINVAL, "iplan_beh_bwd: dec_thin_part needs dec_grad");
+            const int p_thin = a->d * DHd + a->d + DHd * (a->d + a->Z) + DHd;
+            hipLaunchKernelGGL(beh_dec_thin_grad_kernel, dim3((unsigned)((p_thin + 255) / 256), (unsigned)a->n_nets), dim3(256), 0,
+                               (hipStream_t)stream, *a, (int)grid2.x);
+        }
     } else if (a->bwd_phase != 2) {
+        if (a->dec_thin_part) return fail(IPLAN_EINVAL, "iplan_beh_bwd: dec_thin_part is only supported by the decoder BPTT's second form");
         hipLaunchKernelGGL(beh_dec_bwd_kernel, dgrid, dim3(DEC_THREADS), lds, (hipStream_t)stream, *a);
     }
     if (a->bwd_phase != 1) {

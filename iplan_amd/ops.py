@@ -895,6 +895,17 @@ def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_nor
     a.enc_grad, a.enc_grad_s_net = enc_arena.grad.data_ptr(), enc_arena.grad.stride(0)
     a.enc_grad_beta = 1.0 if accumulate else 0.0
     a.penalty, a.E_norm = float(penalty), int(E_norm)      # behavior_variation_penalty: the stability term's weight in the loss
+    # decoder BPTT, second form (the default): the thin weight gradients (out.*, linear.*) are accumulated in the kernel and
+    # reduced into the arena by its last window range; the first form (IPLAN_DEC_BWD_V1=1) and IPLAN_DEC_THIN_ROWS=1 (A/B knob)
+    # stream row gradients to iplan_wgrad instead
+    thin = not os.environ.get("IPLAN_DEC_BWD_V1") and not os.environ.get("IPLAN_DEC_THIN_ROWS")
+    tp = None
+    if thin:
+        tp = torch.empty(n_nets, (tiles + L.BEH_DEC_BWD2_TILES - 1) // L.BEH_DEC_BWD2_TILES, L.BEH_DEC_THIN_PART, **f32)
+        a.dec_thin_part, a.dec_grad, a.dec_grad_s_net = tp.data_ptr(), dec_arena.grad.data_ptr(), dec_arena.grad.stride(0)
+        a.dec_grad_beta = 1.0 if accumulate else 0.0
+    else:
+        a.dec_thin_part = None
     SD, DD = L.BEH_SAVE_DEC, L.BEH_DSAVE_DEC
     n_in = J * Lw
     sd = fwd["saved_dec"].data_ptr()
@@ -909,8 +920,9 @@ def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_nor
         w = Wgrad(dec_arena.grad, n_nets, tag="iplan_wgrad:beh_dec")
         ddp, sdp, n = dd.data_ptr() + 4 * s0 * 256, sd + 4 * s0 * 256, (s1 - s0) * 16
         cg = dict(dy_cg_stride=cgs, x_cg_stride=cgs)
-        w.add(ddp, dd_st, d, tiles, n, x=sdp, x_strides=sd_st, K=H, x_col0=416, beta=beta,
-              dw_off=off("decoder.out.weight"), db_off=off("decoder.out.bias"), **cg)
+        if not thin:
+            w.add(ddp, dd_st, d, tiles, n, x=sdp, x_strides=sd_st, K=H, x_col0=416, beta=beta,
+                  dw_off=off("decoder.out.weight"), db_off=off("decoder.out.bias"), **cg)
         w.add(ddp, dd_st, 3 * H, tiles, n, x=sdp, x_strides=sd_st, K=H, x_col0=32, beta=beta, seg=(3 * H, 80, 0),
               dw_off=off("decoder.rnn.weight_ih_l0"), db_off=off("decoder.rnn.bias_ih_l0"), **cg)
         # recurrent operand = the previous step's hidden state (16 rows back); the step before a range's first one is still in
@@ -918,9 +930,10 @@ def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_nor
         w.add(ddp, dd_st, 3 * H, tiles, n, x=sdp, x_strides=sd_st, K=H, x_col0=352, x_shift=-16, x_pre_valid=s0 > 0, beta=beta,
               dw_off=off("decoder.rnn.weight_hh_l0"), db_off=off("decoder.rnn.bias_hh_l0"), seg=(2 * H, 80, 80 + 3 * H), **cg)
         # input Linear: the record keeps its input row [x_t || latent] as one tile
-        w.add(ddp, dd_st, H, tiles, n, x=sdp, x_strides=sd_st, K=d + Z, beta=beta, seg=(H, 16, 0),
-              dw_off=off("decoder.linear.weight"), db_off=off("decoder.linear.bias"), **cg)
-        w._keep += [dd, fwd]
+        if not thin:
+            w.add(ddp, dd_st, H, tiles, n, x=sdp, x_strides=sd_st, K=d + Z, beta=beta, seg=(H, 16, 0),
+                  dw_off=off("decoder.linear.weight"), db_off=off("decoder.linear.bias"), **cg)
+        w._keep += [dd, fwd, tp]
         w.run(lib)
 
     # Pipeline: the decoder BPTT runs in pieces (top windows first) on the main stream; the weight-gradient contraction
@@ -960,7 +973,7 @@ def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_nor
             a.bwd_phase = 2
             _launch("beh_enc_bwd_kernel", lambda: lib.call("iplan_beh_bwd", a, side2.cuda_stream), stream=side2)
     a.bwd_phase, a.bwd_j_lo, a.bwd_j_hi = 0, 0, 0
-    out = dict(dsave_dec=dd, dsave_lat=dl, enc_part=ep)
+    out = dict(dsave_dec=dd, dsave_lat=dl, enc_part=ep, dec_thin_part=tp)
     if defer_dec_wgrad:
         ev_bptt = None
         if dev.type == "cuda":

@@ -498,7 +498,11 @@ def check_fc1_split_vs_fp32(device, rows_per_ep=7, n_eps=5, seed=3, N=5, log=Non
     return worst
 
 
-def test_fc1_split_vs_fp32_emulated():
+@pytest.mark.parametrize("shape", ["full", "small"])
+def test_fc1_split_vs_fp32_emulated(monkeypatch, shape):
+    """both forward shapes at one size: four row tiles per wave (the full buffer's) and one (small batches: a data-parallel
+    rank's share of the PPO rows)"""
+    monkeypatch.setenv("IPLAN_AC_SPLIT_SHAPE", shape)
     check_fc1_split_vs_fp32("cpu")
     check_fc1_split_vs_fp32("cpu", rows_per_ep=13, n_eps=5, seed=4)     # 65 rows: three 32-row blocks, the last one ragged
 
