@@ -1609,7 +1609,7 @@ constexpr int B2_GX = B2_TILES * 8 * 3 * 256;               // floats: [tile][ch
 constexpr int B2_LX = 2 * B2_TILES * 4 * 256;               //         [window parity][tile][q][64 lanes x f32x4]  d loss / d latent shares
 constexpr int B2_DY = 4 * B2_TILES * 256;                   //         [step & 3][tile][64 lanes x f32x4]  loss gradient of a step (published 2 ahead)
 constexpr int B2_TURN = 8 * 2 * 256;                        //         [wave][2][16 x 16]  operand tiles turned into MFMA A / B order (thin weight gradients)
-constexpr int B2_CNT_INTS = 16;                             // gcnt | rcnt | lcnt | ocnt | dcnt | pad
+constexpr int B2_CNT_INTS = 16;                             // gcnt | rcnt | lcnt | ocnt | dcnt[B2_TILES] | pad
 constexpr int B2_LDS_FLOATS = B2_GX + B2_LX + B2_DY + B2_TURN + B2_CNT_INTS + D2_MAX_WINDOWS;
 // thin weight-gradient partials of a workgroup (IplanBehArgs.dec_thin_part)
 constexpr int TP_WOUT = 0, TP_BOUT = 1024, TP_WLIN = 1040, TP_BLIN = 2064;
@@ -1733,7 +1733,14 @@ __device__ __forceinline__ void b2_recurrent(const IplanBehArgs& a, const B2Ctx&
         if (tn < 0) { tn = Lw - 1; --jn; }
         if (s + 1 >= x.steps) { jn = j; tn = t; }
         d2_wait(x.rcnt, 8 * s);                                   // every reader is done with step s - 1's pieces: the slots are free
-        d2_wait(x.dcnt, x.n_live * (s + 1));                      // dy of step s is there (published a step ahead)
+        // dy of step s is there (published two steps ahead).  ONE COUNTER PER TILE: a single counter over the three owners
+        // reaches its target at step 0 with (2, 1, 0) publications -- two owners through dy(0), dy(1) and the third not started
+        // (cold start) -- and this wave would read an unwritten slot; from step 1 on the rcnt wait above already implies
+        // that every owner has finished its previous iteration.  [found on the GPU as a rare run-to-run difference of the
+        // gradients: scripts/dev/beh_repro.py; the fibre emulator schedules the owners first]
+#pragma unroll
+        for (int k = 0; k < B2_TILES; ++k)
+            if (FAST || c[k].live) d2_wait(x.dcnt + k, s + 1);
         // ---- lane-local: output / tanh / dropout backward, gate backward of the own units; pieces published tile by tile
 #pragma unroll
         for (int k = 0; k < B2_TILES; ++k) {
@@ -1887,7 +1894,7 @@ __device__ __forceinline__ void b2_input(const IplanBehArgs& a, const B2Ctx& x, 
                 for (int i = 0; i < 4; ++i) dy[i] -= pen * df[i] / nrm;
         }
         *(reinterpret_cast<f32x4*>(x.s_dy + ((sidx & 3) * B2_TILES + ko) * 256) + l) = dy;
-        d2_signal(x.dcnt);
+        d2_signal(x.dcnt + ko);
         if (!thin) st4<FAST>(ddo, sd_lane + (uint32_t)(((int64_t)jj * Lw + tt) * 1024) + x.cgs * REC_CG(DD_DY), ovalid, dy);
     };
     int j = x.j_hi - 1, t = Lw - 1, w = 0;                          // w: windows finished in this launch

@@ -1,0 +1,12 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"; O=gpurun_out/r4e; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
+for v in base thinrows bwdv1; do
+  unset IPLAN_DEC_THIN_ROWS IPLAN_DEC_BWD_V1
+  [ $v = thinrows ] && export IPLAN_DEC_THIN_ROWS=1
+  [ $v = bwdv1 ] && export IPLAN_DEC_BWD_V1=1
+  echo "== $v" >> $O/table.txt
+  timeout 400 python scripts/dev/beh_grad_table.py 2 2>&1 | grep -v amdgpu >> $O/table.txt
+  timeout 400 python scripts/dev/beh_grad_table.py 2 2>&1 | grep -v amdgpu | grep "dec rnn.weight_ih\|dec decoder.rnn.weight_ih" >> $O/table.txt
+done
+cat $O/table.txt

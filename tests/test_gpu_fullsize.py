@@ -30,3 +30,24 @@ def test_gat_entity_count_edges_vs_oracle(N):
     """minimum (2), ragged (17) and maximum (64) entity counts against the CPU oracle"""
     from tests.test_gpu_gat import gat_vs_oracle
     gat_vs_oracle(B=3, N=N, D=13, seed=N)
+
+
+def test_behavior_learn_bitwise_reproducible_from_a_cold_process():
+    """Behavior_policy.learn at config 3 repeated in a FRESH process (cold code objects, the caching allocator's free blocks
+    poisoned with NaN / huge values before every call): every repetition's gradient arenas bit-identical, no NaN / Inf.  Round 4:
+    the decoder BPTT's second form hands data between waves through LDS counters -- a counter that let step 0 start before the
+    third tile's first hand-off had been published showed up exactly here, as a rare run-to-run difference of ~1e-5 ... 2e-3 of
+    the gradients that no oracle comparison on a warm process caught (scripts/dev/beh_repro.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env_extra in ({}, {"IPLAN_DEC_THIN_ROWS": "1"}):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev", "beh_repro.py"), "2"], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if "nan/inf" in ln]
+        assert len(lines) == 6, r.stdout[-2000:]
+        for ln in lines:
+            assert "nan/inf: [False, False]" in ln and "(enc, dec): [0.0, 0.0]" in ln, ln
