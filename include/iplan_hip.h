@@ -700,6 +700,9 @@ typedef struct {
     float* dec_grad;            /* decoder gradient arena                                                          */
     int64_t dec_grad_s_net;
     float dec_grad_beta;
+    int32_t fwd_skip_act;       /* forward (second form): do not store the output layer's input (record columns 416..479) --
+                                   only the out.weight contraction of iplan_wgrad reads it, and with dec_thin_part the BPTT
+                                   re-forms it from the hidden state it holds anyway: 64 of the 480 floats a chain-step stores */
 } IplanBehArgs;
 
 int iplan_beh_fwd(const IplanBehArgs* args, iplan_stream_t stream);

@@ -356,7 +356,7 @@ class BehArgs(C.Structure):
         ("bwd_j_lo", i32), ("bwd_j_hi", i32), ("dec_carry", fp),
         ("fwd_phase", i32), ("fwd_j_lo", i32), ("fwd_j_hi", i32), ("enc_carry", fp), ("win_norm", fp),
         ("enc_grad_beta", C.c_float), ("penalty", C.c_float), ("E_norm", i32),
-        ("dec_thin_part", fp), ("dec_grad", fp), ("dec_grad_s_net", i64), ("dec_grad_beta", C.c_float),
+        ("dec_thin_part", fp), ("dec_grad", fp), ("dec_grad_s_net", i64), ("dec_grad_beta", C.c_float), ("fwd_skip_act", i32),
     ]
 
 

@@ -1265,7 +1265,8 @@ __device__ __forceinline__ uint32_t d2_sd_off(const D2Ctx& x, int step) {
 
 // ---- B_q: the recurrence.  FAST = all three tiles exist and are full: no predication, no branch around any memory operation
 // (a branch around a load or a store makes the compiler drain the wait counters at its join).
-template <bool FAST>
+// SAVE_ACT: store the output layer's input (compile-time: no branch around the store; see IplanBehArgs.fwd_skip_act)
+template <bool FAST, bool SAVE_ACT>
 __device__ __forceinline__ void d2_recurrent(const IplanBehArgs& a, const D2Ctx& x, const DecTile (&c)[D2_TILES]) {
     const int q = x.q, l = x.l, g = x.g, net = x.net, Lw = x.Lw;
     (void)g;
@@ -1335,7 +1336,7 @@ __device__ __forceinline__ void d2_recurrent(const IplanBehArgs& a, const D2Ctx&
             const f32x4 km = keep_tile(a, net, j, c[k].row, t, q, valid, c[k].rows);
             f32x4 act;
             for (int i = 0; i < 4; ++i) act[i] = tanh_f(o[k].h[i]) * (km[i] * inv_keep);
-            if (!(D2_ABL & 1)) st4<FAST>(sdb, so + x.cgs * REC_CG(SD_A + 16 * q), valid, act);
+            if (SAVE_ACT && !(D2_ABL & 1)) st4<FAST>(sdb, so + x.cgs * REC_CG(SD_A + 16 * q), valid, act);
             yp[k] = mma_block(wout, act, bout);                                      // own share of y = W_out act + b
         }
         D2_CLK(3);
@@ -1578,7 +1579,8 @@ __global__ __launch_bounds__(D2_THREADS, 2) void beh_dec_fwd2_kernel(IplanBehArg
     __syncthreads();
     const bool fastu = uniform_i(fast ? 1 : 0) != 0;
     if (role == 0) {
-        if (fastu) d2_recurrent<true>(a, x, c); else d2_recurrent<false>(a, x, c);
+        if (a.fwd_skip_act) { if (fastu) d2_recurrent<true, false>(a, x, c); else d2_recurrent<false, false>(a, x, c); }
+        else { if (fastu) d2_recurrent<true, true>(a, x, c); else d2_recurrent<false, true>(a, x, c); }
     } else if (x.q == 0) {
         if (fastu) d2_input<true, true>(a, x, c); else d2_input<false, true>(a, x, c);
     } else {

@@ -769,6 +769,12 @@ def _piece_bounds(J, pieces):
     return [0] + [s0 + round((J - s0) * k / pieces) for k in range(pieces + 1)]
 
 
+def _beh_thin_in_kernel():
+    """decoder BPTT second form with the thin weight gradients accumulated in the kernel (the default): not with the first form
+    (IPLAN_DEC_BWD_V1=1) nor with the A/B knob IPLAN_DEC_THIN_ROWS=1"""
+    return not os.environ.get("IPLAN_DEC_BWD_V1") and not os.environ.get("IPLAN_DEC_THIN_ROWS")
+
+
 def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p, keep=None, seed=0, hard=False, win_norm=None,
                 lib=None):
     """Forward of Behavior_policy.learn for all nets.  hist [n_nets, E, T, N, d] (first three dims may be
@@ -791,6 +797,9 @@ def beh_forward(enc_arena, dec_arena, hist, mask, L_win, Z, coef, thres, drop_p,
         assert keep.dtype == torch.uint8 and keep.shape == (n_nets, J, rows, L_win, 64) and keep.is_contiguous()
         a.keep = keep.data_ptr()
     a.seed, a.drop_p, a.coef, a.thres = seed, drop_p, coef, thres
+    # the output layer's input is only read by the out.weight contraction of iplan_wgrad; the BPTT's second form accumulates that
+    # gradient itself (beh_backward: ``thin``) and the forward then need not store it (64 of 480 floats per chain-step)
+    a.fwd_skip_act = 1 if (_beh_thin_in_kernel() and not os.environ.get("IPLAN_FWD_SAVE_ACT")) else 0     # (IPLAN_FWD_SAVE_ACT=1: A/B knob)
     if win_norm is not None:                               # per-window mask sums over all data-parallel ranks' envs
         assert win_norm.shape == (n_nets, J) and win_norm.dtype == torch.float32 and win_norm.is_contiguous()
         a.win_norm = win_norm.data_ptr()
@@ -898,7 +907,8 @@ def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_nor
     # decoder BPTT, second form (the default): the thin weight gradients (out.*, linear.*) are accumulated in the kernel and
     # reduced into the arena by its last window range; the first form (IPLAN_DEC_BWD_V1=1) and IPLAN_DEC_THIN_ROWS=1 (A/B knob)
     # stream row gradients to iplan_wgrad instead
-    thin = not os.environ.get("IPLAN_DEC_BWD_V1") and not os.environ.get("IPLAN_DEC_THIN_ROWS")
+    thin = _beh_thin_in_kernel()
+    assert thin or not a.fwd_skip_act, "the forward skipped the output layer's input: the row-gradient path needs it"
     tp = None
     if thin:
         tp = torch.empty(n_nets, (tiles + L.BEH_DEC_BWD2_TILES - 1) // L.BEH_DEC_BWD2_TILES, L.BEH_DEC_THIN_PART, **f32)
