@@ -463,3 +463,21 @@ def test_behavior_learn_decoder_bptt_both_forms_emulated(monkeypatch):
     monkeypatch.setenv("IPLAN_BEH_PIECES", "3")
     w3 = check_behavior_learn_vs_oracle(_small(**kw), 3, "cpu", seed=3)
     assert w3["grad"] < 1e-5, w3
+
+
+OTHER_DIMS = dict(obs_shape_single=7, latent_dim=5, max_history_len=4, episode_limit=12, n_actions=4, n_agents=3, max_vehicle_num=6, pred_length=3)
+
+
+def check_other_runtime_dims(device):
+    """Every RUN-TIME dimension of the path off its shipped value at once -- entity features d = 7 (5), latent Z = 5 (8), window
+    L = 4 (10), 4 actions (5), 3 agents (5), prediction horizon 3 (5), N = 6, T = 12: the three learners against the oracle.  (What is
+    fixed at compile time are the hidden widths 64 / 32 / 32 / 64, one GRU layer, and the MLP depth: DESIGN.md section 7.)"""
+    from tests.oracle_checks import check_behavior_learn_vs_oracle, check_ppo_train_vs_oracle, check_prediction_learn_vs_oracle
+    out = dict(behaviour=check_behavior_learn_vs_oracle(_small(**OTHER_DIMS), 3, device, seed=3),
+               prediction=check_prediction_learn_vs_oracle(_small(**OTHER_DIMS), 3, device, seed=4, gate_e32_factor=4.0),
+               ppo=check_ppo_train_vs_oracle(_small(**OTHER_DIMS), device, seed=6))
+    return out
+
+
+def test_other_runtime_dims_vs_oracle_emulated():
+    check_other_runtime_dims("cpu")

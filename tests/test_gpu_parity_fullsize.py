@@ -193,3 +193,11 @@ def test_behavior_learn_encoder_fp32_form_gpu(monkeypatch):
     _log("behavior_learn_cfg3_E32_agent2_enc_fp32", check_behavior_learn_vs_oracle(_args(batch_size_run=32), 32, "cuda", seed=23, agents=(2,)))
     b = _args(max_vehicle_num=9, n_agents=2, episode_limit=20, batch_size_run=4)
     _log("behavior_learn_ragged_enc_fp32", check_behavior_learn_vs_oracle(b, 4, "cuda", seed=43))
+
+
+def test_other_runtime_dims_vs_oracle_gpu():
+    """d = 7, Z = 5, L = 4, 4 actions, 3 agents, prediction horizon 3 (every run-time dimension off its shipped value) on the GPU"""
+    from tests.test_emu_learners import check_other_runtime_dims
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    for k, w in check_other_runtime_dims("cuda").items():
+        _log("other_runtime_dims_" + k, w)
