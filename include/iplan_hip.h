@@ -270,6 +270,8 @@ typedef struct {
     int32_t ksplit_wg;
     float* ks_scratch;
     int32_t* ks_count;
+    int32_t act_tanh;           /* MLPBase activation (mlp.py:10, args.use_ReLU): 0 = ReLU (shipped), 1 = tanh -- forward and, through
+                                   IplanAcBwdArgs.fwd, the backward tail (round 4: the second activation of this kernel family) */
 } IplanAcFwdArgs;
 
 int iplan_ac_fwd(const IplanAcFwdArgs* args, iplan_stream_t stream);

@@ -196,7 +196,7 @@ class AcFwdArgs(C.Structure):
         ("onehot_out", fp), ("oh_s_net", i64), ("oh_s_row", i64),
         ("ln_stats", fp), ("ln_stats_s_net", i64), ("ln_stats_mode", i32), ("phase_clocks", fp),
         ("packed_actor", fp), ("packed_critic", fp), ("packed_s_net", i64), ("fc1_pre", fp),
-        ("ksplit_wg", i32), ("ks_scratch", fp), ("ks_count", fp),
+        ("ksplit_wg", i32), ("ks_scratch", fp), ("ks_count", fp), ("act_tanh", i32),
     ]
 
 

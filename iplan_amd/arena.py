@@ -30,6 +30,8 @@ class ParamArena:
         # in-place writes through a Parameter bump THAT Parameter's ``_version`` (``p.data = view`` below gives it its own
         # counter, not the arena tensor's): derived caches (ops.Fc1Pack) watch both
         self.version = 0
+        # MLPBase activation of an actor / critic stack (mlp.py:10: tanh when args.use_ReLU is off): read by ops.ac_forward
+        self.act_tanh = bool(getattr(self.modules[0], "act_tanh", False))
         self.data = torch.zeros(self.n_nets, self.size, dtype=torch.float32, device=device)
         self.grad = torch.zeros_like(self.data)
         for i, m in enumerate(self.modules):

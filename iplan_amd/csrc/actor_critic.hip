@@ -16,6 +16,13 @@
 
 namespace iplan {
 
+// MLPBase activation (utils/mappo_utils/mlp.py:10: [nn.Tanh(), nn.ReLU()][use_ReLU]); `tanh` is wave-uniform
+__device__ __forceinline__ f32x4 ac_act4(f32x4 v, bool tanh) {
+    f32x4 r;
+    for (int q = 0; q < 4; ++q) r[q] = tanh ? tanh_f(v[q]) : (v[q] > 0.0f ? v[q] : 0.0f);
+    return r;
+}
+
 constexpr int AM = IPLAN_AC_HIDDEN;    // 64
 constexpr int AT = AM / 16;            // 4 tiles
 #ifndef AC_RT
@@ -457,6 +464,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     if (STAGED2) __syncthreads();                               // the staged tail weights (every wave gets here: ks == 1)
     if (part != 0) return;
 
+  const bool act_tanh = a.act_tanh != 0;                       // (uniform) MLPBase activation: tanh instead of ReLU (args.use_ReLU off)
   for (int rt = 0; rt < RT; ++rt) {
     const int r = rr[rt];
     const bool valid = vld[rt];
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     for (int t = 0; t < AT; ++t) h[t] = vload(hrow, valid, AM, t);
     f32x4 f[AT], gmv[AT], btv[AT];
     for (int t = 0; t < AT; ++t) {
-        f[t] = relu4(acc[t] + pv(TP_FC1B, IPLAN_AC_FC1_B, t));
+        f[t] = ac_act4(acc[t] + pv(TP_FC1B, IPLAN_AC_FC1_B, t), act_tanh);
         if (sv) vstore(sv, valid, AM, t, f[t]);                       // a1
     }
     for (int t = 0; t < AT; ++t) { gmv[t] = pv(TP_LN1W, IPLAN_AC_LN1_W, t); btv[t] = pv(TP_LN1B, IPLAN_AC_LN1_B, t); }
@@ -485,8 +493,8 @@ __global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
     if (sv) for (int t = 0; t < AT; ++t) vstore(sv + AM, valid, AM, t, f[t]);   // f1
     f32x4 f2[AT];
     for (int t = 0; t < AT; ++t) {
-        if (lds_tail) f2[t] = relu4(dense_tile<AT>(s_tw, TLDW, 16 * t, f, pv(TP_FC2B, IPLAN_AC_FC2_B, t)));
-        else f2[t] = relu4(dense_tile_ga<AT>(P + nw.off[IPLAN_AC_FC2_W], AM, AM, 16 * t, f, bfrag_a(P + nw.off[IPLAN_AC_FC2_B], t)));
+        if (lds_tail) f2[t] = ac_act4(dense_tile<AT>(s_tw, TLDW, 16 * t, f, pv(TP_FC2B, IPLAN_AC_FC2_B, t)), act_tanh);
+        else f2[t] = ac_act4(dense_tile_ga<AT>(P + nw.off[IPLAN_AC_FC2_W], AM, AM, 16 * t, f, bfrag_a(P + nw.off[IPLAN_AC_FC2_B], t)), act_tanh);
         if (sv) vstore(sv + 2 * AM, valid, AM, t, f2[t]);             // a2
     }
     for (int t = 0; t < AT; ++t) { gmv[t] = pv(TP_LN2W, IPLAN_AC_LN2_W, t); btv[t] = pv(TP_LN2B, IPLAN_AC_LN2_B, t); }

@@ -66,6 +66,7 @@ __device__ __forceinline__ void store_ln_part(float* __restrict__ dst, const f32
 
 __global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
     const IplanAcFwdArgs& fa = a.fwd;
+    const bool act_tanh = fa.act_tanh != 0;                     // (uniform) MLPBase activation of the forward pass
     const int net = (int)blockIdx.y;
     const int which = fa.which == 2 ? (int)blockIdx.z : fa.which;
     const IplanAcNet& nw = which ? fa.critic : fa.actor;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
         ln_bwd_tiles(d, xh, P + nw.off[IPLAN_AC_LN2_W], rs2, dgam, dbet);
         store_ln_part(lnp + 2 * BM, dgam, dbet);
         for (int t = 0; t < BT; ++t) {
-            for (int q = 0; q < 4; ++q) d[t][q] = a2[t][q] > 0.f ? d[t][q] : 0.f;
+            for (int q = 0; q < 4; ++q) d[t][q] = act_tanh ? d[t][q] * (1.0f - a2[t][q] * a2[t][q]) : (a2[t][q] > 0.f ? d[t][q] : 0.f);
             vstore(ds + BM, valid, BM, t, d[t]);                  // dz2
         }
     }
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
         ln_bwd_tiles(d, xh, P + nw.off[IPLAN_AC_LN1_W], rs1, dgam, dbet);
         store_ln_part(lnp + 4 * BM, dgam, dbet);
         for (int t = 0; t < BT; ++t) {
-            for (int q = 0; q < 4; ++q) d[t][q] = a1[t][q] > 0.f ? d[t][q] : 0.f;
+            for (int q = 0; q < 4; ++q) d[t][q] = act_tanh ? d[t][q] * (1.0f - a1[t][q] * a1[t][q]) : (a1[t][q] > 0.f ? d[t][q] : 0.f);
             vstore(ds, valid, BM, t, d[t]);                       // dz1
         }
     }

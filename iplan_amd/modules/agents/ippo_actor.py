@@ -22,10 +22,11 @@ class _FusedNet(nn.Module):
         self._n_actions = args.n_actions
         self._arena = None
         self._net = 0
-        if args.rnn_hidden_dim != 64 or args.mlp_hidden_dim != 64 or args.layer_N != 1 or not args.use_ReLU \
+        self.act_tanh = not args.use_ReLU      # mlp.py:10 [nn.Tanh(), nn.ReLU()][use_ReLU]; ParamArena hands it to the kernels
+        if args.rnn_hidden_dim != 64 or args.mlp_hidden_dim != 64 or args.layer_N != 1 \
                 or not args.use_feature_normalization or not args.use_recurrent_policy or args.recurrent_N != 1:
             raise NotImplementedError("iplan_amd builds the actor/critic kernel for the reference's shipped "
-                                      "configuration (hidden 64, layer_N 1, ReLU, feature norm, 1 GRU layer)")
+                                      "configuration (hidden 64, layer_N 1, ReLU or tanh, feature norm, 1 GRU layer)")
 
     def attach(self, arena, net):
         self._arena, self._net = arena, net

@@ -96,3 +96,4 @@ class _SingleNetView:
         self.shapes = arena.shapes
         self.size = arena.size
         self.trainable = arena.trainable
+        self.act_tanh = getattr(arena, "act_tanh", False)

@@ -192,6 +192,7 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
     a = L.AcFwdArgs()
     a.n_agents, a.rows, a.which = n_agents, rows, which
     a.ksplit = ksplit if ksplit is not None else (8 if rows <= 512 else 1)
+    a.act_tanh = int(bool(getattr(actor_arena if which != 1 else critic_arena, "act_tanh", False)))
     spec.fill(a.feat)
     out = {}
     f32 = dict(dtype=torch.float32, device=dev)

@@ -295,32 +295,34 @@ def _relu_hinted(z, hint, delta):
     return z * torch.where(amb, hint, own).to(z.dtype)
 
 
-def ac_trunk(p, x, h, relu_hint=None, hint_delta=1e-5):
+def ac_trunk(p, x, h, relu_hint=None, hint_delta=1e-5, use_relu=True):
     """MLPBase (mlp.py:44-52, 24-28; layer_N = 1) + RNNLayer (rnn.py:24-27,77).
-    x [R,F], h [R,M] -> (features [R,M], h' [R,M]).  ``relu_hint`` = (fc1 branch, fc2 branch): see _relu_hinted."""
+    x [R,F], h [R,M] -> (features [R,M], h' [R,M]).  ``relu_hint`` = (fc1 branch, fc2 branch): see _relu_hinted.
+    ``use_relu`` = args.use_ReLU: active_func = [nn.Tanh(), nn.ReLU()][use_ReLU] (mlp.py:10)."""
     h1, h2 = relu_hint if relu_hint is not None else (None, None)
+    act = (lambda z, hint: _relu_hinted(z, hint, hint_delta)) if use_relu else (lambda z, hint: torch.tanh(z))
     f = layer_norm(x, p["base.feature_norm.weight"], p["base.feature_norm.bias"])
-    f = _relu_hinted(f @ p["base.mlp.fc1.0.weight"].t() + p["base.mlp.fc1.0.bias"], h1, hint_delta)
+    f = act(f @ p["base.mlp.fc1.0.weight"].t() + p["base.mlp.fc1.0.bias"], h1)
     f = layer_norm(f, p["base.mlp.fc1.2.weight"], p["base.mlp.fc1.2.bias"])
-    f = _relu_hinted(f @ p["base.mlp.fc2.0.0.weight"].t() + p["base.mlp.fc2.0.0.bias"], h2, hint_delta)
+    f = act(f @ p["base.mlp.fc2.0.0.weight"].t() + p["base.mlp.fc2.0.0.bias"], h2)
     f = layer_norm(f, p["base.mlp.fc2.0.2.weight"], p["base.mlp.fc2.0.2.bias"])
     hn = gru_cell(f, h, p["rnn.rnn.weight_ih_l0"], p["rnn.rnn.weight_hh_l0"],
                   p["rnn.rnn.bias_ih_l0"], p["rnn.rnn.bias_hh_l0"])
     return layer_norm(hn, p["rnn.norm.weight"], p["rnn.norm.bias"]), hn
 
 
-def actor_logits(p, x, h, avail=None, relu_hint=None):
-    f, hn = ac_trunk(p, x, h, relu_hint)
+def actor_logits(p, x, h, avail=None, relu_hint=None, use_relu=True):
+    f, hn = ac_trunk(p, x, h, relu_hint, use_relu=use_relu)
     logits = f @ p["act.action_out.linear.weight"].t() + p["act.action_out.linear.bias"]
     if avail is not None:
         logits = torch.where(avail == 0, torch.full_like(logits, -1e10), logits)   # distributions.py:66-67
     return logits, hn
 
 
-def actor_evaluate(p, x, h, actions, avail=None, relu_hint=None):
+def actor_evaluate(p, x, h, actions, avail=None, relu_hint=None, use_relu=True):
     """R_Actor.evaluate_actions (ippo_actor.py:74-102, act.py:159-164):
     -> (logp [R,1], entropy scalar = unmasked mean over rows)."""
-    logits, _ = actor_logits(p, x, h, avail, relu_hint)
+    logits, _ = actor_logits(p, x, h, avail, relu_hint, use_relu=use_relu)
     logp_all = torch.log_softmax(logits, dim=-1)
     logp = logp_all.gather(-1, actions.long().reshape(-1, 1))
     pr = logp_all.exp()
@@ -328,9 +330,9 @@ def actor_evaluate(p, x, h, actions, avail=None, relu_hint=None):
     return logp, ent
 
 
-def critic_value(p, x, h, relu_hint=None):
+def critic_value(p, x, h, relu_hint=None, use_relu=True):
     """R_Critic.forward (ippo_critic.py:47-65); PopArt.forward is a plain Linear (popart.py:41-46)."""
-    f, hn = ac_trunk(p, x, h, relu_hint)
+    f, hn = ac_trunk(p, x, h, relu_hint, use_relu=use_relu)
     return f @ p["v_out.weight"].t() + p["v_out.bias"], hn
 
 
@@ -536,8 +538,9 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
                                args.n_agents, gat, behv)
     masks_all = 1.0 - f["terminated"][:, :, i].to(dt)
     F_ = x_all.shape[-1]
+    use_relu = bool(getattr(args, "use_ReLU", True))
     with torch.no_grad():
-        v_all, _ = critic_value(critic_p, x_all.reshape(-1, F_), f["rnn_states_critics"][:, :, i].reshape(-1, M))
+        v_all, _ = critic_value(critic_p, x_all.reshape(-1, F_), f["rnn_states_critics"][:, :, i].reshape(-1, M), use_relu=use_relu)
         v_all = v_all.reshape(E, T + 1, 1)
         rets = gae_returns(f["reward"][:, :-1, i].to(dt), v_all, masks_all, args.gamma, args.gae_lambda, getattr(args, "use_gae", True))
         adv = normalise_advantages(rets, v_all[:, :-1], masks_all[:, :-1])
@@ -546,7 +549,7 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
         hc = f["rnn_states_critics"][:, :-1, i].reshape(-1, M)
         acts = f["actions"][:, :-1, i].reshape(-1, 1)
         avail = f["avail_actions"][:, :-1, i].reshape(-1, args.n_actions)
-        old_logp, _ = actor_evaluate(actor_p, x, ha, acts, avail)
+        old_logp, _ = actor_evaluate(actor_p, x, ha, acts, avail, use_relu=use_relu)
     ms = [{k: torch.zeros_like(v) for k, v in prm.items()} for prm in (actor_p, critic_p)]
     vs = [{k: torch.zeros_like(v) for k, v in prm.items()} for prm in (actor_p, critic_p)]
     steps = [0, 0]
@@ -554,8 +557,8 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
     loss_kw = {k: getattr(args, k, True) for k in ("use_huber_loss", "use_clipped_value_loss", "use_value_active_masks", "use_policy_active_masks")}
 
     def objectives(ap, cp, sl, hints=(None, None)):
-        logp, ent = actor_evaluate(ap, x[sl], ha[sl], acts[sl], avail[sl], relu_hint=hints[0])
-        val, _ = critic_value(cp, x[sl], hc[sl], relu_hint=hints[1])
+        logp, ent = actor_evaluate(ap, x[sl], ha[sl], acts[sl], avail[sl], relu_hint=hints[0], use_relu=use_relu)
+        val, _ = critic_value(cp, x[sl], hc[sl], relu_hint=hints[1], use_relu=use_relu)
         return ppo_losses(logp, ent, val, old_logp[sl], adv.reshape(-1, 1)[sl], v_all[:, :-1].reshape(-1, 1)[sl],
                           rets.reshape(-1, 1)[sl], masks_all[:, :-1].reshape(-1, 1)[sl],
                           args.clip_param, args.huber_delta, args.entropy_coef, args.value_loss_coef, **loss_kw) + (ent,)

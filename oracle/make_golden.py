@@ -452,6 +452,11 @@ def golden_ippo_train(seed=70, env="highway"):
         args = small_args(max_vehicle_num=7, n_agents=2, episode_limit=6, batch_size_run=4,
                           buffer_size=4, batch_size=3, ppo_epoch=3)
         tag = "ippo_train"
+    elif env == "highway_tanh":
+        # the second MLPBase activation (utils/mappo_utils/mlp.py:10, args.use_ReLU off): tanh in fc1 / fc2, tanh-gain init
+        args = small_args(max_vehicle_num=6, n_agents=2, episode_limit=6, batch_size_run=4,
+                          buffer_size=4, batch_size=3, ppo_epoch=3, use_ReLU=False)
+        tag = "ippo_train_tanh"
     else:
         args = default_args("mpe_easy", use_cuda=False, episode_limit=8, batch_size_run=4,
                             buffer_size=4, batch_size=3, ppo_epoch=2)
@@ -533,6 +538,7 @@ def main():
     golden_rollout_step()
     golden_ippo_train(70, "highway")
     golden_ippo_train(80, "mpe_easy")
+    golden_ippo_train(75, "highway_tanh")
     golden_checkpoint()
     golden_behavior_hard_learn()
     golden_obs_wrapper()

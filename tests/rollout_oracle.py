@@ -53,14 +53,14 @@ def oracle_rollout(loop, obs, noise, q_all):
             last = onehot[:, t - 1] if t > 0 else torch.zeros_like(onehot[:, 0])
             x = O.build_inputs_rollout(history[:, t], att[:, t], lat[:, t], last, nA, gat_on, beh_on)
             for i in range(nA):
-                logits, hn = O.actor_logits(act_p[i], x[:, i], ha[:, t, i], torch.ones(E, a.n_actions, dtype=torch.int32))
+                logits, hn = O.actor_logits(act_p[i], x[:, i], ha[:, t, i], torch.ones(E, a.n_actions, dtype=torch.int32), use_relu=getattr(a, "use_ReLU", True))
                 pr = torch.softmax(logits, -1)
                 act = (pr / q_all[t, i]).argmax(-1)
                 actions[:, t, i, 0] = act
                 onehot[:, t, i] = torch.nn.functional.one_hot(act, a.n_actions).float()
                 logp[:, t, i] = torch.log_softmax(logits, -1).gather(-1, act[:, None])[:, 0]
                 ha[:, t + 1, i] = hn
-                v, hcn = O.critic_value(cri_p[i], x[:, i], hc[:, t, i])
+                v, hcn = O.critic_value(cri_p[i], x[:, i], hc[:, t, i], use_relu=getattr(a, "use_ReLU", True))
                 values[:, t, i] = v[:, 0]
                 hc[:, t + 1, i] = hcn
             if gat_on:

@@ -302,14 +302,15 @@ def test_gat_entity_count_edges_emulated(N):
     gat_vs_oracle(B=2, N=N, D=13, seed=N, device="cpu")
 
 
-@pytest.mark.parametrize("cfg", ["iplan", "gat_only", "plain"])
+@pytest.mark.parametrize("cfg", ["iplan", "gat_only", "plain", "tanh"])
 def test_device_resident_rollout_matches_oracle_emulated(cfg):
     """The path bench.py times -- SyntheticLoop._rollout_body: in-place write_back / out= launches into the episode
     buffer -- against the oracle stepped the same way with the same draws, every field, every step (tests/rollout_oracle.py);
     config 3 (full iPLAN), config 2 (GAT on, Behaviour off) and config 1 (both off) feature layouts."""
     from iplan_amd.config import default_args
     from tests.rollout_oracle import check_rollout_body
-    kw = dict(iplan={}, gat_only=dict(Behavior_enable=False), plain=dict(Behavior_enable=False, GAT_enable=False, GAT_use_behavior=False))[cfg]
+    kw = dict(iplan={}, gat_only=dict(Behavior_enable=False), plain=dict(Behavior_enable=False, GAT_enable=False, GAT_use_behavior=False),
+              tanh=dict(use_ReLU=False))[cfg]                  # (mlp.py:10: the actor/critic trunk's second activation)
     args = default_args("highway", use_cuda=False, max_vehicle_num=5, n_agents=2, episode_limit=4, batch_size_run=3,
                         max_history_len=3, **kw)
     worst = check_rollout_body(args, 3, "cpu", seed=5)

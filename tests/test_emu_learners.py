@@ -57,7 +57,7 @@ def check_ippo_train(g, device):
         assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (k, got, ref)
 
 
-@pytest.mark.parametrize("tag", ["ippo_train", "ippo_train_mpe"])
+@pytest.mark.parametrize("tag", ["ippo_train", "ippo_train_mpe", "ippo_train_tanh"])
 def test_ippo_train_emulated(golden, tag):
     check_ippo_train(golden(tag), "cpu")
 
@@ -326,6 +326,13 @@ def test_ppo_train_vs_oracle_emulated(cfg):
     from tests.oracle_checks import check_ppo_train_vs_oracle
     kw = dict(iplan={}, gat_only=dict(Behavior_enable=False), plain=dict(Behavior_enable=False, GAT_enable=False, GAT_use_behavior=False))[cfg]
     check_ppo_train_vs_oracle(_small(**kw), "cpu", seed=6)
+
+
+def test_ppo_train_tanh_vs_oracle_emulated():
+    """args.use_ReLU off (utils/mappo_utils/mlp.py:10): tanh in fc1 / fc2 of actor and critic, forward and backward tail"""
+    from tests.oracle_checks import check_ppo_train_vs_oracle
+    w = check_ppo_train_vs_oracle(_small(use_ReLU=False), "cpu", seed=6)
+    assert w.get("relu_branches_from_hint", 0) == 0, w
 
 
 def test_gat_fwd_bwd_vs_oracle_emulated():

@@ -5,7 +5,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("tag", ["ippo_train", "ippo_train_mpe"])
+@pytest.mark.parametrize("tag", ["ippo_train", "ippo_train_mpe", "ippo_train_tanh"])
 def test_ippo_train_matches_reference(golden, tag):
     from tests.test_emu_learners import check_ippo_train
     check_ippo_train(golden(tag), "cuda")

@@ -201,3 +201,16 @@ def test_other_runtime_dims_vs_oracle_gpu():
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     for k, w in check_other_runtime_dims("cuda").items():
         _log("other_runtime_dims_" + k, w)
+
+
+def test_tanh_activation_vs_oracle_gpu(golden):
+    """args.use_ReLU off (utils/mappo_utils/mlp.py:10): the actor/critic kernels' second activation -- the reference-recorded
+    fixture (tests/golden/ippo_train_tanh.pt), IPPOLearner.train at the full config-3 size (one epoch, agent 2, split-bf16 fc1
+    path) and the rollout body (actions bit-equal) against the oracle"""
+    from tests.oracle_checks import check_ppo_train_vs_oracle
+    from tests.rollout_oracle import check_rollout_body
+    from tests.test_emu_learners import check_ippo_train
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    check_ippo_train(golden("ippo_train_tanh"), "cuda")
+    _log("tanh_ppo_train_cfg3_22950rows_agent2_1epoch", check_ppo_train_vs_oracle(_args(ppo_epoch=1, use_ReLU=False), "cuda", seed=44, agents=(2,)))
+    _log("tanh_rollout_body_cfg3_E32_T4", check_rollout_body(_args(episode_limit=4, batch_size_run=32, use_ReLU=False), 32, "cuda", seed=45))
