@@ -415,11 +415,17 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
     f_fc1 = nA * 2.0 * rows * F * 2 * M                                                  # fc1 of actor + critic: 2 F M FLOP per row and net
     b_fc1 = nA * (4.0 * rows * kpad32 + 2 * 4.0 * rows * M)                              # fragments once + z1 of both nets
     b_tail = nA * 2 * 4.0 * rows * (M + M + 648)                                         # z1 + h in, the activation record out
+    fused_ac = not os.environ.get("IPLAN_NO_FUSE_AC") and not os.environ.get("IPLAN_NO_FUSE_ENC")      # harness._rollout_body
+    # actor + critic forward of one vector step (rows (2 F M + 14 M^2 + 2 M n_out) per net)
+    f_ac = (nA * E * (2 * (2.0 * F * M + 14.0 * M * M) + 2.0 * M * (args.n_actions + 1))) if fused_ac else 0.0
     out = [
-        entry("gat_enc_fwd_kernel", "gat_fwd_kernel", "mfma",
-              gat_algorithmic_flops(nA, E, N, d + Z) + nA * V * (Lw * (2 * d * R + 12 * R * R) + 2 * R * Z), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
+        entry("gat_enc_ac_fwd_kernel" if fused_ac else "gat_enc_fwd_kernel", "gat_fwd_kernel", "mfma",
+              gat_algorithmic_flops(nA, E, N, d + Z) + nA * V * (Lw * (2 * d * R + 12 * R * R) + 2 * R * Z) + f_ac, 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
               f"the rollout's vector step as one launch: GAT_latent_update (5 nets x {E} envs x 55 entities = 160 scene workgroups, 6.41 GFLOP) "
-              f"+ the behaviour encoder's latent_update behind them (1.1 GFLOP), {rollouts_per_step * (T + 1)} launches per step (the episode-initial GAT "
+              f"+ the behaviour encoder's latent_update behind them (1.1 GFLOP)"
+              + (f" + the NEXT step's select_actions_ippo as the grid's last workgroups ({f_ac / 1e9:.2f} GFLOP; it waits for the scenes, so the "
+                 "launch lasts GAT + the action selection's tail)" if fused_ac else "")
+              + f", {rollouts_per_step * (T + 1)} launches per step (the episode-initial GAT "
               "update of each rollout runs alone); fp32 results: "
               "the 54-step bi-GRU recurrence (84 % of the algorithmic FLOPs) is issued as 6 bf16 piece products per fp32 product "
               "on the bf16 matrix cores (fp32-exact split, DESIGN.md section 4), the rest as fp32 MFMA; peak = the fp32 MFMA / vector peak"),

@@ -275,6 +275,12 @@ typedef struct {
 } IplanAcFwdArgs;
 
 int iplan_ac_fwd(const IplanAcFwdArgs* args, iplan_stream_t stream);
+/* One rollout vector step as ONE launch (runners/ippo_parallel_runner.py:166-268, controllers/dcntrl_controller.py:27-58): the
+ * latent updates of step t (iplan_gat_enc_fwd) and, behind them in the same grid, select_actions_ippo of step t + 1, which reads
+ * exactly what they write (the environment steps after the action selection, not between the two).  `ac` must be a rollout-shaped
+ * iplan_ac_fwd argument set (ksplit 8, nothing saved).  `sync`: 3 int32 counters owned by the caller, zero before the first use,
+ * private to one stream; [0] / [1] are back at zero when the launch ends, [2] != 0 reports a wait that gave up (poll limit). */
+int iplan_gat_enc_ac_fwd(const IplanGatFwdArgs* gat, const IplanEncFwdArgs* enc, const IplanAcFwdArgs* ac, int32_t* sync, iplan_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Gumbel(0, 1) samples  g = -log(-log(u)),  u uniform on (0, 1): the noise F.gumbel_softmax draws inside

@@ -54,7 +54,7 @@ ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_st
                 "iplan_ac_xhat_pack", "iplan_ac_fc1_split_fwd", "iplan_ac_bwd_fc1_split",
                 "iplan_p2p_publish", "iplan_p2p_reduce"]
 RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups", "iplan_sizeof", "iplan_ac_packed_floats",
-                    "iplan_p2p_alloc", "iplan_p2p_free", "iplan_p2p_export", "iplan_p2p_open", "iplan_p2p_close", "iplan_gat_enc_fwd", "iplan_gumbel_noise", "iplan_ac_xhat_floats", "iplan_ac_fc1_split_chunks"]      # non (args*, stream) signatures
+                    "iplan_p2p_alloc", "iplan_p2p_free", "iplan_p2p_export", "iplan_p2p_open", "iplan_p2p_close", "iplan_gat_enc_fwd", "iplan_gat_enc_ac_fwd", "iplan_gumbel_noise", "iplan_ac_xhat_floats", "iplan_ac_fc1_split_chunks"]      # non (args*, stream) signatures
 
 
 class Lib:
@@ -84,6 +84,7 @@ class Lib:
         cdll.iplan_wgrad_workspace_floats.restype = C.c_size_t
         cdll.iplan_wgrad_workspace_floats.argtypes = [C.c_void_p]
         cdll.iplan_gat_enc_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        cdll.iplan_gat_enc_ac_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         cdll.iplan_gumbel_noise.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]
         cdll.iplan_p2p_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
         cdll.iplan_p2p_free.argtypes = [C.c_void_p]

@@ -56,14 +56,17 @@ class DcntrlMAC:
         t = t.to(self.device) if t.device != self.device else t
         return t if dtype is None or t.dtype == dtype else t.to(dtype)
 
-    def select_actions_ippo(self, ep_batch, t_ep, test_mode=False, q_noise=None, as_numpy=True, write_back=False, phase_clocks=None):
+    def select_actions_ippo(self, ep_batch, t_ep, test_mode=False, q_noise=None, as_numpy=True, write_back=False, phase_clocks=None, launch=True):
         """One fused launch: features gathered in place from ``ep_batch`` at ``t_ep``, all agents,
         actor + critic (controllers/dcntrl_controller.py:27-58).  Returns the reference's 5-tuple
         (values [E,nA], actions [E,nA], list of nA logp [E,1], rnn_states_actors [1,E,nA,M],
         rnn_states_critics [1,E,nA,M]); numpy for the array items unless ``as_numpy=False``.
         ``write_back=True`` (device-resident rollouts): the kernel additionally writes the actions, their
         one-hot and the new GRU states straight into ``ep_batch`` (actions / actions_onehot at ``t_ep``, rnn
-        states at ``t_ep + 1``), i.e. the ``EpisodeBatch.update`` of ippo_parallel_runner.py:260-266."""
+        states at ``t_ep + 1``), i.e. the ``EpisodeBatch.update`` of ippo_parallel_runner.py:260-266.
+        ``launch=False`` (with ``write_back``): nothing is enqueued; returns the prepared launch for
+        ``Prediction_policy.GAT_latent_update(..., fuse_ac=...)`` of step ``t_ep - 1``, whose launch then carries this action
+        selection behind the latent updates it reads (ops.gat_forward)."""
         a = self.args
         nA, N, M = self.n_agents, a.max_vehicle_num, a.rnn_hidden_dim
         E = ep_batch.batch_size
@@ -103,7 +106,10 @@ class DcntrlMAC:
                            h_strides=(ha.stride(1), ha.stride(0)), avail=avail,
                            avail_strides=(avail.stride(1), avail.stride(0)),
                            mode=0 if test_mode else 1, q_noise=q_noise, n_actions=a.n_actions, phase_clocks=phase_clocks,
-                           packed=self.fc1_pack.get(spec, fold=E <= 512), **wb)
+                           packed=self.fc1_pack.get(spec, fold=E <= 512), launch=launch, **wb)
+        if not launch:
+            assert write_back
+            return o
         values = o["values"].t()                                          # [E, nA]
         logps = [o["logp"][i].reshape(E, 1) for i in range(nA)]
         if write_back:

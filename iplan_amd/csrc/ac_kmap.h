@@ -92,13 +92,16 @@ __device__ __forceinline__ int korder_of_column(const KMap& k, int c) {
     return k.kt0[s] * 16 + e * k.w[s] + r;
 }
 
-// this lane's 4 raw features of one row for a k-tile
+// this lane's 4 raw features of one row for a k-tile; COH: blocks 1 and 2 (the latents) are read device-coherently -- in the
+// fused rollout launch other workgroups of the same launch write them (ac_fwd_body.h)
+template <bool COH = false>
 __device__ __forceinline__ f32x4 kfeat(const KMap& k, const KTile& kt, const float* const (&src)[3], bool valid, int last, int net) {
     f32x4 v = splat4(0.f);
     if (!valid || kt.nv == 0) return v;
     if (kt.s < 3) {
         const float* p = src[kt.s] + kt.f0;
-        if (kt.nv == 4) v = ldu4(p);
+        if (COH && kt.s > 0) { for (int q = 0; q < 4; ++q) if (q < kt.nv) v[q] = coh_load(p + q); }
+        else if (kt.nv == 4) v = ldu4(p);
         else for (int q = 0; q < 4; ++q) if (q < kt.nv) v[q] = as_global(p)[q];
     } else {
         for (int q = 0; q < 4; ++q) {

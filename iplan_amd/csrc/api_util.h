@@ -25,6 +25,8 @@ inline int check_launch(const char* what) {
     return IPLAN_OK;
 }
 
+int ac_fwd_check(const IplanAcFwdArgs* a);   // argument checks of iplan_ac_fwd (actor_critic.hip), also used by iplan_gat_enc_ac_fwd
+
 __host__ __device__ inline bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
 
 }  // namespace iplan

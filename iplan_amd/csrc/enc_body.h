@@ -11,6 +11,8 @@ constexpr int ELD = ER + 4;    // padded LDS leading dimension
 constexpr int ENC_LDS_FLOATS = ER * 20 + 2 * 3 * ER * ELD + 16 * ELD + ER + 2 * 3 * ER + 16;     // 33.6 KB
 
 // `lds`: >= ENC_LDS_FLOATS floats, 16-byte aligned; `tile` = the wave's 16-row tile index; all threads of the block call it.
+// COH: the new latent is stored device-coherently (read by other workgroups of the same launch: gat.hip, gat_enc_ac_fwd_kernel)
+template <bool COH = false>
 __device__ __forceinline__ void enc_fwd_block(const IplanEncFwdArgs& a, int net, int tile, float* __restrict__ lds) {
     float* s_lin = lds;
     float* s_wih = s_lin + ER * 20;
@@ -79,7 +81,7 @@ __device__ __forceinline__ void enc_fwd_block(const IplanEncFwdArgs& a, int net,
         for (int q = 0; q < 4; ++q) lat[q] = a.one_minus_c * pv[q] + lat[q] * a.c;   // stable_behavior_policy.py:118
     }
     float* lrow = a.latent_out + (int64_t)net * a.lo_s_net + (int64_t)b * a.lo_s_b + (int64_t)i * a.Z;
-    vstore(lrow, valid, a.Z, 0, lat);
+    vstore_c<COH>(lrow, valid, a.Z, 0, lat);
 }
 
 }  // namespace iplan

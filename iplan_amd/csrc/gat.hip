@@ -22,6 +22,7 @@
 #include "api_util.h"
 #include "wave_tile.h"
 #include "enc_body.h"
+#include "ac_fwd_body.h"
 
 namespace iplan {
 
@@ -39,7 +40,9 @@ struct GatShared {                      // LDS of one scene (147 KB)
     float pl[2][NP][NP][2];
 };
 
-// one scene = workgroup `block` of the launch (512 threads)
+// one scene = workgroup `block` of the launch (512 threads); COH: the new latent is stored device-coherently (read by other
+// workgroups of the same launch: gat_enc_ac_fwd_kernel)
+template <bool COH = false>
 __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int block, GatShared& sh) {
     auto& s_B = sh.B;
     auto& s_q = sh.q;
@@ -377,7 +380,7 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
         }
         const GruGates o = gru_gates(pr, pz, gn, hn, hp[t]);
         float* orow = a.out + (int64_t)net * a.out_s_net + (int64_t)b * a.out_s_b + (int64_t)node * GH;
-        vstore(orow, valid, GH, t, o.h);
+        vstore_c<COH>(orow, valid, GH, t, o.h);
         if (sv.cell) {
             float* row = sv.cell + (sb * N + node) * (4 * GH);
             vstore(row, valid, GH, t, o.r);
@@ -415,6 +418,36 @@ __global__ __launch_bounds__(512) void gat_enc_fwd_kernel(IplanGatFwdArgs a, Ipl
     }
 }
 
+// ... and the NEXT step's action selection behind both (runners/ippo_parallel_runner.py:166-268: select_actions of step t + 1
+// reads exactly what the latent updates of step t write, and nothing sits between them -- the environment steps AFTER the
+// action selection).  The actor/critic workgroups are the last ones of the grid: they stage their tail weights, compute
+// W_hh h and the history block of the fc1 contraction while the scenes run, wait until every scene and encoder workgroup has
+// counted itself into sync[0] (ac_fwd_body.h), and go on with the latent blocks.  One launch boundary per vector step instead of
+// two, and the action selection's prologue off the critical path.
+union GatAcShared {
+    GatShared gat;
+    AcShared<1> ac;
+};
+
+__global__ __launch_bounds__(512) void gat_enc_ac_fwd_kernel(IplanGatFwdArgs a, IplanEncFwdArgs e, IplanAcFwdArgs c, int n_gat, int enc_blocks_per_net,
+                                                             int n_enc, int ac_gx, int32_t* sync) {
+    __shared__ __attribute__((aligned(16))) GatAcShared sh;
+    static_assert(sizeof(GatShared) >= sizeof(float) * ENC_LDS_FLOATS, "encoder LDS must fit into the scene's");
+    const int block = (int)blockIdx.x;
+    if (block < n_gat) {
+        gat_fwd_block<true>(a, block, sh.gat);
+        ac_signal_producer_done(sync);
+    } else if (block < n_gat + n_enc) {
+        const int j = block - n_gat, net = j / enc_blocks_per_net, tb = j - net * enc_blocks_per_net;
+        enc_fwd_block<true>(e, net, tb * 8 + wave_id(), reinterpret_cast<float*>(&sh));
+        ac_signal_producer_done(sync);
+    } else {
+        const int j = block - n_gat - n_enc, gy = c.n_agents, gz = c.which == 2 ? 2 : 1;
+        const AcGrid gp = {j % ac_gx, (j / ac_gx) % gy, j / (ac_gx * gy), ac_gx, gy, gz};
+        ac_fwd_body<1, false, true>(c, gp, sh.ac, AcProducers{sync, n_gat + n_enc, ac_gx * gy * gz});
+    }
+}
+
 }  // namespace iplan
 
 static int check_gat(const IplanGatFwdArgs* a, const char* what);
@@ -431,6 +464,26 @@ extern "C" int iplan_gat_enc_fwd(const IplanGatFwdArgs* a, const IplanEncFwdArgs
     hipLaunchKernelGGL(gat_enc_fwd_kernel, dim3((unsigned)(n_gat + per_net * e->n_nets)), dim3(512), 0, (hipStream_t)stream, *a, *e,
                        n_gat, per_net);
     return check_launch("iplan_gat_enc_fwd");
+}
+
+extern "C" int iplan_gat_enc_ac_fwd(const IplanGatFwdArgs* a, const IplanEncFwdArgs* e, const IplanAcFwdArgs* c, int32_t* sync, iplan_stream_t stream) {
+    using namespace iplan;
+    if (int rc = check_gat(a, "iplan_gat_enc_ac_fwd")) return rc;
+    if (!e || !c || !sync) return fail(IPLAN_EINVAL, "iplan_gat_enc_ac_fwd: null encoder / actor-critic args or sync");
+    if (e->d < 1 || e->d > 16 || e->Z < 1 || e->Z > 16 || e->L < 1 || e->n_nets < 1 || e->B < 1 || e->N < 1)
+        return fail(IPLAN_EINVAL, "iplan_gat_enc_ac_fwd: unsupported encoder dims d=%d Z=%d L=%d", e->d, e->Z, e->L);
+    if (!e->x || !e->h0 || !e->hL || !e->latent_out || !e->params)
+        return fail(IPLAN_EINVAL, "iplan_gat_enc_ac_fwd: null encoder tensor pointer");
+    if (int rc = ac_fwd_check(c)) return rc;
+    if (c->ksplit != 8 || c->saved || c->fc1_pre || c->ln_stats_mode != 0)
+        return fail(IPLAN_EINVAL, "iplan_gat_enc_ac_fwd: the actor/critic part must be a rollout-shaped launch (ksplit 8, one-pass "
+                                  "LayerNorm statistics, nothing saved)");
+    const int n_gat = a->n_nets * a->B, per_net = (e->B * e->N + 127) / 128, n_enc = per_net * e->n_nets;
+    const int tiles = (c->rows + 15) / 16, ac_gx = tiles * (c->ksplit_wg > 1 ? c->ksplit_wg : 1);
+    const int n_ac = ac_gx * c->n_agents * (c->which == 2 ? 2 : 1);
+    hipLaunchKernelGGL(gat_enc_ac_fwd_kernel, dim3((unsigned)(n_gat + n_enc + n_ac)), dim3(512), 0, (hipStream_t)stream, *a, *e, *c,
+                       n_gat, per_net, n_enc, ac_gx, sync);
+    return check_launch("iplan_gat_enc_ac_fwd");
 }
 
 static int check_gat(const IplanGatFwdArgs* a, const char* what) {

@@ -298,6 +298,41 @@ __device__ __forceinline__ void vstore(float* __restrict__ row, bool valid, int 
     }
 }
 
+// Device-coherent accesses (agent scope, relaxed): a value written by one workgroup of a launch and read by another of the SAME
+// launch -- possibly behind another XCD's L2 -- goes around the non-coherent caches (sc1 stores write through, sc1 loads do not
+// hit stale lines), so that neither side needs a cache write-back / invalidate (the fused rollout launch, ac_fwd_body.h).
+#ifndef IPLAN_FUSED_FENCES
+#define IPLAN_FUSED_FENCES 0          // 1 (A/B builds): plain stores / loads + one agent-scope release / acquire fence per workgroup
+#endif
+__device__ __forceinline__ void coh_store(float* p, float v) {
+#if defined(IPLAN_HOST_EMULATION) || IPLAN_FUSED_FENCES
+    *p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ float coh_load(const float* p) {
+#if defined(IPLAN_HOST_EMULATION) || IPLAN_FUSED_FENCES
+    return *p;
+#else
+    return __hip_atomic_load(as_global(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ f32x4 coh_load4(const float* p) {
+    f32x4 v;
+    for (int q = 0; q < 4; ++q) v[q] = coh_load(p + q);
+    return v;
+}
+// vstore with device-coherent stores (COH) or plain ones
+template <bool COH>
+__device__ __forceinline__ void vstore_c(float* __restrict__ row, bool valid, int dim, int t, f32x4 v) {
+    if (!COH) { vstore(row, valid, dim, t, v); return; }
+    const int c = 16 * t + 4 * (lane_id() >> 4);
+    if (valid)
+        for (int q = 0; q < 4; ++q)
+            if (c + q < dim) coh_store(row + c + q, v[q]);
+}
+
 // Aligned whole-tile variants (row 16-byte aligned, tile t entirely inside the vector): one predicated 16-byte
 // access, none of the per-lane alignment / tail branching of vload / vstore.
 __device__ __forceinline__ f32x4 vload_a(const float* __restrict__ row, bool valid, int t) {

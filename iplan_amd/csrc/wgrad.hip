@@ -15,7 +15,8 @@
 //
 // The contraction streams every row once per wave job, so it is HBM-bound by the bytes its jobs REQUEST: waves
 // that read the same rows drift apart by far more than the L2 a streaming wave can count on, i.e. sharing
-// through the cache does not happen.  Hence two job shapes:
+// through the cache does not happen (round 4: the two wide jobs of a GRU -- same dY rows -- as the two waves of one workgroup,
+// i.e. on one CU and at one pace: wide kernel 2.84 -> 2.79 ms, cycle unchanged; not kept).  Hence two job shapes:
 //   wide   12 x 4 tiles (192 accumulator registers, one wave per SIMD): a GRU weight [192 x 64] is ONE job --
 //          its dY rows and its X rows are read exactly once.  Since round 3 these jobs run on the bf16 matrix cores
 //          (wgrad_partial_bf16_kernel below: fp32-exact split-bf16 products, 32-row blocks); the fp32 kernel keeps the

@@ -186,15 +186,25 @@ class SyntheticLoop:
         # One launch per step for both latent updates (iplan_gat_enc_fwd: GAT's whole-CU workgroups are dispatched ahead of the
         # encoder's, and the two cross-stream joins of a step disappear); IPLAN_NO_FUSE_ENC=1: two launches on two streams
         fuse = self.prediction is not None and self.behavior is not None and not os.environ.get("IPLAN_NO_FUSE_ENC")
+        # ... and the NEXT step's action selection rides in it too (iplan_gat_enc_ac_fwd): select_actions of step t + 1 reads what
+        # the latent updates of step t write and nothing sits between the two (the environment steps after the action
+        # selection), so its workgroups queue behind the scenes' in the same grid -- one launch per vector step.
+        # IPLAN_NO_FUSE_AC=1: two launches per step (A/B knob)
+        fuse_ac = fuse and not os.environ.get("IPLAN_NO_FUSE_AC")
         for t in range(T):
-            self.mac.select_actions_ippo(batch, t, test_mode=False, q_noise=q_all[t], as_numpy=False, write_back=True)
+            if not (fuse_ac and t > 0):
+                self.mac.select_actions_ippo(batch, t, test_mode=False, q_noise=q_all[t], as_numpy=False, write_back=True)
             # env.step would run here; its outputs are the pre-generated tensors
             if fuse:
                 window = hist_all[t + 1:t + 1 + L].permute(1, 2, 3, 0, 4)
                 enc = self.behavior.latent_update(window, eh[t & 1], D["behavior_latent"][:, t], out_latent=D["behavior_latent"][:, t + 1],
                                                   out_hidden=eh[(t + 1) & 1][:, 0], launch=False)
+                nxt = None
+                if fuse_ac and t + 1 < T:
+                    nxt = self.mac.select_actions_ippo(batch, t + 1, test_mode=False, q_noise=q_all[t + 1], as_numpy=False, write_back=True,
+                                                       launch=False)
                 self.prediction.GAT_latent_update(D["history"][:, t + 1], D["attention_latent"][:, t], D["behavior_latent"][:, t],
-                                                  noise=noise[t], out=D["attention_latent"][:, t + 1], fuse_enc=enc)
+                                                  noise=noise[t], out=D["attention_latent"][:, t + 1], fuse_enc=enc, fuse_ac=nxt)
                 continue
             if two_streams:
                 side.wait_stream(main)
@@ -266,7 +276,10 @@ class SyntheticLoop:
         # after another; only the host read-backs are deferred to the join.
         main = torch.cuda.current_stream(dev)
         if getattr(self, "_lstreams", None) is None:
-            self._lstreams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+            # IPLAN_PPO_PRIO=1 (A/B knob): the PPO update's stream at high priority -- its ~25 small launches per epoch are a latency
+            # chain that otherwise queues for CU slots behind the behaviour kernels' long-lived workgroups
+            prio = -1 if os.environ.get("IPLAN_PPO_PRIO") else 0
+            self._lstreams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=prio))
         fins = []
         # the behaviour learner's data-movement head first: its tiny launches would otherwise sit behind the side learners' kernels
         prep = self.behavior.prepare_learn(batch) if getattr(type(self.behavior), "learn_takes_prepared", False) else None

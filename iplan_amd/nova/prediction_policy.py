@@ -70,7 +70,7 @@ class Prediction_policy:
                       weight_decay=self.weight_decay) for i in range(self.n_agents)]
 
     # ---------------------------------------------------------------------------- rollout
-    def GAT_latent_update(self, history_single, encoder_hidden, behavior_latent=None, noise=None, out=None, fuse_enc=None):
+    def GAT_latent_update(self, history_single, encoder_hidden, behavior_latent=None, noise=None, out=None, fuse_enc=None, fuse_ac=None):
         """history_single [E,nA,N,d], encoder_hidden [E,nA,N,A], behavior_latent [E,nA,N,Z] ->
         attention latent [E,nA,N,A]  (nova/prediction_policy.py:92-118).
         numpy in -> numpy out (drop-in for ParallelRunner); device tensors in -> device tensor out.
@@ -86,7 +86,7 @@ class Prediction_policy:
         if noise is None:
             noise = gumbel_noise((nA, E, N, N - 1, 2), self.device)
         out, _ = ops.gat_forward(self.gat_arena, hist.permute(1, 0, 2, 3), lat, hid.permute(1, 0, 2, 3), noise,
-                                 out=None if out is None else out.permute(1, 0, 2, 3), fuse_enc=fuse_enc)
+                                 out=None if out is None else out.permute(1, 0, 2, 3), fuse_enc=fuse_enc, fuse_ac=fuse_ac)
         out = out.permute(1, 0, 2, 3)          # [E, nA, N, A] view
         return out.cpu().numpy() if as_np else out
 

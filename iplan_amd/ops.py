@@ -30,12 +30,14 @@ def _nb_strides(t, inner):
     return t.stride(0), t.stride(1)
 
 
-def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None, phase_clocks=None, lib=None, fuse_enc=None):
+def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None, phase_clocks=None, lib=None, fuse_enc=None, fuse_ac=None):
     """GAT_Net.forward for all nets.  src0 [n_nets,B,N,d0], src1 [n_nets,B,N,d1] or None,
     h_prev [n_nets,B,N,A] (first two dims may be arbitrarily strided views), noise
     [n_nets,B,N,N-1,2] contiguous.  Returns (out [n_nets,B,N,A], saved dict or None).
     ``fuse_enc``: what ``enc_forward(..., launch=False)`` returned -- the encoder's latent update of the same rollout step rides
-    in this launch (iplan_gat_enc_fwd: the GAT scenes' workgroups first, the encoder's behind them)."""
+    in this launch (iplan_gat_enc_fwd: the GAT scenes' workgroups first, the encoder's behind them).
+    ``fuse_ac`` (with ``fuse_enc``): what ``ac_forward(..., launch=False)`` returned for the NEXT step's action selection -- it
+    reads what this launch writes and runs as its last workgroups (iplan_gat_enc_ac_fwd)."""
     lib = _lib(lib)
     n_nets, B, N, d0 = src0.shape
     d1 = 0 if src1 is None else src1.shape[-1]
@@ -78,7 +80,17 @@ def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None
         )
         for k, v in saved.items():
             setattr(a.saved, k, v.data_ptr())
-    if fuse_enc is not None:
+    if fuse_enc is not None and fuse_ac is not None:
+        sync = _fused_sync(dev)
+
+        def fused3():
+            rc = lib.c.iplan_gat_enc_ac_fwd(C.byref(a), C.byref(fuse_enc["args"]), C.byref(fuse_ac["_args"]), C.c_void_p(sync.data_ptr()),
+                                            C.c_void_p(L.current_stream(dev) or 0))
+            if rc != 0:
+                raise L.IplanError(f"iplan_gat_enc_ac_fwd failed ({rc}): {lib.c.iplan_last_error().decode()}")
+        _launch("gat_fwd_kernel", fused3)
+    elif fuse_enc is not None:
+        assert fuse_ac is None
         def fused():
             rc = lib.c.iplan_gat_enc_fwd(C.byref(a), C.byref(fuse_enc["args"]), C.c_void_p(L.current_stream(dev) or 0))
             if rc != 0:
@@ -90,6 +102,23 @@ def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None
         saved["_args"] = a
         saved["_keep"] = (src0, src1, h_prev, noise, out)
     return out, saved
+
+
+_FUSED_SYNC = {}
+
+
+def _fused_sync(dev):
+    """the 3 counters of iplan_gat_enc_ac_fwd, private to (device, current stream)"""
+    key = (str(dev), L.current_stream(dev))
+    buf = _FUSED_SYNC.get(key)
+    if buf is None:
+        buf = _FUSED_SYNC[key] = torch.zeros(4, dtype=torch.int32, device=dev)
+    return buf
+
+
+def fused_sync_error():
+    """True if any fused rollout launch gave up waiting for its producers (reads the device: tests / end of a rollout only)"""
+    return any(int(b[2]) != 0 for b in _FUSED_SYNC.values())
 
 
 def enc_forward(arena, x, h0, prev_latent, coef, Z, out_lat=None, out_h=None, lib=None, launch=True):
@@ -178,8 +207,10 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
                h_strides=(0, 0), avail=None, avail_strides=(0, 0), mode=0, q_noise=None, actions_in=None,
                act_strides=(0, 0), n_actions=5, ksplit=None, save=False, want_probs=False, want_entropy=False,
                want_h=True, h_out=None, actions_out=None, onehot_out=None, ln_stats=None, ln_stats_mode=0, phase_clocks=None,
-               packed=None, xhat=None, lib=None):
+               packed=None, xhat=None, lib=None, launch=True):
     """Fused actor (which=0) / critic (1) / both (2) forward for all agents.
+    ``launch=False`` (rollout shape only): everything is set up but nothing is enqueued -- the returned dict goes to
+    ``gat_forward(fuse_ac=...)``, whose launch runs this action selection behind the latent updates it depends on.
     Returns a dict with the requested outputs, each laid out [n_agents, rows, ...].
     Optional in-place destinations (rollout: write straight into the episode buffer):
       h_out = (actor_tensor, critic_tensor, (s_net, s_row));  actions_out = (int64 tensor, (s_net, s_row));
@@ -293,8 +324,11 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
                 work=2.0 * n_agents * rows * spec.F * 2 * L.AC_HIDDEN)
         a.fc1_pre = z1.data_ptr()
         out["_xhat"] = xhat
-    _launch("ac_fwd_kernel:train" if save else ("ac_fwd_kernel:rollout" if rows <= 512 else "ac_fwd_kernel:infer"),
-            lambda: lib.call("iplan_ac_fwd", a, L.current_stream(dev)))
+    if launch:
+        _launch("ac_fwd_kernel:train" if save else ("ac_fwd_kernel:rollout" if rows <= 512 else "ac_fwd_kernel:infer"),
+                lambda: lib.call("iplan_ac_fwd", a, L.current_stream(dev)))
+    else:
+        assert a.ksplit == 8 and not save and xhat is None and a.ln_stats_mode == 0, "launch=False is for the rollout-shaped forward"
     out["_args"] = a
     out["_keep"] = (spec, h_actor, h_critic, avail, q_noise, actions_in, h_out, actions_out, onehot_out, ln_stats, packed, z1, xhat, ks_bufs)
     return out

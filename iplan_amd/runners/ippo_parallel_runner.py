@@ -145,11 +145,18 @@ class ParallelRunner:
                                                       out=D("attention_latent")[:, 0], noise=None if noise is None else noise[a.episode_limit])
         D("filled")[:, 0] = 1
         act_host = torch.empty(E, nA, dtype=torch.long, pin_memory=dev.type == "cuda")
+        import os
+        # the next step's action selection reads exactly what this step's latent updates write and the simulator only steps after
+        # it: with both incentives on it rides in their launch (iplan_gat_enc_ac_fwd).  IPLAN_NO_FUSE_AC=1: its own launch
+        fuse_ac = a.GAT_enable and a.Behavior_enable and not os.environ.get("IPLAN_NO_FUSE_AC")
+        ac_in_flight = False
         for _ in range(a.episode_limit):
             t = self.t
             # actions, their one-hot and the new GRU states go straight into the episode container
             # (the reference never forwards test_mode to the controller -- it samples in test runs too, :172-173)
-            self.mac.select_actions_ippo(self.batch, t_ep=t, as_numpy=False, write_back=True, q_noise=None if q_all is None else q_all[t])
+            if not ac_in_flight:           # (otherwise it rode in the previous step's latent-update launch, see below)
+                self.mac.select_actions_ippo(self.batch, t_ep=t, as_numpy=False, write_back=True, q_noise=None if q_all is None else q_all[t])
+            ac_in_flight = False
             if terminated.any():                 # envs that terminated earlier store action 0 (action2env_tuple, :81-83, 177-180)
                 dead = torch.as_tensor(np.flatnonzero(terminated), device=dev)
                 D("actions")[dead, t] = 0
@@ -190,8 +197,17 @@ class ParallelRunner:
             if a.GAT_enable and a.Behavior_enable:           # both latent updates of the step in one launch (iplan_gat_enc_fwd)
                 enc = self.behavior_learner.latent_update(self._to_dev("window", window, torch.float32), eh[t & 1], D("behavior_latent")[:, t],
                                                           out_latent=D("behavior_latent")[:, t + 1], out_hidden=eh[(t + 1) & 1][:, 0], launch=False)
+                nxt = None
+                step_noise = None if noise is None else noise[t]
+                if fuse_ac and t + 1 < a.episode_limit:
+                    if step_noise is None:       # random draws in the two-launch order: this update's gumbel samples, then the action race's
+                        from ..nova.GAT_Net import gumbel_noise
+                        step_noise = gumbel_noise((nA, E, self.max_vehicle_num, self.max_vehicle_num - 1, 2), dev)
+                    nxt = self.mac.select_actions_ippo(self.batch, t_ep=t + 1, as_numpy=False, write_back=True, launch=False,
+                                                       q_noise=None if q_all is None else q_all[t + 1])
+                    ac_in_flight = True
                 self.prediction_learner.GAT_latent_update(D("history")[:, t + 1], D("attention_latent")[:, t], D("behavior_latent")[:, t],
-                                                          out=D("attention_latent")[:, t + 1], fuse_enc=enc, noise=None if noise is None else noise[t])
+                                                          out=D("attention_latent")[:, t + 1], fuse_enc=enc, fuse_ac=nxt, noise=step_noise)
             elif a.GAT_enable:
                 self.prediction_learner.GAT_latent_update(D("history")[:, t + 1], D("attention_latent")[:, t], D("behavior_latent")[:, t],
                                                           out=D("attention_latent")[:, t + 1], noise=None if noise is None else noise[t])

@@ -3,6 +3,8 @@
 (runners/ippo_parallel_runner.py:105-281 order of calls: select_actions_ippo -> [env.step] -> GAT_latent_update ->
 latent_update -> EpisodeBatch.update), with the random draws (gumbel noise, exponential race) injected into both.
 Shared by the emulated (CPU) and the ``-m gpu`` tests."""
+import os
+
 import torch
 
 from oracle import iplan_oracle as O
@@ -89,6 +91,25 @@ def check_rollout_body(args, E, device, seed=0, tol=1e-5):
         loop._rollout_body(obs, batch, noise=noise.to(device), q_all=q_all.to(device))
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize()
+    from iplan_amd import ops
+    assert not ops.fused_sync_error(), "a fused rollout launch gave up waiting for its latent updates"
+    # the one-launch vector step (latent updates + the next step's action selection, iplan_gat_enc_ac_fwd) against the two-launch
+    # form: the same source in the same order -- actions bit-equal; the float fields to fp32 round-off (on the GPU the two kernels
+    # are separate instantiations of the scene body and the compiler contracts a few multiply-adds differently: 1e-7 measured,
+    # scripts/dev/fused_step_probe.py; the emulated build is bit-identical)
+    if not os.environ.get("IPLAN_NO_FUSE_AC") and loop.prediction is not None and loop.behavior is not None:
+        os.environ["IPLAN_NO_FUSE_AC"] = "1"
+        try:
+            batch2 = loop.new_batch()
+            with torch.no_grad():
+                loop._rollout_body(obs, batch2, noise=noise.to(device), q_all=q_all.to(device))
+        finally:
+            del os.environ["IPLAN_NO_FUSE_AC"]
+        for k in ("actions", "actions_onehot"):
+            assert torch.equal(batch[k], batch2[k]), ("fused vs two-launch step differ", k)
+        for k in ("attention_latent", "behavior_latent", "rnn_states_actors", "rnn_states_critics"):
+            e = (batch[k].double() - batch2[k].double()).abs().max().item()
+            assert e <= 2e-6 * max(1.0, batch2[k].abs().max().item()), ("fused vs two-launch step differ", k, e)
     ref = oracle_rollout(loop, obs, noise, q_all)
     got = {k: batch[k].cpu() for k in ("history", "attention_latent", "behavior_latent", "rnn_states_actors", "rnn_states_critics",
                                        "actions", "actions_onehot")}
