@@ -311,6 +311,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timed = ops.TIMERS.summary()
+    scene_clocks = ops.TIMERS.clocks.get("gat_scenes_clocks", [])
+    if scene_clocks:                                        # span of the scenes inside the sampled fused launches (100 MHz stamps)
+        spans = [(c.view(-1, 5)[:, 4].max() - c.view(-1, 5)[:, 0].min()).item() / 100.0 for c in scene_clocks]
+        timed["gat_scenes_span_us"] = (len(spans), sum(spans) / len(spans), 0.0)
     ops.TIMERS = None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -396,6 +400,7 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
     pmc, pmc_src = load_pmc_traffic(E)
 
     def traffic_of(key):
+        key = key.replace("fwd2_kernel", "fwd_kernel").replace("bwd2_kernel", "bwd_kernel")      # (the PMC summary's keys name the kernel family)
         t = pmc.get(key)
         if t is not None and key == "iplan_wgrad:beh_dec":
             t = t // pieces(key)
@@ -419,20 +424,22 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
     # actor + critic forward of one vector step (rows (2 F M + 14 M^2 + 2 M n_out) per net)
     f_ac = (nA * E * (2 * (2.0 * F * M + 14.0 * M * M) + 2.0 * M * (args.n_actions + 1))) if fused_ac else 0.0
     out = [
-        entry("gat_enc_ac_fwd_kernel" if fused_ac else "gat_enc_fwd_kernel", "gat_fwd_kernel", "mfma",
+        entry("gat_enc_ac_fwd_kernel" if fused_ac else "gat_enc_fwd_kernel", "gat_enc_ac_fwd_kernel" if fused_ac else "gat_fwd_kernel", "mfma",
               gat_algorithmic_flops(nA, E, N, d + Z) + nA * V * (Lw * (2 * d * R + 12 * R * R) + 2 * R * Z) + f_ac, 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
               f"the rollout's vector step as one launch: GAT_latent_update (5 nets x {E} envs x 55 entities = 160 scene workgroups, 6.41 GFLOP) "
               f"+ the behaviour encoder's latent_update behind them (1.1 GFLOP)"
               + (f" + the NEXT step's select_actions_ippo as the grid's last workgroups ({f_ac / 1e9:.2f} GFLOP; it waits for the scenes, so the "
                  "launch lasts GAT + the action selection's tail)" if fused_ac else "")
-              + f", {rollouts_per_step * (T + 1)} launches per step (the episode-initial GAT "
-              "update of each rollout runs alone); fp32 results: "
+              + (f", {rollouts_per_step * (T - 1)} launches per step (an episode's first action selection, its initial GAT update and its "
+                 "last latent updates are launches of their own)" if fused_ac else
+                 f", {rollouts_per_step * (T + 1)} launches per step (the episode-initial GAT update of each rollout runs alone)")
+              + "; fp32 results: "
               "the 54-step bi-GRU recurrence (84 % of the algorithmic FLOPs) is issued as 6 bf16 piece products per fp32 product "
               "on the bf16 matrix cores (fp32-exact split, DESIGN.md section 4), the rest as fp32 MFMA; peak = the fp32 MFMA / vector peak"),
-        entry("beh_dec_bwd_kernel", "beh_dec_bwd_kernel", "mfma", f_dec / pieces("beh_dec_bwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
+        entry("beh_dec_bwd_kernel" if os.environ.get("IPLAN_DEC_BWD_V1") else "beh_dec_bwd2_kernel", "beh_dec_bwd_kernel", "mfma", f_dec / pieces("beh_dec_bwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
               f"decoder BPTT of Behavior_policy.learn (backward-data pass = 1x the forward FLOPs) in {pieces('beh_dec_bwd_kernel')} "
               "window-range launches per learn(), beside the weight-gradient contraction and the encoder BPTT of the previous range"),
-        entry("beh_dec_fwd_kernel", "beh_dec_fwd_kernel", "mfma", f_dec / pieces("beh_dec_fwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
+        entry("beh_dec_fwd_kernel" if os.environ.get("IPLAN_DEC_FWD_V1") else "beh_dec_fwd2_kernel", "beh_dec_fwd_kernel", "mfma", f_dec / pieces("beh_dec_fwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
               f"decoder forward of Behavior_policy.learn in {pieces('beh_dec_fwd_kernel')} window-range launches, beside the encoder forward"),
         entry("beh_enc_bwd_kernel", "beh_enc_bwd_kernel", "mfma", 2 * f_enc / pieces("beh_enc_bwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
               "encoder BPTT with in-kernel weight gradients (2x the forward FLOPs), side stream"),
@@ -454,6 +461,14 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
               "reads z1 and the stored GRU state, writes the 648-float activation record per row and net",
               traffic_key="ac_fwd_kernel:train"),
     ]
+    n_sc, sc_us, _ = timed.get("gat_scenes_span_us", (0, nan, 0.0))
+    if n_sc:
+        f_scenes = gat_algorithmic_flops(nA, E, N, d + Z) + nA * V * (Lw * (2 * d * R + 12 * R * R) + 2 * R * Z)
+        out[0]["scenes"] = {"what": "the GAT scenes + encoder tiles INSIDE the launch: first scene's entry stamp to the last scene's end stamp "
+                                    "(wall_clock64, 100 MHz, thread 0 of every scene workgroup), mean over the sampled launches; the rest of the launch "
+                                    "is the next step's action selection, a latency chain behind the last scene (DESIGN.md section 4)",
+                            "launches_sampled": n_sc, "span_us": sc_us, "algorithmic_gflop": f_scenes / 1e9,
+                            "achieved": f_scenes / (sc_us * 1e-6) / 1e12, "frac": f_scenes / (sc_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
     return out
 
 

@@ -82,13 +82,19 @@ def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None
             setattr(a.saved, k, v.data_ptr())
     if fuse_enc is not None and fuse_ac is not None:
         sync = _fused_sync(dev)
+        if TIMERS is not None and phase_clocks is None and TIMERS.sample("gat_scenes_clocks", 32):
+            # bench.py's roofline: in-kernel stamps of the scenes (entry / end of every scene workgroup, wall_clock64 = 100 MHz) of
+            # every 32nd fused launch -- the launch's own duration also holds the next step's action selection behind them
+            clocks = torch.zeros(n_nets * B * 5, dtype=torch.int64, device=dev)
+            a.phase_clocks = clocks.data_ptr()
+            TIMERS.clocks.setdefault("gat_scenes_clocks", []).append(clocks)
 
         def fused3():
             rc = lib.c.iplan_gat_enc_ac_fwd(C.byref(a), C.byref(fuse_enc["args"]), C.byref(fuse_ac["_args"]), C.c_void_p(sync.data_ptr()),
                                             C.c_void_p(L.current_stream(dev) or 0))
             if rc != 0:
                 raise L.IplanError(f"iplan_gat_enc_ac_fwd failed ({rc}): {lib.c.iplan_last_error().decode()}")
-        _launch("gat_fwd_kernel", fused3)
+        _launch("gat_enc_ac_fwd_kernel", fused3)
     elif fuse_enc is not None:
         assert fuse_ac is None
         def fused():
@@ -436,6 +442,12 @@ class KernelTimers:
         self.every = dict(every or {})
         self.count = {}
         self.spans = {}
+        self.clocks = {}                                    # name -> device buffers of in-kernel stamps (read after a synchronise)
+
+    def sample(self, name, every):
+        n = self.count.get(name, 0)
+        self.count[name] = n + 1
+        return n % every == 0
 
     def launch(self, name, fn, stream=None, work=0.0):
         n = self.count.get(name, 0)

@@ -1,14 +1,14 @@
 """GPU busy / idle time of the LAST bench cycle in a rocprofv3 kernel trace, and a per-phase timeline: the cycle is cut at the
-first gat_fwd launch after each PPO epoch block.  python scripts/trace_busy.py <kernel_trace.csv>
+first fused vector-step launch of a rollout.  python scripts/trace_busy.py <kernel_trace.csv>
 Prints: cycle wall time, union of kernel intervals (GPU busy), idle gaps by size class, and the phases (rollout = from a
-rollout's first gat_fwd to its last ac_fwd<1>; learn = until the next rollout's first gat_fwd)."""
+rollout's first vector-step launch -- gat_enc_ac_fwd / gat_enc_fwd -- to the end of its last one; learn = until the next rollout's first)."""
 import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = sorted(((r["Kernel_Name"].split("(")[0], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows), key=lambda r: r[1])
-# rollouts: runs of gat_fwd launches; a new rollout starts when the gap since the previous gat_fwd exceeds 2 ms
-gat = [k for k in ks if "gat_enc_fwd" in k[0] or "gat_fwd" in k[0]]
+# rollouts: runs of vector-step launches; a new rollout starts when the gap since the previous one exceeds 2 ms
+gat = [k for k in ks if "gat_enc" in k[0]]
 starts = [gat[0][1]]
 for a, b in zip(gat, gat[1:]):
     if b[1] - a[2] > 2_000_000:
@@ -36,5 +36,5 @@ for lo, hi in ((0, 5e3), (5e3, 2e4), (2e4, 1e5), (1e5, 1e6), (1e6, 1e9)):
 # phases of the cycle's rollouts
 for i in range(8):
     a, b = starts[-16 + i], starts[-16 + i + 1]
-    last_ac = max(k[2] for k in ks if a <= k[1] < b and "ac_fwd_kernel<1" in k[0])
+    last_ac = max(k[2] for k in gat if a <= k[1] < b)
     print(f"  rollout {i}: {(last_ac - a) / 1e6:6.2f} ms, then until the next rollout {(b - last_ac) / 1e6:6.2f} ms")

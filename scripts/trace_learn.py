@@ -6,7 +6,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = sorted(((r["Kernel_Name"].split("(")[0].replace("iplan::", "").replace("void ", ""), int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
               r.get("Stream_Id", ""), r.get("Queue_Id", "")) for r in rows), key=lambda r: r[1])
-ge = [i for i, k in enumerate(ks) if "gat_enc_fwd" in k[0]]
+ge = [i for i, k in enumerate(ks) if "gat_enc" in k[0]]
 # rollout boundaries: gaps > 2 ms between consecutive fused launches
 bounds = [j for i, j in zip(ge, ge[1:]) if ks[j][1] - ks[i][2] > 2_000_000]
 j1 = bounds[len(bounds) // 2]                     # first launch of some mid-run rollout

@@ -16,7 +16,7 @@ def show(sel, t0):
         print(f"  {k[0][:70]:70s} start {(k[1] - t0) / 1e3:9.1f} us  dur {(k[2] - k[1]) / 1e3:8.1f} us  q{k[3]}")
 
 
-ge = [i for i, k in enumerate(ks) if "gat_enc_fwd" in k[0]]
+ge = [i for i, k in enumerate(ks) if "gat_enc" in k[0]]
 bounds = [(i, j) for i, j in zip(ge, ge[1:]) if ks[j][1] - ks[i][2] > 2_000_000]
 if bounds:
     i0, j1 = bounds[len(bounds) // 2]
