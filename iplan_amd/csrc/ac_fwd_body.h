@@ -89,7 +89,7 @@ __device__ __forceinline__ void ac_wait_producers(const AcProducers& pr) {
     if (threadIdx.x == 0) {
         int spins = 0;
         while (__hip_atomic_load(pr.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pr.n_prod) {
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(2);
             if (++spins > (1 << 22)) { __hip_atomic_store(pr.sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
 #if IPLAN_FUSED_FENCES
@@ -387,7 +387,8 @@ __device__ __forceinline__ void ac_fwd_body(const IplanAcFwdArgs& a, const AcGri
     };
     auto fload = [&](int T, int s, FOps& o) {
         const int f0 = 16 * (T - km.kt0[s]) + 4 * g;
-        for (int t = 0; t < RT; ++t) o.x[t] = (FUSED && s > 0) ? coh_load4(src[t][s] + f0) : ldu4(src[t][s] + f0);
+        // (fused launch, latent blocks: device-coherent and FIRST in the slot -- the fragment loads below are what the compiler waits for)
+        for (int t = 0; t < RT; ++t) o.x[t] = (FUSED && s > 0) ? coh_load16_untracked(src[t][s] + f0) : ldu4(src[t][s] + f0);
         if (pkw) {                                          // one contiguous 1 KiB block per fragment, 64 B for gamma / beta
             o.gm = *reinterpret_cast<const f32x4*>(pkg + T * 16 + 4 * g);
             o.bt = *reinterpret_cast<const f32x4*>(pkb + T * 16 + 4 * g);
@@ -514,8 +515,7 @@ __device__ __forceinline__ void ac_fwd_body(const IplanAcFwdArgs& a, const AcGri
                     // coh_load) and the stores are drained before the ticket is taken -- round 3's form, an agent-scope release /
                     // acquire pair around plain accesses, is an L2 write-back and an L2 invalidate per workgroup on the launch's
                     // critical path (IPLAN_FUSED_FENCES=1 builds keep it)
-                    for (int t = 0; t < AT; ++t)
-                        for (int q = 0; q < 4; ++q) coh_store(slot + (t * 64 + l) * 4 + q, accs[0][t][q]);
+                    for (int t = 0; t < AT; ++t) coh_store16(slot + (t * 64 + l) * 4, accs[0][t]);
                     if (g == 0) { coh_store(slot + AT * 256 + n, sx); coh_store(slot + AT * 256 + 16 + n, sxx); }
                     int ticket = 0;
 #ifdef IPLAN_HOST_EMULATION
@@ -550,11 +550,14 @@ __device__ __forceinline__ void ac_fwd_body(const IplanAcFwdArgs& a, const AcGri
 #endif
                     sx = 0.f; sxx = 0.f;
                     for (int t = 0; t < AT; ++t) accs[0][t] = splat4(0.f);
-                    for (int q2 = 0; q2 < KW; ++q2) {
-                        const float* sl = a.ks_scratch + ((int64_t)unit * KW + q2) * IPLAN_AC_KS_SLOT_FLOATS;
-                        for (int t = 0; t < AT; ++t) accs[0][t] += coh_load4(sl + (t * 64 + l) * 4);
-                        sx += coh_load(sl + AT * 256 + n);
-                        sxx += coh_load(sl + AT * 256 + 16 + n);
+                    for (int q2 = 0; q2 < KW; ++q2) {                // (one load instruction per tile; the slot's statistics -- loaded
+                        const float* sl = a.ks_scratch + ((int64_t)unit * KW + q2) * IPLAN_AC_KS_SLOT_FLOATS;   // after them -- carry the wait)
+                        f32x4 pt[AT];
+                        for (int t = 0; t < AT; ++t) pt[t] = coh_load16_untracked(sl + (t * 64 + l) * 4);
+                        const float psx = coh_load(sl + AT * 256 + n), psxx = coh_load(sl + AT * 256 + 16 + n);
+                        for (int t = 0; t < AT; ++t) accs[0][t] += after_load(pt[t], psxx);
+                        sx += psx;
+                        sxx += psxx;
                     }
                 }
                 mu[0] = sx / (float)F;

@@ -34,10 +34,11 @@ constexpr int QST = 33;                // padded row stride of q/k/v/x tables
 #define IPLAN_GAT_BF3 1                // recurrence on the bf16 matrix cores (fp32-exact split); 0 = fp32 MFMA (A/B builds)
 #endif
 
-struct GatShared {                      // LDS of one scene (147 KB)
+struct GatShared {                      // LDS of one scene (157 KB)
     float B[2][NP][BST];
-    float q[NP][QST], k[NP][QST], v[NP][QST], x[NP][QST];
+    float q[NP][QST], k[NP][QST], v[NP][QST], x[NP][QST], x1[NP][QST];      // x / x1: the two directions' partial aggregates (phase 3)
     float pl[2][NP][NP][2];
+    float sm[2][4][16][2];              // phase 3: (running maximum, partial denominator) of an ego's softmax, per direction wave
 };
 
 // one scene = workgroup `block` of the launch (512 threads); COH: the new latent is stored device-coherently (read by other
@@ -49,6 +50,8 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
     auto& s_k = sh.k;
     auto& s_v = sh.v;
     auto& s_x = sh.x;
+    auto& s_x1 = sh.x1;
+    auto& s_sm = sh.sm;
     auto& s_pl = sh.pl;
 
     const int net = block / a.B;
@@ -263,16 +266,28 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
     //   S^T[j][i] = k_j . q_i            A = k rows (LDS), B = q rows of the ego tile (LDS)        32 MFMAs
     //   w[i][j]   = softmax_j(S) * gumbel-gate(i, j)      lane (ego n, g) holds j = 16T + 4g + q
     //   x[i][c]   = sum_j w[i][j] v[j][c]  A = w straight from these registers, B = v rows (LDS)    32 MFMAs
-    if (dir == 0 && tile_live) {
-        const float hb0 = P[a.off[IPLAN_GAT_HARD_B]], hb1 = P[a.off[IPLAN_GAT_HARD_B] + 1];
+    // (phase 4's recurrent operand: requested here, it lands while phase 3 runs)
+    f32x4 hp4[2];
+    {
+        const float* hrow4 = a.h_prev + (int64_t)net * a.h_s_net + (int64_t)b * a.h_s_b + (int64_t)imin(node, N - 1) * GH + 4 * g;
+        for (int T = 0; T < 2; ++T) hp4[T] = *(const IPLAN_GLOBAL_AS f32x4*)(hrow4 + 16 * T);
+    }
+    // Both waves of an ego tile work (round 4; the direction-1 wave used to idle here for 9.4 us): wave `dir` takes the neighbour tiles
+    // T = 2 dir, 2 dir + 1 (j in [32 dir, 32 dir + 32)) -- its share of the scores, of the gumbel gates (half of the phase: 16 pairs per
+    // lane with two exponentials and four LDS reads each) and of the aggregation.  The two halves of an ego's softmax meet once in LDS
+    // (running maximum + partial denominator, combined in direction order), the two partial aggregates in phase 4.
+    const int T0 = 2 * dir;
+    f32x4 sc[2], aw[2];
+    float gz0[2][4], gz1[2][4];
+    float m_own = -INFINITY, den_own = 0.f;
+    const int i = node;                                      // this lane's ego (column)
+    const int NT = (N + 15) / 16;
+    if (tile_live) {
         const float* noise = a.noise + sb * N * (N - 1) * 2;
-        const int i = node;                                  // this lane's ego (column)
-        const int NT = (N + 15) / 16;
-        // gumbel noise of the lane's 16 (ego, neighbour) pairs: issued first, consumed after the score GEMM
-        float gz0[4][4], gz1[4][4];
-        for (int T = 0; T < 4; ++T)
+        // gumbel noise of the lane's 8 (ego, neighbour) pairs: issued first, consumed after the score GEMM
+        for (int T = 0; T < 2; ++T)
             for (int q = 0; q < 4; ++q) {
-                const int j = 16 * T + 4 * g + q;
+                const int j = 16 * (T0 + T) + 4 * g + q;
                 const bool ok = valid && j < N && j != i;
                 const int sidx = j - (j > i ? 1 : 0);
                 const float* gz = noise + ((int64_t)i * (N - 1) + (ok ? sidx : 0)) * 2;
@@ -280,41 +295,47 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
                 gz1[T][q] = ok ? gz[1] : 0.f;
             }
         GAT_SUBCLK(5);
-        f32x4 sc[4];
-        for (int T = 0; T < 4; ++T) sc[T] = splat4(0.f);
+        for (int T = 0; T < 2; ++T) sc[T] = splat4(0.f);
         for (int ks = 0; ks < GH / 4; ++ks) {
             const float qv = s_q[node][4 * ks + g];
-            for (int T = 0; T < 4; ++T)
-                if (T < NT) sc[T] = mfma4(s_k[16 * T + n][4 * ks + g], qv, sc[T]);
+            for (int T = 0; T < 2; ++T)
+                if (T0 + T < NT) sc[T] = mfma4(s_k[16 * (T0 + T) + n][4 * ks + g], qv, sc[T]);
         }
         GAT_SUBCLK(6);
-        float m = -INFINITY;
-        for (int T = 0; T < 4; ++T)
+        for (int T = 0; T < 2; ++T)
             for (int q = 0; q < 4; ++q) {
-                const int j = 16 * T + 4 * g + q;
+                const int j = 16 * (T0 + T) + 4 * g + q;
                 const bool ok = j < N && j != i;
                 sc[T][q] = ok ? sc[T][q] / 5.656854249492381f : -INFINITY;     // / sqrt(attention_dim)  (GAT_Net.py:126)
-                m = fmaxf(m, sc[T][q]);
+                m_own = fmaxf(m_own, sc[T][q]);
             }
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
-        float den = 0.f;
-        f32x4 w[4];
-        for (int T = 0; T < 4; ++T)
+        m_own = fmaxf(m_own, __shfl_xor(m_own, 16));
+        m_own = fmaxf(m_own, __shfl_xor(m_own, 32));
+        for (int T = 0; T < 2; ++T)
             for (int q = 0; q < 4; ++q) {
-                const int j = 16 * T + 4 * g + q;
-                const float e = (j < N && j != i) ? expf(sc[T][q] - m) : 0.f;
-                w[T][q] = e;
-                den += e;
+                const int j = 16 * (T0 + T) + 4 * g + q;
+                const float e = (j < N && j != i && m_own > -INFINITY) ? expf(sc[T][q] - m_own) : 0.f;
+                aw[T][q] = e;
+                den_own += e;
             }
-        den = group_sum(den);
+        den_own = group_sum(den_own);
+        if (g == 0) { s_sm[dir][tile][n][0] = m_own; s_sm[dir][tile][n][1] = den_own; }
+    }
+    __syncthreads();
+    if (tile_live) {
+        // softmax over ALL neighbours of the ego: m = max of the halves, den = den_0 e^(m_0 - m) + den_1 e^(m_1 - m) (direction order)
+        const float m0 = s_sm[0][tile][n][0], d0 = s_sm[0][tile][n][1], m1 = s_sm[1][tile][n][0], d1 = s_sm[1][tile][n][1];
+        const float m = fmaxf(m0, m1);
+        const float den = (m0 > -INFINITY ? d0 * expf(m0 - m) : 0.f) + (m1 > -INFINITY ? d1 * expf(m1 - m) : 0.f);
+        const float resc = m_own > -INFINITY ? expf(m_own - m) : 0.f;
+        const float hb0 = P[a.off[IPLAN_GAT_HARD_B]], hb1 = P[a.off[IPLAN_GAT_HARD_B] + 1];
         GAT_SUBCLK(7);
-        for (int T = 0; T < 4; ++T)
+        for (int T = 0; T < 2; ++T)
             for (int q = 0; q < 4; ++q) {
-                const int j = 16 * T + 4 * g + q;
+                const int j = 16 * (T0 + T) + 4 * g + q;
                 const bool ok = valid && j < N && j != i;
                 const int sidx = j - (j > i ? 1 : 0);
-                const float soft = w[T][q] / den;
+                const float soft = aw[T][q] * resc / den;
                 float hard = 0.f;
                 if (ok) {
                     const float l0 = hb0 + s_pl[0][i][sidx][0] + s_pl[1][i][sidx][0];
@@ -326,24 +347,22 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
                     if (sv.soft) sv.soft[(sb * N + i) * (N - 1) + sidx] = soft;
                     if (sv.hard) sv.hard[(sb * N + i) * (N - 1) + sidx] = hard;
                 }
-                w[T][q] = ok ? soft * hard : 0.f;            // no renormalisation (GAT_Net.py:132)
+                aw[T][q] = ok ? soft * hard : 0.f;            // no renormalisation (GAT_Net.py:132)
             }
         GAT_SUBCLK(8);
+        float (*dstx)[QST] = dir ? s_x1 : s_x;               // this direction's partial aggregate; phase 4 adds the two
         for (int ct = 0; ct < 2; ++ct) {
             f32x4 xa = splat4(0.f);
-            for (int T = 0; T < 4; ++T)
-                if (T < NT)
+            for (int T = 0; T < 2; ++T)
+                if (T0 + T < NT)
                     for (int q = 0; q < 4; ++q) {
-                        const int j = 16 * T + 4 * g + q;
-                        xa = mfma4(w[T][q], s_v[j < N ? j : 0][16 * ct + n], xa);
+                        const int j = 16 * (T0 + T) + 4 * g + q;
+                        xa = mfma4(aw[T][q], s_v[j < N ? j : 0][16 * ct + n], xa);
                     }
             // D layout: lane (c = n, g) holds x[ego 16 tile + 4g + q][16 ct + n]
             for (int q = 0; q < 4; ++q) {
                 const int e = 16 * tile + 4 * g + q;
-                if (e < N) {
-                    s_x[e][16 * ct + n] = xa[q];
-                    if (sv.x) sv.x[(sb * N + e) * GH + 16 * ct + n] = xa[q];
-                }
+                if (e < N) dstx[e][16 * ct + n] = xa[q];
             }
         }
     }
@@ -355,12 +374,12 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
     if (tile_live) {
         const int t = dir;                                      // wave (dir,tile) produces output tile `dir`
         f32x4 x[2], hp[2];
-        const float* hrow = a.h_prev + (int64_t)net * a.h_s_net + (int64_t)b * a.h_s_b + (int64_t)node * GH;
         for (int T = 0; T < 2; ++T) {
             x[T] = splat4(0.f);
             if (valid)
-                for (int q = 0; q < 4; ++q) x[T][q] = s_x[node][16 * T + 4 * g + q];
-            hp[T] = vload(hrow, valid, GH, T);
+                for (int q = 0; q < 4; ++q) x[T][q] = s_x[node][16 * T + 4 * g + q] + s_x1[node][16 * T + 4 * g + q];
+            if (sv.x && dir == 0) vstore(sv.x + (sb * N + node) * GH, valid, GH, T, x[T]);
+            for (int q = 0; q < 4; ++q) hp[T][q] = valid ? hp4[T][q] : 0.f;
         }
         const float* Wi = P + a.off[IPLAN_GAT_C_WIH];
         const float* Wc = P + a.off[IPLAN_GAT_C_WHH];

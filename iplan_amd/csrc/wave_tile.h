@@ -323,14 +323,49 @@ __device__ __forceinline__ f32x4 coh_load4(const float* p) {
     for (int q = 0; q < 4; ++q) v[q] = coh_load(p + q);
     return v;
 }
+// The same 16 bytes as ONE load instruction that the compiler does not take for an atomic: it gives every returning atomic a full
+// `s_waitcnt vmcnt(0)`, which turned an operand ring of coh_load4's into one memory round trip per k-tile whatever its depth
+// (profiles/r04a_notes.md).  The instruction is invisible to the compiler's wait-count bookkeeping, so the CALLER guarantees the
+// wait: loads return in order, hence the value is there once a compiler-visible load issued AFTER this one has been waited for
+// (ac_fwd_body.h: the weight fragments of the same ring slot); the compiler's own counts can only come out too strict, never
+// too loose.  16-byte aligned address.
+__device__ __forceinline__ f32x4 coh_load16_untracked(const float* p) {
+#if defined(IPLAN_HOST_EMULATION) || IPLAN_FUSED_FENCES
+    return *reinterpret_cast<const f32x4*>(p);
+#else
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+#endif
+}
+// ... and its store counterpart (16-byte aligned address; the caller drains vmcnt before it publishes)
+__device__ __forceinline__ void coh_store16(float* p, f32x4 v) {
+#if defined(IPLAN_HOST_EMULATION) || IPLAN_FUSED_FENCES
+    *reinterpret_cast<f32x4*>(p) = v;
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+// make `v` (loaded by coh_load16_untracked) usable only after `dep` -- a compiler-visible load issued after it -- has arrived
+__device__ __forceinline__ f32x4 after_load(f32x4 v, float dep) {
+#if !defined(IPLAN_HOST_EMULATION)
+    asm volatile("" : "+v"(v) : "v"(dep));
+#endif
+    return v;
+}
 // vstore with device-coherent stores (COH) or plain ones
 template <bool COH>
 __device__ __forceinline__ void vstore_c(float* __restrict__ row, bool valid, int dim, int t, f32x4 v) {
     if (!COH) { vstore(row, valid, dim, t, v); return; }
     const int c = 16 * t + 4 * (lane_id() >> 4);
-    if (valid)
-        for (int q = 0; q < 4; ++q)
-            if (c + q < dim) coh_store(row + c + q, v[q]);
+    if (valid) {
+        if (c + 3 < dim && ((((size_t)(row + c)) & 15) == 0)) {
+            coh_store16(row + c, v);
+        } else {
+            for (int q = 0; q < 4; ++q)
+                if (c + q < dim) coh_store(row + c + q, v[q]);
+        }
+    }
 }
 
 // Aligned whole-tile variants (row 16-byte aligned, tile t entirely inside the vector): one predicated 16-byte
