@@ -486,6 +486,16 @@ __device__ __forceinline__ void ac_fwd_body(const IplanAcFwdArgs& a, const AcGri
     if (fclk) fclk[3] = IPLAN_CLOCK();
     if (ks > 1) {
         for (int t = 0; t < AT; ++t) s_acc[w][t][l] = accs[0][t];
+        if (fold) {                                           // W gamma, W beta and the row statistics of the 8 waves: parked with the
+            fsx = group_sum(fsx);                             // partial tiles, ONE barrier for both (it sits on the launch's critical path)
+            fsxx = group_sum(fsxx);
+            if (g == 0) { s_red[w][n] = fsx; s_red2[w][n] = fsxx; }
+            if (!pkc)
+                for (int t = 0; t < AT; ++t) {
+                    const float c1 = group_sum(c1a[t]), c2 = group_sum(c2a[t]);
+                    if (g == 0) { s_cc[w][0][16 * t + n] = c1; s_cc[w][1][16 * t + n] = c2; }
+                }
+        }
         __syncthreads();
         if (part == 0) {
             for (int t = 0; t < AT; ++t) {
@@ -494,16 +504,7 @@ __device__ __forceinline__ void ac_fwd_body(const IplanAcFwdArgs& a, const AcGri
                 accs[0][t] = sum;
             }
         }
-        if (fold) {                                           // W gamma, W beta and the row statistics of the 8 waves
-            fsx = group_sum(fsx);
-            fsxx = group_sum(fsxx);
-            if (g == 0) { s_red[w][n] = fsx; s_red2[w][n] = fsxx; }
-            if (!pkc)
-                for (int t = 0; t < AT; ++t) {
-                    const float c1 = group_sum(c1a[t]), c2 = group_sum(c2a[t]);
-                    if (g == 0) { s_cc[w][0][16 * t + n] = c1; s_cc[w][1][16 * t + n] = c2; }
-                }
-            __syncthreads();
+        if (fold) {
             if (part == 0) {
                 float sx = 0.f, sxx = 0.f;
                 for (int p2 = 0; p2 < ks; ++p2) { sx += s_red[w + p2][n]; sxx += s_red2[w + p2][n]; }

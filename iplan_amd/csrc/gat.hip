@@ -164,7 +164,8 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
         // W_hh h on the bf16 matrix cores, fp32-exact (wave_tile.h, split-bf16): the three pieces of every weight
         // fragment are loop invariants in registers, the hidden state is split once per step.  42 K=32 MFMAs per step
         // (7 chains x 6 piece products) that run BESIDE the gate arithmetic of the SIMD's other wave, instead of 56
-        // fp32 MFMAs that take the VALU's issue time (1 792 of a step's 2 700 cycles).
+        // fp32 MFMAs that take the VALU's issue time (1 792 of a step's 2 700 cycles).  (Fetching the pieces in front of the
+        // barrier that ends phase 1 was measured: phases 1 / 2 +1.4 / +1.8 us, 247 registers -- not kept.)
         Bf3 whh[6], wl;
         for (int t = 0; t < 6; ++t) whh[t] = wfrag_bf3(Whh, GH, 3 * GH, 16 * t, 0);
         wl = wfrag_bf3(Wh + dir * GH, 2 * GH, 2, 0, 0);
@@ -367,6 +368,18 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
         }
     }
     GAT_SUBCLK(9);
+    // (phase 4's weight fragments -- output tile `dir` of the GRUCell -- are requested before the barrier: they land while the slower
+    // waves of the scene finish phase 3)
+    f32x4 w4i[3][2], w4c[3][2];
+    {
+        const float* Wi = P + a.off[IPLAN_GAT_C_WIH];
+        const float* Wc = P + a.off[IPLAN_GAT_C_WHH];
+        for (int gt = 0; gt < 3; ++gt)
+            for (int T = 0; T < 2; ++T) {
+                w4i[gt][T] = wfrag_a(Wi, GH, 3 * GH, gt * GH + 16 * dir, 16 * T);
+                w4c[gt][T] = wfrag_a(Wc, GH, 3 * GH, gt * GH + 16 * dir, 16 * T);
+            }
+    }
     __syncthreads();
     if (clk && threadIdx.x == 0) clk[3] = IPLAN_CLOCK();
 
@@ -381,8 +394,6 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
             if (sv.x && dir == 0) vstore(sv.x + (sb * N + node) * GH, valid, GH, T, x[T]);
             for (int q = 0; q < 4; ++q) hp[T][q] = valid ? hp4[T][q] : 0.f;
         }
-        const float* Wi = P + a.off[IPLAN_GAT_C_WIH];
-        const float* Wc = P + a.off[IPLAN_GAT_C_WHH];
         const float* bi = P + a.off[IPLAN_GAT_C_BIH];
         const float* bc = P + a.off[IPLAN_GAT_C_BHH];
         f32x4 pr = bfrag(bi, 3 * GH, t) + bfrag(bc, 3 * GH, t);
@@ -390,12 +401,12 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
         f32x4 gn = bfrag(bi, 3 * GH, 4 + t);
         f32x4 hn = bfrag(bc, 3 * GH, 4 + t);
         for (int T = 0; T < 2; ++T) {
-            pr = mma_block(wfrag_a(Wi, GH, 3 * GH, 16 * t, 16 * T), x[T], pr);
-            pr = mma_block(wfrag_a(Wc, GH, 3 * GH, 16 * t, 16 * T), hp[T], pr);
-            pz = mma_block(wfrag_a(Wi, GH, 3 * GH, GH + 16 * t, 16 * T), x[T], pz);
-            pz = mma_block(wfrag_a(Wc, GH, 3 * GH, GH + 16 * t, 16 * T), hp[T], pz);
-            gn = mma_block(wfrag_a(Wi, GH, 3 * GH, 2 * GH + 16 * t, 16 * T), x[T], gn);
-            hn = mma_block(wfrag_a(Wc, GH, 3 * GH, 2 * GH + 16 * t, 16 * T), hp[T], hn);
+            pr = mma_block(w4i[0][T], x[T], pr);
+            pr = mma_block(w4c[0][T], hp[T], pr);
+            pz = mma_block(w4i[1][T], x[T], pz);
+            pz = mma_block(w4c[1][T], hp[T], pz);
+            gn = mma_block(w4i[2][T], x[T], gn);
+            hn = mma_block(w4c[2][T], hp[T], hn);
         }
         const GruGates o = gru_gates(pr, pz, gn, hn, hp[t]);
         float* orow = a.out + (int64_t)net * a.out_s_net + (int64_t)b * a.out_s_b + (int64_t)node * GH;
