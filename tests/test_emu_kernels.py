@@ -317,6 +317,19 @@ def test_device_resident_rollout_matches_oracle_emulated(cfg):
     assert max(worst.values()) < 1e-5
 
 
+@pytest.mark.parametrize("kw", ["1", "2", "8"])
+def test_device_resident_rollout_other_ksplit_wg_emulated(kw, monkeypatch):
+    """The one-launch vector step with the action selection's K split over 1 / 2 / 8 workgroups per unit instead of the 4 the launch
+    size picks (IplanAcFwdArgs.ksplit_wg; 1 = no cross-workgroup exchange: the shape of large env counts): every field against the
+    oracle and against the two-launch form."""
+    from iplan_amd.config import default_args
+    from tests.rollout_oracle import check_rollout_body
+    monkeypatch.setenv("IPLAN_AC_KSPLIT_WG", kw)
+    args = default_args("highway", use_cuda=False, max_vehicle_num=5, n_agents=2, episode_limit=3, batch_size_run=3, max_history_len=3)
+    worst = check_rollout_body(args, 3, "cpu", seed=7)
+    assert max(worst.values()) < 1e-5
+
+
 def check_seq2seq(golden, device):
     """nova/Seq2Seq.py forward (a19): same constructor / state_dict / random draws as the reference class, outputs recorded from it"""
     import numpy as np

@@ -214,3 +214,12 @@ def test_tanh_activation_vs_oracle_gpu(golden):
     check_ippo_train(golden("ippo_train_tanh"), "cuda")
     _log("tanh_ppo_train_cfg3_22950rows_agent2_1epoch", check_ppo_train_vs_oracle(_args(ppo_epoch=1, use_ReLU=False), "cuda", seed=44, agents=(2,)))
     _log("tanh_rollout_body_cfg3_E32_T4", check_rollout_body(_args(episode_limit=4, batch_size_run=32, use_ReLU=False), 32, "cuda", seed=45))
+
+
+@pytest.mark.parametrize("kw", ["1", "2"])
+def test_rollout_body_config3_other_ksplit_wg(kw, monkeypatch):
+    """the fused vector step with 1 / 2 workgroups per action-selection unit (the shapes larger env counts pick) at config 3 width"""
+    from tests.rollout_oracle import check_rollout_body
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    monkeypatch.setenv("IPLAN_AC_KSPLIT_WG", kw)
+    _log("rollout_body_cfg3_E32_T3_ksplit_wg" + kw, check_rollout_body(_args(episode_limit=3, batch_size_run=32), 32, "cuda", seed=46))
