@@ -330,6 +330,9 @@ class SyntheticLoop:
         for f in getattr(self, "_late", ()):                 # the previous cycle's read-backs: long complete, no waiting
             f()
         self._late = late
+        if not run_ahead:                                    # (the learners' read-backs above have synchronised with the rollout's stream;
+            from . import ops                                #  with host run-ahead the flag is read in finish())
+            ops.check_fused_sync()
         if pe is not None:
             e2.record()
             pe.append((e0, e1, e2))
@@ -340,3 +343,5 @@ class SyntheticLoop:
         for f in getattr(self, "_late", ()):
             f()
         self._late = []
+        from . import ops
+        ops.check_fused_sync()

@@ -127,6 +127,15 @@ def fused_sync_error():
     return any(int(b[2]) != 0 for b in _FUSED_SYNC.values())
 
 
+def check_fused_sync():
+    """Raise if a fused vector-step launch ran its action selection on stale latents (its wait hit the poll limit -- a scene or
+    encoder workgroup never reported).  One 4-byte read-back per stream that ever ran a fused launch: call it where the host
+    synchronises anyway (end of an episode / a training cycle)."""
+    if fused_sync_error():
+        raise L.IplanError("iplan_gat_enc_ac_fwd: an action selection gave up waiting for the latent updates of its launch "
+                           "(sync[2] != 0); the episode's actions from that step on are not valid")
+
+
 def enc_forward(arena, x, h0, prev_latent, coef, Z, out_lat=None, out_h=None, lib=None, launch=True):
     """EncoderRNN + soft update for all nets.  x [n_nets,B,N,L,d] (any strides as long as the last dim is
     contiguous: a sliding window over a time-major observation log is read in place), h0 [n_nets,B,N,R],

@@ -227,6 +227,9 @@ class ParallelRunner:
             # the last step's host -> device copies read the pinned staging buffers asynchronously and nothing after them
             # synchronises: the next run()'s reset() would overwrite 'single' / 'state' / 'obs' while they are in flight
             torch.cuda.current_stream(dev).synchronize()
+        if fuse_ac:
+            from .. import ops
+            ops.check_fused_sync()
         avg_win_rates, avg_rwd, avg_len = np.mean(episode_wins, axis=0), np.mean(episode_returns, axis=0), np.mean(episode_lengths, axis=0)
         if not test_mode:
             self.t_env += self.env_steps_this_run

@@ -223,3 +223,11 @@ def test_rollout_body_config3_other_ksplit_wg(kw, monkeypatch):
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     monkeypatch.setenv("IPLAN_AC_KSPLIT_WG", kw)
     _log("rollout_body_cfg3_E32_T3_ksplit_wg" + kw, check_rollout_body(_args(episode_limit=3, batch_size_run=32), 32, "cuda", seed=46))
+
+
+def test_rollout_body_config4_width_vs_oracle():
+    """256 envs on one GPU (BASELINE config 4, N = 1: 1 280 scene + 560 encoder + 160 actor/critic workgroups per fused launch, the
+    action selection's K split over one workgroup per unit): two vector steps against the oracle and the two-launch form"""
+    from tests.rollout_oracle import check_rollout_body
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    _log("rollout_body_cfg4_E256_T2", check_rollout_body(_args(episode_limit=2, batch_size_run=256), 256, "cuda", seed=47))
