@@ -190,7 +190,8 @@ class SyntheticLoop:
         # the latent updates of step t write and nothing sits between the two (the environment steps after the action
         # selection), so its workgroups queue behind the scenes' in the same grid -- one launch per vector step.
         # IPLAN_NO_FUSE_AC=1: two launches per step (A/B knob)
-        fuse_ac = fuse and not os.environ.get("IPLAN_NO_FUSE_AC")
+        fuse_ac = fuse and not os.environ.get("IPLAN_NO_FUSE_AC") and E <= 512      # (beyond 512 rows per net the action selection is the
+                                                                                    #  streaming launch shape, not the K-split one the fusion carries)
         for t in range(T):
             if not (fuse_ac and t > 0):
                 self.mac.select_actions_ippo(batch, t, test_mode=False, q_noise=q_all[t], as_numpy=False, write_back=True)

@@ -148,7 +148,7 @@ class ParallelRunner:
         import os
         # the next step's action selection reads exactly what this step's latent updates write and the simulator only steps after
         # it: with both incentives on it rides in their launch (iplan_gat_enc_ac_fwd).  IPLAN_NO_FUSE_AC=1: its own launch
-        fuse_ac = a.GAT_enable and a.Behavior_enable and not os.environ.get("IPLAN_NO_FUSE_AC")
+        fuse_ac = a.GAT_enable and a.Behavior_enable and not os.environ.get("IPLAN_NO_FUSE_AC") and E <= 512
         ac_in_flight = False
         for _ in range(a.episode_limit):
             t = self.t
