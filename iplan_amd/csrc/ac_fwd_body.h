@@ -54,8 +54,9 @@ struct AcGrid {                         // the workgroup's position in the (tile
 // No cache maintenance on either side (an agent-scope release / acquire pair is an L2 write-back / invalidate per workgroup --
 // measured: the launch 65 us longer, polling with acquire loads included): the few values that cross -- the new attention
 // and behaviour latents -- are written with device-coherent stores (vstore_c<true>) and read with device-coherent loads
-// (coh_load4, kfeat<true>), the producers drain their stores (vmcnt 0) before they count themselves in, and the consumers
-// issue the loads after they saw the count.
+// (coh_load16_untracked in the operand ring, kfeat<true> for the ragged tiles), the producers drain their stores (vmcnt 0)
+// before they count themselves in, and the consumers issue the loads after they saw the count.  A wait that gives up leaves the
+// counters unusable (late producers still count): sync[2] stays set and the host refuses to go on (ops.check_fused_sync).
 struct AcProducers {
     int32_t* sync;
     int n_prod, n_cons;

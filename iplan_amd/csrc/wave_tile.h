@@ -318,14 +318,9 @@ __device__ __forceinline__ float coh_load(const float* p) {
     return __hip_atomic_load(as_global(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
-__device__ __forceinline__ f32x4 coh_load4(const float* p) {
-    f32x4 v;
-    for (int q = 0; q < 4; ++q) v[q] = coh_load(p + q);
-    return v;
-}
-// The same 16 bytes as ONE load instruction that the compiler does not take for an atomic: it gives every returning atomic a full
-// `s_waitcnt vmcnt(0)`, which turned an operand ring of coh_load4's into one memory round trip per k-tile whatever its depth
-// (profiles/r04_notes.md).  The instruction is invisible to the compiler's wait-count bookkeeping, so the CALLER guarantees the
+// 16 bytes as ONE load instruction that the compiler does not take for an atomic: it gives every returning atomic (which is what
+// coh_load is to it) a full `s_waitcnt vmcnt(0)`, which turned an operand ring of four coh_load's per k-tile into one memory
+// round trip per k-tile whatever its depth (profiles/r04_notes.md).  The instruction is invisible to the compiler's wait-count bookkeeping, so the CALLER guarantees the
 // wait: loads return in order, hence the value is there once a compiler-visible load issued AFTER this one has been waited for
 // (ac_fwd_body.h: the weight fragments of the same ring slot); the compiler's own counts can only come out too strict, never
 // too loose.  16-byte aligned address.
