@@ -330,6 +330,25 @@ def test_device_resident_rollout_other_ksplit_wg_emulated(kw, monkeypatch):
     assert max(worst.values()) < 1e-5
 
 
+def test_fused_step_give_up_flag_raises_emulated():
+    """sync[2] of a fused vector-step launch (a wait that hit its poll limit) is what the host refuses to go on with"""
+    from iplan_amd import _lib as L, ops
+    from iplan_amd.config import default_args
+    from iplan_amd.harness import SyntheticLoop
+    args = default_args("highway", use_cuda=False, max_vehicle_num=5, n_agents=2, episode_limit=3, batch_size_run=2, max_history_len=3)
+    loop = SyntheticLoop(args, 2, seed=0, device="cpu")
+    loop.rollout()
+    assert ops._FUSED_SYNC and not ops.fused_sync_error()
+    ops.check_fused_sync()
+    buf = next(iter(ops._FUSED_SYNC.values()))
+    buf[2] = 1
+    try:
+        with pytest.raises(L.IplanError):
+            ops.check_fused_sync()
+    finally:
+        buf[2] = 0
+
+
 def check_seq2seq(golden, device):
     """nova/Seq2Seq.py forward (a19): same constructor / state_dict / random draws as the reference class, outputs recorded from it"""
     import numpy as np
