@@ -272,6 +272,8 @@ typedef struct {
     int32_t* ks_count;
     int32_t act_tanh;           /* MLPBase activation (mlp.py:10, args.use_ReLU): 0 = ReLU (shipped), 1 = tanh -- forward and, through
                                    IplanAcBwdArgs.fwd, the backward tail (round 4: the second activation of this kernel family) */
+    int32_t fc1_pre_parts;      /* 0 / 1: fc1_pre is one array; > 1: that many arrays [2, n_agents, rows, 64] back to back
+                                   (iplan_ac_fc1_split_fwd with kparts), added in order                                       */
 } IplanAcFwdArgs;
 
 int iplan_ac_fwd(const IplanAcFwdArgs* args, iplan_stream_t stream);
@@ -446,8 +448,13 @@ typedef struct {
     const float* xf;
     void* wsplit;                /* workspace, n_agents * KS * 24576 bytes: the bf16 pieces of W o gamma in fragment order */
     float* wbeta;                /* workspace [2, n_agents, 64]: W beta                                                  */
-    float* z1;                   /* out [2, n_agents, rows, 64]                                                           */
+    float* z1;                   /* out [kparts][2, n_agents, rows, 64]: part p holds the contribution of K-step range p (part 0 + W beta) */
+    int32_t kparts;              /* 0 / 1: one part (the whole K loop in one workgroup).  > 1 -- small batches only (<= iplan_ac_fc1_split_parts):
+                                    a data-parallel rank's 2 880 rows are 113 workgroups of one 79-step K chain each; the chain is dealt
+                                    to `kparts` workgroups and iplan_ac_fwd(fc1_pre, fc1_pre_parts) adds the parts in order            */
 } IplanAcFc1SplitArgs;
+/* the number of parts the host layer should ask for at this size (1 = the full-buffer shape) */
+int iplan_ac_fc1_split_parts(int32_t n_agents, int32_t rows);
 int iplan_ac_fc1_split_fwd(const IplanAcFc1SplitArgs* args, iplan_stream_t stream);
 /* args->xb set, fwd.which = 2, fc1_chunk_rows a multiple of 32; g_part as for iplan_ac_bwd_fc1.  iplan_ac_fc1_split_chunks:
  * the row chunking that fills the chip once (returns fc1_chunks, writes fc1_chunk_rows). */

@@ -54,7 +54,7 @@ ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_st
                 "iplan_ac_xhat_pack", "iplan_ac_fc1_split_fwd", "iplan_ac_bwd_fc1_split",
                 "iplan_p2p_publish", "iplan_p2p_reduce"]
 RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups", "iplan_sizeof", "iplan_ac_packed_floats",
-                    "iplan_p2p_alloc", "iplan_p2p_free", "iplan_p2p_export", "iplan_p2p_open", "iplan_p2p_close", "iplan_gat_enc_fwd", "iplan_gat_enc_ac_fwd", "iplan_gumbel_noise", "iplan_ac_xhat_floats", "iplan_ac_fc1_split_chunks"]      # non (args*, stream) signatures
+                    "iplan_p2p_alloc", "iplan_p2p_free", "iplan_p2p_export", "iplan_p2p_open", "iplan_p2p_close", "iplan_gat_enc_fwd", "iplan_gat_enc_ac_fwd", "iplan_gumbel_noise", "iplan_ac_xhat_floats", "iplan_ac_fc1_split_chunks", "iplan_ac_fc1_split_parts"]      # non (args*, stream) signatures
 
 
 class Lib:
@@ -79,6 +79,7 @@ class Lib:
         cdll.iplan_ac_packed_floats.restype = C.c_int64
         cdll.iplan_ac_packed_floats.argtypes = [C.c_void_p]
         cdll.iplan_ac_fc1_split_chunks.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+        cdll.iplan_ac_fc1_split_parts.argtypes = [C.c_int32, C.c_int32]
         cdll.iplan_ac_xhat_floats.restype = C.c_int64
         cdll.iplan_ac_xhat_floats.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         cdll.iplan_wgrad_workspace_floats.restype = C.c_size_t
@@ -197,7 +198,7 @@ class AcFwdArgs(C.Structure):
         ("onehot_out", fp), ("oh_s_net", i64), ("oh_s_row", i64),
         ("ln_stats", fp), ("ln_stats_s_net", i64), ("ln_stats_mode", i32), ("phase_clocks", fp),
         ("packed_actor", fp), ("packed_critic", fp), ("packed_s_net", i64), ("fc1_pre", fp),
-        ("ksplit_wg", i32), ("ks_scratch", fp), ("ks_count", fp), ("act_tanh", i32),
+        ("ksplit_wg", i32), ("ks_scratch", fp), ("ks_count", fp), ("act_tanh", i32), ("fc1_pre_parts", i32),
     ]
 
 
@@ -207,7 +208,7 @@ class AcXhatArgs(C.Structure):
 
 class AcFc1SplitArgs(C.Structure):
     _fields_ = [("n_agents", i32), ("rows", i32), ("feat", AcFeatures), ("actor", AcNet), ("critic", AcNet), ("xf", fp),
-                ("wsplit", fp), ("wbeta", fp), ("z1", fp)]
+                ("wsplit", fp), ("wbeta", fp), ("z1", fp), ("kparts", i32)]
 
 
 class AcPackArgs(C.Structure):

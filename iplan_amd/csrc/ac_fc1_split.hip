@@ -99,9 +99,8 @@ __global__ __launch_bounds__(128) void ac_xhat_pack_kernel(IplanAcXhatArgs a) {
 }
 
 // ---- weight pieces: (W o gamma) in A-fragment order, three bf16 pieces ------------------------------------------------
-// grid (KS, n_agents, 2), 256 threads = 4 output tiles x 64 lanes
-__global__ __launch_bounds__(256) void ac_fc1_wsplit_kernel(IplanAcFc1SplitArgs a) {
-    const int ks = (int)blockIdx.x, net = (int)blockIdx.y, which = (int)blockIdx.z;
+// block (ks, net, which), 256 threads = 4 output tiles x 64 lanes
+__device__ __forceinline__ void ac_fc1_wsplit_block(const IplanAcFc1SplitArgs& a, int ks, int net, int which) {
     const IplanAcNet& nw = which ? a.critic : a.actor;
     const float* __restrict__ P = nw.params + (int64_t)net * nw.params_s_net;
     const KMap km = make_kmap(a.feat);
@@ -126,15 +125,13 @@ __global__ __launch_bounds__(256) void ac_fc1_wsplit_kernel(IplanAcFc1SplitArgs 
     dst[128] = s.p2;
 }
 
-// (W beta)[o]: grid (n_agents, 2, 8), 256 threads = 8 output rows x 32 threads striding the feature axis together
-__global__ __launch_bounds__(256) void ac_fc1_wbeta_kernel(IplanAcFc1SplitArgs a) {
-    __shared__ float s_p[8][32];
-    const int net = (int)blockIdx.x, which = (int)blockIdx.y;
+// (W beta)[o]: block (net, which, 8-row group bz), 256 threads = 8 output rows x 32 threads striding the feature axis together
+__device__ __forceinline__ void ac_fc1_wbeta_block(const IplanAcFc1SplitArgs& a, int net, int which, int bz, float (&s_p)[8][32]) {
     const IplanAcNet& nw = which ? a.critic : a.actor;
     const float* __restrict__ P = nw.params + (int64_t)net * nw.params_s_net;
     const IplanAcFeatures& ft = a.feat;
     const int F = ft.N * (ft.w[0] + ft.w[1] + ft.w[2]) + ft.n_actions + ft.n_id;
-    const int part = (int)threadIdx.x & 31, ro = (int)threadIdx.x >> 5, o = (int)blockIdx.z * 8 + ro;
+    const int part = (int)threadIdx.x & 31, ro = (int)threadIdx.x >> 5, o = bz * 8 + ro;
     float c = 0.f;
     for (int k = part; k < F; k += 32) c = fmaf(P[nw.off[IPLAN_AC_FC1_W] + (int64_t)o * F + k], P[nw.off[IPLAN_AC_FN_B] + k], c);
     s_p[ro][part] = c;
@@ -143,6 +140,19 @@ __global__ __launch_bounds__(256) void ac_fc1_wbeta_kernel(IplanAcFc1SplitArgs a
         float s = 0.f;
         for (int k = 0; k < 32; ++k) s += s_p[ro][k];
         a.wbeta[((int64_t)which * a.n_agents + net) * SM + o] = s;
+    }
+}
+
+// Both weight preparations of an epoch as ONE launch (they are independent, and each was a 20 - 25 us link of the chain between an
+// epoch's optimiser step and its forward pass): blocks [0, KS n_agents 2) split the weights, the rest compute W beta.
+__global__ __launch_bounds__(256) void ac_fc1_wprep_kernel(IplanAcFc1SplitArgs a, int KS) {
+    __shared__ float s_p[8][32];
+    const int b = (int)blockIdx.x, n_ws = KS * a.n_agents * 2;
+    if (b < n_ws) {
+        ac_fc1_wsplit_block(a, b % KS, (b / KS) % a.n_agents, b / (KS * a.n_agents));
+    } else {
+        const int j = b - n_ws;
+        ac_fc1_wbeta_block(a, j % a.n_agents, (j / a.n_agents) & 1, j / (2 * a.n_agents), s_p);
     }
 }
 
@@ -190,16 +200,19 @@ __global__ __launch_bounds__(64 * NW) void ac_fc1_split_fwd_kernel(IplanAcFc1Spl
         for (int o = 0; o < S_OT; ++o) acc[t][o] = splat4(0.f);
     bf16x8 wst[WST];
     f32x4 xr[RT][2];
-    for (int i = 0; i < WST; ++i) wst[i] = wsrc[tx + NTH * i];
+    // K-step range of this workgroup: all of it, or part blockIdx.z of a.kparts (small batches)
+    const int kparts = a.kparts > 1 ? a.kparts : 1, kp = (int)blockIdx.z;
+    const int ks_lo = (int)((int64_t)KS * kp / kparts), ks_hi = (int)((int64_t)KS * (kp + 1) / kparts);
+    for (int i = 0; i < WST; ++i) wst[i] = wsrc[(int64_t)ks_lo * S_FRAG + tx + NTH * i];
     for (int t = 0; t < RT; ++t) {
-        xr[t][0] = *reinterpret_cast<const f32x4*>(xp[t]);
-        xr[t][1] = *reinterpret_cast<const f32x4*>(xp[t] + 4);
+        xr[t][0] = *reinterpret_cast<const f32x4*>(xp[t] + (int64_t)ks_lo * 512);
+        xr[t][1] = *reinterpret_cast<const f32x4*>(xp[t] + (int64_t)ks_lo * 512 + 4);
     }
-    for (int i = 0; i < WST; ++i) s_w[0][tx + NTH * i] = wst[i];
+    for (int i = 0; i < WST; ++i) s_w[ks_lo & 1][tx + NTH * i] = wst[i];
     __syncthreads();
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = ks_lo; ks < ks_hi; ++ks) {
         const int cur = ks & 1;
-        const bool more = ks + 1 < KS;
+        const bool more = ks + 1 < ks_hi;
         Bf3 xs[RT];
 #if AC_SPLIT_ABL == 1
         for (int t = 0; t < RT; ++t) {
@@ -236,13 +249,15 @@ __global__ __launch_bounds__(64 * NW) void ac_fc1_split_fwd_kernel(IplanAcFc1Spl
         __syncthreads();
 #endif
     }
+    float* __restrict__ zout = a.z1 + (int64_t)kp * 2 * a.n_agents * a.rows * SM;          // part kp of the output
     for (int o = 0; o < S_OT; ++o) {
         const int which = o >> 2, oc = 16 * (o & 3) + 4 * g;
-        const f32x4 c = *reinterpret_cast<const f32x4*>(a.wbeta + ((int64_t)which * a.n_agents + net) * SM + oc);
+        f32x4 c = splat4(0.f);
+        if (kp == 0) c = *reinterpret_cast<const f32x4*>(a.wbeta + ((int64_t)which * a.n_agents + net) * SM + oc);
         for (int t = 0; t < RT; ++t) {
             const int r = tile[t] * 16 + n;
             if (tile[t] < tiles && r < a.rows)
-                *reinterpret_cast<f32x4*>(a.z1 + (((int64_t)which * a.n_agents + net) * a.rows + r) * SM + oc) = acc[t][o] + c;
+                *reinterpret_cast<f32x4*>(zout + (((int64_t)which * a.n_agents + net) * a.rows + r) * SM + oc) = acc[t][o] + c;
         }
     }
 }
@@ -357,6 +372,23 @@ extern "C" int iplan_ac_xhat_pack(const IplanAcXhatArgs* a, iplan_stream_t strea
     return check_launch("iplan_ac_xhat_pack");
 }
 
+// small batches: one row tile per wave (IPLAN_AC_SPLIT_SHAPE=full / small forces a shape: tests run both at one size)
+static bool split_small_shape(int n_agents, int rows) {
+    const char* shape = getenv("IPLAN_AC_SPLIT_SHAPE");
+    const int tiles = (rows + 15) / 16;
+    return shape ? shape[0] == 's' : tiles * n_agents <= 2 * 256 * AC_SPLIT_NW;
+}
+
+// K parts of the small-batch forward: as many as bring its workgroup count to about two per CU, at most 4 (the consumer re-reads
+// every part; a part may come out empty when there are fewer K steps than parts -- it then holds zeros / W beta alone)
+extern "C" int iplan_ac_fc1_split_parts(int32_t n_agents, int32_t rows) {
+    if (n_agents < 1 || rows < 1 || !split_small_shape(n_agents, rows)) return 1;
+    const char* e = getenv("IPLAN_AC_SPLIT_KPARTS");
+    if (e && e[0]) return iplan::imax(1, iplan::imin(8, atoi(e)));
+    const int wgs = ((rows + 15) / 16 + AC_SPLIT_NW - 1) / AC_SPLIT_NW * n_agents;
+    return iplan::imax(1, iplan::imin(4, 512 / iplan::imax(wgs, 1)));
+}
+
 extern "C" int iplan_ac_fc1_split_fwd(const IplanAcFc1SplitArgs* a, iplan_stream_t stream) {
     using namespace iplan;
     if (!a || a->n_agents < 1 || a->rows < 1 || !a->xf || !a->wsplit || !a->wbeta || !a->z1 || !a->actor.params || !a->critic.params ||
@@ -366,14 +398,15 @@ extern "C" int iplan_ac_fc1_split_fwd(const IplanAcFc1SplitArgs* a, iplan_stream
     for (int s = 0; s < 3; ++s) kt += (a->feat.N * a->feat.w[s] + 15) / 16;
     kt += (a->feat.n_actions + a->feat.n_id + 15) / 16;
     const int KS = (kt + 1) / 2, tiles = (a->rows + 15) / 16;
-    hipLaunchKernelGGL(ac_fc1_wsplit_kernel, dim3((unsigned)KS, (unsigned)a->n_agents, 2), dim3(256), 0, (hipStream_t)stream, *a);
-    hipLaunchKernelGGL(ac_fc1_wbeta_kernel, dim3((unsigned)a->n_agents, 2, SM / 8), dim3(256), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(ac_fc1_wprep_kernel, dim3((unsigned)(KS * a->n_agents * 2 + a->n_agents * 2 * (SM / 8))), dim3(256), 0, (hipStream_t)stream, *a, KS);
     constexpr int TPW = AC_SPLIT_NW * SF_RT;                       // row tiles per workgroup
-    // small batches: one row tile per wave (IPLAN_AC_SPLIT_SHAPE=full / small forces a shape: tests run both at one size)
-    const char* shape = getenv("IPLAN_AC_SPLIT_SHAPE");
-    const bool small = shape ? shape[0] == 's' : tiles * a->n_agents <= 2 * 256 * AC_SPLIT_NW;
+    const bool small = split_small_shape(a->n_agents, a->rows);
+    const int kparts = a->kparts > 1 ? a->kparts : 1;
+    if (kparts > 1 && (!small || kparts > iplan_ac_fc1_split_parts(a->n_agents, a->rows)))
+        return fail(IPLAN_EINVAL, "iplan_ac_fc1_split_fwd: kparts = %d, but iplan_ac_fc1_split_parts() allows %d at this size", kparts,
+                    iplan_ac_fc1_split_parts(a->n_agents, a->rows));
     if (small) {
-        hipLaunchKernelGGL((ac_fc1_split_fwd_kernel<AC_SPLIT_NW, 1>), dim3((unsigned)((tiles + AC_SPLIT_NW - 1) / AC_SPLIT_NW), (unsigned)a->n_agents),
+        hipLaunchKernelGGL((ac_fc1_split_fwd_kernel<AC_SPLIT_NW, 1>), dim3((unsigned)((tiles + AC_SPLIT_NW - 1) / AC_SPLIT_NW), (unsigned)a->n_agents, (unsigned)kparts),
                            dim3(64 * AC_SPLIT_NW), 0, (hipStream_t)stream, *a);
         return check_launch("iplan_ac_fc1_split_fwd");
     }

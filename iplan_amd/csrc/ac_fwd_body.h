@@ -422,6 +422,10 @@ __device__ __forceinline__ void ac_fwd_body(const IplanAcFwdArgs& a, const AcGri
         for (int t = 0; t < RT; ++t) {
             const float* zrow = a.fc1_pre + (((int64_t)which * a.n_agents + net) * a.rows + (vld[t] ? rr[t] : 0)) * AM;
             for (int o = 0; o < AT; ++o) accs[t][o] = vload_a(zrow, vld[t], o);
+            // (small batches: the K loop of the split contraction ran in fc1_pre_parts workgroups -- their parts, in order)
+            const int64_t zpart = 2 * (int64_t)a.n_agents * a.rows * AM;
+            for (int pp = 1; pp < a.fc1_pre_parts; ++pp)
+                for (int o = 0; o < AT; ++o) accs[t][o] += vload_a(zrow + pp * zpart, vld[t], o);
         }
     }
     for (int s = 0; s < (PRE ? 0 : 4); ++s) {

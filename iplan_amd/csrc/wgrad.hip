@@ -42,6 +42,10 @@ constexpr int WG_TK = 4;            // k-tiles per wave job (both shapes)
 #ifndef IPLAN_WG_WIDE_SLOTS
 #define IPLAN_WG_WIDE_SLOTS 1024    // wave slots one round of wide jobs fills (1024 SIMDs x resident wide waves per SIMD)
 #endif
+#ifndef IPLAN_WG_MIN_ROWS
+#define IPLAN_WG_MIN_ROWS 64        // shortest row chunk of a wave job.  256 until round 4: a data-parallel rank's 2 880 PPO rows were then
+#endif                              // 12 chunks per problem -- a handful of long waves per launch; 64 (45 chunks): rank-of-8 step 41.9 -> 40.3 ms,
+                                    // config 3 unchanged (272 ms); 32: no better at 2 880 rows, worse at 22 950 (profiles/r04_notes.md)
 constexpr int WG_TO_WIDE = IPLAN_WG_TO_WIDE;      // o-tiles per wave job: wide shape (problems with more than 8 o-tiles) ...
 constexpr int WG_TO_NARROW = 4;     // ... and narrow shape
 
@@ -67,7 +71,7 @@ __host__ __device__ inline WgradGeom wgrad_geom(const IplanWgradProblem& p, int 
     const bool thin = g.to != WG_TO_WIDE && (g.KT <= 1 || g.OT == 1);
     const int target = g.to == WG_TO_WIDE ? chunks_wide : (thin ? 8 * IPLAN_WGRAD_MAX_CHUNKS : IPLAN_WGRAD_MAX_CHUNKS);
     int64_t vr = (g.rows + target - 1) / target;
-    if (vr < 256) vr = 256;
+    if (vr < IPLAN_WG_MIN_ROWS) vr = IPLAN_WG_MIN_ROWS;
     vr = (vr + 15) / 16 * 16;
     g.vrows = (int)vr;
     g.vchunks = (int)((g.rows + vr - 1) / vr);

@@ -332,7 +332,9 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
         s.actor, s.critic = a.actor, a.critic
         KS = (xhat["KT"] + 1) // 2
         ws = workspace(dev, n_agents * KS * 6144 + 2 * n_agents * L.AC_HIDDEN, "fc1_split")
-        z1 = torch.empty(2, n_agents, rows, L.AC_HIDDEN, **f32)
+        kparts = int(lib.c.iplan_ac_fc1_split_parts(n_agents, rows))           # > 1: small batches, the K loop over several workgroups
+        z1 = torch.empty(kparts, 2, n_agents, rows, L.AC_HIDDEN, **f32)
+        s.kparts, a.fc1_pre_parts = kparts, kparts
         s.xf, s.wsplit, s.wbeta, s.z1 = xhat["xf"].data_ptr(), ws.data_ptr(), ws.data_ptr() + 4 * n_agents * KS * 6144, z1.data_ptr()
         # algorithmic work of the launch: 2 FLOP per (row, feature, output) of both nets
         _launch("ac_fc1_split_fwd", lambda: lib.call("iplan_ac_fc1_split_fwd", s, L.current_stream(dev)),

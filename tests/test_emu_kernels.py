@@ -483,7 +483,7 @@ def check_fc1_split_vs_fp32(device, rows_per_ep=7, n_eps=5, seed=3, N=5, log=Non
         bw = ops.ac_backward(out, mac.actor_arena, mac.critic_arena, g_logp=g1, g_entropy=-0.01 / rows, g_values=g2)
         res[tag] = dict(a1=out["saved"][..., 0:M].clone(), logp=out["logp"].clone(), values=out["values"].clone(),
                         dz1=bw["dsave"][..., 0:M].clone(), ga=mac.actor_arena.grad.clone(), gc=mac.critic_arena.grad.clone(),
-                        z1=None if xh is None else out["_keep"][11].clone())
+                        z1=None if xh is None else out["_keep"][11].sum(0))          # ([K parts, 2, nA, rows, 64]: the parts add up)
     # fp64 evaluation from the raw fields
     x = torch.cat([torch.cat([f[key][:, :T].double() for key, _ in mac._widths()], dim=-1).flatten(-2)], dim=-1)   # [eps, T, nA, N*W]
     oh_last = torch.zeros(n_eps, T, nA, args.n_actions, dtype=torch.float64, device=device)
