@@ -286,6 +286,8 @@ class SyntheticLoop:
         prep = self.behavior.prepare_learn(batch) if getattr(type(self.behavior), "learn_takes_prepared", False) else None
         ev = torch.cuda.Event()
         ev.record(main)
+        if self.behavior is not None and hasattr(self.behavior, "flush_decoder"):
+            self.behavior.flush_decoder()                    # (a held-back decoder update of the previous cycle: behind the rollout)
         # IPLAN_BEH_FIRST=1 (A/B knob): behaviour learning -- the critical path of the phase -- is enqueued BEFORE the side
         # learners (read-back staged, so the host goes straight on to them): its first kernels then start ~0.2 ms after the
         # rollout instead of behind prediction learning's ~1.2 ms of host-side sampling + enqueue

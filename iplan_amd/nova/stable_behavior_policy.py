@@ -123,14 +123,30 @@ class Behavior_policy:
     def join_decoder(self):
         """Make the current stream wait for a decoder update that ``learn(..., defer_decoder=True)`` left running on the side
         stream (no-op otherwise).  Everything that reads or writes the decoder's parameters calls this first."""
+        self.flush_decoder()
         ev = getattr(self, "_dec_done", None)
-        if ev is not None:
+        if ev is not None and self.defer_late == 1:
+            # (the update was enqueued moments ago: a host wait here would stall the enqueue of this call's own forward; the
+            # allocator alternates between two sets of record blocks instead)
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            self._dec_done = None
+        elif ev is not None:
             # HOST wait, not just a stream wait: the update holds the previous call's 23 GB of BPTT records (record_stream);
             # until its event has completed the caching allocator cannot hand those blocks to this call and would go to
             # hipMalloc for fresh ones (+13 ms per call, measured)
             ev.synchronize()
             torch.cuda.current_stream(self.device).wait_event(ev)
             self._dec_done = None
+
+    defer_late = int(os.environ.get("IPLAN_DEFER_LATE", "0"))
+
+    def flush_decoder(self):
+        """Enqueue a decoder update that ``learn(..., defer_decoder=True)`` held back (IPLAN_DEFER_LATE), behind the work the
+        current stream holds now.  The training loop calls it when the next rollout has been enqueued; ``join_decoder`` calls it too."""
+        f = getattr(self, "_dec_pending", None)
+        if f is not None:
+            self._dec_pending = None
+            f()
 
     learn_takes_prepared = True         # (subclasses with their own ``learn`` signature switch it off)
 
@@ -219,19 +235,30 @@ class Behavior_policy:
                 # plain side stream by default; IPLAN_DEFER_CUS=k restricts it to k CUs (see harness.py / profiles/r02e_notes.md)
                 self._dec_stream = masked_stream(dev, int(os.environ.get("IPLAN_DEFER_CUS", "0")))
             ds = self._dec_stream if on_gpu else None                   # (CPU / emulator: same code, run in line)
-            bwd["dec_wgrad"](ds)
-            with (torch.cuda.stream(ds) if on_gpu else contextlib.nullcontext()):
-                if getattr(self, "dp", None) is not None:
-                    self.dp.all_reduce_grads(self.dec_arena)
-                # (its own norm buffer: the encoder half of the NEXT call fills the shared one on the main stream while this
-                # half may still be running here)
-                if getattr(self, "_dec_sq_buf", None) is None:
-                    self._dec_sq_buf = torch.zeros(nA, len(self.behavior_optimizer[0].slices), dtype=torch.float32, device=dev)
-                sq_d = step_all(self.behavior_optimizer, max_norm, slices=(1,), steps=steps, sq=self._dec_sq_buf)
-                self._dec_sq = sq_d[:, 1].clone()
-                if on_gpu:
-                    self._dec_done = torch.cuda.Event()
-                    self._dec_done.record(ds)
+
+            def update(bwd=bwd):
+                bwd["dec_wgrad"](ds)                                    # (behind whatever the CALLER's stream holds at this point)
+                with (torch.cuda.stream(ds) if on_gpu else contextlib.nullcontext()):
+                    if getattr(self, "dp", None) is not None:
+                        self.dp.all_reduce_grads(self.dec_arena)
+                    # (its own norm buffer: the encoder half of the NEXT call fills the shared one on the main stream while this
+                    # half may still be running here)
+                    if getattr(self, "_dec_sq_buf", None) is None:
+                        self._dec_sq_buf = torch.zeros(nA, len(self.behavior_optimizer[0].slices), dtype=torch.float32, device=dev)
+                    sq_d = step_all(self.behavior_optimizer, max_norm, slices=(1,), steps=steps, sq=self._dec_sq_buf)
+                    self._dec_sq = sq_d[:, 1].clone()
+                    if on_gpu:
+                        self._dec_done = torch.cuda.Event()
+                        self._dec_done.record(ds)
+
+            # IPLAN_DEFER_LATE=1 (A/B knob): the update is not enqueued here but handed to the training loop, which starts it
+            # (flush_decoder) once the NEXT rollout is on the device -- the wide contraction holds every SIMD for ~2.7 ms, and
+            # started here it does so in front of that rollout's first, latency-bound launches.  Same values either way.
+            if on_gpu and self.defer_late:
+                self._dec_pending = update
+            else:
+                update()
+            del update
             del bwd
             dec_col = prev_dec if prev_dec is not None else torch.zeros(nA, device=dev)
             host_dev, split = torch.cat([loss_dev.reshape(-1), sq[:, 0].sqrt(), dec_col.sqrt()]), True
