@@ -132,6 +132,8 @@ def check_fused_sync():
     encoder workgroup never reported).  One 4-byte read-back per stream that ever ran a fused launch: call it where the host
     synchronises anyway (end of an episode / a training cycle)."""
     if fused_sync_error():
+        for b in _FUSED_SYNC.values():                       # (a producer that reports after the give-up would leave the counters off by
+            b.zero_()                                        #  one for every later launch: start the next one from a clean state)
         raise L.IplanError("iplan_gat_enc_ac_fwd: an action selection gave up waiting for the latent updates of its launch "
                            "(sync[2] != 0); the episode's actions from that step on are not valid")
 

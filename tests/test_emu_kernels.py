@@ -341,12 +341,15 @@ def test_fused_step_give_up_flag_raises_emulated():
     assert ops._FUSED_SYNC and not ops.fused_sync_error()
     ops.check_fused_sync()
     buf = next(iter(ops._FUSED_SYNC.values()))
-    buf[2] = 1
+    buf[0], buf[2] = 1, 1                                  # (a producer that reported after the give-up: a count left behind)
     try:
         with pytest.raises(L.IplanError):
             ops.check_fused_sync()
+        assert int(buf.abs().sum()) == 0                     # ... and the counters start clean again
+        loop.rollout()
+        ops.check_fused_sync()
     finally:
-        buf[2] = 0
+        buf.zero_()
 
 
 def check_seq2seq(golden, device):
