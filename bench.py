@@ -460,6 +460,10 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
               f"the 64-wide tail of the actor + critic forward of one PPO epoch from the stored fc1 pre-activations ({rows} rows, 5 agents): "
               "reads z1 and the stored GRU state, writes the 648-float activation record per row and net",
               traffic_key="ac_fwd_kernel:train"),
+        entry("ac_bwd_tail_kernel", "ac_bwd_tail_kernel", "hbm", 0.0, 1e9, HBM_PEAK_GBS, "GB/s",
+              "the 64-wide tail of the actor + critic backward of one PPO epoch: reads 8 of the record's 10 rows per net and row + the hidden "
+              "state, writes the 400-float row gradients the weight-gradient contractions read, weights (transposed) staged in LDS",
+              traffic_key="ac_bwd_tail_kernel", work_from_timer=True),
     ]
     n_sc, sc_us, _ = timed.get("gat_scenes_span_us", (0, nan, 0.0))
     if n_sc:

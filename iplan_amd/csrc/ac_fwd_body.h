@@ -23,7 +23,7 @@ constexpr int AT = AM / 16;            // 4 tiles
 
 
 // LDS of one workgroup of the forward (a struct, so that the fused launch can overlay it with the GAT scene's)
-template <int RT>
+template <int RT, int NW = 8>          // NW: waves per workgroup
 struct AcShared {
 #ifdef AC_NO_STAGED_TAIL                // A/B builds (scripts/build_variants.sh)
     static constexpr bool STAGED_BUILD = false, STAGED2 = false;
@@ -33,7 +33,7 @@ struct AcShared {
     static constexpr int TLDW = AM + 8;
     static constexpr int TW_ROWS = STAGED2 ? AM + 3 * AM + 16 + 3 * AM : (STAGED_BUILD ? AM + 3 * AM + 16 : 0);
     static constexpr int TP_FLOATS = 912;
-    float red[8][16], red2[8][16], cc[8][2][AM];
+    float red[NW][16], red2[NW][16], cc[NW][2][AM];
     float hand[4];                        // [0]: the tail's hand-over flag (1 = this workgroup runs the tail)
     __attribute__((aligned(16))) f32x4 acc[RT == 1 ? 8 : 1][AT][64];
     __attribute__((aligned(16))) float tw[TW_ROWS ? TW_ROWS * TLDW : 4];
@@ -106,8 +106,8 @@ __device__ __forceinline__ void ac_wait_producers(const AcProducers& pr) {
 #endif
 }
 
-template <int RT, bool PRE, bool FUSED>
-__device__ __forceinline__ void ac_fwd_body(const IplanAcFwdArgs& a, const AcGrid& gp, AcShared<RT>& sh, const AcProducers& prod) {
+template <int RT, bool PRE, bool FUSED, int NW = 8>
+__device__ __forceinline__ void ac_fwd_body(const IplanAcFwdArgs& a, const AcGrid& gp, AcShared<RT, NW>& sh, const AcProducers& prod) {
     auto& s_red = sh.red;
     auto& s_red2 = sh.red2;
     auto& s_cc = sh.cc;
@@ -126,15 +126,15 @@ __device__ __forceinline__ void ac_fwd_body(const IplanAcFwdArgs& a, const AcGri
 #else
     constexpr bool STAGED_BUILD = RT == 1, STAGED2 = RT == 2;
 #endif
-    constexpr int TW_ROWS = AcShared<RT>::TW_ROWS;
-    static_assert(TLDW == AcShared<RT>::TLDW, "tail weight row stride");
+    constexpr int TW_ROWS = AcShared<RT, NW>::TW_ROWS;
+    static_assert(TLDW == AcShared<RT, NW>::TLDW, "tail weight row stride");
     auto& s_tw = sh.tw;                                                                    // fc2 | W_ih | head rows (| W_hh)
     auto& s_gh = sh.gh;
     // the tail's parameter VECTORS (biases, LayerNorm gamma / beta): 26 of them per row tile, each a dependent ~1 us L2 round
     // trip when read where it is used (37 of the 50 us a row tile's tail took in the streaming form)
     constexpr int TP_FC1B = 0, TP_LN1W = 64, TP_LN1B = 128, TP_FC2B = 192, TP_LN2W = 256, TP_LN2B = 320, TP_BIH = 384, TP_BHH = 576,
                   TP_LN3W = 768, TP_LN3B = 832, TP_HEADB = 896, TP_FLOATS = 912;
-    static_assert(TP_FLOATS == AcShared<RT>::TP_FLOATS, "tail parameter vectors");
+    static_assert(TP_FLOATS == AcShared<RT, NW>::TP_FLOATS, "tail parameter vectors");
     auto& s_tp = sh.tp;
 
     // XCD-aware placement (speed only, any placement is correct): workgroup b runs on XCD b % 8 and every (net, actor|critic)
@@ -161,7 +161,7 @@ __device__ __forceinline__ void ac_fwd_body(const IplanAcFwdArgs& a, const AcGri
     const IplanAcFeatures& ft = a.feat;
     const int l = lane_id(), w = uniform_i(wave_id()), n = l & 15, g = l >> 4;
     const int ks = RT == 1 ? a.ksplit : 1;
-    const int groups = 8 / ks;
+    const int groups = NW / ks;
     const int part = w % ks;
     // Rollout shape, K split over KW WORKGROUPS as well (a.ksplit_wg): 2 row tiles x 10 nets are 20 workgroups on 256 CUs and
     // the F-wide contraction is a latency chain of ~20 k-tiles per wave; with KW = 4 every wave owns ~5 and the partial sums
@@ -212,7 +212,7 @@ __device__ __forceinline__ void ac_fwd_body(const IplanAcFwdArgs& a, const AcGri
     if (STAGED_BUILD && staged) {
         // (a) 4352 16-byte chunks of [fc2.weight 64x64 | rnn.weight_ih 192x64 | head n_out x 64 (zero padded to 16 rows)]
         const float* Wsrc[3] = {P + nw.off[IPLAN_AC_FC2_W], P + nw.off[IPLAN_AC_WIH], P + nw.off[IPLAN_AC_HEAD_W]};
-        for (int c = (int)threadIdx.x; c < (AM + 3 * AM + 16) * 16; c += 512) {
+        for (int c = (int)threadIdx.x; c < (AM + 3 * AM + 16) * 16; c += 64 * NW) {
             const int r = c >> 4, c4 = c & 15;
             f32x4 v = splat4(0.f);
             if (r < AM) v = *reinterpret_cast<const f32x4*>(Wsrc[0] + r * AM + 4 * c4);
@@ -225,13 +225,13 @@ __device__ __forceinline__ void ac_fwd_body(const IplanAcFwdArgs& a, const AcGri
         const float* hrow0 = hsrc0 + (int64_t)net * a.hs_net + prr[0] * a.hs_row;
         f32x4 h0[AT];
         for (int t = 0; t < AT; ++t) h0[t] = vload(hrow0, vld[0], AM, t);
-        for (int t = w; t < 3 * AT; t += 8)
+        for (int t = w; t < 3 * AT; t += NW)
             s_gh[t][l] = dense_tile_ga<AT>(P + nw.off[IPLAN_AC_WHH], AM, 3 * AM, 16 * t, h0, bfrag_a(P + nw.off[IPLAN_AC_BHH], t));
     }
 
     if (STAGED2) {      // 7424 16-byte chunks: [fc2 64 | rnn.weight_ih 192 | head n_out (zero padded to 16) | rnn.weight_hh 192] x 64
         const float* Wsrc[4] = {P + nw.off[IPLAN_AC_FC2_W], P + nw.off[IPLAN_AC_WIH], P + nw.off[IPLAN_AC_HEAD_W], P + nw.off[IPLAN_AC_WHH]};
-        for (int c = (int)threadIdx.x; c < TW_ROWS * 16; c += 512) {
+        for (int c = (int)threadIdx.x; c < TW_ROWS * 16; c += 64 * NW) {
             const int r = c >> 4, c4 = c & 15;
             f32x4 v = splat4(0.f);
             if (r < AM) v = *reinterpret_cast<const f32x4*>(Wsrc[0] + r * AM + 4 * c4);
@@ -250,7 +250,7 @@ __device__ __forceinline__ void ac_fwd_body(const IplanAcFwdArgs& a, const AcGri
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
             const int len = k == 10 ? 16 : ((k == 6 || k == 7) ? 3 * AM : AM), have = k == 10 ? nw.n_out : len;
-            for (int i = (int)threadIdx.x; i < len; i += 512) s_tp[tp_off[k] + i] = i < have ? P[nw.off[tp_src[k]] + i] : 0.f;
+            for (int i = (int)threadIdx.x; i < len; i += 64 * NW) s_tp[tp_off[k] + i] = i < have ? P[nw.off[tp_src[k]] + i] : 0.f;
         }
     }
 

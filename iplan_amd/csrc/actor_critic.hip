@@ -14,11 +14,17 @@
 
 namespace iplan {
 
-template <int RT, bool PRE>
-__global__ __launch_bounds__(512) void ac_fwd_kernel(IplanAcFwdArgs a) {
-    __shared__ __attribute__((aligned(16))) AcShared<RT> sh;
+// NW = waves per workgroup.  The PPO epoch's tail launch (PRE: fc1 pre-activations given, one wave per pair of row tiles, the
+// 64-wide weights staged in LDS -- one workgroup per CU) runs 16 waves behind one staging when 8-wave workgroups would need more
+// than one round over the chip: a tile pair's tail is a chain of dependent stages (LDS fragment -> MFMA chain -> LayerNorm -> ...),
+// and with 2 waves per SIMD the SIMDs sat 1.2 waves deep on average (SQ_WAVE_CYCLES, profiles/r04d_pmc_ppo_train.txt).  128
+// registers per lane are enough for it.  Small batches (a data-parallel rank's 2 880 rows: 120 workgroups) keep 8 waves -- one
+// round either way, and more CUs share it.
+template <int RT, bool PRE, int NW>
+__global__ __launch_bounds__(64 * NW) void ac_fwd_kernel(IplanAcFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) AcShared<RT, NW> sh;
     const AcGrid gp = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z};
-    ac_fwd_body<RT, PRE, false>(a, gp, sh, AcProducers{nullptr, 0, 0});
+    ac_fwd_body<RT, PRE, false, NW>(a, gp, sh, AcProducers{nullptr, 0, 0});
 }
 
 // fc1.weight / feature_norm.{weight, bias} -> the forward kernels' K order and MFMA fragment order (see the header)
@@ -113,13 +119,18 @@ extern "C" int iplan_ac_fwd(const IplanAcFwdArgs* a, iplan_stream_t stream) {
     using namespace iplan;
     if (int rc = ac_fwd_check(a)) return rc;
     const int tiles = (a->rows + 15) / 16;
+    const unsigned nz = a->which == 2 ? 2u : 1u;
     if (a->ksplit == 8) {
-        dim3 grid((unsigned)(tiles * (a->ksplit_wg > 1 ? a->ksplit_wg : 1)), (unsigned)a->n_agents, a->which == 2 ? 2u : 1u);
-        hipLaunchKernelGGL((ac_fwd_kernel<1, false>), grid, dim3(512), 0, (hipStream_t)stream, *a);
+        dim3 grid((unsigned)(tiles * (a->ksplit_wg > 1 ? a->ksplit_wg : 1)), (unsigned)a->n_agents, nz);
+        hipLaunchKernelGGL((ac_fwd_kernel<1, false, 8>), grid, dim3(512), 0, (hipStream_t)stream, *a);
     } else {
-        dim3 grid((unsigned)((tiles + 8 * AC_RT - 1) / (8 * AC_RT)), (unsigned)a->n_agents, a->which == 2 ? 2u : 1u);   // 8 waves x AC_RT row tiles
-        if (a->fc1_pre) hipLaunchKernelGGL((ac_fwd_kernel<AC_RT, true>), grid, dim3(512), 0, (hipStream_t)stream, *a);
-        else hipLaunchKernelGGL((ac_fwd_kernel<AC_RT, false>), grid, dim3(512), 0, (hipStream_t)stream, *a);
+        const int wg8 = (tiles + 8 * AC_RT - 1) / (8 * AC_RT);                                    // 8 waves x AC_RT row tiles per workgroup
+        const char* env = getenv("IPLAN_AC_PRE_WAVES");                                          // (A/B knob: 8 or 16)
+        const bool wide = a->fc1_pre && (env ? atoi(env) == 16 : (int64_t)wg8 * a->n_agents * nz > 256);
+        dim3 grid((unsigned)(wide ? (wg8 + 1) / 2 : wg8), (unsigned)a->n_agents, nz);
+        if (wide) hipLaunchKernelGGL((ac_fwd_kernel<AC_RT, true, 16>), grid, dim3(1024), 0, (hipStream_t)stream, *a);
+        else if (a->fc1_pre) hipLaunchKernelGGL((ac_fwd_kernel<AC_RT, true, 8>), grid, dim3(512), 0, (hipStream_t)stream, *a);
+        else hipLaunchKernelGGL((ac_fwd_kernel<AC_RT, false, 8>), grid, dim3(512), 0, (hipStream_t)stream, *a);
     }
     return check_launch("iplan_ac_fwd");
 }

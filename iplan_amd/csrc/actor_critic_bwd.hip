@@ -23,12 +23,13 @@ constexpr int BM = IPLAN_AC_HIDDEN;    // 64
 constexpr int BT = BM / 16;            // 4 tiles
 
 // LayerNorm backward on a 64-wide per-chain vector.  dy -> dx (in place); dgam/dbet accumulate.
+// (gamma: 64 floats in LDS)
 __device__ __forceinline__ void ln_bwd_tiles(f32x4 (&dy)[BT], const f32x4 (&xhat)[BT], const float* __restrict__ gamma,
                                              float rstd, f32x4 (&dgam)[BT], f32x4 (&dbet)[BT]) {
     float s1 = 0.f, s2 = 0.f;
     f32x4 dxh[BT];
     for (int t = 0; t < BT; ++t) {
-        const f32x4 gm = bfrag_a(gamma, t);
+        const f32x4 gm = bfrag_lds(gamma, t);
         for (int q = 0; q < 4; ++q) {
             dgam[t][q] = dy[t][q] * xhat[t][q];
             dbet[t][q] = dy[t][q];
@@ -64,7 +65,23 @@ __device__ __forceinline__ void store_ln_part(float* __restrict__ dst, const f32
         }
 }
 
-__global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
+// The three backward-data products of a tile (head^T, W_ih^T, fc2^T) read their weights TRANSPOSED from LDS: a workgroup of
+// BWD_TAIL_WAVES waves stages  W_ih^T [64][192], fc2^T [64][64], head^T [64][16]  (76 KB: two workgroups per CU, four waves per
+// SIMD at <= 128 registers) so that an A fragment is one ds_read_b128.  Read from global memory they were 4 dword loads per
+// fragment from 4 rows of the row-major weight (68 KB per tile through L1/L2, each layer's loads in front of its MFMA chain):
+// the launch sat at 14 % MFMA-busy with 42 % of its wave-cycles waiting for an instruction's operands
+// (profiles/r04d_pmc_ppo_train.txt).  Summation order per accumulator as before (k-tile outer, sub-step inner).
+constexpr int BWD_TAIL_WAVES = 8;
+constexpr int BT_LDI = 3 * BM + 8, BT_LDF = BM + 8, BT_LDH = 16 + 8;      // row strides (floats): conflict-free b128 fragments
+struct AcBwdTailShared {
+    __attribute__((aligned(16))) float wih_t[BM * BT_LDI];                // W_ih^T:  [input feature][gate row]
+    __attribute__((aligned(16))) float fc2_t[BM * BT_LDF];                // fc2^T
+    __attribute__((aligned(16))) float head_t[BM * BT_LDH];               // head^T, rows >= n_out zero
+    __attribute__((aligned(16))) float gam[3][BM];                        // LN3 / LN2 / LN1 weight
+};
+
+__global__ __launch_bounds__(64 * BWD_TAIL_WAVES, 4) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
+    __shared__ AcBwdTailShared sh;
     const IplanAcFwdArgs& fa = a.fwd;
     const bool act_tanh = fa.act_tanh != 0;                     // (uniform) MLPBase activation of the forward pass
     const int net = (int)blockIdx.y;
@@ -73,9 +90,35 @@ __global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
     const float* __restrict__ P = nw.params + (int64_t)net * nw.params_s_net;
     const IplanAcFeatures& ft = fa.feat;
     const int l = lane_id(), n = l & 15, g = l >> 4;
-    const int tile = (int)blockIdx.x * 4 + wave_id();
+    const int tile = (int)blockIdx.x * BWD_TAIL_WAVES + wave_id();
     const int tiles = (fa.rows + 15) / 16;
+    {
+        // 16-byte chunks of the row-major weights (coalesced), scattered into the transposed LDS images
+        const float* Wi = P + nw.off[IPLAN_AC_WIH];
+        const float* W2 = P + nw.off[IPLAN_AC_FC2_W];
+        const float* Wh = P + nw.off[IPLAN_AC_HEAD_W];
+        constexpr int NT = 64 * BWD_TAIL_WAVES;
+        for (int c = (int)threadIdx.x; c < (3 * BM + BM + 16) * 16; c += NT) {
+            const int r = c >> 4, c4 = c & 15;
+            if (r < 3 * BM) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(Wi + r * BM + 4 * c4);
+                for (int q = 0; q < 4; ++q) sh.wih_t[(4 * c4 + q) * BT_LDI + r] = v[q];
+            } else if (r < 4 * BM) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(W2 + (r - 3 * BM) * BM + 4 * c4);
+                for (int q = 0; q < 4; ++q) sh.fc2_t[(4 * c4 + q) * BT_LDF + (r - 3 * BM)] = v[q];
+            } else {
+                const int k = r - 4 * BM;
+                f32x4 v = splat4(0.f);
+                if (k < nw.n_out) v = *reinterpret_cast<const f32x4*>(Wh + k * BM + 4 * c4);
+                for (int q = 0; q < 4; ++q) sh.head_t[(4 * c4 + q) * BT_LDH + k] = v[q];
+            }
+        }
+        const int gsrc[3] = {IPLAN_AC_LN3_W, IPLAN_AC_LN2_W, IPLAN_AC_LN1_W};
+        for (int i = (int)threadIdx.x; i < 3 * BM; i += NT) sh.gam[i / BM][i % BM] = P[nw.off[gsrc[i / BM]] + i % BM];
+    }
+    __syncthreads();
     if (tile >= tiles) return;
+    const int o4[BT] = {0, 16, 32, 48};
     const int r = tile * 16 + n;
     const bool valid = r < fa.rows;
     const int64_t pr = valid ? (int64_t)(r / ft.T) * ft.T_phys + (r % ft.T) : 0;
@@ -150,12 +193,13 @@ __global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
     f32x4 dgam[BT], dbet[BT];
     // ---- f3 = LN3(hnew)
     f32x4 d[BT];
-    for (int t = 0; t < BT; ++t) d[t] = dense_tile_gt<1>(P + nw.off[IPLAN_AC_HEAD_W], BM, n_out, BM, 16 * t, dhead, splat4(0.f));
+    for (int t = 0; t < BT; ++t) d[t] = splat4(0.f);
+    dense_multi<BT, 1>(sh.head_t, BT_LDH, o4, 0, dhead, d);
     {
         f32x4 xh[BT];
         for (int t = 0; t < BT; ++t)
             for (int q = 0; q < 4; ++q) xh[t][q] = (hnew[t][q] - mu3) * rs3;
-        ln_bwd_tiles(d, xh, P + nw.off[IPLAN_AC_LN3_W], rs3, dgam, dbet);
+        ln_bwd_tiles(d, xh, sh.gam[0], rs3, dgam, dbet);
         store_ln_part(lnp, dgam, dbet);
     }
     // ---- GRU step
@@ -177,7 +221,8 @@ __global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
             vstore(ds + 5 * BM, valid, BM, t, o.dnh);
         }
     }
-    for (int t = 0; t < BT; ++t) d[t] = dense_tile_gta<3 * BT>(P + nw.off[IPLAN_AC_WIH], BM, 16 * t, dg, splat4(0.f));
+    for (int t = 0; t < BT; ++t) d[t] = splat4(0.f);
+    dense_multi<BT, 3 * BT>(sh.wih_t, BT_LDI, o4, 0, dg, d);
     // ---- f2 = LN2(a2), a2 = ReLU(fc2(f1))
     {
         f32x4 xh[BT], a2[BT];
@@ -185,7 +230,7 @@ __global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
             a2[t] = vload(sv + 2 * BM, valid, BM, t);
             for (int q = 0; q < 4; ++q) xh[t][q] = (a2[t][q] - mu2) * rs2;
         }
-        ln_bwd_tiles(d, xh, P + nw.off[IPLAN_AC_LN2_W], rs2, dgam, dbet);
+        ln_bwd_tiles(d, xh, sh.gam[1], rs2, dgam, dbet);
         store_ln_part(lnp + 2 * BM, dgam, dbet);
         for (int t = 0; t < BT; ++t) {
             for (int q = 0; q < 4; ++q) d[t][q] = act_tanh ? d[t][q] * (1.0f - a2[t][q] * a2[t][q]) : (a2[t][q] > 0.f ? d[t][q] : 0.f);
@@ -194,7 +239,8 @@ __global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
     }
     {
         f32x4 df1[BT];
-        for (int t = 0; t < BT; ++t) df1[t] = dense_tile_gta<BT>(P + nw.off[IPLAN_AC_FC2_W], BM, 16 * t, d, splat4(0.f));
+        for (int t = 0; t < BT; ++t) df1[t] = splat4(0.f);
+        dense_multi<BT, BT>(sh.fc2_t, BT_LDF, o4, 0, d, df1);
         for (int t = 0; t < BT; ++t) d[t] = df1[t];
     }
     // ---- f1 = LN1(a1), a1 = ReLU(fc1(LN_F(x)))
@@ -204,7 +250,7 @@ __global__ __launch_bounds__(256) void ac_bwd_tail_kernel(IplanAcBwdArgs a) {
             a1[t] = vload(sv, valid, BM, t);
             for (int q = 0; q < 4; ++q) xh[t][q] = (a1[t][q] - mu1) * rs1;
         }
-        ln_bwd_tiles(d, xh, P + nw.off[IPLAN_AC_LN1_W], rs1, dgam, dbet);
+        ln_bwd_tiles(d, xh, sh.gam[2], rs1, dgam, dbet);
         store_ln_part(lnp + 4 * BM, dgam, dbet);
         for (int t = 0; t < BT; ++t) {
             for (int q = 0; q < 4; ++q) d[t][q] = act_tanh ? d[t][q] * (1.0f - a1[t][q] * a1[t][q]) : (a1[t][q] > 0.f ? d[t][q] : 0.f);
@@ -441,8 +487,8 @@ extern "C" int iplan_ac_bwd_tail(const IplanAcBwdArgs* a, iplan_stream_t stream)
     if (int rc = check_bwd_args(a, "iplan_ac_bwd_tail")) return rc;
     if (!a->ln_part) return fail(IPLAN_EINVAL, "iplan_ac_bwd_tail: ln_part missing");
     const int tiles = (a->fwd.rows + 15) / 16;
-    dim3 grid((unsigned)((tiles + 3) / 4), (unsigned)a->fwd.n_agents, a->fwd.which == 2 ? 2u : 1u);
-    hipLaunchKernelGGL(ac_bwd_tail_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    dim3 grid((unsigned)((tiles + BWD_TAIL_WAVES - 1) / BWD_TAIL_WAVES), (unsigned)a->fwd.n_agents, a->fwd.which == 2 ? 2u : 1u);
+    hipLaunchKernelGGL(ac_bwd_tail_kernel, grid, dim3(64 * BWD_TAIL_WAVES), 0, (hipStream_t)stream, *a);
     return check_launch("iplan_ac_bwd_tail");
 }
 

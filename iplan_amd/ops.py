@@ -587,6 +587,11 @@ def _ac_wgrad(w, arena, head_names, saved, dsave, which, n_agents, rows, T, h, h
     w._keep += [sv, ds, lp]
 
 
+def n_which_rows(which, n_agents, rows):
+    """rows x agents x nets of an actor/critic launch (which = 2: both nets)"""
+    return (2 if which == 2 else 1) * n_agents * rows
+
+
 def ac_backward(fwd, actor_arena, critic_arena, g_logp=None, g_entropy=0.0, g_values=None, lib=None):
     """Backward of an ``ac_forward(..., mode=2, save=True)`` launch: fills the gradient arenas of the
     nets that took part.  g_logp / g_values [n_agents, rows]; g_entropy: per-row tensor or a constant."""
@@ -636,7 +641,10 @@ def ac_backward(fwd, actor_arena, critic_arena, g_logp=None, g_entropy=0.0, g_va
     g_part = workspace(dev, n_which * n_agents * chunks * L.AC_HIDDEN * Fpad, "fc1")
     a.g_part, a.fc1_chunk_rows, a.fc1_chunks = g_part.data_ptr(), chunk_rows, chunks
     stream = L.current_stream(dev)
-    lib.call("iplan_ac_bwd_tail", a, stream)
+    # (algorithmic bytes: the record slots the tail reads -- a1, a2, the four gate rows, h', f3, the statistics -- + the row's hidden state,
+    # the row gradients and the per-tile LayerNorm partials written)
+    _launch("ac_bwd_tail_kernel", lambda: lib.call("iplan_ac_bwd_tail", a, stream),
+            work=4.0 * n_which_rows(which, n_agents, rows) * (8 * L.AC_HIDDEN + 8 + L.AC_HIDDEN + L.AC_DSAVE_FLOATS + L.AC_LNPART_FLOATS / 16.0))
     ev_tail = None
     if which == 2 and dev.type == "cuda":
         ev_tail = torch.cuda.Event()

@@ -328,6 +328,13 @@ def test_ppo_train_vs_oracle_emulated(cfg):
     check_ppo_train_vs_oracle(_small(**kw), "cpu", seed=6)
 
 
+def test_ppo_train_wide_tail_workgroups_vs_oracle_emulated(monkeypatch):
+    """the PPO epoch's forward tail in its 16-wave workgroup form (what a full 22 950-row batch gets; small batches default to 8 waves)"""
+    from tests.oracle_checks import check_ppo_train_vs_oracle
+    monkeypatch.setenv("IPLAN_AC_PRE_WAVES", "16")
+    check_ppo_train_vs_oracle(_small(batch_size_run=5, buffer_size=6, batch_size=5), "cpu", seed=16)
+
+
 def test_ppo_train_tanh_vs_oracle_emulated():
     """args.use_ReLU off (utils/mappo_utils/mlp.py:10): tanh in fc1 / fc2 of actor and critic, forward and backward tail"""
     from tests.oracle_checks import check_ppo_train_vs_oracle
