@@ -37,7 +37,7 @@ def bytes_of(k):
 per_launch = {}
 for key, sub in (("gat_enc_fwd_kernel", "gat_enc_fwd_kernel"), ("gat_enc_ac_fwd_kernel", "gat_enc_ac_fwd_kernel"),
                  ("beh_dec_bwd_kernel", "beh_dec_bwd"), ("beh_dec_fwd_kernel", "beh_dec_fwd"),
-                 ("beh_enc_bwd_kernel", "beh_enc_bwd_kernel"), ("ac_fwd_kernel:train", "ac_fwd_kernel<2, true>"),
+                 ("beh_enc_bwd_kernel", "beh_enc_bwd_kernel"), ("ac_fwd_kernel:train", "ac_fwd_kernel<2, true"),
                  ("ac_fc1_split_fwd", "ac_fc1_split_fwd_kernel"), ("ac_fc1_split_wgrad", "ac_fc1_split_wgrad_kernel"),
                  ("ac_bwd_tail_kernel", "ac_bwd_tail_kernel")):
     if key.startswith("gat_enc") and not [k for k in merged if sub in k]:
