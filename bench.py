@@ -391,8 +391,13 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
         if work_from_timer:
             work = w
         ach = work / sec / unit_scale if n else nan
+        tr = traffic_of(traffic_key or kernel)
+        # no row may imply more than the HBM peak (a counter file matched to the wrong launches did): the PMC figure is of
+        # another run of the same kernels, so allow for box-to-box spread in the duration (8 %), nothing more
+        if tr is not None and n and sec > 0:
+            assert tr / sec / 1e9 <= 1.08 * HBM_PEAK_GBS, (kernel, "PMC traffic / measured launch time exceeds the HBM peak", tr, sec)
         return {"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                "traffic": traffic_of(traffic_key or kernel), "us_per_launch": sec * 1e6 if n else nan,
+                "traffic": tr, "us_per_launch": sec * 1e6 if n else nan,
                 "traffic_source": pmc_src,
                 "launches_timed": n, ("algorithmic_gbyte_per_launch" if bound == "hbm" else "algorithmic_gflop_per_launch"): work / 1e9,
                 "note": note}

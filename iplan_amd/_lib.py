@@ -341,6 +341,7 @@ BEH_SAVE_DEC, BEH_SAVE_ENC, BEH_SAVE_LAT = 496, 192, 32
 BEH_ENC_PART = 7408
 BEH_DSAVE_DEC, BEH_DSAVE_LAT = 336, 16
 BEH_DEC_THIN_PART, BEH_DEC_BWD2_TILES = 2144, 3
+BEH_D2_MAX_WINDOWS = 512                              # csrc/behavior_learn.hip: D2_MAX_WINDOWS (windows per launch of the decoder's second forms)
 
 
 class BehArgs(C.Structure):

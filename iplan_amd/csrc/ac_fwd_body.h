@@ -404,10 +404,14 @@ __device__ __forceinline__ void ac_fwd_body(const IplanAcFwdArgs& a, const AcGri
         for (int oo = 0; oo < AT; ++oo) o.wf[oo] = ldu4(W1 + (int64_t)(16 * oo + n) * F + c0);
     };
     auto fmma = [&](const FOps& o) {
-        if (fold) { fold_mma(o.x[0], o.gm, o.bt, o.wf, 4); return; }
+        // fused launch: o.x may come from coh_load16_untracked, which the compiler's wait counts do not see -- tie it to the LAST tracked
+        // load of the same ring slot (loads return in order), so that its first use cannot be scheduled in front of that load's wait
+        f32x4 ox[RT];
+        for (int t = 0; t < RT; ++t) ox[t] = FUSED ? after_load(o.x[t], o.wf[AT - 1][3]) : o.x[t];
+        if (fold) { fold_mma(ox[0], o.gm, o.bt, o.wf, 4); return; }
         f32x4 xn[RT];
         for (int t = 0; t < RT; ++t)
-            for (int q = 0; q < 4; ++q) xn[t][q] = vld[t] ? (o.x[t][q] - mu[t]) * rstd[t] * o.gm[q] + o.bt[q] : 0.f;
+            for (int q = 0; q < 4; ++q) xn[t][q] = vld[t] ? (ox[t][q] - mu[t]) * rstd[t] * o.gm[q] + o.bt[q] : 0.f;
         for (int oo = 0; oo < AT; ++oo)
             for (int t = 0; t < RT; ++t) accs[t][oo] = mma_block(o.wf[oo], xn[t], accs[t][oo]);
     };
@@ -481,6 +485,12 @@ __device__ __forceinline__ void ac_fwd_body(const IplanAcFwdArgs& a, const AcGri
                 }
             }
             T_slow = b_lo + ((f_hi - b_lo + T_st - 1) / T_st) * T_st;              // first owned tile at or past f_hi
+#if !defined(IPLAN_HOST_EMULATION)
+            // every ring slot has been consumed here (its wait covered the slot's untracked load: fmma); the explicit drain makes that hold
+            // on EVERY control-flow path the compiler emitted, feasible or not, before the ring's registers are reused
+            // (scripts/check_untracked_load_waits.py walks the paths) -- nothing is in flight at this point, it costs nothing
+            if (FUSED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         }
         for (int T = T_slow; T < b_end; T += T_st) {        // ragged / gathered / one-hot tiles
             KOps o;

@@ -43,7 +43,8 @@ struct GatShared {                      // LDS of one scene (157 KB)
 
 // one scene = workgroup `block` of the launch (512 threads); COH: the new latent is stored device-coherently (read by other
 // workgroups of the same launch: gat_enc_ac_fwd_kernel)
-template <bool COH = false>
+// FOLD: the gates' exp2 constants folded into the recurrence's operands (below; launches that do not store the gate record)
+template <bool COH = false, bool FOLD = false>
 __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int block, GatShared& sh) {
     auto& s_B = sh.B;
     auto& s_q = sh.q;
@@ -77,6 +78,12 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
     int64_t* clk = a.phase_clocks ? a.phase_clocks + (int64_t)block * CLK_STRIDE : nullptr;
     if (clk && threadIdx.x == 0) clk[0] = IPLAN_CLOCK();
 
+    // FOLD (the launcher picks it when the gate record is not stored): the gates' exp2 constants -- sigmoid(x) = rcp(1 + exp2(-log2e x)), tanh(x) = 1 - 2 rcp(exp2(2 log2e x) + 1)
+    // -- are folded into the recurrence's OPERANDS once per launch (x-projection, W_b h_j rows, b_hn, and W_hh's rows before their bf16
+    // split), so the pre-activations arrive scaled and the 48 multiplies per wave-step in front of v_exp are gone (gru_gates_folded).  The
+    // training form stores hn for the backward pass and keeps the plain operands.
+    constexpr float GATE_RZ = -1.4426950408889634f, GATE_N = 2.8853900817779268f;
+    constexpr bool fold = IPLAN_GAT_BF3 && FOLD;
     const float* bih = P + a.off[dir ? IPLAN_GAT_R_BIH : IPLAN_GAT_F_BIH];
     const float* bhh = P + a.off[dir ? IPLAN_GAT_R_BHH : IPLAN_GAT_F_BHH];
 
@@ -121,6 +128,7 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
                 ac = mma_block(wfrag_a(Wih, 2 * GH, 3 * GH, 16 * t, 16 * T), h[T], ac);
                 bc = mma_block(wfrag_a(Wih, 2 * GH, 3 * GH, 16 * t, GH + 16 * T), h[T], bc);
             }
+            if (fold) { const float cs = t < 4 ? GATE_RZ : GATE_N; ac *= cs; bc *= cs; }
             areg[t] = ac;
             if (valid) *reinterpret_cast<f32x4*>(&s_B[dir][node][16 * t + 4 * g]) = bc;
         }
@@ -155,7 +163,7 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
     if (tile_live) {
         const float* Whh = P + a.off[dir ? IPLAN_GAT_R_WHH : IPLAN_GAT_F_WHH];   // [3H][H]
         const float* Wh = P + a.off[IPLAN_GAT_HARD_W];                           // [2][2H]
-        const f32x4 bhn0 = bfrag(bhh, 3 * GH, 4), bhn1 = bfrag(bhh, 3 * GH, 5);
+        const f32x4 bhn0 = bfrag(bhh, 3 * GH, 4) * (fold ? GATE_N : 1.0f), bhn1 = bfrag(bhh, 3 * GH, 5) * (fold ? GATE_N : 1.0f);
         // hard-attention logits as a 7th MFMA chain: A = hard_encoding.weight[:, dir*H:(dir+1)*H] (2 real rows),
         // B = the hidden state -> class c of chain n lands in lane (n, g = 0), register c.  The chain runs one
         // step behind (it contracts the SAME h operand the recurrent chains use), so it rides along in the
@@ -167,7 +175,7 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
         // fp32 MFMAs that take the VALU's issue time (1 792 of a step's 2 700 cycles).  (Fetching the pieces in front of the
         // barrier that ends phase 1 was measured: phases 1 / 2 +1.4 / +1.8 us, 247 registers -- not kept.)
         Bf3 whh[6], wl;
-        for (int t = 0; t < 6; ++t) whh[t] = wfrag_bf3(Whh, GH, 3 * GH, 16 * t, 0);
+        for (int t = 0; t < 6; ++t) whh[t] = wfrag_bf3_scaled(Whh, GH, 3 * GH, 16 * t, 0, fold ? (t < 4 ? GATE_RZ : GATE_N) : 1.0f);
         wl = wfrag_bf3(Wh + dir * GH, 2 * GH, 2, 0, 0);
 #else
         f32x4 whh[6][2];
@@ -227,8 +235,14 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
             }
             const f32x4 pr0 = acc[0] + bc[0], pr1 = acc[1] + bc[1], pz0 = acc[2] + bc[2], pz1 = acc[3] + bc[3];
             const f32x4 gn0 = areg[4] + bc[4], gn1 = areg[5] + bc[5];
-            const GruGates o0 = gru_gates(pr0, pz0, gn0, acc[4], h0);
-            const GruGates o1 = gru_gates(pr1, pz1, gn1, acc[5], h1);
+            GruGates o0, o1;
+            if constexpr (fold) {
+                o0 = gru_gates_folded(pr0, pz0, gn0, acc[4], h0);
+                o1 = gru_gates_folded(pr1, pz1, gn1, acc[5], h1);
+            } else {
+                o0 = gru_gates(pr0, pz0, gn0, acc[4], h0);
+                o1 = gru_gates(pr1, pz1, gn1, acc[5], h1);
+            }
             h0 = o0.h;
             h1 = o1.h;
             if (sv.gru) {
@@ -425,9 +439,10 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
     }
 }
 
+template <bool FOLD>
 __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
     __shared__ __attribute__((aligned(16))) GatShared sh;
-    gat_fwd_block(a, (int)blockIdx.x, sh);
+    gat_fwd_block<false, FOLD>(a, (int)blockIdx.x, sh);
 }
 
 // The rollout's vector step: GAT_latent_update and the behaviour encoder's latent_update read the PREVIOUS latents, are
@@ -436,12 +451,13 @@ __global__ __launch_bounds__(512) void gat_fwd_kernel(IplanGatFwdArgs a) {
 // instead of 108 us in the kernel trace), and every step paid two cross-stream event round trips.  One launch instead: the
 // first n_nets * B workgroups are the GAT scenes (dispatched first, one CU each), the following ones run the encoder, eight
 // 16-row tiles each, on the CUs that are left (its LDS is the head of the same allocation).
+template <bool FOLD>
 __global__ __launch_bounds__(512) void gat_enc_fwd_kernel(IplanGatFwdArgs a, IplanEncFwdArgs e, int n_gat, int enc_blocks_per_net) {
     __shared__ __attribute__((aligned(16))) GatShared sh;
     static_assert(sizeof(GatShared) >= sizeof(float) * ENC_LDS_FLOATS, "encoder LDS must fit into the scene's");
     const int block = (int)blockIdx.x;
     if (block < n_gat) {
-        gat_fwd_block(a, block, sh);
+        gat_fwd_block<false, FOLD>(a, block, sh);
     } else {
         const int j = block - n_gat, net = j / enc_blocks_per_net, tb = j - net * enc_blocks_per_net;
         enc_fwd_block(e, net, tb * 8 + wave_id(), reinterpret_cast<float*>(&sh));
@@ -459,13 +475,14 @@ union GatAcShared {
     AcShared<1> ac;
 };
 
+template <bool FOLD>
 __global__ __launch_bounds__(512) void gat_enc_ac_fwd_kernel(IplanGatFwdArgs a, IplanEncFwdArgs e, IplanAcFwdArgs c, int n_gat, int enc_blocks_per_net,
                                                              int n_enc, int ac_gx, int32_t* sync) {
     __shared__ __attribute__((aligned(16))) GatAcShared sh;
     static_assert(sizeof(GatShared) >= sizeof(float) * ENC_LDS_FLOATS, "encoder LDS must fit into the scene's");
     const int block = (int)blockIdx.x;
     if (block < n_gat) {
-        gat_fwd_block<true>(a, block, sh.gat);
+        gat_fwd_block<true, FOLD>(a, block, sh.gat);
         ac_signal_producer_done(sync);
     } else if (block < n_gat + n_enc) {
         const int j = block - n_gat, net = j / enc_blocks_per_net, tb = j - net * enc_blocks_per_net;
@@ -491,8 +508,8 @@ extern "C" int iplan_gat_enc_fwd(const IplanGatFwdArgs* a, const IplanEncFwdArgs
     if (!e->x || !e->h0 || !e->hL || !e->latent_out || !e->params)
         return fail(IPLAN_EINVAL, "iplan_gat_enc_fwd: null encoder tensor pointer");
     const int n_gat = a->n_nets * a->B, per_net = (e->B * e->N + 127) / 128;
-    hipLaunchKernelGGL(gat_enc_fwd_kernel, dim3((unsigned)(n_gat + per_net * e->n_nets)), dim3(512), 0, (hipStream_t)stream, *a, *e,
-                       n_gat, per_net);
+    if (a->saved.gru) hipLaunchKernelGGL(gat_enc_fwd_kernel<false>, dim3((unsigned)(n_gat + per_net * e->n_nets)), dim3(512), 0, (hipStream_t)stream, *a, *e, n_gat, per_net);
+    else hipLaunchKernelGGL(gat_enc_fwd_kernel<true>, dim3((unsigned)(n_gat + per_net * e->n_nets)), dim3(512), 0, (hipStream_t)stream, *a, *e, n_gat, per_net);
     return check_launch("iplan_gat_enc_fwd");
 }
 
@@ -511,8 +528,8 @@ extern "C" int iplan_gat_enc_ac_fwd(const IplanGatFwdArgs* a, const IplanEncFwdA
     const int n_gat = a->n_nets * a->B, per_net = (e->B * e->N + 127) / 128, n_enc = per_net * e->n_nets;
     const int tiles = (c->rows + 15) / 16, ac_gx = tiles * (c->ksplit_wg > 1 ? c->ksplit_wg : 1);
     const int n_ac = ac_gx * c->n_agents * (c->which == 2 ? 2 : 1);
-    hipLaunchKernelGGL(gat_enc_ac_fwd_kernel, dim3((unsigned)(n_gat + n_enc + n_ac)), dim3(512), 0, (hipStream_t)stream, *a, *e, *c,
-                       n_gat, per_net, n_enc, ac_gx, sync);
+    if (a->saved.gru) hipLaunchKernelGGL(gat_enc_ac_fwd_kernel<false>, dim3((unsigned)(n_gat + n_enc + n_ac)), dim3(512), 0, (hipStream_t)stream, *a, *e, *c, n_gat, per_net, n_enc, ac_gx, sync);
+    else hipLaunchKernelGGL(gat_enc_ac_fwd_kernel<true>, dim3((unsigned)(n_gat + n_enc + n_ac)), dim3(512), 0, (hipStream_t)stream, *a, *e, *c, n_gat, per_net, n_enc, ac_gx, sync);
     return check_launch("iplan_gat_enc_ac_fwd");
 }
 
@@ -534,6 +551,7 @@ static int check_gat(const IplanGatFwdArgs* a, const char* what) {
 extern "C" int iplan_gat_fwd(const IplanGatFwdArgs* a, iplan_stream_t stream) {
     using namespace iplan;
     if (int rc = check_gat(a, "iplan_gat_fwd")) return rc;
-    hipLaunchKernelGGL(gat_fwd_kernel, dim3((unsigned)(a->n_nets * a->B)), dim3(512), 0, (hipStream_t)stream, *a);
+    if (a->saved.gru) hipLaunchKernelGGL(gat_fwd_kernel<false>, dim3((unsigned)(a->n_nets * a->B)), dim3(512), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(gat_fwd_kernel<true>, dim3((unsigned)(a->n_nets * a->B)), dim3(512), 0, (hipStream_t)stream, *a);
     return check_launch("iplan_gat_fwd");
 }

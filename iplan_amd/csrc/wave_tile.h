@@ -129,6 +129,17 @@ __device__ __forceinline__ Bf3 wfrag_bf3(const float* __restrict__ W, int ld, in
     return split_bf3(lo, hi);
 }
 
+// ... of c * W (c = 1: the same pieces as wfrag_bf3)
+__device__ __forceinline__ Bf3 wfrag_bf3_scaled(const float* __restrict__ W, int ld, int rows, int o0, int k0, float c) {
+    const int l = lane_id();
+    const int r = o0 + (l & 15);
+    const int rc = r < rows ? r : rows - 1;
+    const float* p = W + (size_t)rc * ld + k0 + 4 * (l >> 4);
+    f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 16);
+    if (r >= rows) lo = hi = f32x4{0.f, 0.f, 0.f, 0.f};
+    return split_bf3(lo * c, hi * c);
+}
+
 // Same for the TRANSPOSE of a row-major matrix (A operand of y = W^T x): output rows o0..o0+15 of W^T = columns of W, K slots
 // k0..k0+31 = rows of W (full tiles only; strided loads, done once per launch).
 __device__ __forceinline__ Bf3 wfrag_t_bf3(const float* __restrict__ W, int ld, int o0, int k0) {
@@ -411,6 +422,26 @@ __device__ __forceinline__ GruGates gru_gates(f32x4 pre_r, f32x4 pre_z, f32x4 gi
         o.z[q] = sigmoid_f(pre_z[q]);
         o.hn[q] = gh_n[q];
         o.n[q] = tanh_f(gi_n[q] + o.r[q] * gh_n[q]);
+        o.h[q] = (1.0f - o.z[q]) * o.n[q] + o.z[q] * h_prev[q];
+    }
+    return o;
+}
+
+// The same step with the gates' exp2 constants already folded into the pre-activations: pre_r, pre_z = -log2e x (r / z gate), gi_n and
+// gh_n = 2 log2e x (both parts of the n gate; o.hn is the SCALED value -- callers that store it use gru_gates).
+__device__ __forceinline__ GruGates gru_gates_folded(f32x4 pre_r, f32x4 pre_z, f32x4 gi_n, f32x4 gh_n, f32x4 h_prev) {
+    GruGates o;
+    for (int q = 0; q < 4; ++q) {
+#ifdef IPLAN_EXACT_GATES
+        o.r[q] = 1.0f / (1.0f + exp2f(pre_r[q]));
+        o.z[q] = 1.0f / (1.0f + exp2f(pre_z[q]));
+        o.n[q] = 1.0f - 2.0f / (exp2f(gi_n[q] + o.r[q] * gh_n[q]) + 1.0f);
+#else
+        o.r[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre_r[q]));
+        o.z[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pre_z[q]));
+        o.n[q] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(gi_n[q] + o.r[q] * gh_n[q]) + 1.0f);
+#endif
+        o.hn[q] = gh_n[q];
         o.h[q] = (1.0f - o.z[q]) * o.n[q] + o.z[q] * h_prev[q];
     }
     return o;

@@ -136,6 +136,13 @@ class IPPOLearner:
         self.last_step_params = None
         self.last_step_moments = None                        # ((exp_avg, exp_avg_sq, steps taken) of the actor arena, same of the critic arena)
         self.last_step_relu = None                           # ([2, nA, rows, M] bool, same): which side of the fc1 / fc2 ReLU kink each unit took
+        # ... and the same at EARLIER optimiser steps of one train(): ``probe_steps`` = step indices (0-based) whose complete
+        # state -- parameters, moments and ReLU branches before the step, clipped gradients and parameters after it -- goes to
+        # ``step_probes[k]``; ``probe_all_adam`` keeps parameters / moments / clipped gradients / result of EVERY step (no
+        # ReLU record), enough to replay each Adam update in fp64 (tests/oracle_checks.py)
+        self.probe_steps = ()
+        self.probe_all_adam = False
+        self.step_probes = {}
 
         self.clip_param = args.clip_param
         self.ppo_epoch = args.ppo_epoch
@@ -175,6 +182,27 @@ class IPPOLearner:
         from ..optim import _moments
         return tuple(tuple(t.clone() for t in _moments(arena)) + (opts[0]._steps,)
                      for arena, opts in ((self.mac.actor_arena, self.actor_optimizers), (self.mac.critic_arena, self.critic_optimizers)))
+
+    def _probe_before(self, k, n_steps, out):
+        """diagnostics: snapshot the state optimiser step ``k`` of ``n_steps`` starts from (gradients are in the arenas already)"""
+        mac = self.mac
+        last = self.probe_last_step and k == n_steps - 1
+        full = last or k in self.probe_steps
+        if not (full or self.probe_all_adam):
+            return
+        rec = dict(params=(mac.actor_arena.data.clone(), mac.critic_arena.data.clone()), moments=self._moment_snapshot())
+        if full:
+            rec["relu"] = (out["saved"][..., 0:64] > 0, out["saved"][..., 128:192] > 0)       # fc1 / fc2 ReLU branches taken
+        self.step_probes[k] = rec
+        if last:
+            self.last_step_params, self.last_step_moments, self.last_step_relu = rec["params"], rec["moments"], rec["relu"]
+
+    def _probe_after(self, k):
+        rec = self.step_probes.get(k)
+        if rec is not None and "post" not in rec:
+            mac = self.mac
+            rec["grads"] = (mac.actor_arena.grad.clone(), mac.critic_arena.grad.clone())      # clipped (the Adam launch writes them back)
+            rec["post"] = (mac.actor_arena.data.clone(), mac.critic_arena.data.clone())
 
     def lr_decay(self, episode, episodes):
         for n in range(self.n_agents):
@@ -217,6 +245,7 @@ class IPPOLearner:
         if not self.buffers[0].can_sample():
             return
         print("TRAINING IPPO")
+        self.step_probes = {}
         if self.use_linear_lr_decay:
             self.lr_decay(t_env, self.t_max)
         a, d, nA = self.args, self.store.data, self.n_agents
@@ -348,14 +377,12 @@ class IPPOLearner:
                             g_entropy=-self.entropy_coef / n_rows, g_values=g_v)
             if self.dp is not None:
                 self.dp.all_reduce_grads(mac.actor_arena, mac.critic_arena)
-            if self.probe_last_step and ep == self.ppo_epoch - 1:
-                self.last_step_params = (mac.actor_arena.data.clone(), mac.critic_arena.data.clone())
-                self.last_step_moments = self._moment_snapshot()
-                self.last_step_relu = (out["saved"][..., 0:64] > 0, out["saved"][..., 128:192] > 0)       # fc1 / fc2 ReLU branches taken
+            self._probe_before(ep, self.ppo_epoch, out)
             sq_a = step_all(self.actor_optimizers, max_norm)
             norms[ep, 0] = sq_a[:, 0]
             sq_c = step_all(self.critic_optimizers, max_norm)
             norms[ep, 1] = sq_c[:, 0]
+            self._probe_after(ep)
         self.store.clear()
 
         # train_info (:305-310): averages over agents x epochs -- ONE host read-back
@@ -437,12 +464,10 @@ class IPPOLearner:
                 pl.stats = stats[k].data_ptr()
                 lib.call("iplan_ppo_loss", pl, stream)
                 ops.ac_backward(out, mac.actor_arena, mac.critic_arena, g_logp=g_logp, g_entropy=-self.entropy_coef / float(mbs), g_values=g_v)
-                if self.probe_last_step and k == self.ppo_epoch * nmb - 1:
-                    self.last_step_params = (mac.actor_arena.data.clone(), mac.critic_arena.data.clone())
-                    self.last_step_moments = self._moment_snapshot()
-                    self.last_step_relu = (out["saved"][..., 0:64] > 0, out["saved"][..., 128:192] > 0)
+                self._probe_before(k, self.ppo_epoch * nmb, out)
                 norms[k, 0] = step_all(self.actor_optimizers, max_norm)[:, 0]
                 norms[k, 1] = step_all(self.critic_optimizers, max_norm)[:, 0]
+                self._probe_after(k)
         self.store.clear()
         st_d = stats.mean(dim=(0, 1))
         nr_d = norms.sqrt().mean(dim=(0, 2)) if max_norm is not None else th.zeros(2, device=dev)
@@ -548,12 +573,10 @@ class IPPOLearner:
             ops.ac_backward(out, mac.actor_arena, mac.critic_arena, g_logp=g_logp, g_entropy=(w * (-self.entropy_coef / float(mbs))).contiguous(),
                             g_values=g_v)
             dp.all_reduce_grads(mac.actor_arena, mac.critic_arena)
-            if self.probe_last_step and k == steps - 1:
-                self.last_step_params = (mac.actor_arena.data.clone(), mac.critic_arena.data.clone())
-                self.last_step_moments = self._moment_snapshot()
-                self.last_step_relu = (out["saved"][..., 0:64] > 0, out["saved"][..., 128:192] > 0)
+            self._probe_before(k, steps, out)
             norms[k, 0] = step_all(self.actor_optimizers, max_norm)[:, 0]
             norms[k, 1] = step_all(self.critic_optimizers, max_norm)[:, 0]
+            self._probe_after(k)
         self.store.clear()
         st_d = stats.mean(dim=(0, 1))
         nr_d = norms.sqrt().mean(dim=(0, 2)) if max_norm is not None else th.zeros(2, device=dev)

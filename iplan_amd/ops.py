@@ -241,6 +241,9 @@ def ac_forward(actor_arena, critic_arena, which, spec, rows, n_agents, h_actor=N
     a.n_agents, a.rows, a.which = n_agents, rows, which
     a.ksplit = ksplit if ksplit is not None else (8 if rows <= 512 else 1)
     a.act_tanh = int(bool(getattr(actor_arena if which != 1 else critic_arena, "act_tanh", False)))
+    if which == 2:                                            # one flag for both nets of the launch (and of its backward tail)
+        assert bool(getattr(actor_arena, "act_tanh", False)) == bool(getattr(critic_arena, "act_tanh", False)), \
+            "actor and critic of one fused launch must use the same trunk activation (args.use_ReLU)"
     spec.fill(a.feat)
     out = {}
     f32 = dict(dtype=torch.float32, device=dev)
@@ -1026,6 +1029,12 @@ def beh_backward(enc_arena, dec_arena, fwd, accumulate=False, penalty=0.0, E_nor
         main = torch.cuda.current_stream(dev)
     pieces = max(1, min(_beh_pieces("BWD", 6 if side is not None else 1), J))
     bounds = _piece_bounds(J, pieces)
+    if thin:
+        # the in-kernel thin gradients exist in the BPTT's second form only, which takes at most BEH_D2_MAX_WINDOWS windows per launch
+        # (iplan_beh_bwd returns EINVAL beyond): episodes longer than that get more pieces instead of failing
+        while max(b1 - b0 for b0, b1 in zip(bounds[:-1], bounds[1:])) > L.BEH_D2_MAX_WINDOWS:
+            pieces += 1
+            bounds = [round(J * k / pieces) for k in range(pieces + 1)]
     pieces = len(bounds) - 1
     carry = torch.empty(n_nets, tiles, 2, 512, **f32)
     ecarry = torch.empty(n_nets, tiles, 768, **f32)

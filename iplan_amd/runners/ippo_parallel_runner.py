@@ -20,7 +20,7 @@ from functools import partial
 import numpy as np
 import torch
 
-from .. import synth
+from .. import ops, synth
 from ..observation_wrapper import observersation_state_history_wrapper
 
 
@@ -150,6 +150,7 @@ class ParallelRunner:
         # it: with both incentives on it rides in their launch (iplan_gat_enc_ac_fwd).  IPLAN_NO_FUSE_AC=1: its own launch
         fuse_ac = a.GAT_enable and a.Behavior_enable and not os.environ.get("IPLAN_NO_FUSE_AC") and E <= 512
         ac_in_flight = False
+        sync_host = None
         for _ in range(a.episode_limit):
             t = self.t
             # actions, their one-hot and the new GRU states go straight into the episode container
@@ -163,8 +164,16 @@ class ParallelRunner:
                 D("actions_onehot")[dead, t] = 0
                 D("actions_onehot")[dead, t, :, 0] = 1
             act_host.copy_(D("actions")[:, t, :, 0], non_blocking=True)    # the ONE device -> host copy of the step
+            if fuse_ac and dev.type == "cuda":
+                # ... plus the fused launch's give-up flag (4 bytes): an action selection that stopped waiting for its launch's latent
+                # updates must abort the episode BEFORE env.step sees its actions, not at the episode's end
+                if sync_host is None:
+                    sync_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                sync_host.copy_(ops._fused_sync(dev)[2:3], non_blocking=True)
             if dev.type == "cuda":
                 torch.cuda.current_stream(dev).synchronize()
+            if sync_host is not None and int(sync_host[0]) != 0:
+                ops.check_fused_sync()                       # raises
             t0 = time.perf_counter()
             actions = act_host.numpy()
             action_env = [tuple(row) for row in actions.astype(np.float64)]
@@ -228,7 +237,6 @@ class ParallelRunner:
             # synchronises: the next run()'s reset() would overwrite 'single' / 'state' / 'obs' while they are in flight
             torch.cuda.current_stream(dev).synchronize()
         if fuse_ac:
-            from .. import ops
             ops.check_fused_sync()
         avg_win_rates, avg_rwd, avg_len = np.mean(episode_wins, axis=0), np.mean(episode_returns, axis=0), np.mean(episode_lengths, axis=0)
         if not test_mode:

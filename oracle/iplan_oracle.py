@@ -221,10 +221,19 @@ def behavior_windows(history, mask, j, L):
 
 
 def behavior_learn_loss(enc_p, dec_p, history, mask, L, coef, drop_masks, drop_p,
-                        penalty=0.0, thres=0.005):
+                        penalty=0.0, thres=0.005, env_slice=None):
     """One agent's loss in Behavior_policy.learn.  history [E,T,N,d] (already [:, :-1]),
     mask [E,T] with the env-dependent polarity already applied, drop_masks [J, E*N, L, Hd].
-    Returns (behavior_error, stability_error, loss)."""
+    Returns (behavior_error, stability_error, loss).
+
+    ``env_slice`` (a slice of the env axis): the SHARE of those envs in the three values.  The loss is a sum over envs --
+    every window's numerator sum|next - pred| m is, its normaliser sum(m) + EPS depends on the masks alone and the stability
+    term is a plain sum / E / L -- and the envs never interact (carried states and latents are per (env, entity) row), so the
+    shares of a partition of the envs add up to the whole-batch values and their gradients to the whole-batch gradient.  Used
+    where the autograd graph of the whole batch does not fit the host (256 envs x 79 windows in fp64 ~ 120 GB); the CPU suite
+    checks the partition against the whole (tests/test_oracle_golden.py)."""
+    if env_slice is not None:
+        return _behavior_learn_share(enc_p, dec_p, history, mask, L, coef, drop_masks, drop_p, penalty, thres, env_slice)
     E, T, N, d = history.shape
     Z = enc_p["out.weight"].shape[0]
     R = enc_p["rnn.weight_hh_l0"].shape[1]
@@ -247,6 +256,39 @@ def behavior_learn_loss(enc_p, dec_p, history, mask, L, coef, drop_masks, drop_p
         latent = (1.0 - coef) * latent + new_lat.reshape(E, N, Z) * coef                  # :230
         beh = beh + masked_l1(nxt, pred, mn, d * N)                                       # :233-235
         stab = stab + torch.clamp(st - thres, min=0).sum() / E / L                        # :238-240
+    beh = beh / J
+    stab = stab / J
+    return beh, stab, beh + penalty * stab
+
+
+def _behavior_learn_share(enc_p, dec_p, history, mask, L, coef, drop_masks, drop_p, penalty, thres, sl):
+    """behavior_learn_loss restricted to the envs ``sl`` under the WHOLE batch's normalisers (see there)"""
+    E_all, T, N, d = history.shape
+    h, m = history[sl], mask[sl]
+    E = h.shape[0]
+    lo = range(E_all)[sl][0]
+    Z = enc_p["out.weight"].shape[0]
+    R = enc_p["rnn.weight_hh_l0"].shape[1]
+    Hd = dec_p["decoder.rnn.weight_hh_l0"].shape[1]
+    dp = strip_prefix(dec_p, "decoder.")
+    J = T - 1 - L
+    latent = torch.zeros(E, N, Z, dtype=h.dtype)
+    eh = torch.zeros(E * N, R, dtype=h.dtype)
+    dh = torch.zeros(E * N, Hd, dtype=h.dtype)
+    beh = 0.0
+    stab = 0.0
+    for j in range(J):
+        curr, nxt, mn = behavior_windows(h, m, j, L)
+        den = mask[:, j + 1:j + L + 1].to(h.dtype).sum() * (N * d)                          # sum of the expanded mask, all envs
+        dec_in = torch.cat([curr, latent[:, :, None, :].expand(E, N, L, Z)], dim=-1)
+        dm = None if drop_masks is None else drop_masks[j][lo * N:(lo + E) * N].to(h.dtype)
+        pred, dh = decoder_forward(dp, dec_in.reshape(E * N, L, d + Z), dh, dm, drop_p)
+        pred = pred.reshape(E, N, L, d)
+        _, eh, new_lat = encoder_forward(enc_p, curr.reshape(E * N, L, d), eh)
+        st = torch.linalg.norm(curr - pred, dim=-1).reshape(-1)
+        latent = (1.0 - coef) * latent + new_lat.reshape(E, N, Z) * coef
+        beh = beh + (torch.abs(nxt - pred) * mn).sum() / (den + EPS) * (d * N)
+        stab = stab + torch.clamp(st - thres, min=0).sum() / E_all / L
     beh = beh / J
     stab = stab / J
     return beh, stab, beh + penalty * stab
@@ -512,7 +554,7 @@ def behavior_fc_learn_loss(enc_p, dec_p, history, L):
 #     num_mini_batch == 1: every epoch is a full-batch step, so the randperm order does not matter.
 # ----------------------------------------------------------------------------------------------
 def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_index_lists=None, probe_last_step=None,
-                    probe_relu_hint=None):
+                    probe_relu_hint=None, probe_steps=None):
     """fields: dict of [E, T+1, nA, ...] episode tensors (the buffer content).  actor_p / critic_p: dicts of leaf
     tensors with requires_grad (updated IN PLACE by Adam).  ``row_index_lists``: optional list (per epoch) of lists of
     row-index tensors (minibatches, generate_data :368-424); default = one minibatch with the first ``rows`` rows.
@@ -524,7 +566,11 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
     ``probe_relu_hint`` = ((actor fc1, fc2 branches), (critic fc1, fc2 branches)), bool [rows of the last minibatch, M]: the
     ReLU branches the implementation took in that step's forward pass, used by the probe evaluation at units within fp32
     rounding of the kink only (_relu_hinted).
-    Returns dict(returns, adv, old_logp, values_all, stats per epoch[, probe_grads])."""
+    ``probe_steps`` = {step index k (0-based): ((actor params, critic params), relu hint or None)}: the same evaluation in front
+    of ANY optimiser step of the run, results in ``probe_grads_by_step[k]`` (``hint_log_by_step[k]`` = the RELU_HINT_LOG entries
+    of that evaluation) -- a gradient in the middle of the 15-epoch trajectory is checked at the implementation's own
+    parameters exactly like the last one.
+    Returns dict(returns, adv, old_logp, values_all, stats per epoch[, probe_grads, probe_grads_by_step])."""
     f, i = fields, agent_id
     gat, behv = args.GAT_enable, args.Behavior_enable
     E, T1 = f["history"].shape[:2]
@@ -565,20 +611,33 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
 
     probe_grads = None
     n_steps = sum(len([slice(0, rows)] if row_index_lists is None else row_index_lists[ep]) for ep in range(args.ppo_epoch))
+    probes = dict(probe_steps or {})
+    if probe_last_step is not None:
+        probes[n_steps - 1] = (probe_last_step, probe_relu_hint)
+    by_step, hint_log_by_step = {}, {}
+
+    def probe_eval(point, hint, sl):
+        pa, pc = ({k: (v.detach().to(dt) if v.is_floating_point() else v.detach()).clone().requires_grad_(v.is_floating_point())
+                   for k, v in src.items()} for src in point)
+        a_obj, _, c_obj, _, _, _ = objectives(pa, pc, sl, hint if hint is not None else (None, None))
+        a_obj.backward()
+        c_obj.backward()
+        out = []
+        for prm in (pa, pc):
+            trainable = [k for k in prm if prm[k].grad is not None]
+            clip_grad_norm([prm[k].grad for k in trainable], args.max_grad_norm)
+            out.append({k: prm[k].grad for k in trainable})
+        return out
+
     for ep in range(args.ppo_epoch):
         batches = [slice(0, rows)] if row_index_lists is None else row_index_lists[ep]
         for sl in batches:
-            if probe_last_step is not None and steps[0] == n_steps - 1:
-                pa, pc = ({k: (v.detach().to(dt) if v.is_floating_point() else v.detach()).clone().requires_grad_(v.is_floating_point())
-                           for k, v in src.items()} for src in probe_last_step)
-                a_obj, _, c_obj, _, _, _ = objectives(pa, pc, sl, probe_relu_hint if probe_relu_hint is not None else (None, None))
-                a_obj.backward()
-                c_obj.backward()
-                probe_grads = []
-                for prm in (pa, pc):
-                    trainable = [k for k in prm if prm[k].grad is not None]
-                    clip_grad_norm([prm[k].grad for k in trainable], args.max_grad_norm)
-                    probe_grads.append({k: prm[k].grad for k in trainable})
+            if steps[0] in probes:
+                n0 = len(RELU_HINT_LOG)
+                by_step[steps[0]] = probe_eval(probes[steps[0]][0], probes[steps[0]][1], sl)
+                hint_log_by_step[steps[0]] = list(RELU_HINT_LOG[n0:])
+                if steps[0] == n_steps - 1 and probe_last_step is not None:
+                    probe_grads = by_step[steps[0]]
             for prm in (actor_p, critic_p):
                 for v in prm.values():
                     v.grad = None
@@ -596,7 +655,8 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
                                   args.lr if gi == 0 else args.critic_lr, args.optim_eps)
             stats.append(dict(policy_loss=float(pol.detach()), value_loss=float(vl.detach()), entropy=float(ent.detach()), ratio=float(ratio.detach().mean()),
                               actor_grad_norm=norms[0], critic_grad_norm=norms[1]))
-    return dict(returns=rets, adv=adv, old_logp=old_logp, values_all=v_all, stats=stats, probe_grads=probe_grads)
+    return dict(returns=rets, adv=adv, old_logp=old_logp, values_all=v_all, stats=stats, probe_grads=probe_grads,
+                probe_grads_by_step=by_step, hint_log_by_step=hint_log_by_step)
 
 
 # ----------------------------------------------------------------------------------------------

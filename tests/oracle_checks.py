@@ -62,8 +62,12 @@ def _fields(args, E, seed, terminated_p, device):
 
 # ------------------------------------------------------------------------------------------------ Behavior_policy.learn
 def check_behavior_learn_vs_oracle(args, E, device, seed=0, tol=1e-5, post_tol=1e-6, with_fp64=True, agents=None, learn_kwargs=None,
-                                   table=None):
-    """``table``: optional list that receives one row per (agent, net, tensor) INSTEAD of asserting (diagnostic scripts)"""
+                                   table=None, oracle_env_chunk=None, fp32_oracle=True):
+    """``table``: optional list that receives one row per (agent, net, tensor) INSTEAD of asserting (diagnostic scripts).
+    ``oracle_env_chunk``: evaluate the ORACLE in shares of that many envs (oracle.behavior_learn_loss(env_slice=...): exact
+    partition of the loss, gradients accumulate) -- config 4's 256 envs, whose whole-batch fp64 autograd graph does not fit a
+    host; ``fp32_oracle=False`` skips the fp32 evaluation beside the fp64 one (bound = tol, no e32 widening; the one-step
+    post check then starts from the fp64 gradients)."""
     from iplan_amd.nova.stable_behavior_policy import Behavior_policy
     args = SimpleNamespace(**dict(vars(args), use_cuda=(torch.device(device).type == "cuda")))
     torch.manual_seed(seed)
@@ -73,7 +77,8 @@ def check_behavior_learn_vs_oracle(args, E, device, seed=0, tol=1e-5, post_tol=1
     pre = dict(enc=[_sd(m) for m in pol.behavior_encoder], dec=[_sd(m) for m in pol.behavior_decoder])
     fields, batch = _fields(args, E, seed + 1, 0.8, device)
     gen = torch.Generator().manual_seed(seed + 2)
-    keep = (torch.rand(nA, J, E * N, Lw, args.decoder_rnn_dim, generator=gen) < 1.0 - args.decoder_dropout).to(torch.uint8)
+    keep = torch.stack([(torch.rand(J, E * N, Lw, args.decoder_rnn_dim, generator=gen) < 1.0 - args.decoder_dropout).to(torch.uint8)
+                        for _ in range(nA)])                  # (per agent: the same draws as one [nA, ...] call, a fifth of its peak memory)
     bl, sl, tl = pol.learn(batch, 0, keep=keep.to(device), **(learn_kwargs or {}))
     pol.join_decoder()                                       # (a deferred decoder update must have landed before its arena is read)
     hist, term = fields["history"][:, :-1], fields["terminated"][:, :-1]
@@ -81,19 +86,34 @@ def check_behavior_learn_vs_oracle(args, E, device, seed=0, tol=1e-5, post_tol=1
     for i in (range(nA) if agents is None else agents):       # ``agents``: replay only these with the (slow) oracle
         mask = term[:, :, i, 0] if args.env != "MPE" else 1 - term[:, :, i, 0]
         res = {}
-        for dt in ((torch.float32, torch.float64) if with_fp64 else (torch.float32,)):
+        dts = (torch.float32, torch.float64) if with_fp64 else (torch.float32,)
+        if not fp32_oracle:
+            assert with_fp64
+            dts = (torch.float64,)
+        for dt in dts:
             ep, dp = _req(pre["enc"][i], dt), _req(pre["dec"][i], dt)
-            beh, stab, loss = O.behavior_learn_loss(ep, dp, hist[:, :, i].to(dt), mask, Lw, args.soft_update_coef, keep[i].to(dt),
-                                                    args.decoder_dropout, args.behavior_variation_penalty, args.thres_small_variation)
-            loss.backward()
+            if oracle_env_chunk is None:
+                beh, stab, loss = O.behavior_learn_loss(ep, dp, hist[:, :, i].to(dt), mask, Lw, args.soft_update_coef, keep[i].to(dt),
+                                                        args.decoder_dropout, args.behavior_variation_penalty, args.thres_small_variation)
+                loss.backward()
+                beh, stab = float(beh.detach()), float(stab.detach())
+            else:
+                beh = stab = 0.0
+                for lo in range(0, E, oracle_env_chunk):
+                    b_, s_, loss = O.behavior_learn_loss(ep, dp, hist[:, :, i].to(dt), mask, Lw, args.soft_update_coef, keep[i],
+                                                         args.decoder_dropout, args.behavior_variation_penalty, args.thres_small_variation,
+                                                         env_slice=slice(lo, min(E, lo + oracle_env_chunk)))
+                    loss.backward()                          # (.grad accumulates over the shares)
+                    beh, stab = beh + float(b_.detach()), stab + float(s_.detach())
+                    del loss, b_, s_
             O.clip_grad_norm([ep[k].grad for k in ep], args.max_grad_norm)
             O.clip_grad_norm([dp[k].grad for k in dp], args.max_grad_norm)
-            res[dt] = (float(beh.detach()), float(stab.detach()), ep, dp)
-        beh, stab, ep32, dp32 = res[torch.float32]
-        _, _, ep_t, dp_t = res[torch.float64 if with_fp64 else torch.float32]     # ground truth for the gradients
+            res[dt] = (beh, stab, ep, dp)
+        beh, stab, ep32, dp32 = res[dts[0]]                                      # (fp32 unless fp32_oracle is off)
+        _, _, ep_t, dp_t = res[dts[-1]]                                          # ground truth for the gradients
         worst["loss"] = max(worst["loss"], abs(float(bl[i]) - beh) / max(1.0, abs(beh)), abs(float(sl[i]) - stab) / max(1.0, abs(stab)))
         gtol = tol
-        if with_fp64:
+        if with_fp64 and fp32_oracle:
             e32 = max(_grad_err(p32[k].grad, pt[k].grad) for p32, pt in ((ep32, ep_t), (dp32, dp_t)) for k in pt)
             worst["fp32_oracle_grad_vs_fp64"] = max(worst["fp32_oracle_grad_vs_fp64"], e32)
             gtol = max(tol, E32_FACTOR * e32)
@@ -230,8 +250,53 @@ def probe_dicts(learner, mac, pre, i):
     return tuple(out)
 
 
+def _snapshot_dicts(snaps, mac, pre, i):
+    """(actor, critic) state dicts of agent i from a pair of arena snapshots [nA, arena floats]"""
+    out = []
+    for snap, arena, sd in ((snaps[0], mac.actor_arena, pre["actors"][i]), (snaps[1], mac.critic_arena, pre["critics"][i])):
+        d = {k: v.clone() for k, v in sd.items()}
+        for k in arena.names:
+            n = int(torch.Size(arena.shapes[k]).numel())
+            d[k] = snap[i, arena.offsets[k]:arena.offsets[k] + n].view(arena.shapes[k]).detach().cpu().clone()
+        out.append(d)
+    return tuple(out)
+
+
+def _arena_slice(snap, arena, i, k):
+    n = int(torch.Size(arena.shapes[k]).numel())
+    return snap[i, arena.offsets[k]:arena.offsets[k] + n].view(arena.shapes[k]).detach().cpu()
+
+
+def check_adam_replay(learner, mac, args, agents, tol=1e-6):
+    """EVERY optimiser step of the train() just run (``learner.probe_all_adam``): the fp64 Adam update from the state the
+    step started from (parameters, both moments, step count) with the step's own clipped gradients must land on the
+    parameters the step produced -- bias correction at every t, the moment recurrences, eps placement, lr.  Conditioning-free
+    (same gradients on both sides) and without an oracle gradient, so it costs nothing at 15 epochs.  Returns the worst
+    error and the number of (step, agent, net) updates checked."""
+    worst, n = 0.0, 0
+    for k in sorted(learner.step_probes):
+        rec = learner.step_probes[k]
+        if "post" not in rec:
+            continue
+        for gi, (arena, lr) in enumerate(((mac.actor_arena, learner.actor_optimizers[0].param_groups[0]["lr"]),
+                                          (mac.critic_arena, learner.critic_optimizers[0].param_groups[0]["lr"]))):
+            m_all, v_all, taken = rec["moments"][gi]
+            for i in agents:
+                w = rec["params"][gi][i].double().cpu().clone()
+                O.adam_step(w, rec["grads"][gi][i].double().cpu(), m_all[i].double().cpu().clone(), v_all[i].double().cpu().clone(),
+                            taken + 1, lr, args.optim_eps)
+                e = _rel(rec["post"][gi][i], w)
+                worst = max(worst, e)
+                n += 1
+                assert e <= tol, ("Adam update replayed in fp64 from the step's own state and gradients", dict(step=k, agent=i, net=gi, err=e))
+                if k + 1 in learner.step_probes:                 # ... and the next step starts where this one ended (nothing else writes the arena)
+                    assert torch.equal(learner.step_probes[k + 1]["params"][gi][i], rec["post"][gi][i])
+                    assert learner.step_probes[k + 1]["moments"][gi][2] == taken + 1
+    return worst, n
+
+
 def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, terminated_p=0.15, also_fp32=True, agents=None,
-                              e32_factor=E32_FACTOR, table=None, assert_grads=True):
+                              e32_factor=E32_FACTOR, table=None, assert_grads=True, mid_probes=(), adam_replay=False, t_env=0):
     """insert buffer_size episodes -> train() (ppo_epoch fused epochs x num_mini_batch steps) vs oracle.ppo_train_agent, every
     agent: clipped gradients of the LAST optimiser step and the post-train parameters.
 
@@ -256,7 +321,13 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
     evaluation takes the branch from there for the units inside that band -- nowhere else; how many units were in the band and
     how many branches actually came from the hint is logged (``relu_units_near_kink`` / ``relu_branches_from_hint``).
     ``table``: optional list that receives one row per (agent, net, tensor) for scripts/ppo_grad_error_table.py (which also
-    passes ``assert_grads=False`` to see every row of a failing case; the tests never do)."""
+    passes ``assert_grads=False`` to see every row of a failing case; the tests never do).
+
+    ``mid_probes``: optimiser-step indices (0-based, < the last) checked THE SAME WAY -- gradient at the learner's own
+    parameters of that step vs the fp64 oracle there (same bound), one fp64 Adam step from that step's own state (moments at
+    t = k + 1) landing on the learner's next parameters (post_tol), hint count per step <= RELU_HINT_MAX -- so that the
+    15-epoch train() the benchmark times is pinned at two points of its trajectory, not only at its end.  ``adam_replay``:
+    check_adam_replay over every step.  ``t_env``: train()'s argument (the linear lr decay hook reads it)."""
     from iplan_amd.controllers.dcntrl_controller import DcntrlMAC
     from iplan_amd.learners.ippo_learner import IPPOLearner
     args = SimpleNamespace(**dict(vars(args), use_cuda=(torch.device(device).type == "cuda")))
@@ -274,7 +345,12 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
     torch.manual_seed(seed + 77)                               # generate_data's randperm draws (num_mini_batch > 1)
     n_steps = args.ppo_epoch * max(1, args.num_mini_batch)
     learner.probe_last_step = True                             # (a single step: the probe point is the pre-train parameters)
-    learner.train(0)
+    learner.probe_steps = tuple(k for k in mid_probes if k < n_steps - 1)
+    learner.probe_all_adam = bool(adam_replay)
+    learner.train(t_env)
+    if getattr(args, "use_linear_lr_decay", False):            # learners/ippo_learner.py:86-91,236-237: lr <- lr (1 - t_env / t_max)
+        args = SimpleNamespace(**dict(vars(args), lr=args.lr - args.lr * (t_env / float(args.t_max)),
+                                      critic_lr=args.critic_lr - args.critic_lr * (t_env / float(args.t_max))))
     index_lists = None
     if args.num_mini_batch > 1:
         torch.manual_seed(seed + 77)
@@ -299,10 +375,16 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
             hint = tuple((r1[w, i].cpu(), r2[w, i].cpu()) for w in range(2))
         il = None if index_lists is None else index_lists[i]
         ap, cp = _req(pre["actors"][i], torch.float64), _req(pre["critics"][i], torch.float64)
+        mids = {}
+        for k in learner.probe_steps:
+            rec = learner.step_probes[k]
+            mids[k] = (_snapshot_dicts(rec["params"], mac, pre, i),
+                       tuple((rec["relu"][0][w, i].cpu(), rec["relu"][1][w, i].cpu()) for w in range(2)))
         O.RELU_HINT_LOG.clear()
-        r64 = O.ppo_train_agent(i, ap, cp, f64, args, row_index_lists=il, probe_last_step=probe, probe_relu_hint=hint)
-        worst["relu_units_near_kink"] = worst.get("relu_units_near_kink", 0) + sum(n for n, _ in O.RELU_HINT_LOG)
-        n_hint = sum(n for _, n in O.RELU_HINT_LOG)
+        r64 = O.ppo_train_agent(i, ap, cp, f64, args, row_index_lists=il, probe_last_step=probe, probe_relu_hint=hint, probe_steps=mids)
+        last_log = r64["hint_log_by_step"].get(n_steps - 1, []) if probe is not None else list(O.RELU_HINT_LOG)
+        worst["relu_units_near_kink"] = worst.get("relu_units_near_kink", 0) + sum(n for n, _ in last_log)
+        n_hint = sum(n for _, n in last_log)
         worst["relu_branches_from_hint"] = worst.get("relu_branches_from_hint", 0) + n_hint
         # the hint is for the handful of units that sit ON the kink; a count that grows is a forward-pass regression hiding
         # behind it (config 3, 1.5 M units per layer: 213 in the band, 1 taken from the hint)
@@ -312,7 +394,8 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
         e32 = 0.0
         if also_fp32:
             a32, c32 = _req(pre["actors"][i]), _req(pre["critics"][i])
-            r32 = O.ppo_train_agent(i, a32, c32, fields, args, row_index_lists=il, probe_last_step=probe, probe_relu_hint=hint)
+            r32 = O.ppo_train_agent(i, a32, c32, fields, args, row_index_lists=il, probe_last_step=probe, probe_relu_hint=hint,
+                                    probe_steps=mids)
             g32 = r32["probe_grads"] if probe is not None else [{k: p[k].grad for k in p if p[k].grad is not None} for p in (a32, c32)]
             for gi, (p32, p64) in enumerate(((a32, ap), (c32, cp))):
                 for k in p64:
@@ -323,6 +406,35 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
                     worst["fp32_oracle_post_vs_fp64"] = max(worst["fp32_oracle_post_vs_fp64"], _rel(p32[k].detach(), p64[k].detach()))
             worst["fp32_oracle_grad_vs_fp64"] = max(worst["fp32_oracle_grad_vs_fp64"], e32)
         gtol = max(tol, e32_factor * e32)
+        # the mid-trajectory probes: the same two checks at optimiser step k (0-based; Adam's t = k + 1)
+        for k in sorted(mids):
+            rec = learner.step_probes[k]
+            gk64 = r64["probe_grads_by_step"][k]
+            nk_hint = sum(n for _, n in r64["hint_log_by_step"][k])
+            worst["mid_relu_branches_from_hint"] = worst.get("mid_relu_branches_from_hint", 0) + nk_hint
+            assert nk_hint <= RELU_HINT_MAX, ("ReLU branches taken from the implementation under test (mid probe)", i, k, nk_hint)
+            ek32 = 0.0
+            if also_fp32:
+                gk32 = r32["probe_grads_by_step"][k]
+                ek32 = max(_grad_err(gk32[gi][kk], gk64[gi][kk]) for gi in range(2) for kk in gk64[gi])
+                worst["mid_fp32_oracle_grad_vs_fp64"] = max(worst.get("mid_fp32_oracle_grad_vs_fp64", 0.0), ek32)
+            gktol = max(tol, e32_factor * ek32)
+            for gi, (name, arena, lr) in enumerate((("actor", mac.actor_arena, args.lr), ("critic", mac.critic_arena, args.critic_lr))):
+                m_all, v_all, taken = rec["moments"][gi]
+                assert taken == k, (taken, k)
+                for kk, g in gk64[gi].items():
+                    e = _grad_err(_arena_slice(rec["grads"][gi], arena, i, kk), g)
+                    worst["mid_grad"] = max(worst.get("mid_grad", 0.0), e)
+                    assert e <= gktol or not assert_grads, ("clipped grad (step %d of %d, at the learner's own parameters) vs fp64 oracle" % (k + 1, n_steps),
+                                                           name, i, kk, e, gktol)
+                    if getattr(args, "weight_decay", 0.0):
+                        continue
+                    w = mids[k][0][gi][kk].double().clone()
+                    O.adam_step(w, g.double(), _arena_slice(m_all, arena, i, kk).double().clone(), _arena_slice(v_all, arena, i, kk).double().clone(),
+                                taken + 1, lr, args.optim_eps)
+                    pp = _rel(_arena_slice(rec["post"][gi], arena, i, kk), w)
+                    worst["mid_post_one_step_from_probe"] = max(worst.get("mid_post_one_step_from_probe", 0.0), pp)
+                    assert pp <= post_tol, ("post, one fp64 Adam step from the learner's own state at step %d" % (k + 1), name, i, kk, pp, post_tol)
         # Post-train parameters, two ways.  (a) ONE STEP FROM THE PROBE POINT (asserted at post_tol, conditioning-free): the fp64
         # Adam step from the state the learner's last step started from -- its own parameters and moments (``last_step_params``,
         # ``last_step_moments``) -- with the fp64 oracle's clipped gradient at that point must land on the learner's final
@@ -383,6 +495,8 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
                     pp = _rel(sd[k], probe_post[gi][k])
                     worst["post_one_step_from_probe"] = max(worst.get("post_one_step_from_probe", 0.0), pp)
                     assert pp <= post_tol, ("post, one fp64 Adam step from the learner's own pre-step state", name, i, k, pp, post_tol)
+    if adam_replay:
+        worst["adam_replay"], worst["adam_replay_updates"] = check_adam_replay(learner, mac, args, list(range(args.n_agents) if agents is None else agents))
     return worst
 
 

@@ -64,3 +64,17 @@ def test_product_path_fails_loudly_without_the_library(tmp_path):
             "try:\n    _lib.get_lib()\nexcept _lib.IplanError as e:\n    print('RAISED', 'no CPU fallback' in str(e))\n") % (ROOT, str(tmp_path / "missing.so"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "RAISED True" in r.stdout, r.stdout + r.stderr
+
+
+def test_untracked_loads_are_waited_for():
+    """the inline-asm `global_load_dwordx4 ... sc1` loads of the fused rollout launch are invisible to the compiler's
+    s_waitcnt bookkeeping -- on every control-flow path of the generated gfx950 code a covering vmcnt wait precedes the first touch
+    of their destination registers (scripts/check_untracked_load_waits.py cross-compiles gat.hip to assembly and walks the paths)"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_untracked_load_waits", os.path.join(root, "scripts", "check_untracked_load_waits.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, bad = mod.check(mod.compile_asm("gat.hip"))
+    assert n >= 16 and not bad, (n, bad[:4])

@@ -328,6 +328,18 @@ def test_ppo_train_vs_oracle_emulated(cfg):
     check_ppo_train_vs_oracle(_small(**kw), "cpu", seed=6)
 
 
+@pytest.mark.parametrize("decay", [False, True])
+def test_ppo_train_15_epochs_vs_oracle_emulated(decay):
+    """the shipped ppo_epoch = 15 (config/algs/ippo.yaml:6; learners/ippo_learner.py:286-303): gradients at the learner's own
+    parameters in front of optimiser steps 8 and 15 vs the fp64 oracle, one fp64 Adam step from each of those states, and EVERY one
+    of the 15 Adam updates replayed in fp64 from its own state (bias correction at t = 1 .. 15); with the linear lr decay hook
+    on (use_linear_lr_decay, t_env = 0.4 t_max: lr and critic_lr x 0.6) in the second case"""
+    from tests.oracle_checks import check_ppo_train_vs_oracle
+    kw = dict(use_linear_lr_decay=True, t_max=1000) if decay else {}
+    w = check_ppo_train_vs_oracle(_small(ppo_epoch=15, **kw), "cpu", seed=6, mid_probes=(7,), adam_replay=True, t_env=400 if decay else 0)
+    assert w["adam_replay_updates"] == 15 * 2 * 2 and "mid_grad" in w, w
+
+
 def test_ppo_train_wide_tail_workgroups_vs_oracle_emulated(monkeypatch):
     """the PPO epoch's forward tail in its 16-wave workgroup form (what a full 22 950-row batch gets; small batches default to 8 waves)"""
     from tests.oracle_checks import check_ppo_train_vs_oracle
@@ -354,6 +366,9 @@ def test_behavior_learn_env_chunks_vs_oracle_emulated(monkeypatch):
     from tests.oracle_checks import check_behavior_learn_vs_oracle
     monkeypatch.setenv("IPLAN_BEH_ENV_CHUNK", "2")
     w = check_behavior_learn_vs_oracle(_small(), 5, "cpu", seed=13)
+    assert w["grad"] < 1e-5, w
+    # ... and against the oracle evaluated in env shares of ANOTHER size, fp64 only (the form of the config-4 GPU test)
+    w = check_behavior_learn_vs_oracle(_small(), 5, "cpu", seed=13, oracle_env_chunk=3, fp32_oracle=False)
     assert w["grad"] < 1e-5, w
 
 

@@ -92,6 +92,34 @@ def test_ppo_train_config3_all_agents_vs_oracle():
     _log("ppo_train_cfg3_22950rows_agents0and4_2epochs", check_ppo_train_vs_oracle(_args(ppo_epoch=2), "cuda", seed=35, agents=(0, 4)))
 
 
+def test_ppo_train_config3_15_epochs_vs_oracle():
+    """the optimiser-step count the benchmark times -- ppo_epoch = 15 (config/algs/ippo.yaml:6,
+    learners/ippo_learner.py:286-303) at the full config-3 / config-4 size (22 950 rows x F = 2485), the agents at both arena ends.
+    Gradients at the learner's own parameters in front of optimiser steps 8 and 15 vs the fp64 oracle (<= max(1e-5, 1.5 e32)), one fp64
+    Adam step from each of those states (moments at t = 8 and t = 15) <= 1e-5, hints <= 8 per step, and EVERY one of the 15 Adam
+    updates of both agents replayed in fp64 from the step's own state and gradients (<= 1e-6)."""
+    from tests.oracle_checks import check_ppo_train_vs_oracle
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    w = check_ppo_train_vs_oracle(_args(ppo_epoch=15), "cuda", seed=54, agents=(0, 4), mid_probes=(7,), adam_replay=True)
+    assert w["adam_replay_updates"] == 15 * 2 * 2, w
+    _log("ppo_train_cfg3_22950rows_agents0and4_15epochs_probes_at_8_and_15", w)
+
+
+def test_config4_learners_on_one_gpu_vs_oracle():
+    """BASELINE config 4 on ONE GPU (what the bench line's ``config4_n1`` times): 256 envs per rollout.
+    Behavior_policy.learn switches to 128-env chunks there (nova/stable_behavior_policy.py: two launches' gradients accumulate under
+    the all-env window normalisers) -- agent 3 replayed by the fp64 oracle in env shares of 32 (exact partition of the loss:
+    tests/test_oracle_golden.py::test_behavior_learn_loss_env_shares_add_up); IPPOLearner.train on 255 x 90 rows of the
+    256-episode buffer that ONE insert of a 256-env rollout fills (one epoch, agent 3)."""
+    from tests.oracle_checks import check_behavior_learn_vs_oracle, check_ppo_train_vs_oracle
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    a = _args(batch_size_run=256)
+    _log("behavior_learn_cfg4_E256_two_chunks_agent3",
+         check_behavior_learn_vs_oracle(a, 256, "cuda", seed=55, agents=(3,), oracle_env_chunk=32, fp32_oracle=False))
+    _log("ppo_train_cfg4_E256_one_insert_22950rows_agent3_1epoch",
+         check_ppo_train_vs_oracle(_args(batch_size_run=256, ppo_epoch=1), "cuda", seed=56, agents=(3,)))
+
+
 def test_prediction_learn_config3_vs_oracle():
     from tests.oracle_checks import check_prediction_learn_vs_oracle
     torch.set_num_threads(min(16, os.cpu_count() or 1))

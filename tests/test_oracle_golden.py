@@ -52,6 +52,36 @@ def test_behavior_learn_loss_matches_reference(golden):
         assert close(beh, g["behavior_loss"][i]) and close(stab, g["stability_loss"][i])
 
 
+def test_behavior_learn_loss_env_shares_add_up(golden):
+    """oracle.behavior_learn_loss(env_slice=...): the shares of a partition of the envs reproduce the reference-recorded loss
+    values and the whole-batch fp64 gradient (the form the config-4 GPU test evaluates the oracle in), penalty on"""
+    g = golden("behavior_learn")
+    a = g["args"]
+    hist = g["fields"]["history"][:, :-1].double()
+    term = g["fields"]["terminated"][:, :-1]
+    E, L = hist.shape[0], a["max_history_len"]
+    J = hist.shape[1] - 1 - L
+    assert E >= 2
+    for i in range(a["n_agents"]):
+        masks = torch.stack(g["dropout"][i * J:(i + 1) * J]).double()
+        kw = (term[:, :, i, 0], L, a["soft_update_coef"], masks, a["decoder_dropout"], 0.3, 0.005)
+        whole = [{k: v.double().clone().requires_grad_(True) for k, v in g["pre"][n][i].items()} for n in ("enc", "dec")]
+        beh, stab, loss = O.behavior_learn_loss(whole[0], whole[1], hist[:, :, i], *kw)
+        loss.backward()
+        parts = [{k: v.double().clone().requires_grad_(True) for k, v in g["pre"][n][i].items()} for n in ("enc", "dec")]
+        b_sum = s_sum = 0.0
+        cut = (E + 1) // 2
+        for sl in (slice(0, cut), slice(cut, E)):
+            b_, s_, l_ = O.behavior_learn_loss(parts[0], parts[1], hist[:, :, i], *kw, env_slice=sl)
+            l_.backward()
+            b_sum, s_sum = b_sum + float(b_), s_sum + float(s_)
+        assert close(b_sum, g["behavior_loss"][i]) and close(s_sum, g["stability_loss"][i])
+        assert abs(b_sum - float(beh)) <= 1e-12 * max(1.0, abs(float(beh))) and abs(s_sum - float(stab)) <= 1e-12 * max(1.0, abs(float(stab)))
+        for w, p in zip(whole, parts):
+            for k in w:
+                assert (w[k].grad - p[k].grad).abs().max().item() <= 1e-12 * max(1.0, w[k].grad.abs().max().item()), k
+
+
 def test_huber_is_one_sided():
     e = torch.tensor([-20.0, -5.0, 5.0, 20.0])
     assert torch.allclose(O.huber_loss(e, 10.0), torch.tensor([0.0, 12.5, 12.5, 150.0]))
