@@ -304,6 +304,7 @@ class PpoLossArgs(C.Structure):
         ("value_preds", fp), ("returns", fp), ("mask", fp),
         ("clip", C.c_float), ("huber_delta", C.c_float), ("value_loss_coef", C.c_float),
         ("g_logp", fp), ("g_values", fp), ("stats", fp), ("mask_sum", fp), ("flags", i32), ("row_count", C.c_float),
+        ("n_parts", i32),
     ]
 
 

@@ -102,15 +102,23 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(IplanPpoLossArgs a) {
     float* __restrict__ g_lp = a.g_logp + (int64_t)net * a.rows;
     float* __restrict__ g_v = a.g_values + (int64_t)net * a.rows;
     const int n = a.rows;
-    float sm = 0.f;
-    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) sm += a.mask[o + i];
-    const float msum_own = block_sum_1024(sm, s_part);
-    const float msum = a.mask_sum ? a.mask_sum[net] : msum_own;
+    // the rows of this workgroup: all of them, or range blockIdx.y of n_parts (then the denominator comes from the caller)
+    const int P = a.n_parts > 1 ? a.n_parts : 1, part = (int)blockIdx.y;
+    const int per = (n + P - 1) / P, r0 = part * per, r1 = r0 + per < n ? r0 + per : n;
+    float msum;
+    if (P > 1) {
+        msum = a.mask_sum[net];
+    } else {
+        float sm = 0.f;
+        for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) sm += a.mask[o + i];
+        const float msum_own = block_sum_1024(sm, s_part);
+        msum = a.mask_sum ? a.mask_sum[net] : msum_own;
+    }
     const float nrow = a.row_count > 0.f ? a.row_count : (float)n;
     const bool mse = a.flags & IPLAN_PPO_MSE, no_vclip = a.flags & IPLAN_PPO_NO_VCLIP;
     const bool v_mean = a.flags & IPLAN_PPO_VALUE_MEAN, p_mean = a.flags & IPLAN_PPO_POLICY_MEAN;
     float pol = 0.f, vls = 0.f, rat = 0.f, en = 0.f;
-    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
+    for (int i = r0 + (int)threadIdx.x; i < r1; i += (int)blockDim.x) {
         const float m = a.mask[o + i], ad = a.adv[o + i];
         const float ratio = expf(logp[i] - a.old_logp[o + i]);
         const float lo = 1.0f - a.clip, hi = 1.0f + a.clip;
@@ -142,12 +150,12 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(IplanPpoLossArgs a) {
     rat = block_sum_1024(rat, s_part);
     en = block_sum_1024(en, s_part);
     if (threadIdx.x == 0) {
-        float* st = a.stats + (int64_t)net * 8;
+        float* st = a.stats + ((int64_t)net * P + part) * 8;
         st[0] = pol;                   // policy_loss (row weights applied above)
         st[1] = vls;                   // value_loss
         st[2] = rat / (float)n;        // imp_weights.mean()
         st[3] = en / (float)n;         // dist_entropy (unmasked mean, act.py:164)
-        st[4] = msum;
+        st[4] = part == 0 ? msum : 0.f;   // (P > 1: every entry is this range's SHARE -- the caller adds the P of them)
     }
 }
 
@@ -167,7 +175,9 @@ extern "C" int iplan_ppo_loss(const IplanPpoLossArgs* a, iplan_stream_t stream) 
     if (!a || a->n_agents < 1 || a->rows < 1 || !a->logp || !a->entropy || !a->values || !a->old_logp || !a->adv ||
         !a->value_preds || !a->returns || !a->mask || !a->g_logp || !a->g_values || !a->stats)
         return fail(IPLAN_EINVAL, "iplan_ppo_loss: bad arguments");
-    hipLaunchKernelGGL(ppo_loss_kernel, dim3((unsigned)a->n_agents), dim3(1024), 0, (hipStream_t)stream, *a);
+    if (a->n_parts > 1 && (!a->mask_sum || a->n_parts > 1024))
+        return fail(IPLAN_EINVAL, "iplan_ppo_loss: n_parts > 1 needs mask_sum (and at most 1024 parts)");
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3((unsigned)a->n_agents, (unsigned)(a->n_parts > 1 ? a->n_parts : 1)), dim3(1024), 0, (hipStream_t)stream, *a);
     return check_launch("iplan_ppo_loss");
 }
 

@@ -350,18 +350,25 @@ class IPPOLearner:
         pl.returns, pl.mask = returns.data_ptr(), mask.data_ptr()
         pl.clip, pl.huber_delta, pl.value_loss_coef = self.clip_param, self.huber_delta, self.value_loss_coef
         g_logp, g_v = th.empty(nA, rows, **f32), th.empty(nA, rows, **f32)
-        stats = th.zeros(self.ppo_epoch, nA, 8, **f32)
+        # the loss launch's rows in `parts` workgroups per agent (one workgroup walked 22 950 rows in 22 dependent rounds: 46.5 us
+        # x 15 epochs): every workgroup needs the losses' denominator sum(mask) up front -- the mask does not change over the
+        # epochs, so it is added up ONCE here -- and writes its range's share of the statistics, added up after the last epoch
+        parts = max(1, min(rows, int(os.environ.get("IPLAN_PPO_LOSS_PARTS", min(64, rows // 1024)))))          # (the knob: tests, A/B)
+        stats = th.zeros(self.ppo_epoch, nA, parts, 8, **f32)
         norms = th.zeros(self.ppo_epoch, 2, nA, **f32)
         pl.g_logp, pl.g_values = g_logp.data_ptr(), g_v.data_ptr()
         pl.flags = self._loss_flags
+        pl.n_parts = parts
         max_norm = self.max_grad_norm if self._use_max_grad_norm else None
         n_rows = float(rows)
+        msum = mask[:, :rows].sum(dim=1).contiguous() if (parts > 1 or self.dp is not None) else None     # (0 / 1 entries: exact in any order)
         if self.dp is not None:
             # the losses' denominators over all ranks: sum(mask) of the PPO rows and the row count (entropy mean)
-            msum = self.dp.all_reduce_sum(mask[:, :rows].sum(dim=1).contiguous())
-            pl.mask_sum = msum.data_ptr()
+            msum = self.dp.all_reduce_sum(msum)
             n_rows = float(self.dp_global_rows if self.dp_global_rows is not None else rows * self.dp.world)
             pl.row_count = n_rows                               # denominator of the unmasked (mean) loss forms
+        if msum is not None:
+            pl.mask_sum = msum.data_ptr()
         # the epochs re-evaluate the SAME rows: their normalised features are gathered once into the fragment-major arrays the
         # split-bf16 fc1 kernels stream (ops.ac_xhat_pack); IPLAN_PPO_FC1_FP32=1 keeps the fp32 contraction (A/B, diagnostics)
         xhat = ops.ac_xhat_pack(spec, rows, nA, ln_stats) if split else None
@@ -386,7 +393,7 @@ class IPPOLearner:
         self.store.clear()
 
         # train_info (:305-310): averages over agents x epochs -- ONE host read-back
-        st_d = stats.mean(dim=(0, 1))
+        st_d = stats.sum(dim=2).mean(dim=(0, 1))
         nr_d = norms.sqrt().mean(dim=(0, 2)) if max_norm is not None else th.zeros(2, device=dev)
 
         staged = AsyncHost(th.cat([st_d.reshape(-1), nr_d.reshape(-1)])) if defer else None     # read back whenever the caller likes
@@ -469,7 +476,7 @@ class IPPOLearner:
                 norms[k, 1] = step_all(self.critic_optimizers, max_norm)[:, 0]
                 self._probe_after(k)
         self.store.clear()
-        st_d = stats.mean(dim=(0, 1))
+        st_d = stats.sum(dim=2).mean(dim=(0, 1))
         nr_d = norms.sqrt().mean(dim=(0, 2)) if max_norm is not None else th.zeros(2, device=dev)
 
         staged = AsyncHost(th.cat([st_d.reshape(-1), nr_d.reshape(-1)]))

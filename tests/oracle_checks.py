@@ -296,7 +296,8 @@ def check_adam_replay(learner, mac, args, agents, tol=1e-6):
 
 
 def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, terminated_p=0.15, also_fp32=True, agents=None,
-                              e32_factor=E32_FACTOR, table=None, assert_grads=True, mid_probes=(), adam_replay=False, t_env=0):
+                              e32_factor=E32_FACTOR, table=None, assert_grads=True, mid_probes=(), adam_replay=False, t_env=0,
+                              check_stats=False):
     """insert buffer_size episodes -> train() (ppo_epoch fused epochs x num_mini_batch steps) vs oracle.ppo_train_agent, every
     agent: clipped gradients of the LAST optimiser step and the post-train parameters.
 
@@ -327,7 +328,9 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
     parameters of that step vs the fp64 oracle there (same bound), one fp64 Adam step from that step's own state (moments at
     t = k + 1) landing on the learner's next parameters (post_tol), hint count per step <= RELU_HINT_MAX -- so that the
     15-epoch train() the benchmark times is pinned at two points of its trajectory, not only at its end.  ``adam_replay``:
-    check_adam_replay over every step.  ``t_env``: train()'s argument (the linear lr decay hook reads it)."""
+    check_adam_replay over every step.  ``t_env``: train()'s argument (the linear lr decay hook reads it).
+    ``check_stats`` (all agents replayed): the logged train_info -- policy / value loss, entropy, ratio averaged over agents x
+    optimiser steps (learners/ippo_learner.py:305-310) -- against the fp32 oracle's per-step values."""
     from iplan_amd.controllers.dcntrl_controller import DcntrlMAC
     from iplan_amd.learners.ippo_learner import IPPOLearner
     args = SimpleNamespace(**dict(vars(args), use_cuda=(torch.device(device).type == "cuda")))
@@ -360,6 +363,7 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
         index_lists = [[[p[i * mbs:(i + 1) * mbs] for i in range(nmb)] for p in pa] for pa in perms]
     worst = dict(grad=0.0, post=0.0, fp32_oracle_grad_vs_fp64=0.0, fp32_oracle_post_vs_fp64=0.0,
                  grad_vs_fp64_trajectory=0.0, fp32_oracle_grad_vs_fp64_trajectory=0.0)
+    oracle_stats = []
     f64 = {k: (v.double() if v.is_floating_point() else v) for k, v in fields.items()}
 
     def probe_of(i):
@@ -397,6 +401,7 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
             r32 = O.ppo_train_agent(i, a32, c32, fields, args, row_index_lists=il, probe_last_step=probe, probe_relu_hint=hint,
                                     probe_steps=mids)
             g32 = r32["probe_grads"] if probe is not None else [{k: p[k].grad for k in p if p[k].grad is not None} for p in (a32, c32)]
+            oracle_stats.extend(r32["stats"])
             for gi, (p32, p64) in enumerate(((a32, ap), (c32, cp))):
                 for k in p64:
                     if p64[k].grad is not None:
@@ -495,6 +500,14 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
                     pp = _rel(sd[k], probe_post[gi][k])
                     worst["post_one_step_from_probe"] = max(worst.get("post_one_step_from_probe", 0.0), pp)
                     assert pp <= post_tol, ("post, one fp64 Adam step from the learner's own pre-step state", name, i, k, pp, post_tol)
+    if check_stats:
+        assert agents is None and also_fp32 and len(oracle_stats) == args.n_agents * n_steps
+        info = learner.last_train_info
+        for mine, theirs in (("policy_loss", "policy_loss"), ("value_loss", "value_loss"), ("dist_entropy", "entropy"), ("ratio", "ratio")):
+            ref = float(np.mean([st[theirs] for st in oracle_stats]))
+            e = abs(info[mine] - ref) / max(1.0, abs(ref))
+            worst["train_info"] = max(worst.get("train_info", 0.0), e)
+            assert e <= 2e-5, ("train_info", mine, info[mine], ref)
     if adam_replay:
         worst["adam_replay"], worst["adam_replay_updates"] = check_adam_replay(learner, mac, args, list(range(args.n_agents) if agents is None else agents))
     return worst

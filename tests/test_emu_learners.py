@@ -340,6 +340,14 @@ def test_ppo_train_15_epochs_vs_oracle_emulated(decay):
     assert w["adam_replay_updates"] == 15 * 2 * 2 and "mid_grad" in w, w
 
 
+def test_ppo_loss_in_parts_vs_oracle_emulated(monkeypatch):
+    """iplan_ppo_loss with the rows of an agent dealt to several workgroups (IplanPpoLossArgs.n_parts: what 22 950 rows get) -- ragged
+    last range, mask sum handed in; gradients and the logged statistics (sum of the ranges' shares) against the oracle"""
+    from tests.oracle_checks import check_ppo_train_vs_oracle
+    monkeypatch.setenv("IPLAN_PPO_LOSS_PARTS", "4")
+    check_ppo_train_vs_oracle(_small(batch_size_run=5, buffer_size=6, batch_size=5), "cpu", seed=17, check_stats=True)
+
+
 def test_ppo_train_wide_tail_workgroups_vs_oracle_emulated(monkeypatch):
     """the PPO epoch's forward tail in its 16-wave workgroup form (what a full 22 950-row batch gets; small batches default to 8 waves)"""
     from tests.oracle_checks import check_ppo_train_vs_oracle
