@@ -404,6 +404,194 @@ __global__ __launch_bounds__(64) void wgrad_partial_bf16_kernel(IplanWgradArgs a
     }
 }
 
+// Two wide jobs that read the SAME dY rows through the same first 8 o-tiles -- the two weights of a GRU: dW_ih from [dr dz dn_i] and
+// the step's input, dW_hh from [dr dz dn_h] and the previous hidden state -- as the two waves of ONE workgroup that walk the rows
+// in step and fetch the shared [dr dz] tiles ONCE: wave w loads and splits shared tiles 4w .. 4w+3, publishes their bf16 pieces in
+// LDS (double buffered, one barrier per 32-row block) and both waves take all eight from there; tiles 8 .. 11 (dn_i / dn_h) and
+// the X operand are each wave's own.  The contraction is HBM-bound by the bytes its waves request (header), and sharing through the
+// caches does not happen (round 4: the same two waves WITHOUT the exchange, 2.84 -> 2.79 ms), so this is a quarter of the bytes
+// gone: 4 (128 + 64 + 64 + 64 + 64) instead of 4 x 2 x (192 + 64) per row.  Same pieces, same products, same accumulation order
+// per output element as wgrad_partial_bf16_kernel<12, 4>: bit-identical partial tiles, same reduction kernel.
+struct WgradPairShared {
+    bf16x8 pc[2][8][3][64];                  // [block parity][shared o-tile][piece][lane]: 48 KiB
+};
+__global__ __launch_bounds__(128) void wgrad_pair_bf16_kernel(IplanWgradArgs a, WgradJobs jl, int chunks_wide) {
+    constexpr int TO = 12, TK = WG_TK, TS = 8, TL = 8;       // o-tiles of a job, shared ones, tiles whose raw values a wave loads
+    __shared__ __attribute__((aligned(16))) WgradPairShared sh;
+    const int w = uniform_i(wave_id());                      // (an SGPR: the problem's fields then come by scalar loads, as in the unpaired kernel)
+    const int pi = jl.pj[2 * blockIdx.x + w] >> 8, pi_other = jl.pj[2 * blockIdx.x + (w ^ 1)] >> 8, net = (int)blockIdx.z;
+    const IplanWgradProblem& p = a.p[pi];
+    const WgradGeom gm = wgrad_geom(p, chunks_wide);         // (the pair has ONE geometry: same O, K and rows -- iplan_wgrad checks)
+    const int vc = (int)blockIdx.y;
+    if (vc >= gm.vchunks) return;                            // (both waves alike)
+    const int l = lane_id(), i = l & 15, g = l >> 4;
+
+    f32x4 acc[TO][TK];
+    float bsum[TL];
+#pragma unroll
+    for (int t = 0; t < TO; ++t)
+#pragma unroll
+        for (int u = 0; u < TK; ++u) acc[t][u] = splat4(0.f);
+#pragma unroll
+    for (int s = 0; s < TL; ++s) bsum[s] = 0.f;
+    const int64_t r_lo = (int64_t)vc * gm.vrows;
+    const int64_t r_hi = gm.rows < r_lo + gm.vrows ? gm.rows : r_lo + gm.vrows;
+    const int o_lo = (int)(r_lo / p.n_inner);
+    const char* __restrict__ abase = reinterpret_cast<const char*>(p.dy + (int64_t)net * p.dy_s_net + (int64_t)o_lo * p.dy_s_outer);
+    const int pre = x_pre_rows(p);
+    const char* __restrict__ xbase = reinterpret_cast<const char*>(p.x + (int64_t)net * p.x_s_net + (int64_t)o_lo * p.x_s_outer - (int64_t)pre * p.x_s_inner);
+    // the tiles this wave loads: slots 0 .. 3 = shared tiles 4w .. 4w+3, slots 4 .. 7 = its own tiles 8 .. 11
+    uint32_t acolb[TL], bcolb[TK];
+#pragma unroll
+    for (int s = 0; s < TL; ++s) {
+        const int t = s < 4 ? 4 * w + s : 4 + s;
+        acolb[s] = 4u * colmap(ocol(p, t * 16 + i), p.dy_cg_stride);
+    }
+#pragma unroll
+    for (int u = 0; u < TK; ++u) bcolb[u] = 4u * colmap(p.x_col0 + u * 16 + i, p.x_cg_stride);
+    int ri[8];
+    uint32_t aoff[8], xoff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t r = r_lo + 8 * g + j;
+        const int ro = (int)(r / p.n_inner);
+        ri[j] = (int)(r - (int64_t)ro * p.n_inner);
+        aoff[j] = (uint32_t)(4 * ((int64_t)(ro - o_lo) * p.dy_s_outer + (int64_t)ri[j] * p.dy_s_inner));
+        xoff[j] = (uint32_t)(4 * ((int64_t)(ro - o_lo) * p.x_s_outer + (int64_t)(ri[j] + p.x_shift + pre) * p.x_s_inner));
+    }
+    const int adv_o = 32 / p.n_inner, adv_i = 32 % p.n_inner;
+    const uint32_t a_adv = (uint32_t)(4 * ((int64_t)adv_o * p.dy_s_outer + (int64_t)adv_i * p.dy_s_inner));
+    const uint32_t x_adv = (uint32_t)(4 * ((int64_t)adv_o * p.x_s_outer + (int64_t)adv_i * p.x_s_inner));
+    const uint32_t a_wrap = (uint32_t)(4 * (p.dy_s_outer - (int64_t)p.n_inner * p.dy_s_inner));
+    const uint32_t x_wrap = (uint32_t)(4 * (p.x_s_outer - (int64_t)p.n_inner * p.x_s_inner));
+    const bool shifted = p.x_shift != 0;
+
+    float ar[TL][8], br[TK][8];
+    uint32_t ao[8], xo[8];
+    bool rvj[8], xvj[8];
+    auto advance = [&](int64_t rb, bool tail) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool rv = !tail || rb + 8 * g + j < r_hi;
+            const bool inr = !shifted || (unsigned)(ri[j] + p.x_shift + pre) < (unsigned)(p.n_inner + pre);
+            ao[j] = rv ? aoff[j] : 0u;
+            xo[j] = (rv && inr) ? xoff[j] : 0u;
+            rvj[j] = rv;
+            xvj[j] = rv && inr;
+            ri[j] += adv_i;
+            aoff[j] += a_adv;
+            xoff[j] += x_adv;
+            if (ri[j] >= p.n_inner) { ri[j] -= p.n_inner; aoff[j] += a_wrap; xoff[j] += x_wrap; }
+        }
+    };
+    // Loads are RAW (rows past the chunk's end / steps in front of a chain's first one read offset 0 -- mapped memory, any value);
+    // the masks of the block a register set was loaded for are applied where the values are consumed, one block later (rvc / xvc).
+    // With the mask at the load (keep_if(load), as the unpaired kernel writes it) the compiler ran every load of this kernel through
+    // one temporary register behind `s_waitcnt vmcnt(0)` -- 96 serial memory round trips per block.
+    bool rvc[8], xvc[8];
+    auto load_b = [&](int u) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) br[u][j] = *reinterpret_cast<const float*>(xbase + (xo[j] + bcolb[u]));
+    };
+    auto load_a = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ar[s][j] = *reinterpret_cast<const float*>(abase + (ao[j] + acolb[s]));
+    };
+    auto split8 = [&](const float (&v)[8], const bool (&ok)[8], float* colsum) {
+        f32x4 lo, hi;
+        float bs = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float m = keep_if(ok[q], v[q]);
+            bs += m;
+            if (q < 4) lo[q] = m; else hi[q - 4] = m;
+        }
+        if (colsum) *colsum += bs;
+        return split_bf3(lo, hi);
+    };
+    auto products = [&](const Bf3& ap, const Bf3 (&bp)[TK], f32x4 (&c)[TK]) {      // smallest piece products first (as the unpaired kernel)
+#pragma unroll
+        for (int u = 0; u < TK; ++u) c[u] = mfma_bf16(ap.p2, bp[u].p0, c[u]);
+#pragma unroll
+        for (int u = 0; u < TK; ++u) c[u] = mfma_bf16(ap.p0, bp[u].p2, c[u]);
+#pragma unroll
+        for (int u = 0; u < TK; ++u) c[u] = mfma_bf16(ap.p1, bp[u].p1, c[u]);
+#pragma unroll
+        for (int u = 0; u < TK; ++u) c[u] = mfma_bf16(ap.p1, bp[u].p0, c[u]);
+#pragma unroll
+        for (int u = 0; u < TK; ++u) c[u] = mfma_bf16(ap.p0, bp[u].p1, c[u]);
+#pragma unroll
+        for (int u = 0; u < TK; ++u) c[u] = mfma_bf16(ap.p0, bp[u].p0, c[u]);
+    };
+    advance(r_lo, r_lo + 32 > r_hi);
+#pragma unroll
+    for (int u = 0; u < TK; ++u) load_b(u);
+#pragma unroll
+    for (int s = 0; s < TL; ++s) load_a(s);
+    int par = 0;
+    for (int64_t rb = r_lo; rb < r_hi; rb += 32, par ^= 1) {
+        const int64_t nb = rb + 32;
+        Bf3 bp[TK];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { rvc[j] = rvj[j]; xvc[j] = xvj[j]; }          // masks of the block in the registers
+#pragma unroll
+        for (int u = 0; u < TK; ++u) bp[u] = split8(br[u], xvc, nullptr);
+        advance(nb, nb + 32 > r_hi);
+#pragma unroll
+        for (int u = 0; u < TK; ++u) load_b(u);
+        // this wave's four shared tiles: split, publish, reload
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const Bf3 ap = split8(ar[s], rvc, &bsum[s]);
+            load_a(s);
+            sh.pc[par][4 * w + s][0][l] = ap.p0;
+            sh.pc[par][4 * w + s][1][l] = ap.p1;
+            sh.pc[par][4 * w + s][2][l] = ap.p2;
+        }
+        // its own tiles 8 .. 11 in front of the barrier (their products do not wait for the other wave)
+#pragma unroll
+        for (int s = 4; s < TL; ++s) {
+            const Bf3 ap = split8(ar[s], rvc, &bsum[s]);
+            load_a(s);
+            products(ap, bp, acc[4 + s]);
+        }
+        IPLAN_LDS_BARRIER();                 // LDS traffic only (__syncthreads would drain the rolling prefetch: 2.9 -> 14 ms, measured);
+                                             // one barrier per block: the parity buffers make the second one unnecessary
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+            Bf3 ap;
+            ap.p0 = sh.pc[par][t][0][l];
+            ap.p1 = sh.pc[par][t][1][l];
+            ap.p2 = sh.pc[par][t][2][l];
+            products(ap, bp, acc[t]);
+        }
+    }
+    const int ldp = gm.KT * 16 + 1;
+    float* __restrict__ part = a.workspace + p.ws_off + ((int64_t)net * gm.vchunks + vc) * gm.part_floats;
+    float* __restrict__ part_other = a.workspace + a.p[pi_other].ws_off + ((int64_t)net * gm.vchunks + vc) * gm.part_floats;
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = t * 16 + 4 * g + q;
+#pragma unroll
+            for (int u = 0; u < TK; ++u) part[(int64_t)o * ldp + u * 16 + i] = acc[t][u][q];
+        }
+    }
+    // bias columns: the column sums of a shared tile were taken by the wave that loaded it and go to BOTH problems' partial tiles
+#pragma unroll
+    for (int s = 0; s < TL; ++s) {
+        const int t = s < 4 ? 4 * w + s : 4 + s;
+        float b = bsum[s];
+        b += __shfl_xor(b, 16);
+        b += __shfl_xor(b, 32);
+        if (g == 0) {
+            part[(int64_t)(t * 16 + i) * ldp + gm.KT * 16] = b;
+            if (s < 4) part_other[(int64_t)(t * 16 + i) * ldp + gm.KT * 16] = b;
+        }
+    }
+}
+
 // grid: (ceil(O*(K+1)/256), problem * n_nets + net)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(IplanWgradArgs a, int chunks_wide) {
     const int pi = (int)blockIdx.y / a.n_nets, net = (int)blockIdx.y % a.n_nets;
@@ -500,6 +688,44 @@ extern "C" int iplan_wgrad(IplanWgradArgs* a, iplan_stream_t stream) {
     if (off > a->workspace_floats)
         return fail(IPLAN_EINVAL, "iplan_wgrad: workspace too small (%lld floats needed, %lld given)", (long long)off,
                     (long long)a->workspace_floats);
+    // Pairs among the wide jobs (wgrad_pair_bf16_kernel): two single-job problems [192 x 64] on the same dY rows whose first 128
+    // output columns are the same dY columns -- the two weights of a 64-wide GRU.  IPLAN_WG_NO_PAIR=1: A/B knob.
+    WgradJobs jpair;
+    jpair.n = 0;
+#ifndef IPLAN_WG_WIDE_FP32
+    if (jl[J_WIDE].n >= 2 && getenv("IPLAN_WG_NO_PAIR") == nullptr) {
+        auto pairable = [&](int i) {
+            const IplanWgradProblem& p = a->p[i];
+            return p.O == 192 && p.K == 64 && !p.x0 && p.x && p.seg_split >= 128 && p.seg_split <= 192;
+        };
+        bool used[IPLAN_WGRAD_MAX] = {};
+        WgradJobs rest;
+        rest.n = 0;
+        for (int k = 0; k < jl[J_WIDE].n; ++k) {
+            const int i = jl[J_WIDE].pj[k] >> 8;
+            if (used[i]) continue;
+            int mate = -1;
+            if (pairable(i))
+                for (int k2 = k + 1; k2 < jl[J_WIDE].n && mate < 0; ++k2) {
+                    const int j = jl[J_WIDE].pj[k2] >> 8;
+                    const IplanWgradProblem &p = a->p[i], &q = a->p[j];
+                    if (!used[j] && j != i && pairable(j) && p.dy == q.dy && p.dy_s_net == q.dy_s_net && p.dy_s_outer == q.dy_s_outer &&
+                        p.dy_s_inner == q.dy_s_inner && p.dy_cg_stride == q.dy_cg_stride && p.n_outer == q.n_outer && p.n_inner == q.n_inner &&
+                        p.seg_c0 == q.seg_c0)
+                        mate = j;
+                }
+            if (mate >= 0) {
+                used[i] = used[mate] = true;
+                jpair.pj[jpair.n++] = i << 8;
+                jpair.pj[jpair.n++] = mate << 8;
+            } else if (!used[i]) {
+                used[i] = true;
+                rest.pj[rest.n++] = jl[J_WIDE].pj[k];
+            }
+        }
+        jl[J_WIDE] = rest;
+    }
+#endif
     // The wide jobs first (one long-lived 372-register wave per SIMD: nothing else gets onto the chip while they run), the
     // thin / square ones -- many short waves -- behind them.  In the training loop this call is the decoder update that
     // Behavior_policy.learn defers beside the next rollout: with the thin kernels in front (1.6 ms) the wide one was still
@@ -512,6 +738,10 @@ extern "C" int iplan_wgrad(IplanWgradArgs* a, iplan_stream_t stream) {
 #ifdef IPLAN_WG_WIDE_FP32                                    // A/B builds: the fp32 MFMA form of the wide jobs
     IPLAN_WGRAD_LAUNCH(J_WIDE, WG_TO_WIDE, WG_TK, IPLAN_WG_WIDE_RB)
 #else
+    if (getenv("IPLAN_WG_DEBUG")) fprintf(stderr, "iplan_wgrad: %d paired GRU jobs, %d single wide jobs, %d row chunks\n", jpair.n, jl[J_WIDE].n, vcs[J_WIDE]);
+    if (jpair.n)
+        hipLaunchKernelGGL(wgrad_pair_bf16_kernel, dim3((unsigned)(jpair.n / 2), (unsigned)vcs[J_WIDE], (unsigned)a->n_nets), dim3(128), 0,
+                           (hipStream_t)stream, *a, jpair, chunks_wide);
     if (jl[J_WIDE].n) {
         bool any_x0 = false;
         for (int k = 0; k < jl[J_WIDE].n; ++k) any_x0 = any_x0 || a->p[jl[J_WIDE].pj[k] >> 8].x0 != nullptr;

@@ -476,7 +476,7 @@ class IPPOLearner:
                 norms[k, 1] = step_all(self.critic_optimizers, max_norm)[:, 0]
                 self._probe_after(k)
         self.store.clear()
-        st_d = stats.sum(dim=2).mean(dim=(0, 1))
+        st_d = stats.mean(dim=(0, 1))
         nr_d = norms.sqrt().mean(dim=(0, 2)) if max_norm is not None else th.zeros(2, device=dev)
 
         staged = AsyncHost(th.cat([st_d.reshape(-1), nr_d.reshape(-1)]))

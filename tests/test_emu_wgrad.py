@@ -125,3 +125,45 @@ def test_wgrad_column_grouped_operands(O, K, s0):
         ref = torch.einsum("tsco,tsck->ok", d[k, :, s0:], xprev[k, :, s0:])
         assert torch.allclose(grad[k, :O * K].view(O, K).double(), ref, rtol=1e-5, atol=2e-4), (O, K, s0)
         assert torch.allclose(grad[k, O * K:O * K + O].double(), d[k, :, s0:].sum((0, 1, 2)), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("s0,steps,tiles", [(0, 7, 3), (3, 9, 2), (0, 70, 1)])
+def test_wgrad_gru_pair_shares_the_gate_gradients(s0, steps, tiles, monkeypatch):
+    """the two wide problems of a 64-wide GRU on column-grouped records (the behaviour decoder's deferred update: dW_ih from
+    [dr dz dn_i] x u, dW_hh from [dr dz dn_h] x h_{t-1}) run as ONE paired launch that fetches [dr dz] once
+    (wgrad_pair_bf16_kernel): against torch, and BIT-identical to the two unpaired jobs (IPLAN_WG_NO_PAIR=1); ragged row tail
+    (rows not a multiple of 32), a window range that starts past step 0, several row chunks"""
+    torch.manual_seed(steps * 10 + s0)
+    n_nets, H, Gd, Gx = 2, 64, 21, 31
+    dy = torch.randn(n_nets, tiles, Gd, steps, 16, 16)              # 336 dY columns: [.. 80 | dr dz dn_i (192) | dn_h (64)]
+    x = torch.randn(n_nets, tiles, Gx, steps, 16, 16)               # 496 record columns: u at 32, h at 352
+    n = steps - s0
+    st = lambda G: (tiles * G * steps * 256, G * steps * 256, 16)   # noqa: E731
+    cg = dict(dy_cg_stride=steps * 256, x_cg_stride=steps * 256)
+
+    def run():
+        grad = torch.zeros(n_nets, 2 * (3 * H * (H + 1)) + 8)
+        w = ops.Wgrad(grad, n_nets)
+        ddp, sdp = dy.data_ptr() + 4 * s0 * 256, x.data_ptr() + 4 * s0 * 256
+        w.add(ddp, st(Gd), 3 * H, tiles, n * 16, x=sdp, x_strides=st(Gx), K=H, x_col0=32, seg=(3 * H, 80, 0), dw_off=0, db_off=3 * H * H, **cg)
+        w.add(ddp, st(Gd), 3 * H, tiles, n * 16, x=sdp, x_strides=st(Gx), K=H, x_col0=352, x_shift=-16, x_pre_valid=s0 > 0,
+              seg=(2 * H, 80, 80 + 3 * H), dw_off=3 * H * (H + 1), db_off=3 * H * (H + 1) + 3 * H * H, **cg)
+        w._keep += [dy, x]
+        w.run()
+        return grad
+
+    paired = run()
+    monkeypatch.setenv("IPLAN_WG_NO_PAIR", "1")
+    plain = run()
+    assert torch.equal(paired, plain)
+    rows = lambda t: t.permute(0, 1, 3, 4, 2, 5).reshape(n_nets, tiles, steps, 16, -1).double()   # noqa: E731
+    d, xs = rows(dy), rows(x)
+    u, h = xs[..., 32:32 + H], xs[..., 352:352 + H]
+    hprev = torch.cat([torch.zeros_like(h[:, :, :1]), h[:, :, :-1]], 2)
+    dgi, dgh = d[..., 80:80 + 3 * H], torch.cat([d[..., 80:80 + 2 * H], d[..., 272:272 + H]], -1)
+    o2 = 3 * H * (H + 1)
+    for k in range(n_nets):
+        for off, dg, xx in ((0, dgi, u), (o2, dgh, hprev)):
+            ref = torch.einsum("tsco,tsck->ok", dg[k, :, s0:], xx[k, :, s0:])
+            assert torch.allclose(paired[k, off:off + 3 * H * H].view(3 * H, H).double(), ref, rtol=1e-5, atol=5e-4)
+            assert torch.allclose(paired[k, off + 3 * H * H:off + 3 * H * (H + 1)].double(), dg[k, :, s0:].sum((0, 1, 2)), rtol=1e-5, atol=2e-4)
