@@ -80,7 +80,8 @@ enum {
 /* Activations kept for the backward pass (contiguous; NULL = inference).  Rows are (b, i) = b*N + i. */
 typedef struct {
     float* h_enc;   /* [n_nets, B*N, H]              ReLU(encoding(obs))                          */
-    float* gru;     /* [n_nets, 2, B*N, N-1, 5H]     per direction and pair step: h, r, z, n, hn  */
+    float* gru;     /* [n_nets, 2, B, ceil(N/16), N-1, 10, 16, 16]  per direction, scene, 16-ego tile and pair step: ten 16-column
+                       groups (h h r r z z n n hn hn) of [16 egos][16 columns] -- 1 KiB blocks, one per wave store / load    */
     float* qkv;     /* [n_nets, B*N, 3A]             q | k | v                                    */
     float* soft;    /* [n_nets, B*N, N-1]            soft attention weights                       */
     float* hard;    /* [n_nets, B*N, N-1]            gumbel-softmax class-1 weights               */
@@ -565,7 +566,7 @@ typedef struct {
     IplanGatFwdArgs fwd;        /* descriptor of the forward launch (saved.* all non-NULL)           */
     const float* g_out;         /* dLoss/d out, rows of A floats: (net,b,i)                          */
     int64_t g_s_net, g_s_b;
-    float* dgru;                /* scratch [n_nets, 2, B*N, N-1, 3H] (kernel-private layout)         */
+    float* dgru;                /* scratch [n_nets, 2, B, ceil(N/16), N-1, 2, 3H] (kernel-private)   */
     float* node_dy;             /* [n_nets, B*N, IPLAN_GAT_NODE_DY]                                  */
     float* hard_part;           /* [n_nets, B, IPLAN_GAT_HARD_PART]                                  */
     float* whh_part;            /* scratch [n_nets, B, 2, 4, IPLAN_GAT_WHH_PART]                     */

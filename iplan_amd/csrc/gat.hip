@@ -246,12 +246,16 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
             h0 = o0.h;
             h1 = o1.h;
             if (sv.gru) {
-                float* row = sv.gru + (((((int64_t)net * 2 + dir) * a.B + b) * N + node) * (N - 1) + s) * (5 * GH);
-                vstore(row, valid, GH, 0, o0.h);          vstore(row, valid, GH, 1, o1.h);
-                vstore(row + GH, valid, GH, 0, o0.r);     vstore(row + GH, valid, GH, 1, o1.r);
-                vstore(row + 2 * GH, valid, GH, 0, o0.z); vstore(row + 2 * GH, valid, GH, 1, o1.z);
-                vstore(row + 3 * GH, valid, GH, 0, o0.n); vstore(row + 3 * GH, valid, GH, 1, o1.n);
-                vstore(row + 4 * GH, valid, GH, 0, o0.hn); vstore(row + 4 * GH, valid, GH, 1, o1.hn);
+                // [net][dir][scene][ego tile][step][group: h h r r z z n n hn hn][16 chains][16 columns]: one 1 KiB block per store
+                // instruction (gat_bwd.hip reads it back the same way)
+                float* blk = sv.gru + ((((((int64_t)net * 2 + dir) * a.B + b) * ((N + 15) / 16) + tile) * (N - 1) + s) * 10) * 256 + n * 16 + 4 * g;
+                if (valid) {
+                    *reinterpret_cast<f32x4*>(blk) = o0.h;             *reinterpret_cast<f32x4*>(blk + 256) = o1.h;
+                    *reinterpret_cast<f32x4*>(blk + 2 * 256) = o0.r;   *reinterpret_cast<f32x4*>(blk + 3 * 256) = o1.r;
+                    *reinterpret_cast<f32x4*>(blk + 4 * 256) = o0.z;   *reinterpret_cast<f32x4*>(blk + 5 * 256) = o1.z;
+                    *reinterpret_cast<f32x4*>(blk + 6 * 256) = o0.n;   *reinterpret_cast<f32x4*>(blk + 7 * 256) = o1.n;
+                    *reinterpret_cast<f32x4*>(blk + 8 * 256) = o0.hn;  *reinterpret_cast<f32x4*>(blk + 9 * 256) = o1.hn;
+                }
             }
             s_prev = s;
             for (int t = 0; t < 6; ++t) bc[t] = bn[t];

@@ -175,10 +175,15 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
     __syncthreads();
     if (clk) clk[3] = IPLAN_CLOCK();
     // ---------------------------------------------------------------- D: BPTT through the pair GRU
-    // dgru: kernel-private scratch, [net][dir][scene][neighbour j][u][3H] with u = the ego's index among the N-1 egos that
-    // see j (i = u + (u >= j)): phase D scatters a pair step's [dr dz dn_i] to its NEIGHBOUR's block, phase E then sums each
-    // block over u as one contiguous stream
-    float* __restrict__ dgru_base = a.dgru + ((((int64_t)net * 2 + dir) * f.B + b) * N) * (int64_t)(N - 1) * (3 * BH);
+    // dgru: kernel-private scratch, [net][dir][scene][ego tile][step][class 2][3H].  A pair step (ego i, step s) belongs to neighbour
+    // j = s + [s >= i], so the 16 egos of a tile feed at most TWO neighbours per step -- class 0: egos i <= s -> j = s + 1; class 1:
+    // egos i > s -> j = s -- and d(W_b h_j) is a SUM over the egos that see j.  Phase D therefore adds a step's [dr dz dn_i] over the
+    // tile's chains per class (one more MFMA against a 0 / 1 operand on the tiles it parks for dW_hh anyway) and stores two
+    // 3H-float rows per wave-step; phase E adds at most eight rows per (node, direction).  Until round 5 every pair step's 3H
+    // floats went out to a neighbour-major scratch and came back in phase E: 2 x 2.3 MB per scene of a kernel that runs AT the
+    // HBM bandwidth (3.8 MB of gate records in + the scratch, 4.5 TB/s over phases D + E: profiles/r05_notes.md).
+    const int NT_live = (N + 15) / 16;
+    float* __restrict__ dgp = a.dgru + ((((int64_t)net * 2 + dir) * f.B + b) * NT_live + tile) * (int64_t)(N - 1) * (2 * 3 * BH);
     if (tile_live) {
         const float* swT = &s_sw[0][0][0] + dir * (BH * WLD);                      // W_hh^T [H][3H] of this direction
         const float* Wh = P + f.off[IPLAN_GAT_HARD_W];                              // [2][2H]
@@ -190,8 +195,14 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
         // chain (the ragged last tile) is a CLONE of the scene's last node: it loads, computes and stores exactly what that
         // node's lane does (same values to the same addresses), so nothing in the step loop is predicated; only the sums
         // over the 16 chains below leave the clones out.
+        // Record layout (gat.hip writes it): [net][dir][scene][ego tile][step][group: h h r r z z n n hn hn][16 chains][16 columns] --
+        // a wave's load of one 16-column group of its 16 chains is ONE contiguous 1 KiB block.  (Chain-major rows of 5H floats until
+        // round 5: every load instruction was 16 separate 64-byte pieces, and the BPTT sat at the memory pipeline's request rate, not
+        // at its latency -- touching the lines three steps ahead made it SLOWER, 345 -> 397 us: profiles/r05_notes.md.)
         const int cnode = imin(node, N - 1);
-        const float* gbase = sv.gru + ((((int64_t)net * 2 + dir) * f.B + b) * N + cnode) * (int64_t)(N - 1) * (5 * BH) + 4 * g;
+        const int NT = (N + 15) / 16;
+        constexpr int REC = 10 * 256;                                               // floats of a tile's record of one step
+        const float* gbase = sv.gru + (((((int64_t)net * 2 + dir) * f.B + b) * NT + tile) * (int64_t)(N - 1)) * REC + (cnode & 15) * 16 + 4 * g;
         float (*turn)[256] = s_turn[w];
         // a parked tile is [16 chains][16 columns], chain r's columns rotated by 4 (r >> 1) (conflict-free ds_write_b128 /
         // ds_read_b32, as in beh_enc_bwd_kernel); pick = operand element [chain 4 s + g][column n]
@@ -209,15 +220,15 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
             const int s = dir ? it : (N - 2 - it);                 // reverse of the forward visiting order
             const int sp = dir ? s + 1 : s - 1;                    // the step the forward came from
             o.has_prev = sp >= 0 && sp <= N - 2;
-            const float* row = gbase + (int64_t)s * (5 * BH);
-            const float* prow = gbase + (int64_t)(o.has_prev ? sp : s) * (5 * BH);
+            const float* row = gbase + (int64_t)s * REC;
+            const float* prow = gbase + (int64_t)(o.has_prev ? sp : s) * REC;
             for (int T = 0; T < 2; ++T) {
-                if (first) o.hs[T] = *reinterpret_cast<const f32x4*>(row + 16 * T);      // later: the previous step's hp
-                o.r[T] = *reinterpret_cast<const f32x4*>(row + BH + 16 * T);
-                o.z[T] = *reinterpret_cast<const f32x4*>(row + 2 * BH + 16 * T);
-                o.nn[T] = *reinterpret_cast<const f32x4*>(row + 3 * BH + 16 * T);
-                o.hn[T] = *reinterpret_cast<const f32x4*>(row + 4 * BH + 16 * T);
-                o.hp[T] = *reinterpret_cast<const f32x4*>(prow + 16 * T);
+                if (first) o.hs[T] = *reinterpret_cast<const f32x4*>(row + 256 * T);     // later: the previous step's hp
+                o.r[T] = *reinterpret_cast<const f32x4*>(row + 256 * (2 + T));
+                o.z[T] = *reinterpret_cast<const f32x4*>(row + 256 * (4 + T));
+                o.nn[T] = *reinterpret_cast<const f32x4*>(row + 256 * (6 + T));
+                o.hn[T] = *reinterpret_cast<const f32x4*>(row + 256 * (8 + T));
+                o.hp[T] = *reinterpret_cast<const f32x4*>(prow + 256 * T);
             }
             o.dd = s_dd[cnode][s];
         };
@@ -245,15 +256,6 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
                 dgh[T] = o2[T].dr; dgh[2 + T] = o2[T].dz; dgh[4 + T] = o2[T].dnh;
                 dhd[T] = o2[T].dh_direct;
             }
-            {   // the pair's input-side gate gradients go to the neighbour's block
-                const int j = s + (s >= cnode ? 1 : 0), u = cnode - (cnode > j ? 1 : 0);
-                float* drow = dgru_base + ((int64_t)j * (N - 1) + u) * (3 * BH) + 4 * g;
-                for (int T = 0; T < 2; ++T) {
-                    *reinterpret_cast<f32x4*>(drow + 16 * T) = o2[T].dr;
-                    *reinterpret_cast<f32x4*>(drow + BH + 16 * T) = o2[T].dz;
-                    *reinterpret_cast<f32x4*>(drow + 2 * BH + 16 * T) = o2[T].dni;
-                }
-            }
             // dW_hh += [dr dz dn_h]^T h_prev over the tile's 16 chains (clones contribute zero): operands turned through LDS
             for (int t = 0; t < 6; ++t) park(t, dgh[t]);
             bNh[0] += dgh[4]; bNh[1] += dgh[5];
@@ -270,6 +272,8 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
                 for (int t = 0; t < 6; ++t) acc = mma_block(wfrag_lds(swT, WLD, 16 * T, 16 * t), dgh[t], acc);
                 dh[T] = acc;
             }
+            // class sums of [dr dz dn_i] over the tile's chains (header of this phase): B operand = the 0 / 1 class membership of chain
+            // 4 s4 + g for class n (n < 2), A = the parked gate-gradient tile -> lane (n = class, g) ends with the sums of columns 4g ..
             for (int s4 = 0; s4 < 4; ++s4) {
                 const float h0 = pick(6, s4), h1 = pick(7, s4);
                 for (int t = 0; t < 6; ++t) {
@@ -278,6 +282,31 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
                     aW[t][1] = mfma4(av, h1, aW[t][1]);
                 }
             }
+            // (two gate tiles at a time, in passes of their own: with all six sums live beside the dW_hh accumulators the loop spilled)
+            auto cmask = [&](int s4) {
+                const int ego = 16 * tile + 4 * s4 + g;
+                return (ego < N && n < 2 && (n == 0 ? ego <= s : ego > s)) ? 1.0f : 0.0f;
+            };
+            float* crow = dgp + ((int64_t)s * 2 + (n & 1)) * (3 * BH) + 4 * g;
+            auto class_rows = [&](int t0) {
+                f32x4 c0 = splat4(0.f), c1 = splat4(0.f);
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const float m = cmask(s4);
+                    c0 = mfma4(pick(t0, s4), m, c0);
+                    c1 = mfma4(pick(t0 + 1, s4), m, c1);
+                }
+                if (n < 2) {
+                    *reinterpret_cast<f32x4*>(crow + 16 * t0) = c0;
+                    *reinterpret_cast<f32x4*>(crow + 16 * (t0 + 1)) = c1;
+                }
+            };
+            class_rows(0);                                                              // dr
+            class_rows(2);                                                              // dz
+            IPLAN_WAVE_SYNC();
+            park(4, o2[0].dni);                                                         // dn_i takes dn_h's slots
+            park(5, o2[1].dni);
+            IPLAN_WAVE_SYNC();
+            class_rows(4);
             IPLAN_WAVE_SYNC();
         }
         {   // this wave's partial of dW_hh / db_hh (reduced over scenes and tiles by gat_whh_grad_kernel, fixed order)
@@ -305,23 +334,28 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
     __syncthreads();
     if (clk) clk[4] = IPLAN_CLOCK();
 
-    // ---------------------------------------------------------------- E: d(W_b h_j) gather per node
-    // node j's block holds the N-1 egos that see it, in ego order: a column sum over contiguous rows, 18 rows in flight
+    // ---------------------------------------------------------------- E: d(W_b h_j) per node = the class rows of the steps that see it
+    // node j is seen at step s = j by the egos i > j (class 1) and at step s = j - 1 by the egos i < j (class 0): at most two rows per
+    // live ego tile, added in tile order (fixed summation order)
     for (int p = w; p < 2 * N; p += 8) {
         const int j = p >> 1, d2 = p & 1;
-        const float* base = a.dgru + (((((int64_t)net * 2 + d2) * f.B + b) * N + j) * (int64_t)(N - 1)) * (3 * BH);
+        const float* base = a.dgru + ((((int64_t)net * 2 + d2) * f.B + b) * NT_live) * (int64_t)(N - 1) * (2 * 3 * BH);
         const int c1 = 64 + (l & 31);                              // (lanes >= 32 repeat lanes < 32)
+        // all (at most 16) loads first, branch-free (a row that does not exist is replaced by an existing one and masked), then the sums
+        float v0[8], v1[8];
+        const bool hasA = j >= 1, hasB = j <= N - 2;
+        for (int tl = 0; tl < 4; ++tl) {
+            const float* tb = base + (int64_t)imin(tl, NT_live - 1) * (N - 1) * (2 * 3 * BH);
+            const float* rowA = tb + ((int64_t)(hasA ? j - 1 : 0) * 2 + 0) * (3 * BH);
+            const float* rowB = tb + ((int64_t)(hasB ? j : 0) * 2 + 1) * (3 * BH);
+            v0[2 * tl] = rowA[l];     v1[2 * tl] = rowA[c1];
+            v0[2 * tl + 1] = rowB[l]; v1[2 * tl + 1] = rowB[c1];
+        }
         float a0 = 0.f, a1 = 0.f;
-        constexpr int UB = 18;
-        for (int u0 = 0; u0 < N - 1; u0 += UB) {
-            float v0[UB], v1[UB];
-            for (int k = 0; k < UB; ++k) {
-                const float* row = base + (int64_t)imin(u0 + k, N - 2) * (3 * BH);
-                v0[k] = row[l];
-                v1[k] = row[c1];
-            }
-            for (int k = 0; k < UB; ++k)
-                if (u0 + k < N - 1) { a0 += v0[k]; a1 += v1[k]; }
+        for (int tl = 0; tl < 4; ++tl) {
+            const bool live = tl < NT_live;
+            a0 += (live && hasA) ? v0[2 * tl] : 0.f;     a1 += (live && hasA) ? v1[2 * tl] : 0.f;
+            a0 += (live && hasB) ? v0[2 * tl + 1] : 0.f; a1 += (live && hasB) ? v1[2 * tl + 1] : 0.f;
         }
         float* brow = ndy + (int64_t)j * DY + DY_DB + d2 * DY_DIR;
         brow[l] = a0;

@@ -71,7 +71,7 @@ def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None
         H = A
         saved = dict(
             h_enc=torch.empty(n_nets, B * N, H, device=dev),
-            gru=torch.empty(n_nets, 2, B * N, N - 1, 5 * H, device=dev),
+            gru=torch.empty(n_nets, 2, B, (N + 15) // 16, N - 1, 10, 16, 16, device=dev),   # tile-major 1 KiB blocks (csrc/gat.hip)
             qkv=torch.empty(n_nets, B * N, 3 * A, device=dev),
             soft=torch.empty(n_nets, B * N, N - 1, device=dev),
             hard=torch.empty(n_nets, B * N, N - 1, device=dev),
@@ -700,7 +700,7 @@ def gat_backward(arena, saved, g_out, phase_clocks=None, lib=None):
     a.fwd = fa
     a.g_out = g_out.data_ptr()
     a.g_s_net, a.g_s_b = _nb_strides(g_out, N * A)
-    dgru = torch.empty(n_nets, 2, B * N, N - 1, 3 * H, **f32)           # kernel-private scratch
+    dgru = torch.empty(n_nets, 2, B, (N + 15) // 16, N - 1, 2, 3 * H, **f32)           # kernel-private scratch (class rows per tile and step)
     whh_part = torch.empty(n_nets, B, 2, 4, L.GAT_WHH_PART, **f32)
     a.whh_part, a.grad, a.grad_s_net = whh_part.data_ptr(), arena.grad.data_ptr(), arena.grad.stride(0)
     node_dy = torch.empty(n_nets, B * N, L.GAT_NODE_DY, **f32)
