@@ -818,6 +818,31 @@ typedef struct {
 int iplan_p2p_publish(const IplanP2pArgs* args, iplan_stream_t stream);
 int iplan_p2p_reduce(const IplanP2pArgs* args, iplan_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * iplan_obs_history_step: one environment step of the id -> slot history wrapper on the device
+ * (observation_wrapper.py:68-141: obs_history_create + obs_history_output + obs_single_history_output).
+ * State (caller-owned device memory, zeroed / -1-filled at the head of an episode -- agent_obs_profile_init,
+ * observation_wrapper.py:26-46, stays on the host: it runs once per episode):
+ *   slot_id[k][i][s] = vehicle id of slot s of (thread k, registered agent i), -1 = free; n_slots[k][i];
+ *   win[k][i][s] = the slot's last L entries, right-aligned (the deque views the reference rebuilds every step).
+ * A step appends this step's observed rows to the slots of their ids (new ids take the next free slot in row order) and a
+ * zero entry to every known slot the agent did not observe; `win` IS obs_history_output(), `single` receives
+ * obs_single_history_output() (any strides: it is written straight into the episode container's history field).
+ * Values are copied bit for bit.  err: 0 ok; |1 an ego id that was never registered (the reference raises ValueError);
+ * |2 more than N vehicles observed by one agent (IndexError).  One wave per (thread, registered agent).            */
+typedef struct {
+    int32_t K, nA, N, L, d, obs_num;
+    const float* obs;            /* [K, nA, obs_num, 1 + d]: id column first; an all-zero row is padding            */
+    const int32_t* agent_ids;    /* [K, nA] ego ids in order of first appearance (unused entries: INT32_MIN)         */
+    int32_t* slot_id;            /* [K, nA, N]                                                                       */
+    int32_t* n_slots;            /* [K, nA]                                                                          */
+    float* win;                  /* [K, nA, N, L, d]                                                                 */
+    float* single;               /* optional: element (k, i, s, c) at k * single_s_k + i * single_s_a + s * d + c    */
+    int64_t single_s_k, single_s_a;
+    int32_t* err;                /* [1] device int, OR-ed                                                            */
+} IplanObsHistArgs;
+int iplan_obs_history_step(const IplanObsHistArgs* args, iplan_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

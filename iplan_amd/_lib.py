@@ -52,7 +52,7 @@ ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_st
                 "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_adv_norm", "iplan_ppo_loss", "iplan_gat_bwd",
                 "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd", "iplan_mlp3_fwd", "iplan_mlp3_bwd", "iplan_seq2seq_fwd", "iplan_ac_pack_fc1",
                 "iplan_ac_xhat_pack", "iplan_ac_fc1_split_fwd", "iplan_ac_bwd_fc1_split",
-                "iplan_p2p_publish", "iplan_p2p_reduce"]
+                "iplan_p2p_publish", "iplan_p2p_reduce", "iplan_obs_history_step"]
 RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups", "iplan_sizeof", "iplan_ac_packed_floats",
                     "iplan_p2p_alloc", "iplan_p2p_free", "iplan_p2p_export", "iplan_p2p_open", "iplan_p2p_close", "iplan_gat_enc_fwd", "iplan_gat_enc_ac_fwd", "iplan_gumbel_noise", "iplan_ac_xhat_floats", "iplan_ac_fc1_split_chunks", "iplan_ac_fc1_split_parts"]      # non (args*, stream) signatures
 
@@ -383,9 +383,16 @@ class Seq2SeqArgs(C.Structure):
 
 
 # ctypes mirror -> C struct name (checked against iplan_sizeof() of the loaded library by tests/test_abi.py)
+class ObsHistArgs(C.Structure):
+    _fields_ = [("K", i32), ("nA", i32), ("N", i32), ("L", i32), ("d", i32), ("obs_num", i32),
+                ("obs", fp), ("agent_ids", C.c_void_p), ("slot_id", C.c_void_p), ("n_slots", C.c_void_p), ("win", fp), ("single", fp),
+                ("single_s_k", i64), ("single_s_a", i64), ("err", C.c_void_p)]
+
+
 STRUCT_MIRRORS = {"IplanGatSaved": GatSaved, "IplanGatFwdArgs": GatFwdArgs, "IplanGatBwdArgs": GatBwdArgs,
                   "IplanEncFwdArgs": EncFwdArgs, "IplanAcNet": AcNet, "IplanAcFeatures": AcFeatures, "IplanAcFwdArgs": AcFwdArgs,
                   "IplanAcBwdArgs": AcBwdArgs, "IplanAdamArgs": AdamArgs, "IplanWgradProblem": WgradProblem,
                   "IplanWgradArgs": WgradArgs, "IplanPpoPrepareArgs": PpoPrepareArgs, "IplanPpoLossArgs": PpoLossArgs,
                   "IplanPdecArgs": PdecArgs, "IplanBehArgs": BehArgs, "IplanMlp3Args": Mlp3Args, "IplanAdvNormArgs": AdvNormArgs, "IplanSeq2SeqArgs": Seq2SeqArgs, "IplanAcPackArgs": AcPackArgs,
-                  "IplanIpcHandle": IpcHandle, "IplanP2pArgs": P2pArgs, "IplanAcXhatArgs": AcXhatArgs, "IplanAcFc1SplitArgs": AcFc1SplitArgs}
+                  "IplanIpcHandle": IpcHandle, "IplanP2pArgs": P2pArgs, "IplanAcXhatArgs": AcXhatArgs, "IplanAcFc1SplitArgs": AcFc1SplitArgs,
+                  "IplanObsHistArgs": ObsHistArgs}

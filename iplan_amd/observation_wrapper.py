@@ -226,3 +226,90 @@ def _conflict_free_groups(kk, aa, active, order):
         keep[first] = False
         remaining, rem_key = remaining[keep], rem_key[keep]
     return groups
+
+
+class DeviceObsHistory:
+    """The same history, device-resident (csrc/obs_history.hip: iplan_obs_history_step): what ParallelRunner
+    uses on a GPU instead of the numpy class above.  Per environment step ONE host -> device copy of the raw observations
+    ([K, nA, obs_num, 1 + d] as float32 through a pinned buffer) and ONE launch; ``win`` ([K, nA, N, L, d] float32) IS
+    obs_history_output() and the single-step view is written wherever the caller points (the episode container's history field).
+    Values are copies: bit-identical to the numpy class after its float32 cast (tests/test_obs_wrapper.py).  Errors the numpy class
+    raises where they occur (unregistered ego id: ValueError; more than max_vehicle_num vehicles: IndexError) are flagged on the
+    device and raised by ``check()``, which the runner calls at its per-step host synchronisation."""
+
+    def __init__(self, n_threads, n_agents, max_vehicle_num, max_history_len, obs_dim, device):
+        import torch
+        self.K, self.nA, self.N, self.L, self.d = n_threads, n_agents, max_vehicle_num, max_history_len, obs_dim
+        self.device = torch.device(device)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        self.slot_id = torch.full((self.K, self.nA, self.N), -1, **i32)
+        self.n_slots = torch.zeros(self.K, self.nA, **i32)
+        self.agent_ids = torch.zeros(self.K, self.nA, **i32)
+        self.win = torch.zeros(self.K, self.nA, self.N, self.L, self.d, dtype=torch.float32, device=self.device)
+        self.err = torch.zeros(1, **i32)
+        self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.device.type == "cuda" else None
+        self._obs_pin = None
+        self._obs_dev = None
+
+    def init(self, obs):
+        """agent_obs_profile_init (observation_wrapper.py:26-46): registered ego ids per thread in order of first appearance,
+        empty histories.  Once per episode: on the host."""
+        import torch
+        obs = np.asarray(obs)
+        K, nA = obs.shape[:2]
+        assert (K, nA) == (self.K, self.nA), (obs.shape, self.K, self.nA)
+        ids = obs[:, :, 0, 0].astype(np.int64)
+        reg = np.full((K, nA), np.iinfo(np.int32).min, dtype=np.int64)
+        n_reg = np.zeros(K, dtype=np.int64)
+        for i in range(nA):
+            seen = (reg == ids[:, i:i + 1]).any(axis=1)
+            rows = np.nonzero(~seen)[0]
+            reg[rows, n_reg[rows]] = ids[rows, i]
+            n_reg[rows] += 1
+        self.agent_ids.copy_(torch.as_tensor(reg.astype(np.int32)))
+        self.slot_id.fill_(-1)
+        self.n_slots.zero_()
+        self.win.zero_()
+        self.err.zero_()
+
+    def step(self, obs, single_out=None):
+        """obs_history_create + the two outputs.  ``single_out``: a [K, nA, N, d] float32 view (last two dims contiguous) that
+        receives obs_single_history_output(); returns ``win`` (= obs_history_output(), valid until the next step())."""
+        import torch
+        from . import _lib as L
+        obs = np.asarray(obs)
+        K, nA, obs_num, W = obs.shape
+        assert (K, nA, W) == (self.K, self.nA, self.d + 1), obs.shape
+        if self.device.type == "cuda":
+            if self._obs_pin is None or self._obs_pin[0].shape != obs.shape:
+                t = torch.empty(obs.shape, dtype=torch.float32, pin_memory=True)
+                self._obs_pin = (t, t.numpy())
+                self._obs_dev = torch.empty(obs.shape, dtype=torch.float32, device=self.device)
+            np.copyto(self._obs_pin[1], obs, casting="unsafe")
+            self._obs_dev.copy_(self._obs_pin[0], non_blocking=True)
+            od = self._obs_dev
+        else:
+            od = torch.as_tensor(obs, dtype=torch.float32).contiguous()
+            self._keep = od
+        a = L.ObsHistArgs()
+        a.K, a.nA, a.N, a.L, a.d, a.obs_num = K, nA, self.N, self.L, self.d, obs_num
+        a.obs, a.agent_ids, a.slot_id, a.n_slots = od.data_ptr(), self.agent_ids.data_ptr(), self.slot_id.data_ptr(), self.n_slots.data_ptr()
+        a.win, a.err = self.win.data_ptr(), self.err.data_ptr()
+        if single_out is not None:
+            assert single_out.shape == (K, nA, self.N, self.d) and single_out.dtype == torch.float32
+            assert single_out.stride(3) == 1 and single_out.stride(2) == self.d, single_out.stride()
+            a.single, a.single_s_k, a.single_s_a = single_out.data_ptr(), single_out.stride(0), single_out.stride(1)
+        L.get_lib().call("iplan_obs_history_step", a, L.current_stream(self.device))
+        return self.win
+
+    def stage_error_flag(self):
+        """enqueue the copy of the error word to the host (read it with check() after the next stream synchronise)"""
+        if self._err_host is not None:
+            self._err_host.copy_(self.err, non_blocking=True)
+
+    def check(self):
+        flag = int(self._err_host[0]) if self._err_host is not None else int(self.err[0])
+        if flag & 1:
+            raise ValueError("an ego id is not in list (it was never registered by agent_obs_profile_init)")
+        if flag & 2:
+            raise IndexError("more than max_vehicle_num vehicles observed by one agent")

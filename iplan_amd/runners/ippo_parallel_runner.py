@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from .. import ops, synth
-from ..observation_wrapper import observersation_state_history_wrapper
+from ..observation_wrapper import DeviceObsHistory, observersation_state_history_wrapper
 
 
 def _dict_batch(scheme, groups, batch_size, max_seq_length, preprocess=None, device="cpu"):
@@ -61,6 +61,7 @@ class ParallelRunner:
                                                                     self.episode_length, args.max_history_len)
         self.device = torch.device(getattr(args, "device", "cuda" if args.use_cuda else "cpu"))
         self._pin = {}
+        self._dev_history = None
         self.host_seconds = 0.0        # time spent outside the device work (env.step + history wrapper), for reporting
 
     def setup(self, scheme, groups, preprocess, mac, behavior_learner, prediction_learner):
@@ -120,6 +121,7 @@ class ParallelRunner:
         ``noise[t]``, the episode-initial one ``noise[T]``) and Exp(1) samples of the action race -- the parity tests inject
         them into this loop and into the oracle (same convention as harness.SyntheticLoop._rollout_body); default: drawn on
         the device per step, like the reference draws them inside F.gumbel_softmax / Categorical.sample."""
+        import os
         import time
         a, E, nA = self.args, self.args.batch_size_run, self.n_agents
         state, obs = self.reset()
@@ -129,12 +131,24 @@ class ParallelRunner:
         terminated = np.zeros(E, dtype=bool)
         alive = np.arange(E)
         hw = self.history_wrapper
-        hw.agent_obs_profile_init(obs)
-        hw.obs_history_create(obs)
-        single = hw.obs_single_history_output()
+        # The id -> slot history: on a GPU it lives in HBM (observation_wrapper.DeviceObsHistory, csrc/obs_history.hip: one 58 KB
+        # copy of the raw observations + one launch per step, the single-step view written straight into the episode container, the
+        # L-step windows read in place by the encoder); the numpy class does the same on the host (CPU runs, IPLAN_HOST_HISTORY=1).
+        dh = None
+        if dev.type == "cuda" and not os.environ.get("IPLAN_HOST_HISTORY"):
+            dh = self._dev_history
+            if dh is None or dh.K != E:
+                dh = self._dev_history = DeviceObsHistory(E, nA, self.max_vehicle_num, a.max_history_len, a.obs_shape_single, dev)
+            dh.init(obs)
+            dh.step(obs, single_out=D("history")[:, 0])
+        else:
+            hw.agent_obs_profile_init(obs)
+            hw.obs_history_create(obs)
+            single = hw.obs_single_history_output()
         state, obs = hw.pure_obs_state_wrapper(state, obs)
         D("avail_actions").fill_(1)                                     # the reference stores all-ones every step (:108, 134)
-        D("history")[:, 0] = self._to_dev("single", single, torch.float32)
+        if dh is None:
+            D("history")[:, 0] = self._to_dev("single", single, torch.float32)
         D("state")[:, 0] = self._to_dev("state", self._masked(state, (E, a.state_shape), alive), torch.float32)
         D("obs")[:, 0] = self._to_dev("obs", self._masked(obs, (E, nA, a.obs_shape), alive), torch.float32)
         for k in ("rnn_states_actors", "rnn_states_critics", "behavior_latent", "attention_latent"):
@@ -164,6 +178,8 @@ class ParallelRunner:
                 D("actions_onehot")[dead, t] = 0
                 D("actions_onehot")[dead, t, :, 0] = 1
             act_host.copy_(D("actions")[:, t, :, 0], non_blocking=True)    # the ONE device -> host copy of the step
+            if dh is not None:
+                dh.stage_error_flag()
             if fuse_ac and dev.type == "cuda":
                 # ... plus the fused launch's give-up flag (4 bytes): an action selection that stopped waiting for its launch's latent
                 # updates must abort the episode BEFORE env.step sees its actions, not at the episode's end
@@ -174,6 +190,8 @@ class ParallelRunner:
                 torch.cuda.current_stream(dev).synchronize()
             if sync_host is not None and int(sync_host[0]) != 0:
                 ops.check_fused_sync()                       # raises
+            if dh is not None:
+                dh.check()                                   # raises what the reference's wrapper raises (unknown ego id / too many vehicles)
             t0 = time.perf_counter()
             actions = act_host.numpy()
             action_env = [tuple(row) for row in actions.astype(np.float64)]
@@ -196,15 +214,20 @@ class ParallelRunner:
                 D("rnn_states_actors")[:, t + 1].zero_()
                 D("rnn_states_critics")[:, t + 1].zero_()
                 break
-            hw.obs_history_create(obs)
-            single = hw.obs_single_history_output()
-            window = hw.obs_history_output() if a.Behavior_enable else None
+            if dh is not None:
+                window_dev = dh.step(obs, single_out=D("history")[:, t + 1])
+            else:
+                hw.obs_history_create(obs)
+                single = hw.obs_single_history_output()
+                window = hw.obs_history_output() if a.Behavior_enable else None
             state, obs = hw.pure_obs_state_wrapper(state, obs)
             self.host_seconds += time.perf_counter() - t0
             # what the simulator produced: one batch of pinned host -> device copies
-            D("history")[:, t + 1] = self._to_dev("single", single, torch.float32)
+            if dh is None:
+                D("history")[:, t + 1] = self._to_dev("single", single, torch.float32)
+                window_dev = self._to_dev("window", window, torch.float32) if a.Behavior_enable else None
             if a.GAT_enable and a.Behavior_enable:           # both latent updates of the step in one launch (iplan_gat_enc_fwd)
-                enc = self.behavior_learner.latent_update(self._to_dev("window", window, torch.float32), eh[t & 1], D("behavior_latent")[:, t],
+                enc = self.behavior_learner.latent_update(window_dev, eh[t & 1], D("behavior_latent")[:, t],
                                                           out_latent=D("behavior_latent")[:, t + 1], out_hidden=eh[(t + 1) & 1][:, 0], launch=False)
                 nxt = None
                 step_noise = None if noise is None else noise[t]
@@ -221,7 +244,7 @@ class ParallelRunner:
                 self.prediction_learner.GAT_latent_update(D("history")[:, t + 1], D("attention_latent")[:, t], D("behavior_latent")[:, t],
                                                           out=D("attention_latent")[:, t + 1], noise=None if noise is None else noise[t])
             elif a.Behavior_enable:
-                self.behavior_learner.latent_update(self._to_dev("window", window, torch.float32), eh[t & 1], D("behavior_latent")[:, t],
+                self.behavior_learner.latent_update(window_dev, eh[t & 1], D("behavior_latent")[:, t],
                                                     out_latent=D("behavior_latent")[:, t + 1], out_hidden=eh[(t + 1) & 1][:, 0])
             D("reward")[:, t] = self._to_dev("reward", self._masked(reward, (E, nA), alive), torch.float32).unsqueeze(-1)
             D("terminated")[:, t] = self._to_dev("terminated", terminated_agent, torch.uint8).unsqueeze(-1)

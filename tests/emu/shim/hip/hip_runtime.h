@@ -183,6 +183,7 @@ inline __emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(__emu_bf16x8 a, __emu
 
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 inline float __expf(float x) { return expf(x); }
 inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }

@@ -80,3 +80,99 @@ def test_unregistered_ego_id_raises_like_the_reference(g):
     bad[1, 0, 0, 0] = 9999
     with pytest.raises(ValueError):
         w.obs_history_create(bad)
+
+
+# ------------------------------------------------------------------------------------------------ the device-resident form
+def check_device_history(g, device):
+    """iplan_obs_history_step (csrc/obs_history.hip) against the reference-recorded fixture, step by step: windows and single-step
+    views bit-identical to the reference's after the float32 cast the runner applies anyway; slot bookkeeping identical; the
+    single-step view written through strides into a larger container"""
+    from iplan_amd.observation_wrapper import DeviceObsHistory
+    D = g["dims"]
+    dh = DeviceObsHistory(D["K"], D["nA"], D["N"], D["L"], D["d"], device)
+    dh.init(g["steps"][0])
+    T = len(g["steps"])
+    # the target of the single-step view: a time slice of an episode container (strided over threads and agents)
+    dense = torch.zeros(D["K"], T + 1, D["nA"], D["N"], D["d"], device=device)
+    for t, obs in enumerate(g["steps"]):
+        win = dh.step(obs, single_out=dense[:, t])
+        dh.stage_error_flag()
+        if torch.device(device).type == "cuda":
+            torch.cuda.synchronize()
+        dh.check()
+        assert torch.equal(win.cpu(), torch.as_tensor(g["hist"][t]).float()), t
+        assert torch.equal(dense[:, t].cpu(), torch.as_tensor(g["single"][t]).float()), t
+    ids = dh.slot_id.cpu().numpy()
+    ns = dh.n_slots.cpu().numpy()
+    got = [[[int(x) for x in ids[k, i, :ns[k, i]]] for i in range(D["nA"])] for k in range(D["K"])]
+    assert got == g["vehicle_ids"]
+
+
+def check_device_history_vs_numpy_stream(device, K=6, nA=3, obs_num=7, d=5, N=12, L=4, T=25, dup=False):
+    """a longer stub-simulator stream (vehicles come and go) against the numpy class, incl. two agents of a thread that report the
+    SAME ego id (both feed one state, in agent order, each with its own zero entries: observation_wrapper.py:92-96)"""
+    from iplan_amd import synth
+    from iplan_amd.observation_wrapper import DeviceObsHistory, observersation_state_history_wrapper as Wrapper
+    env = synth.StubHighwayVecEnv(K, nA, obs_num, d, N, T, seed=3, n_ids=N - nA - 1)
+    w = Wrapper(SimpleNamespace(obs_shape_single=d, batch_size_run=K), nA, N, T + 2, L)
+    dh = DeviceObsHistory(K, nA, N, L, d, device)
+    _, obs = env.reset()
+    if dup:
+        env.obs[:, 1, 2, 0, 0] = env.obs[:, 1, 0, 0, 0]            # thread 1: agent 2 reports agent 0's ego id
+        obs = env.obs[0]
+    w.agent_obs_profile_init(obs)
+    dh.init(obs)
+    single = torch.zeros(K, nA, N, d, device=device)
+    for t in range(T):
+        w.obs_history_create(obs)
+        win = dh.step(obs, single_out=single)
+        assert torch.equal(win.cpu(), torch.as_tensor(w.obs_history_output()).float()), t
+        assert torch.equal(single.cpu(), torch.as_tensor(w.obs_single_history_output()).float()), t
+        _, obs, *_ = env.step([None] * K)
+    dh.stage_error_flag()
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize()
+    dh.check()
+
+
+@pytest.fixture
+def emu_lib():
+    from iplan_amd import _lib as L
+    from tests.emu.emu_lib import get_emu_lib
+    L.use_library_for_tests(get_emu_lib())
+    yield
+    L.use_library_for_tests(None)
+
+
+def test_device_history_matches_reference_emulated(g, emu_lib):
+    check_device_history(g, "cpu")
+
+
+@pytest.mark.parametrize("dup", [False, True])
+def test_device_history_vs_numpy_stream_emulated(emu_lib, dup):
+    check_device_history_vs_numpy_stream("cpu", dup=dup)
+
+
+def test_device_history_errors_emulated(g, emu_lib):
+    from iplan_amd.observation_wrapper import DeviceObsHistory
+    D = g["dims"]
+    dh = DeviceObsHistory(D["K"], D["nA"], D["N"], D["L"], D["d"], "cpu")
+    dh.init(g["steps"][0])
+    bad = np.array(g["steps"][1], copy=True)
+    bad[1, 0, 0, 0] = 9999
+    dh.step(bad)
+    with pytest.raises(ValueError):
+        dh.check()
+    small = DeviceObsHistory(D["K"], D["nA"], 2, D["L"], D["d"], "cpu")
+    small.init(g["steps"][0])
+    with pytest.raises(IndexError):
+        for obs in g["steps"]:
+            small.step(obs)
+            small.check()
+
+
+@pytest.mark.gpu
+def test_device_history_matches_reference_gpu(g):
+    check_device_history(g, "cuda")
+    check_device_history_vs_numpy_stream("cuda", K=32, nA=5, obs_num=15, d=5, N=55, L=10, T=40)
+    check_device_history_vs_numpy_stream("cuda", dup=True)
