@@ -394,10 +394,12 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
         tr = traffic_of(traffic_key or kernel)
         # no row may imply more than the HBM peak (a counter file matched to the wrong launches did): the PMC figure is of
         # another run of the same kernels, so allow for box-to-box spread in the duration (8 %), nothing more
-        if tr is not None and n and sec > 0:
-            assert tr / sec / 1e9 <= 1.08 * HBM_PEAK_GBS, (kernel, "PMC traffic / measured launch time exceeds the HBM peak", tr, sec)
+        rejected = None
+        if tr is not None and n and sec > 0 and tr / sec / 1e9 > 1.08 * HBM_PEAK_GBS:
+            rejected = f"PMC figure {tr} B over the measured {sec * 1e6:.1f} us would be {tr / sec / 1e12:.2f} TB/s > the HBM peak: not reported"
+            tr = None
         return {"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                "traffic": tr, "us_per_launch": sec * 1e6 if n else nan,
+                "traffic": tr, **({"traffic_rejected": rejected} if rejected else {}), "us_per_launch": sec * 1e6 if n else nan,
                 "traffic_source": pmc_src,
                 "launches_timed": n, ("algorithmic_gbyte_per_launch" if bound == "hbm" else "algorithmic_gflop_per_launch"): work / 1e9,
                 "note": note}
@@ -448,9 +450,10 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
               f"decoder forward of Behavior_policy.learn in {pieces('beh_dec_fwd_kernel')} window-range launches, beside the encoder forward"),
         entry("beh_enc_bwd_kernel", "beh_enc_bwd_kernel", "mfma", 2 * f_enc / pieces("beh_enc_bwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
               "encoder BPTT with in-kernel weight gradients (2x the forward FLOPs), side stream"),
-        entry("wgrad_partial_kernel (+reduce)", "iplan_wgrad:beh_dec", "hbm", 0.0, 1e9, HBM_PEAK_GBS, "GB/s",
-              "the iplan_wgrad call on each decoder-BPTT window range of Behavior_policy.learn (4 problems: W_out, W_ih, W_hh, W_lin; 3 partial "
-              "kernels + reduction, side stream): algorithmic bytes = each operand row read once, 4 (O + K) bytes per row and problem",
+        entry("wgrad_pair_bf16_kernel (+reduce)", "iplan_wgrad:beh_dec", "hbm", 0.0, 1e9, HBM_PEAK_GBS, "GB/s",
+              "the deferred iplan_wgrad call of Behavior_policy.learn: the decoder GRU's W_ih and W_hh gradients over all (row, step) records as "
+              "ONE paired launch (the [dr dz] columns both need are fetched once) + reduction, side stream: algorithmic bytes = every operand "
+              "column of every row once, 4 (256 + 64 + 64) bytes per row and step",
               traffic_key="iplan_wgrad:beh_dec", work_from_timer=True),
         entry("ac_fc1_split_fwd_kernel", "ac_fc1_split_fwd", "mfma", f_fc1, 1e12, BF16_MFMA_PEAK_TFLOPS / 6.0, "TFLOP/s",
               f"fc1 of the actor AND the critic of one PPO epoch ({rows} rows x F = {F} x 128 outputs, 5 agents) over the packed normalised "

@@ -551,8 +551,19 @@ class Wgrad:
             need = lib.c.iplan_wgrad_workspace_floats(C.byref(a))
             ws = workspace(dev, need)
             a.workspace, a.workspace_floats = ws.data_ptr(), ws.numel()
-            # algorithmic HBM bytes: every operand row of every problem read exactly once (4 (O + K) bytes per row)
+            # algorithmic HBM bytes: every operand row of every problem read exactly once (4 (O + K) bytes per row) -- with the dY columns
+            # two problems SHARE counted once (the two weights of a GRU: [dr dz] of the same rows; wgrad.hip pairs those jobs and does
+            # read them once since round 5, so the figure is the least any kernel could move, not the least THIS kernel moves)
             nbytes = 4.0 * self.n_nets * sum(p.n_outer * p.n_inner * (p.O + p.K) for p in chunk)
+            seen = {}
+            for p in chunk:
+                if p.O == 192 and p.K == 64 and p.seg_split >= 128:
+                    key = (p.dy, p.dy_s_outer, p.dy_s_inner, p.n_outer, p.n_inner, p.seg_c0)
+                    if key in seen:
+                        nbytes -= 4.0 * self.n_nets * p.n_outer * p.n_inner * 128
+                        del seen[key]
+                    else:
+                        seen[key] = True
             _launch(self.tag, lambda: lib.call("iplan_wgrad", a, stream), work=nbytes)
 
 

@@ -52,17 +52,17 @@ for key, sub, piece in (("gat_enc_fwd_kernel", "gat_enc_fwd_kernel", "rollout"),
 # The piece runs learn(defer_decoder=True) (scripts/gpu_pmc_all.sh: MB_DEFER=1), so these ARE the kernels of the ONE deferred
 # iplan_wgrad call that bench.py times as "iplan_wgrad:beh_dec" (the encoder accumulates its weight gradients in its BPTT kernel
 # and launches no wgrad kernel): traffic / us_per_launch of that line is a bandwidth that can be compared with the HBM peak.
-# Kernels of wgrad.hip ONLY (iplan::wgrad_partial_* / iplan::wgrad_reduce_kernel; NOT ac_fc1_split_wgrad_kernel), behaviour piece ONLY.
+# Kernels of wgrad.hip ONLY (iplan::wgrad_partial_* / wgrad_pair_bf16_kernel / wgrad_reduce_kernel; NOT ac_fc1_split_wgrad_kernel), behaviour piece ONLY.
 learns = pieces["behaviour"][find("beh_enc_grad_kernel", "behaviour")[0]]["FETCH_SIZE"][1]
 tot = 0.0
-wg = [k for k in pieces["behaviour"] if ("wgrad_partial" in k or "wgrad_reduce" in k)]
+wg = [k for k in pieces["behaviour"] if ("wgrad_partial" in k or "wgrad_pair" in k or "wgrad_reduce" in k)]
 assert wg, sorted(pieces["behaviour"])
 for k in wg:
     assert "ac_fc1" not in k, k
     b, n = bytes_of(k, "behaviour")
     tot += b * n
 per_launch["iplan_wgrad:beh_dec"] = dict(bytes=int(tot / learns), dispatches=learns, piece="behaviour", kernels=sorted(wg),
-                                         kernel="wgrad_partial_*kernel<*> + wgrad_reduce_kernel of the deferred decoder update, per learn()")
+                                         kernel="wgrad_pair_bf16_kernel (+ wgrad_partial_*) + wgrad_reduce_kernel of the deferred decoder update, per learn()")
 out = dict(series=series, csrc_sha16=csrc_sha16(), envs_per_gpu=envs, per_launch=per_launch, counters=merged)
 path = os.path.join(ROOT, "profiles", f"{series}_pmc_summary.json")
 with open(path, "w") as f:
