@@ -376,7 +376,7 @@ def main():
 
 
 def rooflines(args, E, timed, opt, rollouts_per_step):
-    """Roofline entries of every kernel above 5 % of a cycle's kernel time (profiles/r02*_full_cycle_kernel_stats.csv):
+    """Roofline entries of every kernel above 5 % of a cycle's kernel time (profiles/history/r02*_full_cycle_kernel_stats.csv):
     ALGORITHMIC work per launch (SURVEY.md §8d convention) / the in-situ mean launch duration.  ``traffic`` =
     HBM bytes per launch from profiles/<series>_pmc_summary.json (load_pmc_traffic: null when that file is not of this build)."""
     nA, N, d, Z = args.n_agents, args.max_vehicle_num, args.obs_shape_single, args.latent_dim

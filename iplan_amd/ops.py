@@ -844,7 +844,7 @@ def _piece_bounds(J, pieces):
     finished the first range; the BPTT walks them top down and the encoder's BPTT of the last range -- plus the gradient
     reduction and the optimiser step the next rollout waits for -- trails the decoder's.  With equal ranges both waits were a
     whole range of encoder work (0.65 ms in front of the decoder forward, 1.3 ms behind the decoder BPTT: rocprofv3 trace of
-    a training cycle, profiles/r02h_cycle_trace_learn_phase.txt); the short range makes them a sixteenth of the episode."""
+    a training cycle, profiles/history/r02h_cycle_trace_learn_phase.txt); the short range makes them a sixteenth of the episode."""
     if pieces <= 1 or J < 4 * pieces or os.environ.get("IPLAN_BEH_EQUAL_PIECES"):
         return [round(J * k / pieces) for k in range(pieces + 1)]
     s0 = max(1, J // 16)

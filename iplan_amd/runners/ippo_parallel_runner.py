@@ -95,7 +95,7 @@ class ParallelRunner:
     def _to_dev(self, name, array, dtype):
         """numpy -> device through a pinned staging buffer (asynchronous on the current stream).  The dtype conversion is a
         single-threaded numpy copy straight into the pinned pages (a torch copy_ of a few hundred KB fans out over every host
-        core: 0.9 ms per call on a 256-core box, profiles/r02b_runner_host_in_loop.txt)."""
+        core: 0.9 ms per call on a 256-core box, profiles/history/r02b_runner_host_in_loop.txt)."""
         a = np.asarray(array)
         if self.device.type != "cuda":
             return torch.as_tensor(a).to(dtype)

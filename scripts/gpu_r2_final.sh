@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 evidence run (one gpurun call): GPU tests + smoke, bench lines (weak default incl. cpu_baseline, strong N=1), rocprofv3
 # kernel statistics of the bench command and of the serial behaviour learn, PMC passes per piece, BASELINE config 5, the
-# device-resident runner with the host in the loop, the single-rank RCCL check.  Outputs -> gpurun_out/final/ (copied to profiles/r02f_*).
+# device-resident runner with the host in the loop, the single-rank RCCL check.  Outputs -> gpurun_out/final/ (copied to profiles/history/r02f_*).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"; O=gpurun_out/final; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log < /dev/null

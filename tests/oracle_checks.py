@@ -8,7 +8,7 @@ post-Adam parameters <= 1e-6 (one step) / 1e-5 (PPO epochs).  Ground truth for g
 oracle (= the reference's own arithmetic) is run beside it, and where the reference's own fp32 rounding error e32 on a
 parameter group exceeds 6.7e-6 the bound widens to E32_FACTOR = 1.5 x e32 ("no worse than one and a half times the
 reference's own distance from the exact result"; 4 x until round 3 -- measured kernel errors are 0.1 ... 0.5 x e32,
-profiles/r03d_parity_errors.json): gradients through the tau = 0.01 gumbel-softmax gate and second-epoch PPO gradients are
+profiles/history/r03d_parity_errors.json): gradients through the tau = 0.01 gumbel-softmax gate and second-epoch PPO gradients are
 conditioned such that NO fp32 implementation, the reference included, reproduces them to 1e-5.  Every check returns the
 worst errors it saw (kernel vs fp64, fp32 oracle vs fp64) so the GPU run can log them (profiles/*_parity_errors.json)."""
 from types import SimpleNamespace
