@@ -80,8 +80,9 @@ enum {
 /* Activations kept for the backward pass (contiguous; NULL = inference).  Rows are (b, i) = b*N + i. */
 typedef struct {
     float* h_enc;   /* [n_nets, B*N, H]              ReLU(encoding(obs))                          */
-    float* gru;     /* [n_nets, 2, B, ceil(N/16), N-1, 10, 16, 16]  per direction, scene, 16-ego tile and pair step: ten 16-column
-                       groups (h h r r z z n n hn hn) of [16 egos][16 columns] -- 1 KiB blocks, one per wave store / load    */
+    float* gru;     /* [n_nets, 2, B, ceil(N/16), N-1, 8, 16, 16]  per direction, scene, 16-ego tile and pair step: eight 16-column
+                       groups (h h r r z z n n) of [16 egos][16 columns] -- 1 KiB blocks, one per wave store / load; the
+                       backward recomputes gh_n = W_hn h_prev + b_hn                                                    */
     float* qkv;     /* [n_nets, B*N, 3A]             q | k | v                                    */
     float* soft;    /* [n_nets, B*N, N-1]            soft attention weights                       */
     float* hard;    /* [n_nets, B*N, N-1]            gumbel-softmax class-1 weights               */

@@ -246,15 +246,14 @@ __device__ __forceinline__ void gat_fwd_block(const IplanGatFwdArgs& a, int bloc
             h0 = o0.h;
             h1 = o1.h;
             if (sv.gru) {
-                // [net][dir][scene][ego tile][step][group: h h r r z z n n hn hn][16 chains][16 columns]: one 1 KiB block per store
-                // instruction (gat_bwd.hip reads it back the same way)
-                float* blk = sv.gru + ((((((int64_t)net * 2 + dir) * a.B + b) * ((N + 15) / 16) + tile) * (N - 1) + s) * 10) * 256 + n * 16 + 4 * g;
+                // [net][dir][scene][ego tile][step][group: h h r r z z n n][16 chains][16 columns]: one 1 KiB block per store
+                // instruction (gat_bwd.hip reads it back the same way; it recomputes hn = W_hn h_prev + b_hn -- a fifth of the record)
+                float* blk = sv.gru + ((((((int64_t)net * 2 + dir) * a.B + b) * ((N + 15) / 16) + tile) * (N - 1) + s) * 8) * 256 + n * 16 + 4 * g;
                 if (valid) {
                     *reinterpret_cast<f32x4*>(blk) = o0.h;             *reinterpret_cast<f32x4*>(blk + 256) = o1.h;
                     *reinterpret_cast<f32x4*>(blk + 2 * 256) = o0.r;   *reinterpret_cast<f32x4*>(blk + 3 * 256) = o1.r;
                     *reinterpret_cast<f32x4*>(blk + 4 * 256) = o0.z;   *reinterpret_cast<f32x4*>(blk + 5 * 256) = o1.z;
                     *reinterpret_cast<f32x4*>(blk + 6 * 256) = o0.n;   *reinterpret_cast<f32x4*>(blk + 7 * 256) = o1.n;
-                    *reinterpret_cast<f32x4*>(blk + 8 * 256) = o0.hn;  *reinterpret_cast<f32x4*>(blk + 9 * 256) = o1.hn;
                 }
             }
             s_prev = s;

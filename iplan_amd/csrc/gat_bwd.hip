@@ -47,6 +47,7 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
     __shared__ float s_dd[BNP][BNP];
     __shared__ __attribute__((aligned(16))) f32x4 s_acc[4][2][64];
     __shared__ float s_red[8];
+    __shared__ __attribute__((aligned(16))) float s_bhn[2][BH];
     __shared__ __attribute__((aligned(16))) float s_turn[8][8][256];       // per wave: 6 gate-gradient tiles + 2 h_prev tiles (phase D)
 
     const IplanGatFwdArgs& f = a.fwd;
@@ -171,6 +172,8 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
         float* swT = &s_sw[0][0][0];
         stage_matrix_t(swT, WLD, BH, P + f.off[IPLAN_GAT_F_WHH], 3 * BH, BH);
         stage_matrix_t(swT + BH * WLD, WLD, BH, P + f.off[IPLAN_GAT_R_WHH], 3 * BH, BH);
+        if (threadIdx.x < 2 * BH)                                  // b_hn of both directions (the recomputed gh_n's bias)
+            s_bhn[threadIdx.x >> 5][threadIdx.x & 31] = P[f.off[(threadIdx.x >> 5) ? IPLAN_GAT_R_BHH : IPLAN_GAT_F_BHH] + 2 * BH + (threadIdx.x & 31)];
     }
     __syncthreads();
     if (clk) clk[3] = IPLAN_CLOCK();
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
         // at its latency -- touching the lines three steps ahead made it SLOWER, 345 -> 397 us: profiles/r05_notes.md.)
         const int cnode = imin(node, N - 1);
         const int NT = (N + 15) / 16;
-        constexpr int REC = 10 * 256;                                               // floats of a tile's record of one step
+        constexpr int REC = 8 * 256;                                                // floats of a tile's record of one step (h r z n)
         const float* gbase = sv.gru + (((((int64_t)net * 2 + dir) * f.B + b) * NT + tile) * (int64_t)(N - 1)) * REC + (cnode & 15) * 16 + 4 * g;
         float (*turn)[256] = s_turn[w];
         // a parked tile is [16 chains][16 columns], chain r's columns rotated by 4 (r >> 1) (conflict-free ds_write_b128 /
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
         for (int t = 0; t < 6; ++t) { aW[t][0] = splat4(0.f); aW[t][1] = splat4(0.f); }   // (db_hh's r, z parts = the da sums below)
         bNh[0] = splat4(0.f); bNh[1] = splat4(0.f);
         struct PairIn {
-            f32x4 hs[2], r[2], z[2], nn[2], hn[2], hp[2];
+            f32x4 hs[2], r[2], z[2], nn[2], hp[2];
             float dd;
             bool has_prev;
         };
@@ -227,7 +230,6 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
                 o.r[T] = *reinterpret_cast<const f32x4*>(row + 256 * (2 + T));
                 o.z[T] = *reinterpret_cast<const f32x4*>(row + 256 * (4 + T));
                 o.nn[T] = *reinterpret_cast<const f32x4*>(row + 256 * (6 + T));
-                o.hn[T] = *reinterpret_cast<const f32x4*>(row + 256 * (8 + T));
                 o.hp[T] = *reinterpret_cast<const f32x4*>(prow + 256 * T);
             }
             o.dd = s_dd[cnode][s];
@@ -243,15 +245,28 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
             f32x4 dgh[6];
             f32x4 dhd[2];
             GruGrads o2[2];
+            // the forward's gh_n = W_hn h_prev + b_hn is not in the record (a fifth of its bytes): recomputed from the previous state
+            // with W_hh^T's LDS copy read transposed (16 fp32 MFMAs per step)
+            f32x4 hpm[2], hnr[2];
+            for (int T = 0; T < 2; ++T) hpm[T] = zero_unless(cur.has_prev, cur.hp[T]);
+            for (int T = 0; T < 2; ++T) {
+                f32x4 acc = *reinterpret_cast<const f32x4*>(&s_bhn[dir][16 * T + 4 * g]);
+                for (int Tk = 0; Tk < 2; ++Tk) {
+                    f32x4 wf;
+                    for (int q = 0; q < 4; ++q) wf[q] = swT[(16 * Tk + 4 * g + q) * WLD + 2 * BH + 16 * T + n];
+                    acc = mma_block(wf, hpm[Tk], acc);
+                }
+                hnr[T] = acc;
+            }
             for (int T = 0; T < 2; ++T) {
                 const f32x4 hs = cur.hs[T];
-                const f32x4 hp = zero_unless(cur.has_prev, cur.hp[T]);
+                const f32x4 hp = hpm[T];
                 f32x4 dht;
                 for (int q = 0; q < 4; ++q) {
                     dht[q] = fmaf(wdiff[T][q], dd, dh[T][q]);
                     hacc[T][q] = fmaf(dd, hs[q], hacc[T][q]);
                 }
-                o2[T] = gru_gates_bwd(dht, cur.r[T], cur.z[T], cur.nn[T], cur.hn[T], hp);
+                o2[T] = gru_gates_bwd(dht, cur.r[T], cur.z[T], cur.nn[T], hnr[T], hp);
                 da[T] += o2[T].dr; da[2 + T] += o2[T].dz; da[4 + T] += o2[T].dni;
                 dgh[T] = o2[T].dr; dgh[2 + T] = o2[T].dz; dgh[4 + T] = o2[T].dnh;
                 dhd[T] = o2[T].dh_direct;
@@ -414,17 +429,35 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
 }
 
 // hard_bi_GRU.weight_hh_l0{,_reverse} / bias_hh gradients <- sum of the wave partials over scenes and live tiles, fixed order.
-// grid: (ceil(IPLAN_GAT_WHH_PART / 256), n_nets * 2)
-__global__ __launch_bounds__(256) void gat_whh_grad_kernel(IplanGatBwdArgs a) {
+// grid: (ceil(IPLAN_GAT_WHH_PART / 64), n_nets * 2); 512 threads = 8 waves x 64 consecutive elements: wave w adds the partial blocks
+// p = w, w + 8, ... (p = scene * tiles + tile) into eight interleaved running sums (64 loads in flight per element instead of one
+// dependent chain over all B * tiles blocks: 405 -> ~40 us at config 5's B = 256), the eight waves' sums meet in LDS in wave order.
+__global__ __launch_bounds__(512) void gat_whh_grad_kernel(IplanGatBwdArgs a) {
+    __shared__ float s_sum[8][64];
     const IplanGatFwdArgs& f = a.fwd;
-    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (e >= 3 * BH * BH + 3 * BH) return;
+    const int l = lane_id(), w = wave_id();
+    const int e = (int)blockIdx.x * 64 + l;
     const int net = (int)blockIdx.y >> 1, dir = (int)blockIdx.y & 1;
-    const int tiles = (f.N + 15) / 16;
+    const int tiles = (f.N + 15) / 16, P = f.B * tiles;
+    const int ec = e < IPLAN_GAT_WHH_PART ? e : IPLAN_GAT_WHH_PART - 1;
+    auto part = [&](int p) {
+        const int b = p / tiles, t = p - b * tiles;
+        return a.whh_part[((((int64_t)net * f.B + b) * 2 + dir) * 4 + t) * (int64_t)IPLAN_GAT_WHH_PART + ec];
+    };
+    float acc[8];
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    int p = w;
+    for (; p + 56 < P; p += 64) {
+        float v[8];
+        for (int k = 0; k < 8; ++k) v[k] = part(p + 8 * k);
+        for (int k = 0; k < 8; ++k) acc[k] += v[k];
+    }
+    for (int k = 0; p < P; p += 8, ++k) acc[k & 7] += part(p);
+    s_sum[w][l] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (w != 0 || e >= 3 * BH * BH + 3 * BH) return;
     float sum = 0.f;
-    for (int b = 0; b < f.B; ++b)
-        for (int t = 0; t < tiles; ++t)
-            sum += a.whh_part[((((int64_t)net * f.B + b) * 2 + dir) * 4 + t) * (int64_t)IPLAN_GAT_WHH_PART + e];
+    for (int k = 0; k < 8; ++k) sum += s_sum[k][l];
     float* g = a.grad + (int64_t)net * a.grad_s_net;
     if (e < 3 * BH * BH) g[f.off[dir ? IPLAN_GAT_R_WHH : IPLAN_GAT_F_WHH] + e] = sum;
     else g[f.off[dir ? IPLAN_GAT_R_BHH : IPLAN_GAT_F_BHH] + (e - 3 * BH * BH)] = sum;
@@ -446,7 +479,7 @@ extern "C" int iplan_gat_bwd(const IplanGatBwdArgs* a, iplan_stream_t stream) {
     if (!aligned16(a->g_out) || (a->g_s_net & 3) || (a->g_s_b & 3) || !aligned16(a->dgru) || !aligned16(a->node_dy))
         return fail(IPLAN_EALIGN, "iplan_gat_bwd: g_out / dgru / node_dy must be 16-byte aligned");
     hipLaunchKernelGGL(gat_bwd_kernel, dim3((unsigned)(f.n_nets * f.B)), dim3(512), 0, (hipStream_t)stream, *a);
-    hipLaunchKernelGGL(gat_whh_grad_kernel, dim3((unsigned)((IPLAN_GAT_WHH_PART + 255) / 256), (unsigned)(f.n_nets * 2)), dim3(256), 0,
+    hipLaunchKernelGGL(gat_whh_grad_kernel, dim3((unsigned)((IPLAN_GAT_WHH_PART + 63) / 64), (unsigned)(f.n_nets * 2)), dim3(512), 0,
                        (hipStream_t)stream, *a);
     return check_launch("iplan_gat_bwd");
 }

@@ -71,7 +71,7 @@ def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None
         H = A
         saved = dict(
             h_enc=torch.empty(n_nets, B * N, H, device=dev),
-            gru=torch.empty(n_nets, 2, B, (N + 15) // 16, N - 1, 10, 16, 16, device=dev),   # tile-major 1 KiB blocks (csrc/gat.hip)
+            gru=torch.empty(n_nets, 2, B, (N + 15) // 16, N - 1, int(os.environ.get("IPLAN_GAT_REC_GROUPS", "8")), 16, 16, device=dev),   # tile-major 1 KiB blocks: h r z n (csrc/gat.hip; the knob: A/B against libraries with a wider record)
             qkv=torch.empty(n_nets, B * N, 3 * A, device=dev),
             soft=torch.empty(n_nets, B * N, N - 1, device=dev),
             hard=torch.empty(n_nets, B * N, N - 1, device=dev),

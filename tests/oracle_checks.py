@@ -296,7 +296,7 @@ def check_adam_replay(learner, mac, args, agents, tol=1e-6):
 
 
 def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, terminated_p=0.15, also_fp32=True, agents=None,
-                              e32_factor=E32_FACTOR, table=None, assert_grads=True, mid_probes=(), adam_replay=False, t_env=0,
+                              e32_factor=E32_FACTOR, table=None, assert_grads=True, mid_probes=(), adam_replay=None, t_env=0,
                               check_stats=False):
     """insert buffer_size episodes -> train() (ppo_epoch fused epochs x num_mini_batch steps) vs oracle.ppo_train_agent, every
     agent: clipped gradients of the LAST optimiser step and the post-train parameters.
@@ -349,6 +349,8 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
     n_steps = args.ppo_epoch * max(1, args.num_mini_batch)
     learner.probe_last_step = True                             # (a single step: the probe point is the pre-train parameters)
     learner.probe_steps = tuple(k for k in mid_probes if k < n_steps - 1)
+    if adam_replay is None:                                    # default: every step of every multi-step run (the post-train
+        adam_replay = not getattr(args, "weight_decay", 0.0)   # bound against the fp64 trajectory is loose by nature; this one is not)
     learner.probe_all_adam = bool(adam_replay)
     learner.train(t_env)
     if getattr(args, "use_linear_lr_decay", False):            # learners/ippo_learner.py:86-91,236-237: lr <- lr (1 - t_env / t_max)
