@@ -18,6 +18,7 @@
 //   beh_enc_bwd  BPTT of the encoder with its weight gradients accumulated IN the kernel (H = 32: the
 //                24 accumulator tiles fit in registers; operands are turned through LDS each step)
 // hidden states and the latent are carried from window to window in registers (D layout of wave_tile.h).
+#define IPLAN_SPLIT_PAIRS           // wave_tile.h: the bf16 split two values at a time (this file's kernels gain by it: learn 15.4 -> 15.0 ms)
 #include <cstdlib>
 
 #include "api_util.h"
@@ -1154,12 +1155,18 @@ __device__ __forceinline__ void d2_wait(const int* c, int target) {
 
 // the three bf16 pieces of a lane's 4 values of ONE 16-tile (half of a K = 32 operand): x = p0 + p1 + p2 exactly
 __device__ __forceinline__ void split_bf3_half(f32x4 v, bf16x4& p0, bf16x4& p1, bf16x4& p2) {
-    for (int j = 0; j < 4; ++j) {
-        const __bf16 b0 = (__bf16)v[j];
-        const float r1 = v[j] - (float)b0;
-        const __bf16 b1 = (__bf16)r1;
-        p0[j] = b0; p1[j] = b1; p2[j] = (__bf16)(r1 - (float)b1);
+    u32x2 q0, q1, q2;                                        // two values per conversion (wave_tile.h: split_bf3_pair)
+    for (int k = 0; k < 2; ++k) {
+        f32x2 w;
+        w[0] = v[2 * k];
+        w[1] = v[2 * k + 1];
+        uint32_t a, b, c;
+        split_bf3_pair(w, a, b, c);
+        q0[k] = a; q1[k] = b; q2[k] = c;
     }
+    p0 = __builtin_bit_cast(bf16x4, q0);
+    p1 = __builtin_bit_cast(bf16x4, q1);
+    p2 = __builtin_bit_cast(bf16x4, q2);
 }
 // 36 MFMAs: acc[gate] += W[gate][chunk] . x[chunk] for 3 gate tiles x 2 k-chunks x 6 piece products, smallest products first,
 // the three accumulator chains issued round-robin

@@ -100,7 +100,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct Bf3 {
     bf16x8 p0, p1, p2;
 };
-__device__ __forceinline__ Bf3 split_bf3(f32x4 lo, f32x4 hi) {
+__device__ __forceinline__ Bf3 split_bf3_scalar(f32x4 lo, f32x4 hi) {
     Bf3 s;
     for (int j = 0; j < 8; ++j) {
         const float v = j < 4 ? lo[j] : hi[j - 4];
@@ -113,6 +113,57 @@ __device__ __forceinline__ Bf3 split_bf3(f32x4 lo, f32x4 hi) {
         s.p2[j] = (__bf16)r2;
     }
     return s;
+}
+// The same split two values at a time: ONE v_cvt_pk_bf16_f32 rounds a pair and IS the packed piece; the pair's bf16 values come back as
+// floats by a shift and a mask, the residuals by one packed subtraction (v_pk_add_f32) -- 36 instead of the 60 VALU instructions the
+// value-at-a-time form compiles to per K = 32 operand (it converts every value alone, and once more to pack the pieces).  Same
+// roundings, exact subtractions: bit-identical pieces.  Which form is FASTER depends on the instruction stream around it (round 5,
+// same-box A/Bs of whole libraries, profiles/r05_notes.md): the behaviour kernels gain (learn 15.4 -> 15.0 ms), the wide weight-gradient
+// contraction LOSES 11 % although its loop shrinks from 2 012 to 1 699 instructions (packed fp32 VALU beside a dense MFMA stream), the GAT
+// recurrence does not move; with plain subtractions instead of the packed one nobody gains.  So a source file opts in
+// (#define IPLAN_SPLIT_PAIRS in front of its includes: behavior_learn.hip) and everybody else keeps the form above.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16_pack2(f32x2 v) {                      // round to nearest even, v[0] in the low half
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ f32x2 bf16_unpack2(uint32_t u) {
+    f32x2 r;
+    r[0] = __builtin_bit_cast(float, u << 16);
+    r[1] = __builtin_bit_cast(float, u & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ void split_bf3_pair(f32x2 v, uint32_t& q0, uint32_t& q1, uint32_t& q2) {
+    q0 = bf16_pack2(v);
+    const f32x2 r1 = v - bf16_unpack2(q0);              // exact
+    q1 = bf16_pack2(r1);
+    const f32x2 r2 = r1 - bf16_unpack2(q1);             // exact, fits 8 bits
+    q2 = bf16_pack2(r2);
+}
+__device__ __forceinline__ Bf3 split_bf3_pairs(f32x4 lo, f32x4 hi) {
+    u32x4 q0, q1, q2;
+    for (int k = 0; k < 4; ++k) {
+        f32x2 v;
+        v[0] = k < 2 ? lo[2 * k] : hi[2 * k - 4];
+        v[1] = k < 2 ? lo[2 * k + 1] : hi[2 * k - 3];
+        uint32_t a, b, c;
+        split_bf3_pair(v, a, b, c);
+        q0[k] = a; q1[k] = b; q2[k] = c;
+    }
+    Bf3 s;
+    s.p0 = __builtin_bit_cast(bf16x8, q0);
+    s.p1 = __builtin_bit_cast(bf16x8, q1);
+    s.p2 = __builtin_bit_cast(bf16x8, q2);
+    return s;
+}
+__device__ __forceinline__ Bf3 split_bf3(f32x4 lo, f32x4 hi) {
+#ifdef IPLAN_SPLIT_PAIRS
+    return split_bf3_pairs(lo, hi);
+#else
+    return split_bf3_scalar(lo, hi);
+#endif
 }
 __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
