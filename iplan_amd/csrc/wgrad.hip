@@ -592,35 +592,30 @@ __global__ __launch_bounds__(128) void wgrad_pair_bf16_kernel(IplanWgradArgs a, 
     }
 }
 
-// grid: (ceil(O*(K+1)/64), problem * n_nets + net); 256 threads = 64 elements x 4 lanes: lane s of an element adds the row chunks
-// vc = s, s + 4, ... into four interleaved running sums (16 loads in flight per element; one thread per element walked up to 128 chunks
-// in 32 dependent rounds: 40 us per launch in the cycle, 62 launches per cycle), the four lanes' sums meet by two shuffles.  Fixed order.
+// grid: (ceil(O*(K+1)/256), problem * n_nets + net)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(IplanWgradArgs a, int chunks_wide) {
     const int pi = (int)blockIdx.y / a.n_nets, net = (int)blockIdx.y % a.n_nets;
     const IplanWgradProblem& p = a.p[pi];
     const WgradGeom gm = wgrad_geom(p, chunks_wide);
-    const int sub = (int)threadIdx.x & 3;
-    const int idx = (int)blockIdx.x * 64 + ((int)threadIdx.x >> 2);
-    const int K1 = p.K + 1, n_el = p.O * K1;
-    const int idc = idx < n_el ? idx : n_el - 1;              // (lanes past the end repeat the last element: the shuffles need every lane)
-    const int o = idc / K1, k = idc - o * K1;
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int K1 = p.K + 1;
+    if (idx >= p.O * K1) return;
+    const int o = idx / K1, k = idx - o * K1;
     const bool is_bias = (k == p.K);
+    if (is_bias ? (p.db_off < 0) : (p.dw_off < 0)) return;
     const int ldp = gm.KT * 16 + 1;
     const float* __restrict__ part = a.workspace + p.ws_off + (int64_t)net * gm.vchunks * gm.part_floats +
                                      (int64_t)o * ldp + (is_bias ? gm.KT * 16 : k);
+    // fixed order: four interleaved running sums (independent loads in flight), combined at the end
     float s4[4] = {0.f, 0.f, 0.f, 0.f};
-    int vc = sub;
-    for (; vc + 12 < gm.vchunks; vc += 16) {
-        const float v0 = part[(int64_t)vc * gm.part_floats], v1 = part[(int64_t)(vc + 4) * gm.part_floats];
-        const float v2 = part[(int64_t)(vc + 8) * gm.part_floats], v3 = part[(int64_t)(vc + 12) * gm.part_floats];
+    int vc = 0;
+    for (; vc + 4 <= gm.vchunks; vc += 4) {
+        const float v0 = part[(int64_t)vc * gm.part_floats], v1 = part[(int64_t)(vc + 1) * gm.part_floats];
+        const float v2 = part[(int64_t)(vc + 2) * gm.part_floats], v3 = part[(int64_t)(vc + 3) * gm.part_floats];
         s4[0] += v0; s4[1] += v1; s4[2] += v2; s4[3] += v3;
     }
-    for (int j = 0; vc < gm.vchunks; vc += 4, ++j) s4[j & 3] += part[(int64_t)vc * gm.part_floats];
+    for (; vc < gm.vchunks; ++vc) s4[vc & 3] += part[(int64_t)vc * gm.part_floats];
     float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-    s += __shfl_xor(s, 1);                                     // (lanes 4e .. 4e+3: both partners add the same two values -> same result)
-    s += __shfl_xor(s, 2);
-    if (sub != 0 || idx >= n_el) return;
-    if (is_bias ? (p.db_off < 0) : (p.dw_off < 0)) return;
     s *= p.scale;
     float* dst = a.grad + (int64_t)net * a.grad_s_net +
                  (is_bias ? p.db_off + o : p.dw_off + (int64_t)o * p.dw_ld + p.dw_col0 + k);
@@ -761,7 +756,7 @@ extern "C" int iplan_wgrad(IplanWgradArgs* a, iplan_stream_t stream) {
     IPLAN_WGRAD_LAUNCH(J_SQUARE, WG_TO_NARROW, WG_TK, 1)
 #undef IPLAN_WGRAD_LAUNCH
     const unsigned z = (unsigned)(a->n_problems * a->n_nets);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((max_elems + 63) / 64), z), dim3(256), 0,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((max_elems + 255) / 256), z), dim3(256), 0,
                        (hipStream_t)stream, *a, chunks_wide);
     return check_launch("iplan_wgrad");
 }

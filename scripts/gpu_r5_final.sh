@@ -20,6 +20,8 @@ rm -rf $O/prof_cycle
 timeout 400 python scripts/microbench.py > $O/microbench.txt 2>&1 < /dev/null
 timeout 400 python scripts/cfg5_bench.py --json $O/cfg5_timings.json > $O/cfg5_timings.txt 2>&1 < /dev/null
 timeout 300 python scripts/bench_runner.py > $O/runner_host_in_loop.txt 2>&1 < /dev/null
+echo "== IPLAN_HOST_HISTORY=1 (the id -> slot history as the numpy class on the host: round 4's form)" >> $O/runner_host_in_loop.txt
+IPLAN_HOST_HISTORY=1 timeout 300 python scripts/bench_runner.py 2>&1 | grep -v amdgpu.ids >> $O/runner_host_in_loop.txt
 timeout 200 python scripts/dev/fused_step_clocks.py > $O/fused_step_clocks.txt 2>&1 < /dev/null
 for v in base nofuse; do
   if [ $v = nofuse ]; then export IPLAN_NO_FUSE_AC=1; else unset IPLAN_NO_FUSE_AC; fi
