@@ -579,12 +579,14 @@ def _ac_wgrad(w, arena, head_names, saved, dsave, which, n_agents, rows, T, h, h
     # head: dY = dhead, X = f3 (slot 9)
     w.add(dptr + 4 * 6 * M, dst, n_out, rows, 1, x=sptr + 4 * 9 * M, x_strides=sst, K=M,
           dw_off=off(head_names[0]), db_off=off(head_names[1]))
-    # GRU input weights: dgi = [dr, dz, dn_i] (cols 0..3M of the gate block), X = f2 (slot 3)
-    w.add(dptr + 4 * 2 * M, dst, 3 * M, rows, 1, x=sptr + 4 * 3 * M, x_strides=sst, K=M,
-          dw_off=off("rnn.rnn.weight_ih_l0"), db_off=off("rnn.rnn.bias_ih_l0"))
-    # GRU hidden weights: dgh = [dr, dz, dn_h], X = the stored hidden state of the row (episode layout)
+    # GRU input weights: dgi = [dr, dz, dn_i] (cols 0..3M of the gate block), X = f2 (slot 3).  Rows indexed (episode, step) like the
+    # hidden weights' problem below -- same dY pointer, strides and row split -- so that iplan_wgrad runs the two as ONE paired launch that
+    # fetches [dr dz] once (wgrad.hip: wgrad_pair_bf16_kernel)
     n_ep = rows // T
     assert n_ep * T == rows
+    w.add(dptr + 4 * 2 * M, (rows * DS, T * DS, DS), 3 * M, n_ep, T, x=sptr + 4 * 3 * M, x_strides=(rows * SF, T * SF, SF), K=M,
+          dw_off=off("rnn.rnn.weight_ih_l0"), db_off=off("rnn.rnn.bias_ih_l0"))
+    # GRU hidden weights: dgh = [dr, dz, dn_h], X = the stored hidden state of the row (episode layout)
     w.add(dptr + 4 * 2 * M, (rows * DS, T * DS, DS), 3 * M, n_ep, T, x=h, x_strides=(h_strides[0], T_phys * h_strides[1], h_strides[1]),
           K=M, dw_off=off("rnn.rnn.weight_hh_l0"), db_off=off("rnn.rnn.bias_hh_l0"), seg=(2 * M, 0, 3 * M))
     # fc2: dY = dz2, X = f1 (slot 1)
