@@ -63,7 +63,7 @@ def measure(Bs=(32, 256), pieces=("gat", "beh"), reps=1.0, device="cuda"):
             def fb():
                 o, saved = ops.gat_forward(arena, obs, None, hid, noise, save=True)
                 ops.gat_backward(arena, saved, gout)
-            t = timed(fb, rn(5), 1)
+            t = timed(fb, rn(10), 2)                      # (4 ms per call: more of them cost nothing; with 3 the mean moved by 6 % between runs)
             rows.append(dict(piece="gat_fwd+bwd(+wgrad)", B=B, ms=t * 1e3, gflop=3 * f / 1e9, tflops=3 * f / t / 1e12,
                              frac=3 * f / t / 1e12 / PEAK))
             del obs, hid, noise, out, gout
