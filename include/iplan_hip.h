@@ -778,9 +778,26 @@ typedef struct {
     int64_t enc_off[4 * IPLAN_S2S_MAX_LAYERS], dec_off[4 * IPLAN_S2S_MAX_LAYERS], lin_off[2];
     float* out;                 /* [rows, P, O]                                                         */
     float* hidden_out;          /* optional [layers, rows, H]: the decoder's final hidden state         */
+    float* save;                /* optional (training): the record iplan_seq2seq_bwd reads,
+                                   [T_in + P, layers, rows, 6H] = h_prev | r | z | n | gh_n | h_new per GRU step (encoder steps first),
+                                   followed by [P, rows, 16 + H] = the decoder step's input (O <= 16 columns) | the output layer's input */
 } IplanSeq2SeqArgs;
 
 int iplan_seq2seq_fwd(const IplanSeq2SeqArgs* args, iplan_stream_t stream);
+
+/* iplan_seq2seq_bwd: the autograd of the above under a loss on `out` (BPTT through the decoder's feedback -- a step whose
+ * input was the previous prediction passes its input gradient on to it -- and through both GRU stacks).  It walks the
+ * data gradients and writes the row-level pre-activation gradients; the weight gradients are dY^T X contractions over them
+ * (iplan_wgrad; iplan_amd/nova/Seq2Seq.py lists the problems):
+ *   dsave [T_in + P, layers, rows, 4H] = dr | dz | dn_i | dn_h per GRU step, followed by [P, rows, 16] = d out (first O columns).
+ * No gradient is returned for in_data / last_location / teacher_location (data).                                          */
+typedef struct {
+    IplanSeq2SeqArgs fwd;       /* the forward launch's arguments (its `save` filled)                   */
+    const float* g_out;         /* [rows, P, O] dLoss/d out                                             */
+    float* dsave;
+} IplanSeq2SeqBwdArgs;
+
+int iplan_seq2seq_bwd(const IplanSeq2SeqBwdArgs* args, iplan_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * One-shot peer-to-peer sum all-reduce of a gradient arena over xGMI (the reference has no

@@ -52,7 +52,7 @@ ENTRY_POINTS = ["iplan_gat_fwd", "iplan_enc_fwd", "iplan_ac_fwd", "iplan_adam_st
                 "iplan_ac_bwd_tail", "iplan_ac_bwd_fc1", "iplan_ac_bwd_fc1_finalize", "iplan_ppo_prepare", "iplan_ppo_adv_norm", "iplan_ppo_loss", "iplan_gat_bwd",
                 "iplan_pdec_fwd", "iplan_pdec_bwd", "iplan_beh_fwd", "iplan_beh_bwd", "iplan_mlp3_fwd", "iplan_mlp3_bwd", "iplan_seq2seq_fwd", "iplan_ac_pack_fc1",
                 "iplan_ac_xhat_pack", "iplan_ac_fc1_split_fwd", "iplan_ac_bwd_fc1_split",
-                "iplan_p2p_publish", "iplan_p2p_reduce", "iplan_obs_history_step"]
+                "iplan_p2p_publish", "iplan_p2p_reduce", "iplan_obs_history_step", "iplan_seq2seq_bwd"]
 RAW_ENTRY_POINTS = ["iplan_grad_sqnorm", "iplan_wgrad_workspace_floats", "iplan_ac_kpad", "iplan_ac_fc1_groups", "iplan_sizeof", "iplan_ac_packed_floats",
                     "iplan_p2p_alloc", "iplan_p2p_free", "iplan_p2p_export", "iplan_p2p_open", "iplan_p2p_close", "iplan_gat_enc_fwd", "iplan_gat_enc_ac_fwd", "iplan_gumbel_noise", "iplan_ac_xhat_floats", "iplan_ac_fc1_split_chunks", "iplan_ac_fc1_split_parts"]      # non (args*, stream) signatures
 
@@ -378,8 +378,12 @@ class Seq2SeqArgs(C.Structure):
     _fields_ = [
         ("rows", i32), ("T_in", i32), ("In", i32), ("H", i32), ("layers", i32), ("P", i32), ("O", i32),
         ("x", fp), ("last", fp), ("teacher", fp), ("coins", fp), ("keep", fp), ("drop_p", C.c_float), ("params", fp),
-        ("enc_off", i64 * 16), ("dec_off", i64 * 16), ("lin_off", i64 * 2), ("out", fp), ("hidden_out", fp),
+        ("enc_off", i64 * 16), ("dec_off", i64 * 16), ("lin_off", i64 * 2), ("out", fp), ("hidden_out", fp), ("save", fp),
     ]
+
+
+class Seq2SeqBwdArgs(C.Structure):
+    _fields_ = [("fwd", Seq2SeqArgs), ("g_out", fp), ("dsave", fp)]
 
 
 # ctypes mirror -> C struct name (checked against iplan_sizeof() of the loaded library by tests/test_abi.py)
@@ -393,6 +397,6 @@ STRUCT_MIRRORS = {"IplanGatSaved": GatSaved, "IplanGatFwdArgs": GatFwdArgs, "Ipl
                   "IplanEncFwdArgs": EncFwdArgs, "IplanAcNet": AcNet, "IplanAcFeatures": AcFeatures, "IplanAcFwdArgs": AcFwdArgs,
                   "IplanAcBwdArgs": AcBwdArgs, "IplanAdamArgs": AdamArgs, "IplanWgradProblem": WgradProblem,
                   "IplanWgradArgs": WgradArgs, "IplanPpoPrepareArgs": PpoPrepareArgs, "IplanPpoLossArgs": PpoLossArgs,
-                  "IplanPdecArgs": PdecArgs, "IplanBehArgs": BehArgs, "IplanMlp3Args": Mlp3Args, "IplanAdvNormArgs": AdvNormArgs, "IplanSeq2SeqArgs": Seq2SeqArgs, "IplanAcPackArgs": AcPackArgs,
+                  "IplanPdecArgs": PdecArgs, "IplanBehArgs": BehArgs, "IplanMlp3Args": Mlp3Args, "IplanAdvNormArgs": AdvNormArgs, "IplanSeq2SeqArgs": Seq2SeqArgs, "IplanSeq2SeqBwdArgs": Seq2SeqBwdArgs, "IplanAcPackArgs": AcPackArgs,
                   "IplanIpcHandle": IpcHandle, "IplanP2pArgs": P2pArgs, "IplanAcXhatArgs": AcXhatArgs, "IplanAcFc1SplitArgs": AcFc1SplitArgs,
                   "IplanObsHistArgs": ObsHistArgs}

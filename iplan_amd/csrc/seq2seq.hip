@@ -3,7 +3,8 @@
 // steps feed the previous prediction (or the teacher's location) back in.  Hidden states of all layers stay in registers
 // in the D layout; weights are read as MFMA A fragments straight from L1/L2 (the whole model is < 200 KB).
 // The reference never calls this module on its training path: it is built for API completeness
-// (same constructor / forward / state_dict), inference only.
+// (same constructor / forward / state_dict).  Round 5: a saving form of the forward and the backward (seq2seq_bwd_kernel below), so
+// that a caller who does train it gets gradients; neither is tuned -- one wave per 16 rows, weights from L1 / L2.
 #include "api_util.h"
 #include "gru_tile.h"
 
@@ -13,7 +14,8 @@ namespace iplan {
 template <int HT>
 __device__ __forceinline__ void gru_layer_step(const float* __restrict__ Wih, const float* __restrict__ Whh,
                                                const float* __restrict__ bih, const float* __restrict__ bhh, int in_dim,
-                                               const f32x4 (&x)[4], int xt, f32x4 (&h)[HT]) {
+                                               const f32x4 (&x)[4], int xt, f32x4 (&h)[HT], float* __restrict__ rec = nullptr,
+                                               bool valid = false) {
     constexpr int H = 16 * HT;
     f32x4 hnew[HT];
     for (int t = 0; t < HT; ++t) {
@@ -30,7 +32,16 @@ __device__ __forceinline__ void gru_layer_step(const float* __restrict__ Wih, co
             pz = mma_block(wfrag_a(Whh, H, 3 * H, H + 16 * t, 16 * T), h[T], pz);
             gh = mma_block(wfrag_a(Whh, H, 3 * H, 2 * H + 16 * t, 16 * T), h[T], gh);
         }
-        hnew[t] = gru_gates(pr, pz, gi, gh, h[t]).h;
+        const GruGates o = gru_gates(pr, pz, gi, gh, h[t]);
+        hnew[t] = o.h;
+        if (rec) {                                           // h_prev | r | z | n | gh_n | h_new of this row (the backward's record)
+            vstore(rec, valid, H, t, h[t]);
+            vstore(rec + H, valid, H, t, o.r);
+            vstore(rec + 2 * H, valid, H, t, o.z);
+            vstore(rec + 3 * H, valid, H, t, o.n);
+            vstore(rec + 4 * H, valid, H, t, o.hn);
+            vstore(rec + 5 * H, valid, H, t, o.h);
+        }
     }
     for (int t = 0; t < HT; ++t) h[t] = hnew[t];
 }
@@ -55,7 +66,8 @@ __global__ __launch_bounds__(256) void seq2seq_fwd_kernel(IplanSeq2SeqArgs a) {
             if (L >= a.layers) break;
             const int in_dim = L ? H : a.In;
             gru_layer_step<HT>(P + a.enc_off[4 * L], P + a.enc_off[4 * L + 1], P + a.enc_off[4 * L + 2], P + a.enc_off[4 * L + 3],
-                               in_dim, x, L ? HT : xt_in, h[L]);
+                               in_dim, x, L ? HT : xt_in, h[L],
+                               a.save ? a.save + (((int64_t)t * a.layers + L) * a.rows + (valid ? row : 0)) * (6 * H) : nullptr, valid);
             for (int T = 0; T < 4; ++T) x[T] = T < HT ? h[L][T] : splat4(0.f);           // the layer above reads this layer's output
         }
     }
@@ -71,7 +83,8 @@ __global__ __launch_bounds__(256) void seq2seq_fwd_kernel(IplanSeq2SeqArgs a) {
             if (L >= a.layers) break;
             const int in_dim = L ? H : a.O;
             gru_layer_step<HT>(P + a.dec_off[4 * L], P + a.dec_off[4 * L + 1], P + a.dec_off[4 * L + 2], P + a.dec_off[4 * L + 3],
-                               in_dim, x, L ? HT : 1, h[L]);
+                               in_dim, x, L ? HT : 1, h[L],
+                               a.save ? a.save + (((int64_t)(a.T_in + t) * a.layers + L) * a.rows + (valid ? row : 0)) * (6 * H) : nullptr, valid);
             for (int T = 0; T < 4; ++T) x[T] = T < HT ? h[L][T] : splat4(0.f);
         }
         f32x4 act[HT];
@@ -79,6 +92,11 @@ __global__ __launch_bounds__(256) void seq2seq_fwd_kernel(IplanSeq2SeqArgs a) {
             f32x4 km = splat4(1.0f);
             if (a.keep) km = vload(a.keep + ((int64_t)t * a.rows + row) * H, valid, H, T);
             for (int q = 0; q < 4; ++q) act[T][q] = tanh_f(x[T][q]) * (km[q] * inv_keep);   // x = the top layer's new hidden state
+        }
+        if (a.save) {                                        // the step's input and the output layer's input
+            float* dr = a.save + (int64_t)(a.T_in + a.P) * a.layers * a.rows * (6 * H) + ((int64_t)t * a.rows + (valid ? row : 0)) * (16 + H);
+            vstore(dr, valid, 16, 0, yin);
+            for (int T = 0; T < HT; ++T) vstore(dr + 16, valid, H, T, act[T]);
         }
         const f32x4 y = dense_tile_g<HT>(P + a.lin_off[0], H, a.O, H, 0, act, bfrag(P + a.lin_off[1], a.O, 0));
         vstore(a.out + ((int64_t)row * a.P + t) * a.O, valid, a.O, 0, y);
@@ -97,7 +115,114 @@ __global__ __launch_bounds__(256) void seq2seq_fwd_kernel(IplanSeq2SeqArgs a) {
     }
 }
 
+// Backward: one wave per 16 rows walks the decoder steps and then the encoder steps in reverse.  dh[L] carries dLoss/d h_L across
+// time (the decoder starts from the encoder's final state, so the same registers run through both stacks); within a step the
+// gradient goes from the output layer down the stack; a decoder step's input gradient is handed to the previous step's output
+// when that output was what it was fed (no teacher forcing at that step).  Only data gradients are propagated here: every GRU
+// step's [dr dz dn_i dn_h] and every d out row go to `dsave`, the weight gradients are contractions over them (iplan_wgrad).
+template <int HT>
+__global__ __launch_bounds__(256) void seq2seq_bwd_kernel(IplanSeq2SeqBwdArgs b) {
+    constexpr int H = 16 * HT;
+    const IplanSeq2SeqArgs& a = b.fwd;
+    const int l = lane_id(), g = l >> 4;
+    const int row = ((int)blockIdx.x * 4 + wave_id()) * 16 + (l & 15);
+    const bool valid = row < a.rows;
+    const int64_t vrow = valid ? row : 0;
+    const float* __restrict__ P = a.params;
+    const float inv_keep = a.keep ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const int64_t n_steps = a.T_in + a.P;
+    const float* __restrict__ drec = a.save + n_steps * a.layers * a.rows * (6 * H);
+    float* __restrict__ ddec = b.dsave + n_steps * a.layers * a.rows * (4 * H);
+    f32x4 dh[IPLAN_S2S_MAX_LAYERS][HT];
+    for (int L = 0; L < IPLAN_S2S_MAX_LAYERS; ++L)
+        for (int t = 0; t < HT; ++t) dh[L][t] = splat4(0.f);
+    f32x4 dyin = splat4(0.f);                                // d Loss / d (input of the decoder step processed last)
+    // one GRU step of layer L backward: dh[L] holds d/d h_new (time + above); returns the layer's input gradient in dx
+    auto layer_bwd = [&](const float* Wih, const float* Whh, int in_dim, int64_t tau, int L, f32x4 (&dhL)[HT], f32x4 (&dx)[HT], int xt_out) {
+        const float* rec = a.save + ((tau * a.layers + L) * a.rows + vrow) * (6 * H);
+        float* dsv = b.dsave + ((tau * a.layers + L) * a.rows + vrow) * (4 * H);
+        f32x4 dgi[3 * HT], dgh[3 * HT], direct[HT];
+        for (int t = 0; t < HT; ++t) {
+            const GruGrads o = gru_gates_bwd(dhL[t], vload(rec + H, valid, H, t), vload(rec + 2 * H, valid, H, t), vload(rec + 3 * H, valid, H, t),
+                                             vload(rec + 4 * H, valid, H, t), vload(rec, valid, H, t));
+            dgi[t] = o.dr; dgi[HT + t] = o.dz; dgi[2 * HT + t] = o.dni;
+            dgh[t] = o.dr; dgh[HT + t] = o.dz; dgh[2 * HT + t] = o.dnh;
+            direct[t] = o.dh_direct;
+            vstore(dsv, valid, H, t, o.dr);
+            vstore(dsv + H, valid, H, t, o.dz);
+            vstore(dsv + 2 * H, valid, H, t, o.dni);
+            vstore(dsv + 3 * H, valid, H, t, o.dnh);
+        }
+        for (int t = 0; t < HT; ++t) dhL[t] = dense_tile_gt<3 * HT>(Whh, H, 3 * H, H, 16 * t, dgh, direct[t]);      // -> d/d h_prev
+        for (int t = 0; t < HT; ++t) dx[t] = t < xt_out ? dense_tile_gt<3 * HT>(Wih, in_dim, 3 * H, in_dim, 16 * t, dgi, splat4(0.f)) : splat4(0.f);
+    };
+    // ---- decoder steps, last first
+    for (int t = a.P - 1; t >= 0; --t) {
+        const int64_t tau = a.T_in + t;
+        // d out[t]: the loss's own gradient + the next step's input gradient where that input was this output
+        f32x4 dy = vload(b.g_out + (vrow * a.P + t) * a.O, valid, a.O, 0);
+        const bool fed_back = t + 1 < a.P && !(a.teacher && a.coins && a.coins[t]);
+        if (fed_back) dy += dyin;
+        for (int q = 0; q < 4; ++q)
+            if (4 * g + q >= a.O || !valid) dy[q] = 0.f;
+        vstore(ddec + ((int64_t)t * a.rows + vrow) * 16, valid, 16, 0, dy);
+        // output layer: y = W act + b, act = tanh(h_top) * keep / (1 - p)
+        const int top = a.layers - 1;
+        const float* rtop = a.save + ((tau * a.layers + top) * a.rows + vrow) * (6 * H);
+        f32x4 dyv[1] = {dy};
+        f32x4 dx[HT];
+#pragma unroll
+        for (int L = IPLAN_S2S_MAX_LAYERS - 1; L >= 0; --L) {
+            if (L >= a.layers) continue;
+            if (L == top) {
+                for (int T = 0; T < HT; ++T) {
+                    const f32x4 dact = dense_tile_gt<1>(P + a.lin_off[0], H, a.O, H, 16 * T, dyv, splat4(0.f));
+                    const f32x4 hn = vload(rtop + 5 * H, valid, H, T);
+                    f32x4 km = splat4(1.0f);
+                    if (a.keep) km = vload(a.keep + ((int64_t)t * a.rows + vrow) * H, valid, H, T);
+                    for (int q = 0; q < 4; ++q) {
+                        const float th = tanh_f(hn[q]);
+                        dh[L][T][q] += dact[q] * (km[q] * inv_keep) * (1.0f - th * th);
+                    }
+                }
+            } else {
+                for (int T = 0; T < HT; ++T) dh[L][T] += dx[T];                   // the layer above's input is this layer's output
+            }
+            const int in_dim = L ? H : a.O;
+            layer_bwd(P + a.dec_off[4 * L], P + a.dec_off[4 * L + 1], in_dim, tau, L, dh[L], dx, L ? HT : 1);
+        }
+        dyin = dx[0];                                          // (layer 0's input gradient: O <= 16 columns)
+    }
+    // ---- encoder steps, last first (the data inputs get no gradient)
+    const int xt_in = (a.In + 15) / 16;
+    (void)xt_in;
+    for (int t = a.T_in - 1; t >= 0; --t) {
+        f32x4 dx[HT];
+#pragma unroll
+        for (int L = IPLAN_S2S_MAX_LAYERS - 1; L >= 0; --L) {
+            if (L >= a.layers) continue;
+            if (L != a.layers - 1)
+                for (int T = 0; T < HT; ++T) dh[L][T] += dx[T];
+            layer_bwd(P + a.enc_off[4 * L], P + a.enc_off[4 * L + 1], L ? H : a.In, t, L, dh[L], dx, L ? HT : 0);
+        }
+    }
+}
+
 }  // namespace iplan
+
+extern "C" int iplan_seq2seq_bwd(const IplanSeq2SeqBwdArgs* b, iplan_stream_t stream) {
+    using namespace iplan;
+    if (!b) return fail(IPLAN_EINVAL, "iplan_seq2seq_bwd: null args");
+    const IplanSeq2SeqArgs* a = &b->fwd;
+    if (a->rows < 1 || a->T_in < 1 || a->In < 1 || a->In > 64 || a->layers < 1 || a->layers > IPLAN_S2S_MAX_LAYERS || a->P < 1 ||
+        a->O < 1 || a->O > 16 || (a->H != 32 && a->H != 64))
+        return fail(IPLAN_EINVAL, "iplan_seq2seq_bwd: unsupported dims");
+    if (!a->save || !a->params || !b->g_out || !b->dsave) return fail(IPLAN_EINVAL, "iplan_seq2seq_bwd: the forward launch did not save its record, or null tensor pointer");
+    const dim3 grid((unsigned)((a->rows + 63) / 64));
+    if (a->H == 32) hipLaunchKernelGGL(seq2seq_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, *b);
+    else hipLaunchKernelGGL(seq2seq_bwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, *b);
+    return check_launch("iplan_seq2seq_bwd");
+}
 
 extern "C" int iplan_seq2seq_fwd(const IplanSeq2SeqArgs* a, iplan_stream_t stream) {
     using namespace iplan;

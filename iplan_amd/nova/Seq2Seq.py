@@ -1,14 +1,18 @@
 """Seq2Seq trajectory predictor (mirror of nova/Seq2Seq.py:6-92): same classes, constructor signatures, ``forward`` contract,
 reshape helpers and ``state_dict`` keys (``encoder.rnn.*_l<k>``, ``decoder.rnn.*_l<k>``, ``decoder.linear.*``), so weights
 interchange with the reference.  The reference never calls it on its training path (it is the GRIP-style baseline the GAT
-replaced); it is provided for API completeness and runs inference through ``iplan_seq2seq_fwd`` (one launch for the encoder
-stack and all autoregressive decoder steps).  Gradients are not implemented for this module."""
+replaced); it is provided for API completeness: ``iplan_seq2seq_fwd`` runs the encoder stack and all autoregressive decoder
+steps in one launch, and when gradients are wanted the forward saves its gate record and ``iplan_seq2seq_bwd`` + ``iplan_wgrad``
+produce the parameter gradients (BPTT through the prediction feedback, like autograd through the reference's loop).  The data
+inputs (in_data, last_location, teacher_location) get no gradient."""
 import numpy as np
 import torch
 import torch.nn as nn
 
 from .. import _lib as L
+from .. import ops
 from ..arena import ParamArena
+from .gat_function import _GradSink, grads_to_params
 
 
 class EncoderRNN(nn.Module):
@@ -52,10 +56,6 @@ class Seq2Seq(nn.Module):
         (nova/Seq2Seq.py:52-70).  One ``np.random.random()`` coin per step decides teacher forcing, drawn in the reference's
         order.  Dropout is active in train() mode like the reference's; ``keep`` ([pred_length, N*V, H] keep flags) may be
         injected, otherwise it is drawn from torch's generator on the input's device."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # a training loop would get a graph-less tensor back: refuse loudly, whatever the inputs' own requires_grad
-            raise NotImplementedError("iplan_amd.nova.Seq2Seq is inference only (forward kernel, no backward): call it under "
-                                      "torch.no_grad() or freeze its parameters")
         dev = in_data.device
         arena = self._own_arena(dev)
         rows, T_in, In = in_data.shape
@@ -85,10 +85,10 @@ class Seq2Seq(nn.Module):
                 a.enc_off[4 * k + j] = arena.off(f"encoder.rnn.{nm}_l{k}")
                 a.dec_off[4 * k + j] = arena.off(f"decoder.rnn.{nm}_l{k}")
         a.lin_off[0], a.lin_off[1] = arena.off("decoder.linear.weight"), arena.off("decoder.linear.bias")
-        out = torch.empty(rows, P, O, dtype=torch.float32, device=dev)
-        a.out = out.data_ptr()
-        L.get_lib().call("iplan_seq2seq_fwd", a, L.current_stream(dev))
-        return out
+        params = [dict(self.named_parameters())[k] for k in arena.names]
+        if torch.is_grad_enabled() and any(q.requires_grad for q in params):
+            return _Seq2SeqFunction.apply(arena, a, keepalive, *params)
+        return _launch_fwd(a, dev, None)
 
     def reshape_for_rnn(self, feature):
         N, C, T, V = feature.size()
@@ -101,3 +101,77 @@ class Seq2Seq(nn.Module):
     def reshape_for_context(self, feature):
         NV, H = feature.size()
         return feature.view(-1, self.num_node, H)
+
+
+def save_floats(rows, T_in, P, layers, H):
+    """floats of IplanSeq2SeqArgs.save / IplanSeq2SeqBwdArgs.dsave (include/iplan_hip.h)"""
+    steps = (T_in + P) * layers * rows
+    return steps * 6 * H + P * rows * (16 + H), steps * 4 * H + P * rows * 16
+
+
+def _launch_fwd(a, dev, save):
+    out = torch.empty(a.rows, a.P, a.O, dtype=torch.float32, device=dev)
+    a.out = out.data_ptr()
+    a.save = save.data_ptr() if save is not None else None
+    L.get_lib().call("iplan_seq2seq_fwd", a, L.current_stream(dev))
+    return out
+
+
+def seq2seq_backward(sink, a, save, g_out):
+    """Parameter gradients of a saving forward launch ``a`` into ``sink.grad`` [1, arena floats]: the BPTT launch writes the
+    row-level gate gradients, eight-ish contractions per layer fold them into the weights (the autograd of nn.GRU / nn.Linear
+    under a loss on nova/Seq2Seq.py:70's output)."""
+    dev = save.device
+    rows, T_in, In, H, layers, P, O = a.rows, a.T_in, a.In, a.H, a.layers, a.P, a.O
+    n_save, n_dsave = save_floats(rows, T_in, P, layers, H)
+    dsave = torch.empty(n_dsave, dtype=torch.float32, device=dev)
+    b = L.Seq2SeqBwdArgs()
+    b.fwd = a
+    g = g_out.to(torch.float32).contiguous()
+    b.g_out, b.dsave = g.data_ptr(), dsave.data_ptr()
+    L.get_lib().call("iplan_seq2seq_bwd", b, L.current_stream(dev))
+    w = ops.Wgrad(sink.grad, 1, tag="iplan_wgrad_seq2seq")
+    off = sink.off
+    sp, dp = save.data_ptr(), dsave.data_ptr()
+    S6, S4 = 6 * H, 4 * H
+    step6, step4 = layers * rows * S6, layers * rows * S4
+    dec_rec = sp + 4 * (T_in + P) * step6                      # [P, rows, 16 + H]
+    ddec = dp + 4 * (T_in + P) * step4                         # [P, rows, 16]
+    for stack, tau0, n_t in (("encoder", 0, T_in), ("decoder", T_in, P)):
+        for k in range(layers):
+            dy = dp + 4 * ((tau0 * layers + k) * rows * S4)
+            rec = sp + 4 * ((tau0 * layers + k) * rows * S6)
+            if k:                                              # the layer below's h_new of the same step
+                xin, xs, K = sp + 4 * ((tau0 * layers + k - 1) * rows * S6 + 5 * H), (0, step6, S6), H
+            elif stack == "encoder":
+                xin, xs, K = a.x, (0, In, T_in * In), In       # in_data [rows, T_in, In] read as (step, row)
+            else:
+                xin, xs, K = dec_rec, (0, rows * (16 + H), 16 + H), O
+            w.add(dy, (0, step4, S4), 3 * H, n_t, rows, x=xin, x_strides=xs, K=K,
+                  dw_off=off(f"{stack}.rnn.weight_ih_l{k}"), db_off=off(f"{stack}.rnn.bias_ih_l{k}"))
+            w.add(dy, (0, step4, S4), 3 * H, n_t, rows, x=rec, x_strides=(0, step6, S6), K=H,
+                  dw_off=off(f"{stack}.rnn.weight_hh_l{k}"), db_off=off(f"{stack}.rnn.bias_hh_l{k}"), seg=(2 * H, 0, 3 * H))
+    w.add(ddec, (0, rows * 16, 16), O, P, rows, x=dec_rec + 4 * 16, x_strides=(0, rows * (16 + H), 16 + H), K=H,
+          dw_off=off("decoder.linear.weight"), db_off=off("decoder.linear.bias"))
+    w._keep += [save, dsave, g]
+    w.run()
+
+
+class _Seq2SeqFunction(torch.autograd.Function):
+    """The parameter tensors are passed as (unused) inputs so autograd routes their gradients; the kernels read the weights
+    from the arena they view (same bookkeeping as nova/gat_function.py)."""
+
+    @staticmethod
+    def forward(ctx, arena, a, keepalive, *params):
+        dev = arena.data.device
+        n_save, _ = save_floats(a.rows, a.T_in, a.P, a.layers, a.H)
+        save = torch.empty(n_save, dtype=torch.float32, device=dev)
+        out = _launch_fwd(a, dev, save)
+        ctx.arena, ctx.a, ctx.keepalive, ctx.rec = arena, a, keepalive, save
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        sink = _GradSink(ctx.arena)
+        seq2seq_backward(sink, ctx.a, ctx.rec, g_out)
+        return (None, None, None, *grads_to_params(sink))

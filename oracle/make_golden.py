@@ -688,8 +688,12 @@ def golden_seq2seq(seed=95):
         patch()
         torch.manual_seed(seed + 2)
         np.random.seed(seed + 3)
-        with torch.no_grad():
-            out = net(x, last, teacher)
+        # the reference's own autograd under a fixed linear loss sum(out * gw): the gradients a training loop over this module would get
+        gw = torch.rand(R, P, No, generator=gen) * 2 - 1
+        out = net(x, last, teacher)
+        (out * gw).sum().backward()
+        grads = {k: v.grad.clone() for k, v in net.named_parameters()}
+        out = out.detach()
         masks = torch.stack(REC["dropout"])                                # [P, R, 1, H]
         unpatch()
         np.random.seed(seed + 3)
@@ -697,8 +701,13 @@ def golden_seq2seq(seed=95):
         p = sd(net)
         o = O.seq2seq_forward(p, x, last, P, teacher, coins, masks, 0.5)
         check(f"seq2seq {tag}", o, out, 1e-5)
+        p64 = {k: v.double().requires_grad_(True) for k, v in p.items()}   # the restatement under autograd, fp64
+        o64 = O.seq2seq_forward(p64, x.double(), last.double(), P, teacher.double(), coins, masks.double(), 0.5)
+        (o64 * gw.double()).sum().backward()
+        for k in grads:
+            check(f"seq2seq {tag} grad {k}", p64[k].grad.float(), grads[k], 1e-4)
         cases.append(dict(tag=tag, dims=dict(C=C, H=H, layers=layers, P=P, O=No, ratio=ratio, R=R, T=T), params=p, x=x, last=last,
-                          teacher=teacher, masks=masks, coins=coins, np_seed=seed + 3, out=out))
+                          teacher=teacher, masks=masks, coins=coins, np_seed=seed + 3, out=out, gw=gw, grads=grads))
         seed += 10
     torch.save(cases, os.path.join(GOLD, "seq2seq.pt"))
 

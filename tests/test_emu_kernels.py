@@ -353,7 +353,8 @@ def test_fused_step_give_up_flag_raises_emulated():
 
 
 def check_seq2seq(golden, device):
-    """nova/Seq2Seq.py forward (a19): same constructor / state_dict / random draws as the reference class, outputs recorded from it"""
+    """nova/Seq2Seq.py forward + backward (a19): same constructor / state_dict / random draws as the reference class, outputs and
+    parameter gradients recorded from it"""
     import numpy as np
     from iplan_amd.nova.Seq2Seq import Seq2Seq
     for g in golden("seq2seq"):
@@ -365,15 +366,22 @@ def check_seq2seq(golden, device):
         with torch.no_grad():
             out = net(g["x"].to(device), g["last"].to(device), g["teacher"].to(device), keep=g["masks"].reshape(d["P"], d["R"], d["H"]).to(device))
         assert out.shape == g["out"].shape and rel_err(out.cpu(), g["out"]) < 1e-5, (g["tag"], rel_err(out.cpu(), g["out"]))
-        import pytest
-        with pytest.raises(NotImplementedError):             # inference only: a training loop must not get a graph-less tensor back
-            net(g["x"].to(device), g["last"].to(device), g["teacher"].to(device))
+        # training form: the saving forward gives the same prediction, and its backward the gradients the reference's autograd gave
+        # under the recorded loss sum(out * gw) -- twice, to see .grad accumulate like torch's
+        for rep in (1, 2):
+            np.random.seed(g["np_seed"])
+            out_t = net(g["x"].to(device), g["last"].to(device), g["teacher"].to(device), keep=g["masks"].reshape(d["P"], d["R"], d["H"]).to(device))
+            assert out_t.requires_grad and torch.equal(out_t.detach().cpu(), out.cpu()), g["tag"]
+            (out_t * g["gw"].to(device)).sum().backward()
+            for k, p in net.named_parameters():
+                e = rel_err(p.grad.cpu() / rep, g["grads"][k])
+                assert e < 1e-5, (g["tag"], k, rep, e)
         x4 = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)          # the reshape helpers (N, C, T, V)
         assert net.reshape_for_rnn(x4).shape == (10, 4, 3)
         assert torch.equal(net.reshape_from_rnn(net.reshape_for_rnn(x4)), x4)
 
 
-def test_seq2seq_forward_emulated(golden):
+def test_seq2seq_forward_and_backward_emulated(golden):
     check_seq2seq(golden, "cpu")
 
 

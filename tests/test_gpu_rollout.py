@@ -38,7 +38,7 @@ def test_reference_checkpoint_matches(golden, tmp_path):
     check_reference_checkpoint(golden, "cuda", tmp_path)
 
 
-def test_seq2seq_forward_matches_reference(golden):
+def test_seq2seq_forward_and_backward_match_reference(golden):
     from tests.test_emu_kernels import check_seq2seq
     check_seq2seq(golden, "cuda")
 
