@@ -785,7 +785,7 @@ typedef struct {
 
 int iplan_seq2seq_fwd(const IplanSeq2SeqArgs* args, iplan_stream_t stream);
 
-/* iplan_seq2seq_bwd: the autograd of the above under a loss on `out` (BPTT through the decoder's feedback -- a step whose
+/* iplan_seq2seq_bwd: the autograd of the above (nova/Seq2Seq.py:52-70 under loss.backward()) for a loss on `out` (BPTT through the decoder's feedback -- a step whose
  * input was the previous prediction passes its input gradient on to it -- and through both GRU stacks).  It walks the
  * data gradients and writes the row-level pre-activation gradients; the weight gradients are dY^T X contractions over them
  * (iplan_wgrad; iplan_amd/nova/Seq2Seq.py lists the problems):

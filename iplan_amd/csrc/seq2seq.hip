@@ -116,13 +116,18 @@ __global__ __launch_bounds__(256) void seq2seq_fwd_kernel(IplanSeq2SeqArgs a) {
 }
 
 // Backward: one wave per 16 rows walks the decoder steps and then the encoder steps in reverse.  dh[L] carries dLoss/d h_L across
-// time (the decoder starts from the encoder's final state, so the same registers run through both stacks); within a step the
+// time (the decoder starts from the encoder's final state, so the same carry runs through both stacks); within a step the
 // gradient goes from the output layer down the stack; a decoder step's input gradient is handed to the previous step's output
 // when that output was what it was fed (no teacher forcing at that step).  Only data gradients are propagated here: every GRU
 // step's [dr dz dn_i dn_h] and every d out row go to `dsave`, the weight gradients are contractions over them (iplan_wgrad).
+// The carry lives in LDS, lane-private slots [wave][layer][tile][lane] (no barrier: a lane only ever touches its own): the layer
+// loop is then a real loop over a.layers and one layer's temporaries (36 tiles) are all the registers hold.  (First form: dh of 4
+// layers in registers under an unrolled layer loop -- 512 registers + 272 bytes of scratch per lane at H = 64, and wrong encoder
+// gradients for layers 0 / 1 at 4 x 64 on the GPU while the host build of the same source was right.)
 template <int HT>
 __global__ __launch_bounds__(256) void seq2seq_bwd_kernel(IplanSeq2SeqBwdArgs b) {
     constexpr int H = 16 * HT;
+    IPLAN_DYN_LDS(s_raw);                                    // [4 waves][layers][HT][64 lanes] f32x4
     const IplanSeq2SeqArgs& a = b.fwd;
     const int l = lane_id(), g = l >> 4;
     const int row = ((int)blockIdx.x * 4 + wave_id()) * 16 + (l & 15);
@@ -130,80 +135,64 @@ __global__ __launch_bounds__(256) void seq2seq_bwd_kernel(IplanSeq2SeqBwdArgs b)
     const int64_t vrow = valid ? row : 0;
     const float* __restrict__ P = a.params;
     const float inv_keep = a.keep ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-    const int64_t n_steps = a.T_in + a.P;
-    const float* __restrict__ drec = a.save + n_steps * a.layers * a.rows * (6 * H);
-    float* __restrict__ ddec = b.dsave + n_steps * a.layers * a.rows * (4 * H);
-    f32x4 dh[IPLAN_S2S_MAX_LAYERS][HT];
-    for (int L = 0; L < IPLAN_S2S_MAX_LAYERS; ++L)
-        for (int t = 0; t < HT; ++t) dh[L][t] = splat4(0.f);
-    f32x4 dyin = splat4(0.f);                                // d Loss / d (input of the decoder step processed last)
-    // one GRU step of layer L backward: dh[L] holds d/d h_new (time + above); returns the layer's input gradient in dx
-    auto layer_bwd = [&](const float* Wih, const float* Whh, int in_dim, int64_t tau, int L, f32x4 (&dhL)[HT], f32x4 (&dx)[HT], int xt_out) {
-        const float* rec = a.save + ((tau * a.layers + L) * a.rows + vrow) * (6 * H);
-        float* dsv = b.dsave + ((tau * a.layers + L) * a.rows + vrow) * (4 * H);
-        f32x4 dgi[3 * HT], dgh[3 * HT], direct[HT];
-        for (int t = 0; t < HT; ++t) {
-            const GruGrads o = gru_gates_bwd(dhL[t], vload(rec + H, valid, H, t), vload(rec + 2 * H, valid, H, t), vload(rec + 3 * H, valid, H, t),
-                                             vload(rec + 4 * H, valid, H, t), vload(rec, valid, H, t));
-            dgi[t] = o.dr; dgi[HT + t] = o.dz; dgi[2 * HT + t] = o.dni;
-            dgh[t] = o.dr; dgh[HT + t] = o.dz; dgh[2 * HT + t] = o.dnh;
-            direct[t] = o.dh_direct;
-            vstore(dsv, valid, H, t, o.dr);
-            vstore(dsv + H, valid, H, t, o.dz);
-            vstore(dsv + 2 * H, valid, H, t, o.dni);
-            vstore(dsv + 3 * H, valid, H, t, o.dnh);
+    const int n_steps = a.T_in + a.P, top = a.layers - 1;
+    const float* __restrict__ keep = a.keep;
+    float* __restrict__ ddec = b.dsave + (int64_t)n_steps * a.layers * a.rows * (4 * H);
+    f32x4* __restrict__ s_dh = reinterpret_cast<f32x4*>(s_raw) + (int64_t)wave_id() * a.layers * HT * 64 + l;   // + (L * HT + t) * 64
+    for (int i = 0; i < a.layers * HT; ++i) s_dh[i * 64] = splat4(0.f);
+    f32x4 dx[HT];                                            // the input gradient of the layer processed last
+    for (int t = 0; t < HT; ++t) dx[t] = splat4(0.f);
+    for (int tau = n_steps - 1; tau >= 0; --tau) {
+        const bool dec = tau >= a.T_in;
+        const int t = tau - a.T_in;                          // decoder step
+        f32x4 dyv[1] = {splat4(0.f)};
+        if (dec) {
+            // d out[t]: the loss's own gradient + the next step's input gradient (dx of its layer 0) where that input was this output
+            f32x4 dy = vload(b.g_out + (vrow * a.P + t) * a.O, valid, a.O, 0);
+            const bool fed_back = t + 1 < a.P && !(a.teacher && a.coins && a.coins[t]);
+            if (fed_back) dy += dx[0];
+            for (int q = 0; q < 4; ++q)
+                if (4 * g + q >= a.O || !valid) dy[q] = 0.f;
+            vstore(ddec + ((int64_t)t * a.rows + vrow) * 16, valid, 16, 0, dy);
+            dyv[0] = dy;
         }
-        for (int t = 0; t < HT; ++t) dhL[t] = dense_tile_gt<3 * HT>(Whh, H, 3 * H, H, 16 * t, dgh, direct[t]);      // -> d/d h_prev
-        for (int t = 0; t < HT; ++t) dx[t] = t < xt_out ? dense_tile_gt<3 * HT>(Wih, in_dim, 3 * H, in_dim, 16 * t, dgi, splat4(0.f)) : splat4(0.f);
-    };
-    // ---- decoder steps, last first
-    for (int t = a.P - 1; t >= 0; --t) {
-        const int64_t tau = a.T_in + t;
-        // d out[t]: the loss's own gradient + the next step's input gradient where that input was this output
-        f32x4 dy = vload(b.g_out + (vrow * a.P + t) * a.O, valid, a.O, 0);
-        const bool fed_back = t + 1 < a.P && !(a.teacher && a.coins && a.coins[t]);
-        if (fed_back) dy += dyin;
-        for (int q = 0; q < 4; ++q)
-            if (4 * g + q >= a.O || !valid) dy[q] = 0.f;
-        vstore(ddec + ((int64_t)t * a.rows + vrow) * 16, valid, 16, 0, dy);
-        // output layer: y = W act + b, act = tanh(h_top) * keep / (1 - p)
-        const int top = a.layers - 1;
-        const float* rtop = a.save + ((tau * a.layers + top) * a.rows + vrow) * (6 * H);
-        f32x4 dyv[1] = {dy};
-        f32x4 dx[HT];
-#pragma unroll
-        for (int L = IPLAN_S2S_MAX_LAYERS - 1; L >= 0; --L) {
-            if (L >= a.layers) continue;
-            if (L == top) {
-                for (int T = 0; T < HT; ++T) {
+        for (int L = top; L >= 0; --L) {
+            const float* rec = a.save + (((int64_t)tau * a.layers + L) * a.rows + vrow) * (6 * H);
+            float* dsv = b.dsave + (((int64_t)tau * a.layers + L) * a.rows + vrow) * (4 * H);
+            const int64_t* off = dec ? a.dec_off : a.enc_off;
+            const float* Wih = P + off[4 * L];
+            const float* Whh = P + off[4 * L + 1];
+            const int in_dim = L ? H : (dec ? a.O : a.In);
+            f32x4 dgi[3 * HT], dgh[3 * HT], direct[HT];
+            for (int T = 0; T < HT; ++T) {
+                f32x4 dhT = s_dh[(L * HT + T) * 64];         // through time
+                if (L != top) dhT += dx[T];                  // the layer above's input is this layer's output
+                else if (dec) {                              // output layer: y = W act + b, act = tanh(h_top) * keep / (1 - p)
                     const f32x4 dact = dense_tile_gt<1>(P + a.lin_off[0], H, a.O, H, 16 * T, dyv, splat4(0.f));
-                    const f32x4 hn = vload(rtop + 5 * H, valid, H, T);
+                    const f32x4 hn = vload(rec + 5 * H, valid, H, T);
                     f32x4 km = splat4(1.0f);
-                    if (a.keep) km = vload(a.keep + ((int64_t)t * a.rows + vrow) * H, valid, H, T);
+                    if (keep) km = vload(keep + ((int64_t)t * a.rows + vrow) * H, valid, H, T);
                     for (int q = 0; q < 4; ++q) {
                         const float th = tanh_f(hn[q]);
-                        dh[L][T][q] += dact[q] * (km[q] * inv_keep) * (1.0f - th * th);
+                        dhT[q] += dact[q] * (km[q] * inv_keep) * (1.0f - th * th);
                     }
                 }
-            } else {
-                for (int T = 0; T < HT; ++T) dh[L][T] += dx[T];                   // the layer above's input is this layer's output
+                const GruGrads o = gru_gates_bwd(dhT, vload(rec + H, valid, H, T), vload(rec + 2 * H, valid, H, T), vload(rec + 3 * H, valid, H, T),
+                                                 vload(rec + 4 * H, valid, H, T), vload(rec, valid, H, T));
+                dgi[T] = o.dr; dgi[HT + T] = o.dz; dgi[2 * HT + T] = o.dni;
+                dgh[T] = o.dr; dgh[HT + T] = o.dz; dgh[2 * HT + T] = o.dnh;
+                direct[T] = o.dh_direct;
+                vstore(dsv, valid, H, T, o.dr);
+                vstore(dsv + H, valid, H, T, o.dz);
+                vstore(dsv + 2 * H, valid, H, T, o.dni);
+                vstore(dsv + 3 * H, valid, H, T, o.dnh);
             }
-            const int in_dim = L ? H : a.O;
-            layer_bwd(P + a.dec_off[4 * L], P + a.dec_off[4 * L + 1], in_dim, tau, L, dh[L], dx, L ? HT : 1);
-        }
-        dyin = dx[0];                                          // (layer 0's input gradient: O <= 16 columns)
-    }
-    // ---- encoder steps, last first (the data inputs get no gradient)
-    const int xt_in = (a.In + 15) / 16;
-    (void)xt_in;
-    for (int t = a.T_in - 1; t >= 0; --t) {
-        f32x4 dx[HT];
-#pragma unroll
-        for (int L = IPLAN_S2S_MAX_LAYERS - 1; L >= 0; --L) {
-            if (L >= a.layers) continue;
-            if (L != a.layers - 1)
-                for (int T = 0; T < HT; ++T) dh[L][T] += dx[T];
-            layer_bwd(P + a.enc_off[4 * L], P + a.enc_off[4 * L + 1], L ? H : a.In, t, L, dh[L], dx, L ? HT : 0);
+            for (int T = 0; T < HT; ++T) s_dh[(L * HT + T) * 64] = dense_tile_gt<3 * HT>(Whh, H, 3 * H, H, 16 * T, dgh, direct[T]);   // -> d/d h_prev
+            // the layer's input gradient: all H columns for an upper layer, the O <= 16 fed-back columns for the decoder's first, none
+            // for the encoder's first (data)
+            const int xt_out = L ? HT : (dec ? 1 : 0);
+            for (int T = 0; T < HT; ++T)
+                dx[T] = T < xt_out ? dense_tile_gt<3 * HT>(Wih, in_dim, 3 * H, in_dim, 16 * T, dgi, splat4(0.f)) : splat4(0.f);
         }
     }
 }
@@ -219,8 +208,9 @@ extern "C" int iplan_seq2seq_bwd(const IplanSeq2SeqBwdArgs* b, iplan_stream_t st
         return fail(IPLAN_EINVAL, "iplan_seq2seq_bwd: unsupported dims");
     if (!a->save || !a->params || !b->g_out || !b->dsave) return fail(IPLAN_EINVAL, "iplan_seq2seq_bwd: the forward launch did not save its record, or null tensor pointer");
     const dim3 grid((unsigned)((a->rows + 63) / 64));
-    if (a->H == 32) hipLaunchKernelGGL(seq2seq_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, *b);
-    else hipLaunchKernelGGL(seq2seq_bwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, *b);
+    const size_t lds = (size_t)4 * a->layers * (a->H / 16) * 64 * 16;      // the carry: <= 64 KiB
+    if (a->H == 32) hipLaunchKernelGGL(seq2seq_bwd_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, *b);
+    else hipLaunchKernelGGL(seq2seq_bwd_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, *b);
     return check_launch("iplan_seq2seq_bwd");
 }
 

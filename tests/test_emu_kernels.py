@@ -385,6 +385,46 @@ def test_seq2seq_forward_and_backward_emulated(golden):
     check_seq2seq(golden, "cpu")
 
 
+def check_seq2seq_shapes_vs_oracle(device, cases=None):
+    """The shapes the fixtures do not hold -- the kernel's limits (4 layers, input width 64, output width 16), one-step encoder /
+    decoder, evaluation mode (no dropout), no teacher, always-teacher -- against the oracle under fp64 autograd (output and every
+    parameter gradient under a random linear loss)."""
+    import numpy as np
+    from oracle import iplan_oracle as O
+    from iplan_amd.nova.Seq2Seq import Seq2Seq
+    #         C   H  layers P  O   R  T  ratio train teacher
+    cases = cases or [(64, 64, 4, 3, 16, 21, 2, 0.0, True, True), (3, 32, 3, 1, 1, 16, 1, 1.0, True, True), (5, 32, 2, 5, 2, 7, 3, 0.5, False, True),
+                      (4, 64, 1, 4, 2, 33, 4, 0.5, True, False)]
+    for i, (C, H, layers, P, No, R, T, ratio, train, with_teacher) in enumerate(cases):
+        torch.manual_seed(100 + i)
+        net = Seq2Seq(C, H, layers, P, num_node=1, output_size=No, dropout=0.25, teacher_forcing_ratio=ratio)
+        net.train(train)
+        gen = torch.Generator().manual_seed(200 + i)
+        x = torch.rand(R, T, C, generator=gen) * 2 - 1
+        last = torch.rand(R, 1, No, generator=gen) * 2 - 1
+        teacher = torch.rand(R, P, No, generator=gen) * 2 - 1 if with_teacher else None
+        gw = torch.rand(R, P, No, generator=gen) * 2 - 1
+        keep = (torch.rand(P, R, H, generator=gen) > 0.25).float()
+        p64 = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+        np.random.seed(300 + i)
+        coins = [bool(np.random.random() < ratio) for _ in range(P)]
+        o64 = O.seq2seq_forward(p64, x.double(), last.double(), P, teacher.double() if with_teacher else None, coins,
+                                keep.double().reshape(P, R, 1, H) if train else None, 0.25)
+        (o64 * gw.double()).sum().backward()
+        np.random.seed(300 + i)
+        out = net(x.to(device), last.to(device), teacher.to(device) if with_teacher else None, keep=keep.to(device))
+        tag = (C, H, layers, P, No, R, T, ratio, train, with_teacher)
+        assert rel_err(out.detach().cpu(), o64.detach().float()) < 1e-5, (tag, rel_err(out.detach().cpu(), o64.detach().float()))
+        (out * gw.to(device)).sum().backward()
+        for k, q in net.named_parameters():
+            e = rel_err(q.grad.cpu(), p64[k].grad.float())
+            assert e < 1e-5, (tag, k, e)
+
+
+def test_seq2seq_limit_shapes_vs_oracle_emulated():
+    check_seq2seq_shapes_vs_oracle("cpu")
+
+
 def test_fc1_pack_follows_parameter_writes_emulated(monkeypatch):
     """ops.Fc1Pack must repack after ANY write to fc1.weight / feature_norm.{weight, bias}: an in-place write through the
     Parameter (p.copy_ / p.mul_ under no_grad: what torch.optim or a re-initialisation does) is seen through the

@@ -43,6 +43,11 @@ def test_seq2seq_forward_and_backward_match_reference(golden):
     check_seq2seq(golden, "cuda")
 
 
+def test_seq2seq_limit_shapes_vs_oracle():
+    from tests.test_emu_kernels import check_seq2seq_shapes_vs_oracle
+    check_seq2seq_shapes_vs_oracle("cuda")
+
+
 def test_gumbel_noise_gpu():
     """the rollout's noise draw (iplan_gumbel_noise, one launch per rollout) on the real kernel"""
     from iplan_amd import _lib as L
