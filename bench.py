@@ -116,14 +116,16 @@ def config5_object():
 
 def strong_loop(total_envs, shard_world, rank, world, emu_world, dev, seed):
     """config 4: the env rows of ONE ``total_envs``-env run sharded over ``shard_world`` ranks; a rank stores its own episodes of
-    the global buffer, and the reference's "first batch_size = buffer_size - 1 episodes" drops the last episode of the last rank"""
+    the global buffer, and the reference's "first batch_size = buffer_size - 1 episodes" drops the last episode of the last rank
+    (iplan_amd.parallel.shard_args: the same helper a run_ippo.py user calls)"""
     from iplan_amd.harness import SyntheticLoop
+    from iplan_amd.parallel import shard_args
     assert total_envs % shard_world == 0, "--total-envs must be divisible by the number of GPUs"
-    E = total_envs // shard_world
     base = default_args("highway")
     drop = base.buffer_size - base.batch_size               # 1: train() uses the first buffer_size - 1 episodes
-    args = default_args("highway", use_cuda=True, batch_size_run=E, buffer_size=E,
-                        batch_size=E - (drop if (rank == world - 1 and not emu_world) else 0))
+    union = default_args("highway", use_cuda=True, batch_size_run=total_envs, buffer_size=total_envs, batch_size=total_envs - drop)
+    args = shard_args(union, shard_world, rank, "strong")   # (--emulate-rank-of W: rank 0 of W, never the rank that drops)
+    E = args.batch_size_run
     return SyntheticLoop(args, E, seed=seed, device=dev), args, E, drop
 
 
@@ -224,9 +226,51 @@ def projection_split(loop, args, E, dev, dist, step_s, emu_world, opt):
             "target": "north_star: >= 6x strong scaling at 8 GPUs (rank step <= config4_n1 step / 6)"}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_argv(n, port, argv):
+    """the command line ``bench.py --gpus n`` re-executes itself under: one rank per GPU of ONE node, rendezvous on 127.0.0.1
+    (the container's hostname may not resolve) -- the same line the driver uses for N > 1 (README.md quick start)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(opt, argv):
+    """``python bench.py --gpus N`` WITHOUT a launcher around it (no WORLD_SIZE in the environment): start the N ranks here.
+    N = 1 goes the same way, so the spawn path is the one the driver's single-GPU line exercises every round.  The ranks'
+    stdout / stderr pass through (rank 0 prints the one JSON line), the exit code is the launcher's (non-zero if any rank died).
+    More ranks than visible GPUs is an error that says so -- never a silent smaller run."""
+    import subprocess
+    cmd = spawn_argv(opt.gpus, free_port(), argv)
+    if opt.print_launch:
+        print(json.dumps({"launch_argv": cmd}))
+        return 0
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if opt.gpus > have:
+        print(f"bench.py: --gpus {opt.gpus} asks for {opt.gpus} ranks, one per GPU, but this process sees {have} GPU(s) "
+              f"(torch.cuda.device_count(); HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')}): not running a smaller job "
+              "under the name of a larger one", file=sys.stderr)
+        return 2
+    env = dict(os.environ, IPLAN_BENCH_SPAWNED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's cross-process buffer sharing needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, opt.gpus))))   # (torchrun would set 1: the cpu_baseline leg wants the cores)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks = GPUs of this node.  Under a launcher (WORLD_SIZE set: the driver's torch.distributed.run line) it must equal "
+                         "WORLD_SIZE; without one, bench.py starts the N ranks itself (launch_ranks)")
+    ap.add_argument("--print-launch", action="store_true", help="print the torch.distributed.run command line --gpus N would start, and exit")
+    ap.add_argument("--in-process", action="store_true",
+                    help="single rank in THIS process, no launcher and no process group (profilers that attach to one process: "
+                         "scripts/gpu_r6_final.sh runs rocprofv3 around this form; the line says launcher.spawned = false)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--envs", type=int, default=32, help="parallel envs per GPU in weak-scaling mode (config 3: 32)")
@@ -249,19 +293,42 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["IPLAN_BENCH_WATCHDOG"]), repeat=True)
 
+    # Who starts the ranks.  Under a launcher (the driver's torch.distributed.run line, or our own launch_ranks) WORLD_SIZE is set
+    # and must agree with --gpus; without one this process IS the launcher.  The single-process diagnostics (--in-process,
+    # --emulate-rank-of) stay here.
+    launched = "WORLD_SIZE" in os.environ
+    single_process = opt.in_process or opt.emulate_rank_of > 1
+    if opt.print_launch or (not launched and not single_process):
+        sys.exit(launch_ranks(opt, [a for a in sys.argv[1:] if a != "--print-launch"]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if opt.gpus != world:
+        print(f"bench.py: --gpus {opt.gpus} but " + (f"the launcher started WORLD_SIZE = {world} rank(s)" if launched else
+              "--in-process / --emulate-rank-of run ONE rank in this process") + ": refusing to print a line under the wrong n_gpus",
+              file=sys.stderr)
+        sys.exit(2)
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if local_rank >= have:
+        print(f"bench.py: rank {rank} (LOCAL_RANK {local_rank}) has no GPU of its own: {have} visible", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    rccl = None
     emu_world = opt.emulate_rank_of if (opt.emulate_rank_of > 1 and world == 1 and opt.scaling == "strong") else 0
-    if world > 1:
+    if launched:
+        # one rank per GPU over RCCL ("nccl" IS RCCL on ROCm) -- also at N = 1, so that the line can say what the collectives ran on
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)                                  # first collective: builds the communicator outside the timed region
+        rccl = {"rccl_ranks": dist.get_world_size(), "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                "all_reduce_of_ones": float(probe.item()), "backend": dist.get_backend()}
+        assert rccl["all_reduce_of_ones"] == world, rccl
     elif emu_world:
         import torch.distributed as dist
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29800 + os.getpid() % 100}", rank=0, world_size=1, device_id=dev)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1, device_id=dev)
 
     strong = opt.scaling == "strong"
     shard_world = emu_world or world                             # how many ranks the global run is split over
@@ -274,10 +341,10 @@ def main():
         loop = SyntheticLoop(args, E, seed=1234 + rank, device=dev)
     if world > 1 or emu_world:
         from iplan_amd.parallel import DataParallel
-        DataParallel(dist.group.WORLD).attach(loop)
+        DataParallel(dist.group.WORLD).attach(loop)               # (strong mode: the union's row counts ride on shard_args' namespace)
         if strong:
-            loop.learner.dp_global_rows = (args.buffer_size * shard_world - drop) * args.episode_limit
-            loop.learner.dp_global_count = args.buffer_size * shard_world * args.episode_limit
+            assert loop.learner.dp_global_rows == (args.buffer_size * shard_world - drop) * args.episode_limit
+            assert loop.learner.dp_global_count == args.buffer_size * shard_world * args.episode_limit
     rollouts_per_step = max(1, args.buffer_size // E)
 
     def one_step():
@@ -340,6 +407,9 @@ def main():
                        "envs_per_gpu": E, "rollouts_per_step": rollouts_per_step,
                        "env_steps_per_step": rollouts_per_step * E * args.episode_limit * world},
             "roofline": rl[0], "roofline_others": rl[1:],
+            # how the ranks came to be: spawned_by_bench = this line's ranks were started by bench.py's own launch_ranks()
+            "launcher": {"launched": launched, "spawned_by_bench": bool(os.environ.get("IPLAN_BENCH_SPAWNED")), "world_size": world,
+                         **(rccl or {"rccl_ranks": None, "note": "single process, no process group (--in-process / --emulate-rank-of)"})},
         }
         if emu_world:
             per_rank = env_steps / dt
@@ -371,7 +441,7 @@ def main():
                 return [clean(v) for v in o]
             return o
         print(json.dumps(clean(line)))
-    if world > 1 or emu_world:
+    if dist is not None and dist.is_initialized():
         dist.destroy_process_group()
 
 

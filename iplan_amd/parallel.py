@@ -157,6 +157,65 @@ class _Bucket:
         self.grad = grad
 
 
+def init_from_env(device=None, backend=None):
+    """One process per GPU, started by ``python -m torch.distributed.run --nproc-per-node N ...`` (or ``bench.py --gpus N``): read
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, bind this process to ITS GPU, create the process group
+    (backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU devices) and return the ``DataParallel`` handle of the default group.
+    ``device``: None = ``cuda:LOCAL_RANK`` when a GPU is visible, else "cpu"."""
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if device is None:
+        device = torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu")
+    device = torch.device(device)
+    if device.type == "cuda":
+        if device.index is None:
+            device = torch.device("cuda", local_rank)
+        if device.index >= torch.cuda.device_count():
+            raise RuntimeError(f"rank {os.environ.get('RANK', '0')} (LOCAL_RANK {local_rank}) has no GPU of its own: "
+                               f"{torch.cuda.device_count()} visible")
+        torch.cuda.set_device(device)
+    if not dist.is_initialized():
+        backend = backend or ("nccl" if device.type == "cuda" else "gloo")
+        kw = {"device_id": device} if (backend == "nccl" and device.type == "cuda") else {}
+        dist.init_process_group(backend, **kw)
+    dp = DataParallel(dist.group.WORLD)
+    dp.device = device
+    return dp
+
+
+def shard_args(args, world, rank, scaling="strong"):
+    """The ``args`` namespace of ONE rank of a ``world``-rank data-parallel run, derived from the single-process namespace
+    (config/default.yaml values: batch_size_run 32, buffer_size 256, batch_size 255).  Returns a shallow copy; ``args`` is not
+    modified.
+
+    * ``scaling="weak"``: every rank runs the configured job (its own ``batch_size_run`` envs, its own ``buffer_size``-episode PPO
+      buffer); the union is ``world`` times the configured batch.  Nothing to change: the copy only records the mode.
+    * ``scaling="strong"`` (BASELINE config 4): the configured job is ONE job sharded over the ranks -- ``batch_size_run``,
+      ``buffer_size`` and ``batch_size`` are the union's and must be divisible by ``world``; rank r owns envs
+      ``[r E / world, (r + 1) E / world)`` and those episodes of the global buffer.  The reference trains on the FIRST
+      ``batch_size`` (= buffer_size - 1) episodes of the buffer (learners/ippo_learner.py:370-372): the episodes it drops are
+      the LAST ones of the union, i.e. the last rank's.  ``dp_global_rows`` / ``dp_global_count`` carry the union's PPO row /
+      stored-entry counts for the advantage statistics and the entropy mean (``DataParallel.attach`` hands them to the learner)."""
+    import copy
+    out = copy.copy(args)
+    out.dp_world, out.dp_rank, out.dp_scaling = world, rank, scaling
+    if scaling == "weak" or world == 1:
+        out.dp_global_rows = out.dp_global_count = None
+        return out
+    if scaling != "strong":
+        raise ValueError(f"scaling must be 'weak' or 'strong', not {scaling!r}")
+    E, B = args.batch_size_run, args.buffer_size
+    if E % world or B % world:
+        raise ValueError(f"strong scaling shards batch_size_run = {E} and buffer_size = {B} over {world} ranks: both must be divisible")
+    drop = B - args.batch_size                              # episodes of the union's buffer train() does not use (reference: 1)
+    if not 0 <= drop < B // world:
+        raise ValueError(f"batch_size = {args.batch_size} must leave the last rank at least one of its {B // world} episodes")
+    T = args.episode_length if getattr(args, "env", None) == "MPE" and hasattr(args, "episode_length") else args.episode_limit
+    out.batch_size_run, out.buffer_size = E // world, B // world
+    out.batch_size = B // world - (drop if rank == world - 1 else 0)
+    out.dp_global_rows, out.dp_global_count = (B - drop) * T, B * T
+    return out
+
+
 class DataParallel:
     def __init__(self, group=None):
         self.group = group
@@ -185,17 +244,43 @@ class DataParallel:
             self.p2p.close()
             self.p2p = None
 
-    def attach(self, loop):
-        """Hook a SyntheticLoop-like object (``.mac``, ``.learner``, ``.behavior``, ``.prediction``): replicas
-        start from rank 0's weights and every learner all-reduces its gradient arenas before stepping."""
-        arenas = [loop.mac.actor_arena, loop.mac.critic_arena]
-        if getattr(loop, "behavior", None) is not None:
-            arenas += [loop.behavior.enc_arena, loop.behavior.dec_arena]
-            loop.behavior.dp = self
-        if getattr(loop, "prediction", None) is not None:
-            arenas += [loop.prediction.gat_arena, loop.prediction.dec_arena]
-            loop.prediction.dp = self
-        loop.learner.dp = self
+    def attach(self, loop=None, *, mac=None, learner=None, behavior=None, prediction=None, runner=None):
+        """Hook the objects of one training process: replicas start from rank 0's weights, every learner all-reduces its loss
+        normalisers and its gradient arenas before stepping, and the runner counts environment steps over ALL ranks.
+
+        Two call forms:
+        * ``attach(loop)`` -- a ``harness.SyntheticLoop``-like object with ``.mac`` / ``.learner`` / ``.behavior`` / ``.prediction``;
+        * ``attach(mac=, learner=, behavior=, prediction=, runner=)`` -- the four objects ``run_ippo.run_sequential`` builds
+          (run_ippo.py:194-222: ``DcntrlMAC``, ``IPPOLearner``, ``Behavior_policy`` or None, ``Prediction_policy`` or None) and its
+          ``ParallelRunner``; call it once, after ``runner.setup(...)`` / ``learner.cuda()`` / ``load_models`` and before the first
+          ``runner.run()``.
+
+        If the learner's ``args`` came from ``shard_args`` in strong mode, the union's row counts it carries
+        (``dp_global_rows`` / ``dp_global_count``) are handed to the learner here."""
+        if loop is not None:
+            mac = mac if mac is not None else loop.mac
+            learner = learner if learner is not None else loop.learner
+            behavior = behavior if behavior is not None else getattr(loop, "behavior", None)
+            prediction = prediction if prediction is not None else getattr(loop, "prediction", None)
+        if mac is None and learner is not None:
+            mac = learner.mac
+        if mac is None or learner is None:
+            raise ValueError("DataParallel.attach needs the controller and the PPO learner (attach(loop) or attach(mac=, learner=, ...))")
+        arenas = [mac.actor_arena, mac.critic_arena]
+        if behavior is not None:
+            if hasattr(behavior, "join_decoder"):
+                behavior.join_decoder()                      # (a deferred decoder update still in flight would race the broadcast)
+            arenas += [behavior.enc_arena, behavior.dec_arena]
+            behavior.dp = self
+        if prediction is not None:
+            arenas += [prediction.gat_arena, prediction.dec_arena]
+            prediction.dp = self
+        learner.dp = self
+        largs = getattr(learner, "args", None)
+        if getattr(largs, "dp_global_rows", None) is not None:
+            learner.dp_global_rows, learner.dp_global_count = largs.dp_global_rows, largs.dp_global_count
+        if runner is not None:
+            runner.dp = self
         for a in arenas:
             self.broadcast_arena(a)
         return self

@@ -63,6 +63,12 @@ class ParallelRunner:
         self._pin = {}
         self._dev_history = None
         self.host_seconds = 0.0        # time spent outside the device work (env.step + history wrapper), for reporting
+        # Data-parallel runs (iplan_amd.parallel.DataParallel.attach(..., runner=self)): this runner steps ITS shard of the parallel
+        # environments (args.batch_size_run = the rank's share); the rollout itself needs no communication -- no env reads another's
+        # data anywhere on the path -- but ``t_env`` drives the schedules every rank must take identically (Behavior_warmup /
+        # GAT_warmup gates and the save / log intervals of run_ippo.py:268-311, the linear lr decay of learners/ippo_learner.py:86-91):
+        # it counts the environment steps of ALL ranks, and the logged episode averages are those of the union.
+        self.dp = None
 
     def setup(self, scheme, groups, preprocess, mac, behavior_learner, prediction_learner):
         try:
@@ -258,12 +264,28 @@ class ParallelRunner:
         if dev.type == "cuda":
             # the last step's host -> device copies read the pinned staging buffers asynchronously and nothing after them
             # synchronises: the next run()'s reset() would overwrite 'single' / 'state' / 'obs' while they are in flight
+            if dh is not None:
+                dh.stage_error_flag()                    # (the episode's LAST history step: the next run()'s init() would clear its flag)
             torch.cuda.current_stream(dev).synchronize()
+        if dh is not None:
+            # Where the raise lands: the history kernel of step t runs behind env.step(t) on the device and its error word reaches
+            # the host with the NEXT per-step synchronisation (or here, for the last step) -- one step after the reference's wrapper,
+            # which raises inside obs_history_create of step t itself.  The episode is aborted either way before its batch is used.
+            dh.check()
         if fuse_ac:
             ops.check_fused_sync()
-        avg_win_rates, avg_rwd, avg_len = np.mean(episode_wins, axis=0), np.mean(episode_returns, axis=0), np.mean(episode_lengths, axis=0)
+        steps_this_run = self.env_steps_this_run
+        if self.dp is not None and self.dp.world > 1:
+            # ONE small all-reduce per episode, after the rollout: [env steps, sum of wins / returns / lengths, envs] over the ranks
+            tot = torch.tensor([float(steps_this_run), float(np.sum(episode_wins)), float(np.sum(episode_returns)),
+                                float(np.sum(episode_lengths)), float(E)], dtype=torch.float64, device=dev)
+            tot = self.dp.all_reduce_sum(tot).cpu().numpy()
+            steps_this_run = int(round(tot[0]))
+            avg_win_rates, avg_rwd, avg_len = tot[1] / tot[4], tot[2] / tot[4], tot[3] / tot[4]
+        else:
+            avg_win_rates, avg_rwd, avg_len = np.mean(episode_wins, axis=0), np.mean(episode_returns, axis=0), np.mean(episode_lengths, axis=0)
         if not test_mode:
-            self.t_env += self.env_steps_this_run
+            self.t_env += steps_this_run
         self._log(avg_win_rates, avg_rwd, avg_len)
         self.log_train_stats_t = self.t_env
         return self.batch, avg_win_rates, avg_rwd, avg_len

@@ -151,6 +151,18 @@ class StubHighwayVecEnv:
         self.end_steps = np.full(K, T + 5) if end_steps is None else np.asarray(end_steps)
         self.t = 0
 
+    def shard(self, lo, hi):
+        """envs [lo, hi) of this vector env as a vector env of their own (a data-parallel rank's share: the same streams the
+        union's env would deliver for those rows)"""
+        import copy
+        out = copy.copy(self)
+        out.K = hi - lo
+        out.obs, out.state, out.reward = self.obs[:, lo:hi], self.state[:, lo:hi], self.reward[:, lo:hi]
+        out.end_steps = self.end_steps[lo:hi]
+        out.t = 0
+        out._k0 = getattr(self, "_k0", 0) + lo
+        return out
+
     def reset(self):
         self.t = 0
         return self.state[0], self.obs[0]
@@ -160,7 +172,7 @@ class StubHighwayVecEnv:
         self.t += 1
         t = min(self.t, self.T + 1)
         term = np.repeat((self.t >= self.end_steps)[:, None], self.nA, axis=1)
-        info = [{"speed": np.full(self.nA, 20.0 + k)} for k in range(self.K)]
+        info = [{"speed": np.full(self.nA, 20.0 + k + getattr(self, "_k0", 0))} for k in range(self.K)]
         return self.state[t], self.obs[t], self.reward[t], np.zeros((self.K, self.nA)), term, info
 
     def close(self):
