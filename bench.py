@@ -35,17 +35,43 @@ from iplan_amd.config import default_args  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32, dense)
 BF16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: v_mfma_f32_16x16x32_bf16, dense (the split-bf16 kernels issue 6 of them per fp32 product)
 HBM_PEAK_GBS = 8000.0                # HBM3E spec (same guide; ~6.3 TB/s is what a float4 copy achieves)
+# kernel sources that no launch of the benchmark cycle comes from (dead code in the reference, ablations, the real runner's history
+# wrapper, the opt-in P2P collective): editing them does not invalidate a counter / kernel-statistics series of the cycle
+NOT_IN_THE_CYCLE = ("seq2seq.hip", "mlp3.hip", "obs_history.hip", "p2p.hip")
+
+
 def csrc_sha16():
-    """Hash of the kernel sources this checkout builds libiplan_hip.so from (every file of iplan_amd/csrc + the C header)."""
+    """Hash of the kernel sources the benchmark cycle's kernels are built from: every file of iplan_amd/csrc except
+    NOT_IN_THE_CYCLE, plus the C header (VERDICT r5 #10: a test-only or dead-code kernel must not invalidate the evidence)."""
     import glob
     import hashlib
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(ROOT, "iplan_amd", "csrc", "*"))) + [os.path.join(ROOT, "include", "iplan_hip.h")]
     for f in files:
-        if os.path.isfile(f) and not f.endswith((".o", ".so")):
+        if os.path.isfile(f) and not f.endswith((".o", ".so")) and os.path.basename(f) not in NOT_IN_THE_CYCLE:
             h.update(os.path.basename(f).encode())
             h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
+
+
+def roofline_coverage(rows, pmc_src_file):
+    """Share of a cycle's KERNEL TIME the roofline rows account for, from the rocprofv3 kernel statistics committed with the
+    counter summary of this build (profiles/<series>_full_cycle_kernel_stats.csv, the same command under --kernel-trace --stats).
+    Every row names the profiler's kernel(s) it stands for (``profile_kernels``: substrings of the demangled name).  A row list
+    that leaves more than 10 % of the kernel time unexplained is an error (VERDICT r5 #2: the worst kernel was missing)."""
+    import csv
+    if pmc_src_file is None:
+        return {"covered_frac": None, "note": "no kernel statistics of this build's kernel sources under profiles/"}
+    f = pmc_src_file.replace("_pmc_summary.json", "_full_cycle_kernel_stats.csv")
+    if not os.path.exists(f):
+        return {"covered_frac": None, "note": f"{os.path.basename(f)} not found"}
+    stats = list(csv.DictReader(open(f)))
+    tot = sum(float(r["TotalDurationNs"]) for r in stats)
+    pats = [p for row in rows for p in row.get("profile_kernels", ())]
+    cov = sum(float(r["TotalDurationNs"]) for r in stats if any(p in r["Name"] for p in pats))
+    missing = sorted(((float(r["TotalDurationNs"]) / tot, r["Name"].split("(")[0][-60:]) for r in stats if not any(p in r["Name"] for p in pats)),
+                     reverse=True)[:4]
+    return {"covered_frac": cov / tot, "source": os.path.basename(f), "largest_uncovered": [{"frac": round(a, 4), "kernel": b} for a, b in missing]}
 
 
 def load_pmc_traffic(envs_per_gpu):
@@ -66,6 +92,8 @@ def load_pmc_traffic(envs_per_gpu):
         # lexicographically last one is named in the refusal below
         if best is None or d.get("csrc_sha16") == sha or best[1].get("csrc_sha16") != sha:
             best = (f, d)
+    global PMC_FILE
+    PMC_FILE = None
     if best is None:
         return {}, "no profiles/*_pmc_summary.json"
     f, d = best
@@ -73,7 +101,11 @@ def load_pmc_traffic(envs_per_gpu):
         return {}, f"{os.path.basename(f)} was measured on kernel sources {d.get('csrc_sha16')}, this build is {sha}: refused"
     if d.get("envs_per_gpu") != envs_per_gpu:
         return {}, f"{os.path.basename(f)} was measured at {d.get('envs_per_gpu')} envs per GPU"
+    PMC_FILE = f
     return {k: v["bytes"] for k, v in d["per_launch"].items()}, f"{os.path.basename(f)} (series {d.get('series')}, kernel sources {d.get('csrc_sha16')})"
+
+
+PMC_FILE = None                              # the counter summary load_pmc_traffic accepted (its series' kernel statistics: roofline_coverage)
 
 
 def gat_algorithmic_flops(n_nets, B, N, D, H=32, A=32):
@@ -86,7 +118,7 @@ def cpu_baseline(args, E):
     """The oracle (CPU port of the reference arithmetic, kind "port") timed on this host's cores on a BOUNDED sample of the
     same workload (oracle/cpu_baseline.py: a rollout vector step at full width plus one Behaviour / Prediction / PPO learner
     pass on a reduced number of envs / rows; warm-up + best of 3; scaled to seconds per env-step and summed).  Reported beside
-    the GPU number, never mixed into it.  profiles/r03_cpu_baseline_anchor.json ties the oracle's speed to the REAL reference
+    the GPU number, never mixed into it.  profiles/r06_cpu_baseline_anchor.json ties the oracle's speed to the REAL reference
     classes timed on identical inputs in the build container (the reference cannot travel to the GPU box)."""
     from oracle.cpu_baseline import measure
     # intra-op threads: the path is thousands of small ATen ops; beyond ~16 threads fork/join overhead dominates (with all
@@ -96,7 +128,7 @@ def cpu_baseline(args, E):
     # batch (anchor file: behaviour_leg_linearity), so a small-batch sample would understate the CPU path
     m = measure("oracle", E, cores, Eb=min(E, 32), reps=2)       # (the behaviour leg: all agents, timed once)
     return dict(value=m["value"], unit="env-steps/s", cores=cores, kind="port",
-                sample=m["sample"] + "; oracle-vs-reference speed on identical inputs: profiles/r03_cpu_baseline_anchor.json")
+                sample=m["sample"] + "; oracle-vs-reference speed on identical inputs (this round's oracle, build container): profiles/r06_cpu_baseline_anchor.json")
 
 
 def config5_object():
@@ -317,18 +349,36 @@ def main():
     dist = None
     rccl = None
     emu_world = opt.emulate_rank_of if (opt.emulate_rank_of > 1 and world == 1 and opt.scaling == "strong") else 0
-    if launched:
-        # one rank per GPU over RCCL ("nccl" IS RCCL on ROCm) -- also at N = 1, so that the line can say what the collectives ran on
+    def init_rccl(**kw):
+        """one rank per GPU over RCCL ("nccl" IS RCCL on ROCm); the first collective builds the communicator outside the timed region.
+        RCCL prints a version banner on fd 1 when it initialises: stdout carries ONE JSON line, so fd 1 points at stderr meanwhile."""
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-        probe = torch.ones(1, device=dev)
-        dist.all_reduce(probe)                                  # first collective: builds the communicator outside the timed region
-        rccl = {"rccl_ranks": dist.get_world_size(), "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev, **kw)
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
+        info = {"rccl_ranks": dist.get_world_size(), "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()),
                 "all_reduce_of_ones": float(probe.item()), "backend": dist.get_backend()}
-        assert rccl["all_reduce_of_ones"] == world, rccl
+        assert info["all_reduce_of_ones"] == dist.get_world_size(), info
+        return dist, info
+
+    # N = 1 under a launcher: the process group is created AFTER the timed region (below) -- its communicator's streams would
+    # otherwise take hardware queues ahead of the training cycle's own streams and change which of those share a queue
+    # (4 hardware queues by default; measured: 272.7 ms per cycle with the group alive against 263-264 ms without,
+    # profiles/r06_notes.md) -- the single-GPU line then times exactly what `--in-process` times.  IPLAN_BENCH_PG_EARLY=1: A/B.
+    pg_late = launched and world == 1 and not os.environ.get("IPLAN_BENCH_PG_EARLY")
+    if launched and not pg_late:
+        dist, rccl = init_rccl()
     elif emu_world:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1, device_id=dev)
+        dist, _ = init_rccl(init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1)
 
     strong = opt.scaling == "strong"
     shard_world = emu_world or world                             # how many ranks the global run is split over
@@ -429,7 +479,12 @@ def main():
             torch.cuda.empty_cache()
             line["config5"] = config5_object()
             line["config4_n1"] = config4_n1_object(opt, dev)
-        if not opt.no_cpu_baseline:
+        if pg_late:
+            torch.cuda.synchronize()
+            dist, rccl = init_rccl()
+            rccl["note"] = "1-rank group created after the timed region (see bench.py: pg_late)"
+            line["launcher"].update(rccl)
+        if not opt.no_cpu_baseline and world == 1:               # (N = 1 only: at N > 1 the other ranks would sit in RCCL's teardown meanwhile)
             line["cpu_baseline"] = cpu_baseline(args, E)
 
         def clean(o):                                            # a kernel that was not launched (diagnostic modes): null, not NaN
@@ -456,10 +511,10 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
     F = N * (d + args.attention_dim + Z) + args.n_actions + nA
     nan = float("nan")
 
-    def entry(kernel, key, bound, work, unit_scale, peak, unit, note, traffic_key=None, work_from_timer=False):
+    def entry(kernel, key, bound, work, unit_scale, peak, unit, note, traffic_key=None, work_from_timer=False, prof=(), work_scale=1.0):
         n, sec, w = timed.get(key, (0, nan, 0.0))
         if work_from_timer:
-            work = w
+            work = w * work_scale
         ach = work / sec / unit_scale if n else nan
         tr = traffic_of(traffic_key or kernel)
         # no row may imply more than the HBM peak (a counter file matched to the wrong launches did): the PMC figure is of
@@ -472,7 +527,7 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
                 "traffic": tr, **({"traffic_rejected": rejected} if rejected else {}), "us_per_launch": sec * 1e6 if n else nan,
                 "traffic_source": pmc_src,
                 "launches_timed": n, ("algorithmic_gbyte_per_launch" if bound == "hbm" else "algorithmic_gflop_per_launch"): work / 1e9,
-                "note": note}
+                "profile_kernels": list(prof), "note": note}
 
     pmc, pmc_src = load_pmc_traffic(E)
 
@@ -500,6 +555,8 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
     fused_ac = not os.environ.get("IPLAN_NO_FUSE_AC") and not os.environ.get("IPLAN_NO_FUSE_ENC")      # harness._rollout_body
     # actor + critic forward of one vector step (rows (2 F M + 14 M^2 + 2 M n_out) per net)
     f_ac = (nA * E * (2 * (2.0 * F * M + 14.0 * M * M) + 2.0 * M * (args.n_actions + 1))) if fused_ac else 0.0
+    S_pred = args.pred_batch_size
+    f_gat_learn = gat_algorithmic_flops(nA, S_pred, N, d + Z)                            # one GAT forward at Prediction_policy.learn's shape
     out = [
         entry("gat_enc_ac_fwd_kernel" if fused_ac else "gat_enc_fwd_kernel", "gat_enc_ac_fwd_kernel" if fused_ac else "gat_fwd_kernel", "mfma",
               gat_algorithmic_flops(nA, E, N, d + Z) + nA * V * (Lw * (2 * d * R + 12 * R * R) + 2 * R * Z) + f_ac, 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
@@ -512,36 +569,64 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
                  f", {rollouts_per_step * (T + 1)} launches per step (the episode-initial GAT update of each rollout runs alone)")
               + "; fp32 results: "
               "the 54-step bi-GRU recurrence (84 % of the algorithmic FLOPs) is issued as 6 bf16 piece products per fp32 product "
-              "on the bf16 matrix cores (fp32-exact split, DESIGN.md section 4), the rest as fp32 MFMA; peak = the fp32 MFMA / vector peak"),
+              "on the bf16 matrix cores (fp32-exact split, DESIGN.md section 4), the rest as fp32 MFMA; peak = the fp32 MFMA / vector peak",
+              prof=("gat_enc_ac_fwd_kernel", "gat_enc_fwd_kernel")),
         entry("beh_dec_bwd_kernel" if os.environ.get("IPLAN_DEC_BWD_V1") else "beh_dec_bwd2_kernel", "beh_dec_bwd_kernel", "mfma", f_dec / pieces("beh_dec_bwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
               f"decoder BPTT of Behavior_policy.learn (backward-data pass = 1x the forward FLOPs) in {pieces('beh_dec_bwd_kernel')} "
-              "window-range launches per learn(), beside the weight-gradient contraction and the encoder BPTT of the previous range"),
+              "window-range launches per learn(), beside the weight-gradient contraction and the encoder BPTT of the previous range",
+              prof=("beh_dec_bwd2_kernel", "beh_dec_bwd_kernel", "beh_dec_thin_grad_kernel")),
         entry("beh_dec_fwd_kernel" if os.environ.get("IPLAN_DEC_FWD_V1") else "beh_dec_fwd2_kernel", "beh_dec_fwd_kernel", "mfma", f_dec / pieces("beh_dec_fwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
-              f"decoder forward of Behavior_policy.learn in {pieces('beh_dec_fwd_kernel')} window-range launches, beside the encoder forward"),
+              f"decoder forward of Behavior_policy.learn in {pieces('beh_dec_fwd_kernel')} window-range launches, beside the encoder forward",
+              prof=("beh_dec_fwd2_kernel", "beh_dec_fwd_kernel")),
         entry("beh_enc_bwd_kernel", "beh_enc_bwd_kernel", "mfma", 2 * f_enc / pieces("beh_enc_bwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
-              "encoder BPTT with in-kernel weight gradients (2x the forward FLOPs), side stream"),
-        entry("wgrad_pair_bf16_kernel (+reduce)", "iplan_wgrad:beh_dec", "hbm", 0.0, 1e9, HBM_PEAK_GBS, "GB/s",
+              "encoder BPTT with in-kernel weight gradients (2x the forward FLOPs), side stream, beside the decoder BPTT: the two share the chip, "
+              "so the in-cycle duration is not the kernel's own (alone: scripts/microbench.py)", prof=("beh_enc_bwd_kernel", "beh_enc_grad_kernel")),
+        entry("beh_enc_fwd_kernel", "beh_enc_fwd_kernel", "mfma", f_enc / pieces("beh_enc_fwd_kernel"), 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
+              f"encoder forward of Behavior_policy.learn ({J} windows x {Lw} GRU32 steps per chain, hidden state carried; SURVEY 8d: "
+              f"{f_enc / nA / J / 1e6:.1f} MFLOP per net and window) in {pieces('beh_enc_fwd_kernel')} window-range launches on a side stream, "
+              "beside the decoder forward (same remark as the encoder BPTT)", prof=("beh_enc_fwd_kernel",)),
+        entry("wgrad_pair_bf16_kernel (+reduce)", "iplan_wgrad:beh_dec", "mfma", 0.0, 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
               "the deferred iplan_wgrad call of Behavior_policy.learn: the decoder GRU's W_ih and W_hh gradients over all (row, step) records as "
-              "ONE paired launch (the [dr dz] columns both need are fetched once) + reduction, side stream: algorithmic bytes = every operand "
-              "column of every row once, 4 (256 + 64 + 64) bytes per row and step",
-              traffic_key="iplan_wgrad:beh_dec", work_from_timer=True),
+              "ONE paired launch (the [dr dz] columns both need are fetched once) + reduction, side stream, beside the next rollout's first "
+              "steps.  Arithmetic intensity 2 x 192 x 64 x 2 FLOP per 1 536 B = 32 FLOP/B, above the fp32 ridge (19.7): the binding roof is the "
+              "matrix pipe -- this row is against the fp32 MFMA peak (as every fp32-result row); the kernel issues its products in split-bf16 "
+              "form, and what it is short of is ISSUE time: 1 395 VALU instructions (the bf16 splitting of 12 operand tiles) beside 288 MFMAs "
+              "per 32-row block and wave.  Next row: the same launches against the HBM roof",
+              traffic_key="iplan_wgrad:beh_dec", work_from_timer=True, work_scale=2.0 * 192 * 64 * 2 / 1536.0,
+              prof=("wgrad_pair_bf16_kernel", "wgrad_reduce_kernel")),
+        entry("wgrad_pair_bf16_kernel (+reduce) (HBM roof)", "iplan_wgrad:beh_dec", "hbm", 0.0, 1e9, HBM_PEAK_GBS, "GB/s",
+              "same launches against the HBM roof: algorithmic bytes = every operand column of every row once, 4 (256 + 64 + 64) bytes per row "
+              "and step", traffic_key="iplan_wgrad:beh_dec", work_from_timer=True),
         entry("ac_fc1_split_fwd_kernel", "ac_fc1_split_fwd", "mfma", f_fc1, 1e12, BF16_MFMA_PEAK_TFLOPS / 6.0, "TFLOP/s",
               f"fc1 of the actor AND the critic of one PPO epoch ({rows} rows x F = {F} x 128 outputs, 5 agents) over the packed normalised "
               "features, fp32-exact split-bf16: 6 bf16 piece products per fp32 product, so peak = the dense bf16 MFMA peak / 6 in "
-              "fp32-equivalent FLOPs (the timed span includes the two small weight-piece kernels in front of the contraction)"),
+              "fp32-equivalent FLOPs (the timed span includes the two small weight-piece kernels in front of the contraction)",
+              prof=("ac_fc1_split_fwd_kernel", "ac_fc1_wprep_kernel", "ac_fc1_wsplit", "ac_fc1_wbeta")),
         entry("ac_fc1_split_fwd_kernel (HBM roof)", "ac_fc1_split_fwd", "hbm", b_fc1, 1e9, HBM_PEAK_GBS, "GB/s",
               "same launches against the HBM roof: the fp32 feature fragments read once for both nets + the pre-activations written",
               traffic_key="ac_fc1_split_fwd"),
         entry("ac_fc1_split_wgrad_kernel", "ac_fc1_split_wgrad", "mfma", f_fc1, 1e12, BF16_MFMA_PEAK_TFLOPS / 6.0, "TFLOP/s",
-              "fc1 weight gradient G = dz1^T xhat of both nets of one PPO epoch, same split-bf16 form (K = rows)"),
+              "fc1 weight gradient G = dz1^T xhat of both nets of one PPO epoch, same split-bf16 form (K = rows)",
+              prof=("ac_fc1_split_wgrad_kernel", "ac_fc1_finalize_kernel")),
         entry("ac_fwd_kernel<PPO tail>", "ac_fwd_kernel:train", "hbm", b_tail, 1e9, HBM_PEAK_GBS, "GB/s",
               f"the 64-wide tail of the actor + critic forward of one PPO epoch from the stored fc1 pre-activations ({rows} rows, 5 agents): "
               "reads z1 and the stored GRU state, writes the 648-float activation record per row and net",
-              traffic_key="ac_fwd_kernel:train"),
+              traffic_key="ac_fwd_kernel:train", prof=("ac_fwd_kernel<2, true",)),
         entry("ac_bwd_tail_kernel", "ac_bwd_tail_kernel", "hbm", 0.0, 1e9, HBM_PEAK_GBS, "GB/s",
               "the 64-wide tail of the actor + critic backward of one PPO epoch: reads 8 of the record's 10 rows per net and row + the hidden "
               "state, writes the 400-float row gradients the weight-gradient contractions read, weights (transposed) staged in LDS",
-              traffic_key="ac_bwd_tail_kernel", work_from_timer=True),
+              traffic_key="ac_bwd_tail_kernel", work_from_timer=True, prof=("ac_bwd_tail_kernel",)),
+        entry("gat_fwd_kernel", "gat_fwd_kernel", "mfma", 0.0, 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
+              f"GAT launches outside the fused vector step: the saving forward of Prediction_policy.learn ({S_pred} sampled rows x 5 nets, "
+              f"{f_gat_learn / 1e9:.2f} GFLOP), each rollout's episode-initial update and its last step's latent updates ({E} envs, 6.41 GFLOP); "
+              "work = the mean over the timed launches of each launch's own algorithmic FLOPs.  The "
+              "in-cycle duration is NOT the kernel's: the episode-initial launch queues behind the deferred decoder contraction that holds "
+              "every SIMD at the rollout's head (DESIGN.md section 9), and the events / the profiler's span include that wait; alone the saving "
+              "forward takes 0.11 ms", work_from_timer=True, prof=("gat_fwd_kernel<",)),
+        entry("gat_bwd_kernel", "gat_bwd_kernel", "mfma", 2 * f_gat_learn, 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s",
+              f"GAT backward of Prediction_policy.learn ({S_pred} sampled rows x 5 nets; backward = 2x the forward FLOPs: pair-GRU BPTT with "
+              "in-kernel dW_hh, attention and node-projection backward), side stream beside behaviour learning",
+              prof=("gat_bwd_kernel", "gat_whh_grad_kernel")),
     ]
     n_sc, sc_us, _ = timed.get("gat_scenes_span_us", (0, nan, 0.0))
     if n_sc:
@@ -551,6 +636,11 @@ def rooflines(args, E, timed, opt, rollouts_per_step):
                                     "is the next step's action selection, a latency chain behind the last scene (DESIGN.md section 4)",
                             "launches_sampled": n_sc, "span_us": sc_us, "algorithmic_gflop": f_scenes / 1e9,
                             "achieved": f_scenes / (sc_us * 1e-6) / 1e12, "frac": f_scenes / (sc_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+    cov = roofline_coverage(out, PMC_FILE)
+    out[0]["rows_cover_kernel_time"] = cov
+    if cov["covered_frac"] is not None and cov["covered_frac"] < 0.90 and not (opt.rollout_only or os.environ.get("IPLAN_BENCH_NO_COVERAGE_CHECK")):
+        raise SystemExit(f"bench.py: the roofline rows explain only {cov['covered_frac']:.1%} of the cycle's kernel time ({cov['source']}); "
+                         f"largest kernels without a row: {cov['largest_uncovered']}")
     return out
 
 

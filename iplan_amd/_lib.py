@@ -314,6 +314,7 @@ PPO_MSE, PPO_NO_VCLIP, PPO_VALUE_MEAN, PPO_POLICY_MEAN = 1, 2, 4, 8
 # ---- GAT backward --------------------------------------------------------------------------------------
 GAT_NODE_DY = 640
 GAT_HARD_PART = 8 * 32 + 16
+GAT_REC_GROUPS = 8                  # 16-column groups of the saved pair-GRU record per (ego tile, step): h r z n x 2 (csrc/gat.hip, gat_bwd.hip: REC = 8 * 256)
 GAT_WHH_PART = 3 * 32 * 32 + 3 * 32
 
 

@@ -198,7 +198,8 @@ __global__ __launch_bounds__(512) void gat_bwd_kernel(IplanGatBwdArgs a) {
         // chain (the ragged last tile) is a CLONE of the scene's last node: it loads, computes and stores exactly what that
         // node's lane does (same values to the same addresses), so nothing in the step loop is predicated; only the sums
         // over the 16 chains below leave the clones out.
-        // Record layout (gat.hip writes it): [net][dir][scene][ego tile][step][group: h h r r z z n n hn hn][16 chains][16 columns] --
+        // Record layout (gat.hip writes it): [net][dir][scene][ego tile][step][group: h h r r z z n n][16 chains][16 columns] (REC = 8 groups x 256 floats;
+        // gh_n = W_hn h_prev + b_hn is recomputed below, not stored) --
         // a wave's load of one 16-column group of its 16 chains is ONE contiguous 1 KiB block.  (Chain-major rows of 5H floats until
         // round 5: every load instruction was 16 separate 64-byte pieces, and the BPTT sat at the memory pipeline's request rate, not
         // at its latency -- touching the lines three steps ahead made it SLOWER, 345 -> 397 us: profiles/r05_notes.md.)

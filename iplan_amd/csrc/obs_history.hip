@@ -9,8 +9,11 @@
 //     slot_id [K, nA, N] int32 (-1 = free)    n_slots [K, nA]    win [K, nA, N, L, d]  (right-aligned last L entries per slot)
 //
 // One wave per (thread k, registered agent index): it owns that pair's slots, pulls the pair's window block into LDS, replays the
-// rows of every agent whose ego id resolves to it IN THE REFERENCE'S ORDER (row-major over the observed rows, agents in order --
-// slot numbers depend on the order of first appearance), appends a zero entry to every known slot an agent did not observe, and
+// rows of every agent whose ego id resolves to it in the NUMPY WRAPPER's order (rows outer, agents inner -- slot numbers depend
+// on the order of first appearance; zero entries after all rows).  That equals the reference's order (agent outer: agent i's
+// rows, then agent i's zero entries, then agent i + 1) whenever the ego ids of a thread are unique, which is every case the
+// reference itself survives: with two agents on one ego id its obs_history_output raises IndexError (the duplicate-id tests
+// compare this kernel with the numpy class only).  It appends a zero entry to every known slot an agent did not observe, and
 // writes the block back together with the single-step view the GAT kernel reads (straight into the episode container).  Values
 // are copied, never computed: the windows are bit-identical to the numpy wrapper's after its float32 cast.
 #include "api_util.h"

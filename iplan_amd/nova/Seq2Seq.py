@@ -57,6 +57,14 @@ class Seq2Seq(nn.Module):
         order.  Dropout is active in train() mode like the reference's; ``keep`` ([pred_length, N*V, H] keep flags) may be
         injected, otherwise it is drawn from torch's generator on the input's device."""
         dev = in_data.device
+        # Gradients flow to the PARAMETERS only (iplan_seq2seq_bwd + iplan_wgrad).  In the reference (plain nn.GRU / nn.Linear
+        # autograd, nova/Seq2Seq.py:41-70) they would also reach in_data / last_location; a caller that feeds this module from a
+        # trainable upstream module must hear about the difference instead of silently training the upstream on zeros (ADVICE r5).
+        if torch.is_grad_enabled():
+            for nm, t in (("in_data", in_data), ("last_location", last_location), ("teacher_location", teacher_location)):
+                if isinstance(t, torch.Tensor) and t.requires_grad:
+                    raise NotImplementedError(f"Seq2Seq.forward: {nm}.requires_grad is set, but this implementation differentiates with respect "
+                                              "to the module's parameters only (no input gradients); detach the input or run under no_grad")
         arena = self._own_arena(dev)
         rows, T_in, In = in_data.shape
         H, layers, O, P = self.encoder.hidden_size, self.encoder.num_layers, self.decoder.output_size, self.pred_length

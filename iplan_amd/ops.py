@@ -30,6 +30,12 @@ def _nb_strides(t, inner):
     return t.stride(0), t.stride(1)
 
 
+def _gat_flops(n_nets, B, N, D, A, H=32):
+    """algorithmic FLOPs of one GAT forward: V (2DH + 24H^2 + 6HA + 12A^2) + P (12H^2 + 8H + 4A) per net"""
+    V, P = B * N, B * N * (N - 1)
+    return float(n_nets * (V * (2 * D * H + 24 * H * H + 6 * H * A + 12 * A * A) + P * (12 * H * H + 8 * H + 4 * A)))
+
+
 def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None, phase_clocks=None, lib=None, fuse_enc=None, fuse_ac=None):
     """GAT_Net.forward for all nets.  src0 [n_nets,B,N,d0], src1 [n_nets,B,N,d1] or None,
     h_prev [n_nets,B,N,A] (first two dims may be arbitrarily strided views), noise
@@ -71,7 +77,7 @@ def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None
         H = A
         saved = dict(
             h_enc=torch.empty(n_nets, B * N, H, device=dev),
-            gru=torch.empty(n_nets, 2, B, (N + 15) // 16, N - 1, int(os.environ.get("IPLAN_GAT_REC_GROUPS", "8")), 16, 16, device=dev),   # tile-major 1 KiB blocks: h r z n (csrc/gat.hip; the knob: A/B against libraries with a wider record)
+            gru=torch.empty(n_nets, 2, B, (N + 15) // 16, N - 1, L.GAT_REC_GROUPS, 16, 16, device=dev),   # tile-major 1 KiB blocks: h r z n (csrc/gat.hip, gat_bwd.hip: REC = 8 * 256 floats per (tile, step))
             qkv=torch.empty(n_nets, B * N, 3 * A, device=dev),
             soft=torch.empty(n_nets, B * N, N - 1, device=dev),
             hard=torch.empty(n_nets, B * N, N - 1, device=dev),
@@ -101,9 +107,9 @@ def gat_forward(arena, src0, src1, h_prev, noise, tau=0.01, save=False, out=None
             rc = lib.c.iplan_gat_enc_fwd(C.byref(a), C.byref(fuse_enc["args"]), C.c_void_p(L.current_stream(dev) or 0))
             if rc != 0:
                 raise L.IplanError(f"iplan_gat_enc_fwd failed ({rc}): {lib.c.iplan_last_error().decode()}")
-        _launch("gat_fwd_kernel", fused)
+        _launch("gat_fwd_kernel", fused, work=_gat_flops(n_nets, B, N, d0 + d1, A))
     else:
-        _launch("gat_fwd_kernel", lambda: lib.call("iplan_gat_fwd", a, L.current_stream(dev)))
+        _launch("gat_fwd_kernel", lambda: lib.call("iplan_gat_fwd", a, L.current_stream(dev)), work=_gat_flops(n_nets, B, N, d0 + d1, A))
     if saved is not None:
         saved["_args"] = a
         saved["_keep"] = (src0, src1, h_prev, noise, out)
@@ -722,7 +728,7 @@ def gat_backward(arena, saved, g_out, phase_clocks=None, lib=None):
     if phase_clocks is not None:                            # int64 [>= 15]: workgroup 0's clocks land in slots 8..14
         assert phase_clocks.dtype == torch.int64 and phase_clocks.numel() >= 15
         a.fwd.phase_clocks = phase_clocks.data_ptr()
-    lib.call("iplan_gat_bwd", a, L.current_stream(dev))
+    _launch("gat_bwd_kernel", lambda: lib.call("iplan_gat_bwd", a, L.current_stream(dev)))
     a.fwd.phase_clocks = fa.phase_clocks
 
     w = Wgrad(arena.grad, n_nets)

@@ -2,14 +2,15 @@
 one training cycle timed either on the oracle (``backend="oracle"``: the in-repo restatement, what the GPU box can run) or
 on the REAL reference classes imported from /root/reference (``backend="reference"``: build container only).
 ``scripts/anchor_cpu_baseline.py`` runs both on identical inputs and commits the ratio (profiles/r0N_cpu_baseline_anchor.json),
-which ties the oracle's speed to the reference's (round 3: profiles/r03_cpu_baseline_anchor.json -- behaviour leg of all agents at Eb = 32).
+which ties the oracle's speed to the reference's (round 6: profiles/r06_cpu_baseline_anchor.json, this round's oracle -- behaviour leg of all
+agents at Eb = 32, PPO leg on all 22 950 rows; round 3's anchor: profiles/r03_cpu_baseline_anchor.json).
 
 Pieces (each: one warm-up call, then the best of ``reps`` timed calls), scaled to seconds per env-step and summed:
   rollout   vector step at full width E: GAT_latent_update + latent_update + select_actions_ippo (5 agents)
   behaviour Behavior_policy.learn forward + backward, ALL n_agents agents one after the other (the reference's loop), Eb envs,
             full 90-step episode -- the dominant CPU leg: timed in full at the width the GPU run uses, not extrapolated from one agent
   predict   Prediction_policy.learn forward + backward, ONE agent, 64 samples
-  ppo       one PPO epoch (actor evaluate + critic, forward + backward), ONE agent, Rp rows
+  ppo       one PPO epoch (actor evaluate + critic, forward + backward), ONE agent, all Rp = batch_size x episode_limit rows
 """
 import os
 import sys
@@ -173,12 +174,16 @@ def _reference_pieces(ca, E, Eb, Rp, ref_root):
     return dict(rollout=rollout, behaviour=behaviour, predict=predict, ppo=ppo)
 
 
-def measure(backend, E, cores, Eb=2, Rp=2048, reps=3, ref_root="/root/reference"):
-    """-> dict(value env-steps/s, seconds per piece call, per_env_step seconds per piece, description)."""
+def measure(backend, E, cores, Eb=2, Rp=None, reps=3, ref_root="/root/reference"):
+    """-> dict(value env-steps/s, seconds per piece call, per_env_step seconds per piece, description).
+    ``Rp``: rows of the PPO leg; default = ALL batch_size x episode_limit rows one agent trains on per epoch (22 950 at config 3;
+    until round 5 a 2 048-row sample scaled linearly -- VERDICT r5 "weak" 4)."""
     from iplan_amd.config import default_args
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     ca = default_args("highway", use_cuda=False)
+    if Rp is None:
+        Rp = ca.batch_size * ca.episode_limit
     pieces = _oracle_pieces(ca, E, Eb, Rp) if backend == "oracle" else _reference_pieces(ca, E, Eb, Rp, ref_root)
     t = {k: _best(fn, reps if k != "rollout" else max(reps, 5)) for k, fn in pieces.items() if k != "behaviour"}
     # the behaviour leg is the long one (all agents, full width): warm up on ONE agent, then time the whole pass once

@@ -602,9 +602,14 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
     stats = []
     loss_kw = {k: getattr(args, k, True) for k in ("use_huber_loss", "use_clipped_value_loss", "use_value_active_masks", "use_policy_active_masks")}
 
+    held = {}
+
     def objectives(ap, cp, sl, hints=(None, None)):
         logp, ent = actor_evaluate(ap, x[sl], ha[sl], acts[sl], avail[sl], relu_hint=hints[0], use_relu=use_relu)
         val, _ = critic_value(cp, x[sl], hc[sl], relu_hint=hints[1], use_relu=use_relu)
+        if val.requires_grad:
+            val.retain_grad()                                 # (probe_eval: the per-row d loss / d value, for the conditioning figure)
+        held["val"] = val
         return ppo_losses(logp, ent, val, old_logp[sl], adv.reshape(-1, 1)[sl], v_all[:, :-1].reshape(-1, 1)[sl],
                           rets.reshape(-1, 1)[sl], masks_all[:, :-1].reshape(-1, 1)[sl],
                           args.clip_param, args.huber_delta, args.entropy_coef, args.value_loss_coef, **loss_kw) + (ent,)
@@ -615,6 +620,7 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
     if probe_last_step is not None:
         probes[n_steps - 1] = (probe_last_step, probe_relu_hint)
     by_step, hint_log_by_step = {}, {}
+    cond_by_step = {}                                         # optimiser step -> conditioning figure of its probe (see probe_eval)
 
     def probe_eval(point, hint, sl):
         pa, pc = ({k: (v.detach().to(dt) if v.is_floating_point() else v.detach()).clone().requires_grad_(v.is_floating_point())
@@ -622,6 +628,12 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
         a_obj, _, c_obj, _, _, _ = objectives(pa, pc, sl, hint if hint is not None else (None, None))
         a_obj.backward()
         c_obj.backward()
+        # Conditioning of the gradients that are plain ROW SUMS of d loss / d value (critic v_out.bias; rnn.norm.bias = that sum times
+        # v_out.weight): sum |g_row| / |sum g_row|.  When the residuals v - return nearly cancel over the rows this is >> 1 and
+        # rounding of the values at the last bit, which no fp32 implementation avoids, moves those gradients by ~ cond x 2^-24 of
+        # their own size (tests/oracle_checks.py uses it as a tolerance term)
+        gv = held["val"].grad
+        held["cond"] = float(gv.abs().sum() / gv.sum().abs().clamp_min(1e-300)) if gv is not None else 1.0
         out = []
         for prm in (pa, pc):
             trainable = [k for k in prm if prm[k].grad is not None]
@@ -635,6 +647,7 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
             if steps[0] in probes:
                 n0 = len(RELU_HINT_LOG)
                 by_step[steps[0]] = probe_eval(probes[steps[0]][0], probes[steps[0]][1], sl)
+                cond_by_step[steps[0]] = held["cond"]
                 hint_log_by_step[steps[0]] = list(RELU_HINT_LOG[n0:])
                 if steps[0] == n_steps - 1 and probe_last_step is not None:
                     probe_grads = by_step[steps[0]]
@@ -656,7 +669,8 @@ def ppo_train_agent(agent_id, actor_p, critic_p, fields, args, rows=None, row_in
             stats.append(dict(policy_loss=float(pol.detach()), value_loss=float(vl.detach()), entropy=float(ent.detach()), ratio=float(ratio.detach().mean()),
                               actor_grad_norm=norms[0], critic_grad_norm=norms[1]))
     return dict(returns=rets, adv=adv, old_logp=old_logp, values_all=v_all, stats=stats, probe_grads=probe_grads,
-                probe_grads_by_step=by_step, hint_log_by_step=hint_log_by_step)
+                probe_grads_by_step=by_step, hint_log_by_step=hint_log_by_step,
+                value_grad_row_sum_cond=cond_by_step)
 
 
 # ----------------------------------------------------------------------------------------------

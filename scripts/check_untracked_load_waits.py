@@ -17,11 +17,36 @@ VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 LOAD = re.compile(r"^(global_load|buffer_load|flat_load|scratch_load|global_atomic\w*\s.*\bsc0\b|image_)")
 
 
-def compile_asm(src="gat.hip"):
-    out = os.path.join(tempfile.mkdtemp(prefix="iplan_asm_"), src + ".s")
+def hipcc_command(src="gat.hip"):
+    """the compile line the shipped object is built with: `make -n` of iplan_amd/csrc/Makefile for <src>'s object (same HIPCC, HIPFLAGS,
+    per-file NOSLP and $(EXTRA)), so that the assembly walked here is the assembly that ships"""
     csrc = os.path.join(ROOT, "iplan_amd", "csrc")
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
-                    "-Wno-unused-result", "-Wno-unused-command-line-argument", "-x", "hip", "--cuda-device-only", "-S", os.path.join(csrc, src), "-o", out], check=True)
+    obj = os.path.join(ROOT, "build", "obj", src + ".o")
+    out = subprocess.run(["make", "-n", "-B", "-C", csrc, obj], check=True, capture_output=True, text=True).stdout
+    for line in out.splitlines():
+        words = line.split()
+        if words and words[0].endswith("hipcc") and any(w.endswith("/" + src) for w in words):
+            return words
+    raise RuntimeError("no hipcc line for %s in `make -n`:\n%s" % (src, out))
+
+
+def compile_asm(src="gat.hip"):
+    import shutil
+    words = hipcc_command(src)
+    if shutil.which(words[0]) is None:
+        raise FileNotFoundError(words[0])
+    out = os.path.join(tempfile.mkdtemp(prefix="iplan_asm_"), src + ".s")
+    cmd, skip = [], False
+    for w in words:                                          # -c ... -o <obj>  ->  --cuda-device-only -S -o <asm>
+        if skip:
+            skip = False
+            continue
+        if w == "-o":
+            skip = True
+            continue
+        cmd.append("--cuda-device-only" if w == "-c" else w)
+    cmd[1:1] = ["-Wno-unused-command-line-argument"]
+    subprocess.run(cmd + ["-S", "-o", out], check=True)
     return out
 
 

@@ -20,6 +20,15 @@ from iplan_amd import synth
 from oracle import iplan_oracle as O
 
 E32_FACTOR = 1.5          # gradient bound = max(tol, E32_FACTOR x the fp32 oracle's own error vs fp64), every learner, every tensor
+# ... plus ONE conditioning term, computed from the data, for the two critic tensors that are plain row sums of d loss / d value
+# (v_out.bias, and rnn.norm.bias = that sum x v_out.weight): COND_ULPS x 2^-24 x cond, cond = sum |g_row| / |sum g_row| as the fp64
+# oracle sees it at the probe point (oracle.ppo_train_agent: value_grad_row_sum_cond).  With well-spread residuals cond is O(1) and
+# the term is 2e-7, far below tol; when the residuals v - return happen to cancel over the rows (the 27-row all-switches-off draw of
+# test_ppo_loss_switches_*: cond ~ 300) last-bit rounding of the values moves these two gradients by ~ cond x 2^-24 of their own
+# size in ANY fp32 implementation -- the fp32 oracle and the kernels land 1 - 2 such units from fp64, in either order depending on
+# the draw (seeds 42 ... 46 of the same case: both at 1e-6).  Replaces round 3 - 5's hand-set "6 x e32" for that test.
+COND_ULPS = 4.0
+ROW_SUM_TENSORS = ("v_out.bias", "rnn.norm.bias")
 RELU_HINT_MAX = 8         # ReLU branches the PPO oracle may take from the learner's own forward pass, per replayed agent
 
 
@@ -413,6 +422,9 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
                     worst["fp32_oracle_post_vs_fp64"] = max(worst["fp32_oracle_post_vs_fp64"], _rel(p32[k].detach(), p64[k].detach()))
             worst["fp32_oracle_grad_vs_fp64"] = max(worst["fp32_oracle_grad_vs_fp64"], e32)
         gtol = max(tol, e32_factor * e32)
+        conds = r64.get("value_grad_row_sum_cond", {})
+        cond = float(conds.get(n_steps - 1, 1.0)) if probe is not None else 1.0
+        worst["value_grad_row_sum_cond"] = max([worst.get("value_grad_row_sum_cond", 1.0), cond] + [float(conds.get(k, 1.0)) for k in mids])
         # the mid-trajectory probes: the same two checks at optimiser step k (0-based; Adam's t = k + 1)
         for k in sorted(mids):
             rec = learner.step_probes[k]
@@ -425,6 +437,7 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
                 gk32 = r32["probe_grads_by_step"][k]
                 ek32 = max(_grad_err(gk32[gi][kk], gk64[gi][kk]) for gi in range(2) for kk in gk64[gi])
                 worst["mid_fp32_oracle_grad_vs_fp64"] = max(worst.get("mid_fp32_oracle_grad_vs_fp64", 0.0), ek32)
+                worst.setdefault("mid_e32_by_step", {})[f"agent{i}_step{k + 1}"] = ek32
             gktol = max(tol, e32_factor * ek32)
             for gi, (name, arena, lr) in enumerate((("actor", mac.actor_arena, args.lr), ("critic", mac.critic_arena, args.critic_lr))):
                 m_all, v_all, taken = rec["moments"][gi]
@@ -432,8 +445,11 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
                 for kk, g in gk64[gi].items():
                     e = _grad_err(_arena_slice(rec["grads"][gi], arena, i, kk), g)
                     worst["mid_grad"] = max(worst.get("mid_grad", 0.0), e)
-                    assert e <= gktol or not assert_grads, ("clipped grad (step %d of %d, at the learner's own parameters) vs fp64 oracle" % (k + 1, n_steps),
-                                                           name, i, kk, e, gktol)
+                    by = worst.setdefault("mid_grad_by_step", {})
+                    by[f"agent{i}_step{k + 1}"] = max(by.get(f"agent{i}_step{k + 1}", 0.0), e)
+                    kktol = max(gktol, COND_ULPS * 2.0 ** -24 * float(conds.get(k, 1.0))) if (name == "critic" and kk in ROW_SUM_TENSORS) else gktol
+                    assert e <= kktol or not assert_grads, ("clipped grad (step %d of %d, at the learner's own parameters) vs fp64 oracle" % (k + 1, n_steps),
+                                                           name, i, kk, e, kktol)
                     if getattr(args, "weight_decay", 0.0):
                         continue
                     w = mids[k][0][gi][kk].double().clone()
@@ -489,7 +505,8 @@ def check_ppo_train_vs_oracle(args, device, seed=0, tol=1e-5, post_tol=1e-5, ter
                         table.append(dict(agent=i, net=name, tensor=k, gmax=float(g64[gi][k].abs().max()), kernel=e,
                                           fp32_oracle=None if g32 is None else _grad_err(g32[gi][k], g64[gi][k]),
                                           kernel_vs_trajectory=et, post=pe))
-                    assert e <= gtol or not assert_grads, ("clipped grad (last step, at the learner's own parameters) vs fp64 oracle", name, i, k, e, gtol)
+                    ktol = max(gtol, COND_ULPS * 2.0 ** -24 * cond) if (name == "critic" and k in ROW_SUM_TENSORS) else gtol
+                    assert e <= ktol or not assert_grads, ("clipped grad (last step, at the learner's own parameters) vs fp64 oracle", name, i, k, e, ktol)
                     # the old comparison -- against the fp64 oracle's OWN trajectory -- measures the conditioning of Adam's
                     # first steps rather than the kernels (docstring), but an error in an EARLIER step shows up only there and
                     # in the post-train parameters: held to a documented loose bound, 1e-2 of the tensor's max or 20 x the

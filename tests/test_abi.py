@@ -76,5 +76,9 @@ def test_untracked_loads_are_waited_for():
     spec = importlib.util.spec_from_file_location("check_untracked_load_waits", os.path.join(root, "scripts", "check_untracked_load_waits.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    n, bad = mod.check(mod.compile_asm("gat.hip"))
+    import shutil
+    import pytest
+    if shutil.which("make") is None or shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) is None:
+        pytest.skip("no hipcc on this box: the assembly check needs the gfx950 cross-compiler")
+    n, bad = mod.check(mod.compile_asm("gat.hip"))          # (compile flags = the Makefile's own line for gat.hip, `make -n`)
     assert n >= 16 and not bad, (n, bad[:4])

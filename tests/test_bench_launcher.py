@@ -58,3 +58,4 @@ def test_gpus_1_goes_through_the_spawn_path_and_reports_rccl():
     la = line["launcher"]
     assert line["n_gpus"] == 1 and la["launched"] and la["spawned_by_bench"] and la["rccl_ranks"] == 1 and la["all_reduce_of_ones"] == 1.0
     assert la["rccl_version"].count(".") == 2
+    assert len([ln for ln in r.stdout.splitlines() if ln.strip()]) == 1, "stdout carries exactly ONE line (RCCL's banner goes to stderr)"

@@ -376,6 +376,11 @@ def check_seq2seq(golden, device):
             for k, p in net.named_parameters():
                 e = rel_err(p.grad.cpu() / rep, g["grads"][k])
                 assert e < 1e-5, (g["tag"], k, rep, e)
+        # the reference's autograd would also differentiate w.r.t. the inputs; this path does not, and says so
+        with pytest.raises(NotImplementedError, match="in_data.requires_grad"):
+            net(g["x"].to(device).requires_grad_(True), g["last"].to(device), g["teacher"].to(device))
+        with torch.no_grad():                                                              # (no graph wanted: fine)
+            net(g["x"].to(device).requires_grad_(True), g["last"].to(device), g["teacher"].to(device))
         x4 = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)          # the reshape helpers (N, C, T, V)
         assert net.reshape_for_rnn(x4).shape == (10, 4, 3)
         assert torch.equal(net.reshape_from_rnn(net.reshape_for_rnn(x4)), x4)

@@ -331,12 +331,12 @@ def test_ppo_train_vs_oracle_emulated(cfg):
 @pytest.mark.parametrize("decay", [False, True])
 def test_ppo_train_15_epochs_vs_oracle_emulated(decay):
     """the shipped ppo_epoch = 15 (config/algs/ippo.yaml:6; learners/ippo_learner.py:286-303): gradients at the learner's own
-    parameters in front of optimiser steps 8 and 15 vs the fp64 oracle, one fp64 Adam step from each of those states, and EVERY one
+    parameters in front of optimiser steps 3, 8 and 15 vs the fp64 oracle, one fp64 Adam step from each of those states, and EVERY one
     of the 15 Adam updates replayed in fp64 from its own state (bias correction at t = 1 .. 15); with the linear lr decay hook
     on (use_linear_lr_decay, t_env = 0.4 t_max: lr and critic_lr x 0.6) in the second case"""
     from tests.oracle_checks import check_ppo_train_vs_oracle
     kw = dict(use_linear_lr_decay=True, t_max=1000) if decay else {}
-    w = check_ppo_train_vs_oracle(_small(ppo_epoch=15, **kw), "cpu", seed=6, mid_probes=(7,), adam_replay=True, t_env=400 if decay else 0)
+    w = check_ppo_train_vs_oracle(_small(ppo_epoch=15, **kw), "cpu", seed=6, mid_probes=(2, 7), adam_replay=True, t_env=400 if decay else 0)
     assert w["adam_replay_updates"] == 15 * 2 * 2 and "mid_grad" in w, w
 
 
@@ -438,10 +438,14 @@ def test_ppo_loss_switches_vs_oracle_emulated(flags):
     """the PPO loss switches of config/algs/ippo.yaml away from their shipped values (learners/ippo_learner.py:142-157,
     190-196, 353-362): MSE instead of Huber, no value clipping, plain means instead of active masks, no GAE"""
     from tests.oracle_checks import check_ppo_train_vs_oracle
-    # all switches off: the NAMED EXCEPTION of tests/test_gpu_parity_fullsize.py::test_ppo_loss_switches_vs_oracle (DESIGN.md
-    # section 5) -- the critic's v_out.bias / rnn.norm.bias gradients are nearly cancelling means of v - return (condition
-    # number ~ 300), any fp32 value head lands 1e-5 ... 4e-5 of the tensor's max from the fp64 result: 6 x e32 for that case
-    check_ppo_train_vs_oracle(_small(ppo_epoch=2, **flags), "cpu", seed=41, e32_factor=6.0 if len(flags) > 1 else 1.5)
+    # Same bound as everywhere (tests/oracle_checks.py: E32_FACTOR, plus the data-derived conditioning term of the two row-sum
+    # tensors).  All switches off at seed 41 is the draw where it matters: the critic's v_out.bias / rnn.norm.bias gradients are
+    # means of v - return that cancel to 1 / 300 over the 27 rows; seed 42 is an ordinary draw of the same case.
+    w = check_ppo_train_vs_oracle(_small(ppo_epoch=2, **flags), "cpu", seed=41)
+    if len(flags) > 1:
+        assert w["value_grad_row_sum_cond"] > 50, w                                 # (the ill-conditioned draw really is one)
+        w2 = check_ppo_train_vs_oracle(_small(ppo_epoch=2, **flags), "cpu", seed=42)
+        assert w2["grad"] < 1e-5, w2
 
 
 def test_behavior_learn_decoder_forward_both_forms_emulated(monkeypatch):

@@ -95,13 +95,21 @@ def test_ppo_train_config3_all_agents_vs_oracle():
 def test_ppo_train_config3_15_epochs_vs_oracle():
     """the optimiser-step count the benchmark times -- ppo_epoch = 15 (config/algs/ippo.yaml:6,
     learners/ippo_learner.py:286-303) at the full config-3 / config-4 size (22 950 rows x F = 2485), the agents at both arena ends.
-    Gradients at the learner's own parameters in front of optimiser steps 8 and 15 vs the fp64 oracle (<= max(1e-5, 1.5 e32)), one fp64
+    Gradients at the learner's own parameters in front of optimiser steps 8, 15 and one randomly drawn other step vs the fp64 oracle (<= max(1e-5, 1.5 e32)), one fp64
     Adam step from each of those states (moments at t = 8 and t = 15) <= 1e-5, hints <= 8 per step, and EVERY one of the 15 Adam
     updates of both agents replayed in fp64 from the step's own state and gradients (<= 1e-6)."""
     from tests.oracle_checks import check_ppo_train_vs_oracle
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    w = check_ppo_train_vs_oracle(_args(ppo_epoch=15), "cuda", seed=54, agents=(0, 4), mid_probes=(7,), adam_replay=True)
+    # ... and ONE MORE step from the thirteen others (VERDICT r5 "missing" 4: the gradient kernels of steps 2-7 and 9-14 ran
+    # unchecked), drawn from the hash of the kernel sources: another step with every build, the same step for every run of one build
+    # (a per-run draw would make the driver's -x suite a lottery on a comparison whose bound is statistical).  IPLAN_PPO_PROBE_STEP
+    # (1-based) pins it; scripts/gpu_r6_final.sh runs steps 2 ... 14 once each on the round's final build (profiles/r06*_ppo_all_steps.json).
+    import bench
+    others = [k for k in range(14) if k != 7]
+    extra = int(os.environ["IPLAN_PPO_PROBE_STEP"]) - 1 if os.environ.get("IPLAN_PPO_PROBE_STEP") else others[int(bench.csrc_sha16(), 16) % len(others)]
+    w = check_ppo_train_vs_oracle(_args(ppo_epoch=15), "cuda", seed=54, agents=(0, 4), mid_probes=tuple(sorted({7, extra})), adam_replay=True)
     assert w["adam_replay_updates"] == 15 * 2 * 2, w
+    w["random_mid_probe_step_1_based"] = extra + 1
     _log("ppo_train_cfg3_22950rows_agents0and4_15epochs_probes_at_8_and_15", w)
 
 
@@ -184,13 +192,15 @@ def test_ppo_loss_switches_vs_oracle():
     from tests.test_emu_learners import _small
     a = _small(ppo_epoch=2, use_huber_loss=False, use_clipped_value_loss=False, use_value_active_masks=False,
                use_policy_active_masks=False, use_gae=False)
-    # NAMED EXCEPTION to the 1.5 x e32 bound: with the unmasked MSE value loss the gradients of the
-    # critic's ``v_out.bias`` and ``rnn.norm.bias`` are plain means of the residuals v - return over the rows, which nearly
-    # cancel in this case (|sum| = 3.9e-3 against sum|.| ~ 1: condition number ~ 300), so ANY fp32 value head lands 1e-5 ...
-    # 4e-5 of the tensor's max from the fp64 result -- the fp32 oracle 7e-6, the kernels 3.7e-5 (their K = 2485 fc1
-    # contraction is one sequential fp32 chain, the oracle's a blocked one) -- while every other tensor of the case sits at
-    # <= 2.6e-6.  Bound for this case: 6 x e32.
-    _log("ppo_loss_switches_all_off", check_ppo_train_vs_oracle(a, "cuda", seed=41, e32_factor=6.0))
+    # Same bound as every learner check (tests/oracle_checks.py: max(1e-5, 1.5 x e32) plus the data-derived conditioning term of the
+    # two row-sum tensors -- at seed 41 the critic's v_out.bias / rnn.norm.bias gradients are means of v - return that cancel to
+    # 1 / 300 over the 27 rows); seed 42 is an ordinary draw of the same case.  Until round 5 this test carried a hand-set "6 x e32".
+    w = check_ppo_train_vs_oracle(a, "cuda", seed=41)
+    assert w["value_grad_row_sum_cond"] > 50, w
+    _log("ppo_loss_switches_all_off", w)
+    w2 = check_ppo_train_vs_oracle(a, "cuda", seed=42)
+    assert w2["grad"] < 1e-5, w2
+    _log("ppo_loss_switches_all_off_seed42", w2)
 
 
 def test_behavior_learn_decoder_forward_first_form_gpu(monkeypatch):

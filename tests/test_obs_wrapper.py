@@ -110,7 +110,9 @@ def check_device_history(g, device):
 
 def check_device_history_vs_numpy_stream(device, K=6, nA=3, obs_num=7, d=5, N=12, L=4, T=25, dup=False):
     """a longer stub-simulator stream (vehicles come and go) against the numpy class, incl. two agents of a thread that report the
-    SAME ego id (both feed one state, in agent order, each with its own zero entries: observation_wrapper.py:92-96)"""
+    SAME ego id (both feed one state, each with its own zero entries).  The duplicate case is device-vs-NUMPY only: the two walk
+    rows-outer / agents-inner, the reference walks agent-outer (observation_wrapper.py:92-96) and itself raises IndexError in
+    obs_history_output with a duplicate ego id, so there is no reference answer to compare with."""
     from iplan_amd import synth
     from iplan_amd.observation_wrapper import DeviceObsHistory, observersation_state_history_wrapper as Wrapper
     env = synth.StubHighwayVecEnv(K, nA, obs_num, d, N, T, seed=3, n_ids=N - nA - 1)
