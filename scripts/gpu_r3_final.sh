@@ -13,7 +13,7 @@ IPLAN_BENCH_WATCHDOG=600 timeout 700 python bench.py > $O/bench_line.json 2> $O/
 IPLAN_BENCH_WATCHDOG=600 timeout 700 python bench.py --scaling strong --no-cpu-baseline > $O/bench_strong_n1_line.json 2> $O/bench_strong.err < /dev/null
 IPLAN_BENCH_WATCHDOG=600 timeout 700 python bench.py --scaling strong --emulate-rank-of 8 --no-cpu-baseline > $O/bench_strong_rank_of_8_projection.json 2> $O/bench_proj.err < /dev/null
 IPLAN_PPO_FC1_FP32=1 IPLAN_BENCH_WATCHDOG=600 timeout 700 python bench.py --no-cpu-baseline > $O/bench_line_fp32_fc1_same_box.json 2> $O/bench_fp32.err < /dev/null
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_cycle" -o cyc -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$R/$O/bench_under_rocprof.json" 2> "$R/$O/bench_under_rocprof.err" < /dev/null )
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_cycle" -o cyc -- python "$R/bench.py" --in-process --steps 2 --warmup 1 --no-cpu-baseline > "$R/$O/bench_under_rocprof.json" 2> "$R/$O/bench_under_rocprof.err" < /dev/null )
 find $O/prof_cycle -name "*kernel_stats.csv" -exec cp {} $O/full_cycle_kernel_stats.csv \;
 f=$(find $O/prof_cycle -name "*kernel_trace.csv" | head -1)
 python scripts/trace_busy.py $f > $O/cycle_trace_busy.txt 2>&1; python scripts/trace_learn.py $f > $O/cycle_trace_learn_phase.txt 2>&1

@@ -40,7 +40,8 @@ def bytes_of(k, piece):
 per_launch = {}
 for key, sub, piece in (("gat_enc_fwd_kernel", "gat_enc_fwd_kernel", "rollout"), ("gat_enc_ac_fwd_kernel", "gat_enc_ac_fwd_kernel", "rollout"),
                         ("beh_dec_bwd_kernel", "beh_dec_bwd", "behaviour"), ("beh_dec_fwd_kernel", "beh_dec_fwd", "behaviour"),
-                        ("beh_enc_bwd_kernel", "beh_enc_bwd_kernel", "behaviour"), ("ac_fwd_kernel:train", "ac_fwd_kernel<2, true", "ppo"),
+                        ("beh_enc_bwd_kernel", "beh_enc_bwd_kernel", "behaviour"), ("beh_enc_fwd_kernel", "beh_enc_fwd_kernel", "behaviour"),
+                        ("ac_fwd_kernel:train", "ac_fwd_kernel<2, true", "ppo"),
                         ("ac_fc1_split_fwd", "ac_fc1_split_fwd_kernel", "ppo"), ("ac_fc1_split_wgrad", "ac_fc1_split_wgrad_kernel", "ppo"),
                         ("ac_bwd_tail_kernel", "ac_bwd_tail_kernel", "ppo")):
     if key.startswith("gat_enc") and not [k for k in pieces[piece] if sub in k]:
