@@ -12,7 +12,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 IPLAN_BENCH_WATCHDOG=600 timeout 700 python bench.py --gpus 1 > $O/bench_line.json 2> $O/bench.err < /dev/null      # the driver's command: bench.py starts its own rank (torch.distributed.run)
 IPLAN_BENCH_WATCHDOG=600 timeout 700 python bench.py --gpus 1 --scaling strong --no-cpu-baseline > $O/bench_strong_n1_line.json 2> $O/bench_strong.err < /dev/null
 IPLAN_BENCH_WATCHDOG=600 timeout 700 python bench.py --scaling strong --emulate-rank-of 8 --no-cpu-baseline > $O/bench_strong_rank_of_8_projection.json 2> $O/bench_proj.err < /dev/null
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_cycle" -o cyc -- python "$R/bench.py" --in-process --in-process --steps 2 --warmup 1 --no-cpu-baseline --no-extras > "$R/$O/bench_under_rocprof.json" 2> "$R/$O/bench_under_rocprof.err" < /dev/null )
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_cycle" -o cyc -- python "$R/bench.py" --in-process --steps 2 --warmup 1 --no-cpu-baseline --no-extras > "$R/$O/bench_under_rocprof.json" 2> "$R/$O/bench_under_rocprof.err" < /dev/null )
 find $O/prof_cycle -name "*kernel_stats.csv" -exec cp {} $O/full_cycle_kernel_stats.csv \;
 f=$(find $O/prof_cycle -name "*kernel_trace.csv" | head -1)
 python scripts/trace_busy.py $f > $O/cycle_trace_busy.txt 2>&1; python scripts/trace_learn.py $f > $O/cycle_trace_learn_phase.txt 2>&1
