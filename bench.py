@@ -291,7 +291,20 @@ def launch_ranks(opt, argv):
     env = dict(os.environ, IPLAN_BENCH_SPAWNED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's cross-process buffer sharing needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, opt.gpus))))   # (torchrun would set 1: the cpu_baseline leg wants the cores)
-    return subprocess.run(cmd, env=env).returncode
+    if opt.gpus > 1:
+        return subprocess.run(cmd, env=env).returncode
+    # N = 1: the rank's stdout is held back until it has ended well -- if the launcher itself fails on this box (no free port, a broken
+    # elastic agent ...) the single-GPU line is still measured, in this process, and says so (launcher.spawn_failed); a failure of the
+    # BENCHMARK shows up in both forms and is not masked
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode == 0 and lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+        return 0
+    print(f"bench.py: the spawned rank ended with rc = {r.returncode} and {len(lines)} JSON line(s); measuring in this process instead",
+          file=sys.stderr)
+    return None
 
 
 def main():
@@ -330,8 +343,14 @@ def main():
     # --emulate-rank-of) stay here.
     launched = "WORLD_SIZE" in os.environ
     single_process = opt.in_process or opt.emulate_rank_of > 1
+    spawn_failed = False
     if opt.print_launch or (not launched and not single_process):
-        sys.exit(launch_ranks(opt, [a for a in sys.argv[1:] if a != "--print-launch"]))
+        rc = launch_ranks(opt, [a for a in sys.argv[1:] if a != "--print-launch"])
+        if rc is not None:
+            sys.exit(rc)
+        spawn_failed = True                                 # (N = 1 only: fall through to the in-process form)
+    if launched and os.environ.get("IPLAN_BENCH_SPAWNED") and os.environ.get("IPLAN_BENCH_TEST_FAIL_IN_RANK"):
+        sys.exit(3)                                         # (tests/test_bench_launcher.py: a launcher that dies -> the N = 1 fallback)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -459,6 +478,7 @@ def main():
             "roofline": rl[0], "roofline_others": rl[1:],
             # how the ranks came to be: spawned_by_bench = this line's ranks were started by bench.py's own launch_ranks()
             "launcher": {"launched": launched, "spawned_by_bench": bool(os.environ.get("IPLAN_BENCH_SPAWNED")), "world_size": world,
+                         **({"spawn_failed": True} if spawn_failed else {}),
                          **(rccl or {"rccl_ranks": None, "note": "single process, no process group (--in-process / --emulate-rank-of)"})},
         }
         if emu_world:

@@ -280,7 +280,20 @@ class SyntheticLoop:
             # IPLAN_PPO_PRIO=1 (A/B knob): the PPO update's stream at high priority -- its ~25 small launches per epoch are a latency
             # chain that otherwise queues for CU slots behind the behaviour kernels' long-lived workgroups
             prio = -1 if os.environ.get("IPLAN_PPO_PRIO") else 0
-            self._lstreams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=prio))
+            # Which streams share a hardware queue is decided HERE, not by creation order (streams.py): prediction learning runs at the
+            # head of the phase beside the encoder's first forward ranges and the decoder's first range -- a queue of its own; the PPO
+            # update's stream must not be the main stream's (train() -> learn order is explicit, below).
+            from . import ops
+            from .streams import distinct_stream, probe_mode
+            if probe_mode() == "full":
+                sides = [ops._side_stream(dev, main.cuda_stream), ops._side_stream(dev, main.cuda_stream, 2)] if self.behavior is not None else []
+                pred_s = distinct_stream(dev, [main] + sides)
+                # ... and the PPO update rides on the prediction learner's stream (behind its 2 ms): the four hardware queues are taken
+                # (main, the encoder's two, this one), a stream of its own would land on one of the encoder's and a rank's small
+                # train() launches would queue between 0.8 ms encoder ranges (rank-of-8 step 39.1 -> 40.7 ms).  IPLAN_PPO_OWN_STREAM=1: A/B
+                self._lstreams = (pred_s, distinct_stream(dev, [main], priority=prio) if os.environ.get("IPLAN_PPO_OWN_STREAM") else pred_s)
+            else:                                             # "min": creation order as before; only the main stream's queue is avoided
+                self._lstreams = (distinct_stream(dev, [main]), torch.cuda.Stream(dev, priority=prio))
         fins = []
         # the behaviour learner's data-movement head first: its tiny launches would otherwise sit behind the side learners' kernels
         prep = self.behavior.prepare_learn(batch) if getattr(type(self.behavior), "learn_takes_prepared", False) else None
@@ -310,6 +323,19 @@ class SyntheticLoop:
                 done = torch.cuda.Event()
                 done.record(strm)
             fins.append((f, done))
+        # Buffer-full cycles (one in eight at config 3): IPPOLearner.train and Behavior_policy.learn each fill the chip, and side by side
+        # they take LONGER than one after the other (round 4, scripts/dev/host_lag.py: 270-272 ms per cycle against 265-268).  Until round 6
+        # which of the two happened was an accident of HIP's stream -> hardware-queue assignment (4 queues: the PPO stream happened to
+        # share one with the main stream, so behaviour learning started when train() was done) -- and a live RCCL communicator, i.e. every
+        # N > 1 rank, takes queues first and flips it (+3 %: profiles/r06_notes.md section 3).  The order is now explicit: the main stream
+        # waits for train() before behaviour learning is enqueued -- when train() is a chip-filling one.  A data-parallel rank's share
+        # (2 880 rows per agent) is a chain of small launches that DOES make progress beside the behaviour kernels (rank-of-8 learn phase
+        # 23.0 ms for 15.1 + 10.1 ms of alone-times): it stays concurrent.  IPLAN_TRAIN_ORDER = serial | concurrent overrides (A/B).
+        order = os.environ.get("IPLAN_TRAIN_ORDER", "auto")
+        big_train = self.args.batch_size * self.args.episode_limit >= 8192
+        if (order == "serial" or (order == "auto" and big_train)) and len(fins) and fins[-1][0] is not None \
+                and self.behavior is not None and not beh_first:
+            main.wait_event(fins[-1][1])
         # IPLAN_RUN_AHEAD=1 (opt-in; measured 362-364 vs 358 ms per cycle with it off, profiles/r02h_notes.md)
         run_ahead = self.behavior is not None and self.defer_decoder and bool(os.environ.get("IPLAN_RUN_AHEAD"))
         if beh_fin is not None:

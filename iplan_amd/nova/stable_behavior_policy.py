@@ -10,7 +10,7 @@ import torch
 from .. import ops
 from ..arena import ParamArena
 from ..optim import FusedAdam, step_all
-from ..streams import AsyncHost, masked_stream
+from ..streams import AsyncHost, distinct_stream, masked_stream, probe_mode
 from .behavior_net import Behavior_Latent_Decoder, EncoderRNN
 from .prediction_policy import _as_dev
 
@@ -233,7 +233,12 @@ class Behavior_policy:
             on_gpu = torch.device(dev).type == "cuda"
             if on_gpu and getattr(self, "_dec_stream", None) is None:
                 # plain side stream by default; IPLAN_DEFER_CUS=k restricts it to k CUs (see harness.py / profiles/r02e_notes.md)
-                self._dec_stream = masked_stream(dev, int(os.environ.get("IPLAN_DEFER_CUS", "0")))
+                cus = int(os.environ.get("IPLAN_DEFER_CUS", "0"))
+                # (beside the NEXT rollout: not on the caller's hardware queue, streams.distinct_stream)
+                # (beside the NEXT rollout: not on the caller's hardware queue when queues are probed, streams.distinct_stream.  Sharing the
+                # prediction learner's stream instead was measured: no better without RCCL, worse with it -- profiles/r06_notes.md section 8)
+                self._dec_stream = masked_stream(dev, cus) if cus > 0 else (
+                    distinct_stream(dev, [torch.cuda.current_stream(dev)]) if probe_mode() == "full" else torch.cuda.Stream(dev))
             ds = self._dec_stream if on_gpu else None                   # (CPU / emulator: same code, run in line)
 
             def update(bwd=bwd):

@@ -448,7 +448,13 @@ def _side_stream(dev, *key):
     k = (str(dev),) + key
     s = _SIDE_STREAMS.get(k)
     if s is None:
-        s = _SIDE_STREAMS[k] = torch.cuda.Stream(dev)
+        # side streams exist to run BESIDE the caller's stream: not on its hardware queue, and the encoder's BPTT stream (tag 2) not on
+        # the forward / in-line stream's either (streams.distinct_stream: probed once, at creation)
+        from .streams import distinct_stream, probe_mode
+        avoid = [torch.cuda.current_stream(dev)]
+        if probe_mode() == "full" and len(key) > 1 and key[1] == 2:
+            avoid.append(_SIDE_STREAMS.get((str(dev), key[0])))
+        s = _SIDE_STREAMS[k] = distinct_stream(dev, avoid)
     return s
 
 _KSPLIT_BUFS = {}

@@ -51,6 +51,86 @@ def masked_stream(device, n_cus, first=0):
         return torch.cuda.Stream(device)
 
 
+# ------------------------------------------------------------------------------------------------ hardware queues
+# HIP runs a process's streams on GPU_MAX_HW_QUEUES hardware queues (4 by default), assigned in creation order; two streams on one
+# queue execute in submission order -- they do not overlap, whatever the events between them say.  The training cycle keeps about
+# eight streams (main, two learner streams, the encoder's forward / BPTT side streams, the deferred decoder update's, ...), so some
+# MUST share, and WHICH ones do decides the cycle: with the encoder-BPTT stream on the main stream's queue the encoder ranges run
+# behind the decoder ranges instead of beside them (+20 ms per cycle).  Until round 6 the good assignment was an accident of creation
+# order -- a live RCCL communicator (every N > 1 rank) creates its streams first and shifts it: 264 -> 271 ... 283 ms by queue count
+# (profiles/r06_notes.md section 8, kernel traces with the queue of every kernel).  The streams that must overlap the main stream are
+# therefore PROBED: ``distinct_stream`` hands out a pool stream that demonstrably does not share a queue with the given ones.
+_probe_state = {}
+
+
+def shares_queue(a, b, device):
+    """Do streams ``a`` and ``b`` execute on the same hardware queue?  A ~0.5 ms spin on ``a``, then a one-element op on ``b``: on one
+    queue the op cannot finish before the spin does.  Synchronises the device (start-up only)."""
+    device = torch.device(device)
+    st = _probe_state.get(str(device))
+    if st is None:
+        st = _probe_state[str(device)] = dict(flag=torch.zeros(1, device=device), cycles=None)
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(2):                                   # (first call: module load)
+            e0.record()
+            torch.cuda._sleep(1_000_000)
+            e1.record()
+            torch.cuda.synchronize(device)
+        ms = max(e0.elapsed_time(e1), 1e-3)
+        st["cycles"] = int(min(max(1_000_000 * 0.5 / ms, 100_000), 50_000_000))     # ~0.5 ms
+    torch.cuda.synchronize(device)
+    a0, a1, b1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    with torch.cuda.stream(a):
+        a0.record(a)
+        torch.cuda._sleep(st["cycles"])
+        a1.record(a)
+    with torch.cuda.stream(b):
+        st["flag"].add_(1.0)
+        b1.record(b)
+    torch.cuda.synchronize(device)
+    return a0.elapsed_time(b1) > 0.5 * a0.elapsed_time(a1)
+
+
+def probe_mode():
+    """IPLAN_QUEUE_PROBE =
+      auto (default): ``full`` when a torch.distributed process group exists (RCCL's communicator has taken hardware queues ahead of the
+                      cycle's streams: every N > 1 rank, ``bench.py --emulate-rank-of``), else ``0`` -- in a process without RCCL the
+                      creation order gives a good assignment 19 times in 20 (traced: main | prediction | encoder BPTT | encoder forward +
+                      PPO), which is 0.8 % faster than the probed one on average, and it is what every evidence series so far ran
+      full: every stream that must overlap another is probed against it, roles created up front (harness.cycle): 264-268 ms per cycle
+            whatever RCCL or GPU_MAX_HW_QUEUES did to the assignment (unprobed: 262 ... 289 ms)
+      min:  creation order, the side streams checked against the main stream's queue only
+      0:    creation order, unchecked"""
+    m = os.environ.get("IPLAN_QUEUE_PROBE", "auto")
+    if m == "auto":
+        try:
+            import torch.distributed as dist
+            m = "full" if (dist.is_available() and dist.is_initialized()) else "0"
+        except Exception:                                    # noqa: BLE001
+            m = "0"
+    return m if m in ("min", "full") else "0"
+
+
+def distinct_stream(device, avoid=(), tries=12, priority=0):
+    """A torch pool stream on ``device`` that shares a hardware queue with none of the streams in ``avoid`` (best effort: after
+    ``tries`` candidates the last one is returned).  CPU devices / IPLAN_QUEUE_PROBE=0: a plain pool stream."""
+    device = torch.device(device)
+    if device.type != "cuda" or probe_mode() == "0" or not hasattr(torch.cuda, "_sleep"):
+        return torch.cuda.Stream(device, priority=priority)
+    avoid = [s for s in avoid if s is not None]
+    held = []                                                # (candidates stay referenced until the choice is made: distinct pool entries)
+    for _ in range(max(1, tries)):
+        c = torch.cuda.Stream(device, priority=priority)
+        held.append(c)
+        try:
+            if not any(shares_queue(o, c, device) for o in avoid):
+                return c
+        except Exception:                                    # noqa: BLE001 -- a probe problem must never cost the run: plain stream
+            return c
+    return held[-1]
+
+
 class AsyncHost:
     """Device tensor -> pinned host copy on a dedicated copy stream, ordered behind everything enqueued so far on the CURRENT
     stream (where the tensor was produced); ``get()`` waits for that copy alone.  A plain ``tensor.cpu()`` is ordered on the

@@ -59,3 +59,15 @@ def test_gpus_1_goes_through_the_spawn_path_and_reports_rccl():
     assert line["n_gpus"] == 1 and la["launched"] and la["spawned_by_bench"] and la["rccl_ranks"] == 1 and la["all_reduce_of_ones"] == 1.0
     assert la["rccl_version"].count(".") == 2
     assert len([ln for ln in r.stdout.splitlines() if ln.strip()]) == 1, "stdout carries exactly ONE line (RCCL's banner goes to stderr)"
+
+
+@pytest.mark.gpu
+def test_a_failing_launcher_does_not_cost_the_single_gpu_line():
+    """if the spawned rank dies (here: on purpose) the N = 1 line is measured in the launching process and says so; still ONE line"""
+    r = _run(["--gpus", "1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], IPLAN_BENCH_TEST_FAIL_IN_RANK="1")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1
+    la = json.loads(out[0])["launcher"]
+    assert la["spawn_failed"] and not la["launched"] and la["rccl_ranks"] is None
+    assert "measuring in this process instead" in r.stderr
