@@ -382,6 +382,11 @@ def main():
             torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
+            try:                                            # the banner sits in C stdio's buffer (fd 1 is a pipe / file: fully buffered) and
+                import ctypes                               # would come out at exit, BEHIND the JSON line: flush it while fd 1 is stderr
+                ctypes.CDLL(None).fflush(None)
+            except Exception:                               # noqa: BLE001
+                pass
             os.dup2(keep, 1)
             os.close(keep)
         info = {"rccl_ranks": dist.get_world_size(), "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()),
