@@ -452,6 +452,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timed = ops.TIMERS.summary()
+    from iplan_amd.streams import probe_mode
+    queue_probe = {"mode": probe_mode(), "streams_replaced_after_first_cycle": getattr(loop, "queue_repairs", None)}
     scene_clocks = ops.TIMERS.clocks.get("gat_scenes_clocks", [])
     if scene_clocks:                                        # span of the scenes inside the sampled fused launches (100 MHz stamps)
         spans = [(c.view(-1, 5)[:, 4].max() - c.view(-1, 5)[:, 0].min()).item() / 100.0 for c in scene_clocks]
@@ -483,7 +485,7 @@ def main():
             "roofline": rl[0], "roofline_others": rl[1:],
             # how the ranks came to be: spawned_by_bench = this line's ranks were started by bench.py's own launch_ranks()
             "launcher": {"launched": launched, "spawned_by_bench": bool(os.environ.get("IPLAN_BENCH_SPAWNED")), "world_size": world,
-                         **({"spawn_failed": True} if spawn_failed else {}),
+                         **({"spawn_failed": True} if spawn_failed else {}), "hardware_queue_probe": queue_probe,
                          **(rccl or {"rccl_ranks": None, "note": "single process, no process group (--in-process / --emulate-rank-of)"})},
         }
         if emu_world:

@@ -94,29 +94,30 @@ def shares_queue(a, b, device):
 
 def probe_mode():
     """IPLAN_QUEUE_PROBE =
-      auto (default): ``full`` when a torch.distributed process group exists (RCCL's communicator has taken hardware queues ahead of the
-                      cycle's streams: every N > 1 rank, ``bench.py --emulate-rank-of``), else ``0`` -- in a process without RCCL the
-                      creation order gives a good assignment 19 times in 20 (traced: main | prediction | encoder BPTT | encoder forward +
-                      PPO), which is 0.8 % faster than the probed one on average, and it is what every evidence series so far ran
-      full: every stream that must overlap another is probed against it, roles created up front (harness.cycle): 264-268 ms per cycle
-            whatever RCCL or GPU_MAX_HW_QUEUES did to the assignment (unprobed: 262 ... 289 ms)
-      min:  creation order, the side streams checked against the main stream's queue only
-      0:    creation order, unchecked"""
-    m = os.environ.get("IPLAN_QUEUE_PROBE", "auto")
-    if m == "auto":
-        try:
-            import torch.distributed as dist
-            m = "full" if (dist.is_available() and dist.is_initialized()) else "0"
-        except Exception:                                    # noqa: BLE001
-            m = "0"
-    return m if m in ("min", "full") else "0"
+      verify (default): streams are created in the old order, and AFTER the first training cycle (every stream has had its first use,
+              i.e. its queue) the pairs that must not share -- main vs the encoder's two side streams vs the prediction learner's -- are
+              probed (harness.SyntheticLoop._verify_queues); a stream that does share is replaced (``distinct_stream``).  Nothing is
+              touched where the creation order came out right (a process without RCCL: traced main | prediction | encoder BPTT | encoder
+              forward + PPO, 19 runs in 20), so the single-GPU line times what every evidence series timed; with a live RCCL group
+              (every N > 1 rank) the encoder-BPTT and prediction streams get replaced: 267 ms against 276 unprobed
+      full:   every stream that overlaps another is probed against it AT CREATION, roles created up front (harness.cycle), the PPO update on
+              the prediction learner's stream: 264-270 ms whatever RCCL or GPU_MAX_HW_QUEUES did (unprobed: 262 ... 289 ms); 0.8 % slower
+              than a good creation-order assignment (the probes' launches change the order of first use)
+      min:    creation order, the side streams checked against the main stream's queue only, at creation
+      0:      creation order, unchecked"""
+    m = os.environ.get("IPLAN_QUEUE_PROBE", "verify")
+    return m if m in ("min", "full", "verify") else "0"
 
 
-def distinct_stream(device, avoid=(), tries=12, priority=0):
+def _probing():
+    return probe_mode() in ("min", "full")
+
+
+def distinct_stream(device, avoid=(), tries=12, priority=0, force=False):
     """A torch pool stream on ``device`` that shares a hardware queue with none of the streams in ``avoid`` (best effort: after
     ``tries`` candidates the last one is returned).  CPU devices / IPLAN_QUEUE_PROBE=0: a plain pool stream."""
     device = torch.device(device)
-    if device.type != "cuda" or probe_mode() == "0" or not hasattr(torch.cuda, "_sleep"):
+    if device.type != "cuda" or not (force or _probing()) or not hasattr(torch.cuda, "_sleep"):
         return torch.cuda.Stream(device, priority=priority)
     avoid = [s for s in avoid if s is not None]
     held = []                                                # (candidates stay referenced until the choice is made: distinct pool entries)
