@@ -370,40 +370,15 @@ class SyntheticLoop:
         return self.E * self.args.episode_limit
 
     def _verify_queues(self, dev, main):
-        """IPLAN_QUEUE_PROBE=verify (the single-process default), once, after the first cycle: the streams that must run BESIDE the main
-        stream -- the encoder's forward / BPTT side streams, the prediction learner's -- are probed against its hardware queue and
-        against each other; one that shares is replaced.  Returns the list of replaced roles (normally empty)."""
+        """IPLAN_QUEUE_PROBE=verify (the default), once, after the first cycle: the streams that must run BESIDE the main stream -- the
+        encoder's forward / BPTT side streams, the prediction learner's -- are probed against its hardware queue and against each other
+        (ops.verify_side_queues); one that shares is replaced.  Returns the list of replaced roles (normally empty)."""
         from . import ops
-        from .streams import distinct_stream, probe_mode, shares_queue
         self._queues_verified = True
-        if probe_mode() != "verify" or not hasattr(torch.cuda, "_sleep"):
-            return []
-        torch.cuda.synchronize(dev)
-        k_f, k_b = (str(dev), main.cuda_stream), (str(dev), main.cuda_stream, 2)
-        roles = {"enc_fwd": ops._SIDE_STREAMS.get(k_f), "enc_bwd": ops._SIDE_STREAMS.get(k_b),
-                 "pred": self._lstreams[0] if getattr(self, "_lstreams", None) else None}
-        replaced = []
-        apart = lambda a, b: {a, b} != {"enc_fwd", "enc_bwd"}    # noqa: E731 -- (the encoder's two never run at the same time: they may share)
-        try:
-            for name in ("enc_bwd", "enc_fwd", "pred"):
-                s = roles[name]
-                if s is None:
-                    continue
-                keep_off = [main] + [o for n, o in roles.items() if n != name and o is not None and apart(name, n)]
-                if any(shares_queue(o, s, dev) for o in keep_off):
-                    new = distinct_stream(dev, keep_off, force=True)
-                    roles[name] = new
-                    replaced.append(name)
-                    if name == "enc_fwd":
-                        ops._SIDE_STREAMS[k_f] = new
-                    elif name == "enc_bwd":
-                        ops._SIDE_STREAMS[k_b] = new
-                    else:
-                        self._lstreams = (new,) + tuple(self._lstreams[1:])
-        except Exception as e:                               # noqa: BLE001 -- never let the check cost the run
-            import sys
-            print(f"[iplan_amd] hardware-queue check skipped ({type(e).__name__}: {str(e)[:100]})", file=sys.stderr)
-        torch.cuda.synchronize(dev)
+        extra = {"pred": self._lstreams[0]} if getattr(self, "_lstreams", None) else {}
+        replaced, roles = ops.verify_side_queues(dev, main, extra)
+        if "pred" in replaced:
+            self._lstreams = (roles["pred"],) + tuple(self._lstreams[1:])
         self.queue_repairs = replaced
         return replaced
 

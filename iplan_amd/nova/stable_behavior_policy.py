@@ -272,6 +272,12 @@ class Behavior_policy:
                 self.dp.all_reduce_grads(self.enc_arena, self.dec_arena)
             sq = step_all(self.behavior_optimizer, max_norm)
             host_dev, split = torch.cat([loss_dev.reshape(-1), sq.sqrt().reshape(-1)]), False
+        if torch.device(dev).type == "cuda" and not getattr(self, "_queues_checked", False):
+            # first learn() done: the encoder's side streams have their hardware queues -- not the caller's, or they get replaced
+            # (ops.verify_side_queues; a training loop with more streams to place, harness.cycle, runs its own wider check)
+            self._queues_checked = True
+            if not defer_readback:
+                ops.verify_side_queues(dev, torch.cuda.current_stream(dev))
         staged = AsyncHost(host_dev) if defer_readback else None
 
         def finish():

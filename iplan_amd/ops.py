@@ -457,6 +457,47 @@ def _side_stream(dev, *key):
         s = _SIDE_STREAMS[k] = distinct_stream(dev, avoid)
     return s
 
+_QUEUES_VERIFIED = set()
+
+
+def verify_side_queues(dev, main, extra=None):
+    """IPLAN_QUEUE_PROBE=verify (streams.probe_mode), once per (device, main stream), AFTER the side streams had their first use: the
+    encoder's forward / BPTT side streams of ``main`` -- and the caller's ``extra`` roles {name: stream} (harness: the prediction
+    learner's) -- must not share ``main``'s hardware queue nor each other's (the encoder's two may: they never run at the same time);
+    one that does is replaced.  -> (list of replaced role names, {name: stream now in use})."""
+    from .streams import distinct_stream, probe_mode, shares_queue
+    key = (str(dev), main.cuda_stream)
+    roles = dict(extra or {})
+    k_f, k_b = (str(dev), main.cuda_stream), (str(dev), main.cuda_stream, 2)
+    roles.update(enc_fwd=_SIDE_STREAMS.get(k_f), enc_bwd=_SIDE_STREAMS.get(k_b))
+    if key in _QUEUES_VERIFIED and not extra:
+        return [], roles
+    _QUEUES_VERIFIED.add(key)
+    if probe_mode() != "verify" or torch.device(dev).type != "cuda" or not hasattr(torch.cuda, "_sleep"):
+        return [], roles
+    replaced = []
+    apart = lambda a, b: {a, b} != {"enc_fwd", "enc_bwd"}    # noqa: E731
+    try:
+        torch.cuda.synchronize(dev)
+        for name in ["enc_bwd", "enc_fwd"] + [n for n in roles if n not in ("enc_bwd", "enc_fwd")]:
+            s = roles.get(name)
+            if s is None:
+                continue
+            keep_off = [main] + [o for n, o in roles.items() if n != name and o is not None and apart(name, n)]
+            if any(shares_queue(o, s, dev) for o in keep_off):
+                roles[name] = distinct_stream(dev, keep_off, force=True)
+                replaced.append(name)
+                if name == "enc_fwd":
+                    _SIDE_STREAMS[k_f] = roles[name]
+                elif name == "enc_bwd":
+                    _SIDE_STREAMS[k_b] = roles[name]
+        torch.cuda.synchronize(dev)
+    except Exception as e:                                   # noqa: BLE001 -- never let the check cost the run
+        import sys
+        print(f"[iplan_amd] hardware-queue check skipped ({type(e).__name__}: {str(e)[:100]})", file=sys.stderr)
+    return replaced, roles
+
+
 _KSPLIT_BUFS = {}
 
 
