@@ -1135,7 +1135,7 @@ constexpr int D2_GI = D2_TILES * 4 * 2 * 3 * 256;          // floats: [tile][q][
 constexpr int D2_HX = D2_TILES * 2 * 2 * 3 * 256;          //         [tile][parity][k-chunk][piece][64 lanes x bf16x8]
 constexpr int D2_UX = D2_HX;
 constexpr int D2_YX = D2_TILES * 2 * 4 * 128;              //         [tile][parity][q][32 lanes x f32x4]  (outputs 0..7: d <= 8)
-constexpr int D2_CNT_INTS = 16;                            // hcnt | ucnt | ycnt | rcnt | gcnt[4] | bcnt[4] | pad
+constexpr int D2_CNT_INTS = 20;                            // hcnt | ucnt | (unused x 2) | gcnt[4] | bcnt[4] | ycnt[4] | rcnt[D2_TILES] | pad
 constexpr int D2_MAX_WINDOWS = 512;                        // per-window loss normalisers of a launch (floats)
 constexpr int D2_LDS_FLOATS = D2_GI + D2_HX + D2_UX + D2_YX + D2_CNT_INTS + D2_MAX_WINDOWS;
 
@@ -1347,12 +1347,19 @@ __device__ __forceinline__ void d2_recurrent(const IplanBehArgs& a, const D2Ctx&
             yp[k] = mma_block(wout, act, bout);                                      // own share of y = W_out act + b
         }
         D2_CLK(3);
-        if (s >= 2) d2_wait(x.rcnt, x.n_live * (s - 1));                              // the output slots of step s - 2 were consumed
+        // the output slots of step s - 2 were consumed -- by EVERY owner: one counter per tile (round 6).  The owners counted into one
+        // until then and this wait read n_live (s - 1); but behind their main loop the owners finish the last D2_LAG steps WITHOUT the
+        // per-step rendezvous of the A-waves (ucnt), one of them could be two outputs ahead of another, the sum was reached, the slot of
+        // step s - 2 overwritten with step s's share and the slower owner stored a wrong y for the last-but-two step of the launch's last
+        // window (seen at tile 108 -- the two-tile workgroup at a net's end --, t = 7, once in ~10 000 forward passes)
+        if (s >= 2)
+            for (int k = 0; k < D2_TILES; ++k)
+                if (FAST || c[k].live) d2_wait(x.rcnt + k, s - 1);
         D2_CLK(4);
 #pragma unroll
         for (int k = 0; k < D2_TILES; ++k)
             if ((FAST || c[k].live) && l < x.YL) *(reinterpret_cast<f32x4*>(x.s_yx + ((k * 2 + (s & 1)) * 4 + q) * 128) + l) = yp[k];
-        d2_signal(x.ycnt);
+        d2_signal(x.ycnt + q);                                                       // (per quarter: see finish_y)
         D2_CLK(5);
         if (++t == Lw) { t = 0; ++j; }
     }
@@ -1435,13 +1442,18 @@ __device__ __forceinline__ void d2_input(const IplanBehArgs& a, const D2Ctx& x, 
     };
     auto finish_y = [&](int s, int jj, int tt, YIn& in) {
         d2_landed<FAST ? D2_VM_WINDOW : 0>(in.nx, in.xt, in.m);
-        d2_wait(x.ycnt, 4 * (s + 1));
+        // ONE counter per quarter (round 6).  Until then the four B-waves counted into one and the owner waited for 4 (s + 1) -- but
+        // the B-waves meet only mid-step (hcnt), not where they publish their share of y: a wave stalled in its record stores of step s
+        // could be a step behind one that had already published step s + 1, the SUM still read 4 (s + 1), and the owner added the stalled
+        // quarter's STALE slot (step s - 2's share): one (tile, step) of y, the loss and everything downstream off by ~1e-6 of a
+        // gradient's max, once in ~300 forward passes at config 3 (profiles/r06_notes.md section 9; scripts/dev/beh_race_hunt.py)
+        for (int qq = 0; qq < 4; ++qq) d2_wait(x.ycnt + qq, s + 1);
         f32x4 yq[4];
         for (int i = 0; i < 4; ++i) {
             yq[i] = splat4(0.f);
             if (l < x.YL) yq[i] = *(reinterpret_cast<const f32x4*>(x.s_yx + ((ko * 2 + (s & 1)) * 4 + i) * 128) + l);
         }
-        d2_signal(x.rcnt);
+        d2_signal(x.rcnt + ko);                              // (this owner's tile: the B-waves wait for every live tile's count)
         const f32x4 y = (yq[0] + yq[1]) + (yq[2] + yq[3]);
         st4<FAST>(d2_sd_base(a, x, co), d2_sd_off(x, jj * Lw + tt) + x.cgs * REC_CG(SD_Y), ovalid, y);
         const f32x4 nx = x_keep(in.nx, beh_y_step(a, jj, tt), vmo), xt = x_keep(in.xt, beh_x_step(a, jj, tt), vmo);
@@ -1573,7 +1585,7 @@ __global__ __launch_bounds__(D2_THREADS, 2) void beh_dec_fwd2_kernel(IplanBehArg
     x.steps_per_chain = (int64_t)x.J * x.Lw;
     x.cgs = (uint32_t)(x.steps_per_chain * 1024);
     x.YL = 16 * ((a.d + 3) / 4);                                                      // lanes that hold real outputs
-    x.hcnt = s_cnt + 0; x.ucnt = s_cnt + 1; x.ycnt = s_cnt + 2; x.rcnt = s_cnt + 3; x.gcnt = s_cnt + 4 + x.q; x.bcnt = s_cnt + 8 + x.q;
+    x.hcnt = s_cnt + 0; x.ucnt = s_cnt + 1; x.ycnt = s_cnt + 12; x.rcnt = s_cnt + 16; x.gcnt = s_cnt + 4 + x.q; x.bcnt = s_cnt + 8 + x.q;
     x.n_live = 0;
     bool fast = true;
 #pragma unroll
