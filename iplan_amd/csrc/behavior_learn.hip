@@ -1139,9 +1139,19 @@ constexpr int D2_CNT_INTS = 20;                            // hcnt | ucnt | (unu
 constexpr int D2_MAX_WINDOWS = 512;                        // per-window loss normalisers of a launch (floats)
 constexpr int D2_LDS_FLOATS = D2_GI + D2_HX + D2_UX + D2_YX + D2_CNT_INTS + D2_MAX_WINDOWS;
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifdef IPLAN_HOST_EMULATION
 __device__ inline void d2_signal(int* c) { IPLAN_WAVE_SYNC(); if (lane_id() == 0) *c += 1; }
 __device__ inline void d2_wait(const int* c, int target) { while (*reinterpret_cast<const volatile int*>(c) < target) iplan_emu::yield_(); }
+// four counters at once (16-byte aligned): every one whose bit is set in `live` has reached `target`
+__device__ inline void d2_wait4(const int* c, int target, int live) {
+    for (;;) {
+        bool ok = true;
+        for (int i = 0; i < 4; ++i) ok = ok && (!((live >> i) & 1) || reinterpret_cast<const volatile int*>(c)[i] >= target);
+        if (ok) return;
+        iplan_emu::yield_();
+    }
+}
 #else
 __device__ __forceinline__ void d2_signal(int* c) {        // (a wave's LDS operations execute in order: the data is there before the count)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1149,6 +1159,18 @@ __device__ __forceinline__ void d2_signal(int* c) {        // (a wave's LDS oper
 }
 __device__ __forceinline__ void d2_wait(const int* c, int target) {
     while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+// four counters with ONE 16-byte LDS read per poll (the counters are dwords bumped by LDS atomics: a 128-bit read sees each of them
+// whole): every one whose bit is set in `live` has reached `target`.  Costs what the single-counter poll cost.
+__device__ __forceinline__ void d2_wait4(const int* c, int target, int live) {
+    const i32x4 dead = {(live & 1) ? 0 : 0x7fffffff, (live & 2) ? 0 : 0x7fffffff, (live & 4) ? 0 : 0x7fffffff, (live & 8) ? 0 : 0x7fffffff};
+    for (;;) {
+        const i32x4 v = *reinterpret_cast<const volatile i32x4*>(c) | dead;
+        const int lo = min(min(v[0], v[1]), min(v[2], v[3]));
+        if (__builtin_amdgcn_readfirstlane(lo) >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
     asm volatile("" ::: "memory");
 }
 #endif
@@ -1295,6 +1317,9 @@ __device__ __forceinline__ void d2_recurrent(const IplanBehArgs& a, const D2Ctx&
         d2_px_write(x, x.s_hx, k, 1, hq[k]);                                         // h_{-1}: parity of step -1
     }
     d2_signal(x.hcnt);
+    int live_mask = 0;                                       // tiles whose owner counts consumed outputs (rcnt[k])
+#pragma unroll
+    for (int k = 0; k < D2_TILES; ++k) live_mask |= (FAST || c[k].live) ? (1 << k) : 0;
     D2_CLK_DECL(8);
     int j = x.j_lo, t = 0;
     for (int s = 0; s < x.steps; ++s) {
@@ -1352,9 +1377,7 @@ __device__ __forceinline__ void d2_recurrent(const IplanBehArgs& a, const D2Ctx&
         // per-step rendezvous of the A-waves (ucnt), one of them could be two outputs ahead of another, the sum was reached, the slot of
         // step s - 2 overwritten with step s's share and the slower owner stored a wrong y for the last-but-two step of the launch's last
         // window (seen at tile 108 -- the two-tile workgroup at a net's end --, t = 7, once in ~10 000 forward passes)
-        if (s >= 2)
-            for (int k = 0; k < D2_TILES; ++k)
-                if (FAST || c[k].live) d2_wait(x.rcnt + k, s - 1);
+        if (s >= 2) d2_wait4(x.rcnt, s - 1, live_mask);
         D2_CLK(4);
 #pragma unroll
         for (int k = 0; k < D2_TILES; ++k)
@@ -1447,7 +1470,7 @@ __device__ __forceinline__ void d2_input(const IplanBehArgs& a, const D2Ctx& x, 
         // could be a step behind one that had already published step s + 1, the SUM still read 4 (s + 1), and the owner added the stalled
         // quarter's STALE slot (step s - 2's share): one (tile, step) of y, the loss and everything downstream off by ~1e-6 of a
         // gradient's max, once in ~300 forward passes at config 3 (profiles/r06_notes.md section 9; scripts/dev/beh_race_hunt.py)
-        for (int qq = 0; qq < 4; ++qq) d2_wait(x.ycnt + qq, s + 1);
+        d2_wait4(x.ycnt, s + 1, 15);
         f32x4 yq[4];
         for (int i = 0; i < 4; ++i) {
             yq[i] = splat4(0.f);
