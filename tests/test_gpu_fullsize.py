@@ -51,3 +51,18 @@ def test_behavior_learn_bitwise_reproducible_from_a_cold_process():
         assert len(lines) == 6, r.stdout[-2000:]
         for ln in lines:
             assert "nan/inf: [False, False]" in ln and "(enc, dec): [0.0, 0.0]" in ln, ln
+
+
+def test_behavior_forward_hand_offs_are_race_free():
+    """Round 6: the decoder forward's second form handed its output shares between waves through two SUMMED LDS counters that did not
+    imply every addend: 1 forward pass in ~300 stored a wrong y for one (tile, step) -- 1e-6 of a gradient's max,
+    inside every parity tolerance.  scripts/dev/beh_race_hunt.py repeats the forward at config 3 on the same inputs and compares every
+    record bit for bit with the first run's: 600 repetitions here (the old kernel: a miss with probability 0.13), 24 000 in the round's
+    probe calls."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev", "beh_race_hunt.py"), "600", "fwd"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "forward: 0 tensor mismatches in 600 repetitions" in r.stdout, r.stdout[-3000:]
