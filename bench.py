@@ -508,9 +508,13 @@ def main():
             line["config4_n1"] = config4_n1_object(opt, dev)
         if pg_late:
             torch.cuda.synchronize()
-            dist, rccl = init_rccl()
-            rccl["note"] = "1-rank group created after the timed region (see bench.py: pg_late)"
-            line["launcher"].update(rccl)
+            try:
+                dist, rccl = init_rccl()
+                rccl["note"] = "1-rank group created after the timed region (see bench.py: pg_late)"
+                line["launcher"].update(rccl)
+            except Exception as e:                               # noqa: BLE001 -- the measurement is done: a group that cannot be
+                dist = None                                      # created must not cost the single-GPU line
+                line["launcher"]["rccl_error"] = f"{type(e).__name__}: {str(e)[:200]}"
         if not opt.no_cpu_baseline and world == 1:               # (N = 1 only: at N > 1 the other ranks would sit in RCCL's teardown meanwhile)
             line["cpu_baseline"] = cpu_baseline(args, E)
 
